@@ -1,0 +1,128 @@
+// pailliercryptolib_amd -- host-side arbitrary-precision integer.
+//
+// IPP-free re-creation of the public surface of the reference's global ::BigNumber
+// (reference: ipcl/include/ipcl/bignum.h:28-161, ipcl/bignum.cpp).  The reference wraps an
+// opaque IppsBigNumState (sign + little-endian 32-bit words); this one is a plain value type
+// over little-endian 64-bit limbs -- the same limb layout the GPU C-ABI (include/pgpu.h) uses,
+// so a BigNumber's magnitude can be memcpy'd straight into a batch buffer.
+//
+// Behaviours the reference's tests pin and that are reproduced here:
+//   Q1  operator% returns the NON-NEGATIVE residue for a negative left operand;
+//   Q7  num2hex is lowercase, "0x"-prefixed, no leading zeros, and zero prints as "0x";
+//       the string ctor understands lowercase hex ("0x...") and decimal;
+//   Q8  num2vec returns at least one 32-bit word, also for the value 0.
+#ifndef PAILLIERCRYPTOLIB_AMD_IPCL_BIGNUM_H_
+#define PAILLIERCRYPTOLIB_AMD_IPCL_BIGNUM_H_
+
+#include <cstddef>
+#include <cstdint>
+#include <ostream>
+#include <string>
+#include <vector>
+
+typedef uint8_t Ipp8u;
+typedef uint32_t Ipp32u;
+typedef int32_t Ipp32s;
+typedef uint64_t Ipp64u;
+// Same enumerator values as ippcp's IppsBigNumSGN so client code that spells them compiles.
+typedef enum { IppsBigNumNEG = 0, IppsBigNumPOS = 1 } IppsBigNumSGN;
+
+class BigNumber {
+ public:
+  BigNumber(Ipp32u value = 0);
+  BigNumber(Ipp32s value);
+  BigNumber(const Ipp32u* pData, int length = 1, IppsBigNumSGN sgn = IppsBigNumPOS);
+  BigNumber(const BigNumber& bn) = default;
+  BigNumber(BigNumber&& bn) = default;
+  BigNumber(const char* s);
+  virtual ~BigNumber() = default;
+
+  // set value from little-endian 32-bit words (reference: bignum.cpp:109-112)
+  void Set(const Ipp32u* pData, int length = 1, IppsBigNumSGN sgn = IppsBigNumPOS);
+
+  static const BigNumber& Zero();
+  static const BigNumber& One();
+  static const BigNumber& Two();
+
+  BigNumber& operator=(const BigNumber& bn) = default;
+  BigNumber& operator=(BigNumber&& bn) = default;
+  BigNumber& operator+=(Ipp32u n);
+  BigNumber& operator+=(const BigNumber& bn);
+  BigNumber& operator-=(Ipp32u n);
+  BigNumber& operator-=(const BigNumber& bn);
+  BigNumber& operator*=(Ipp32u n);
+  BigNumber& operator*=(const BigNumber& bn);
+  BigNumber& operator/=(Ipp32u n);
+  BigNumber& operator/=(const BigNumber& bn);
+  BigNumber& operator%=(Ipp32u n);
+  BigNumber& operator%=(const BigNumber& bn);
+  friend BigNumber operator+(const BigNumber& a, const BigNumber& b);
+  friend BigNumber operator+(const BigNumber& a, Ipp32u);
+  friend BigNumber operator-(const BigNumber& a, const BigNumber& b);
+  friend BigNumber operator-(const BigNumber& a, Ipp32u);
+  friend BigNumber operator*(const BigNumber& a, const BigNumber& b);
+  friend BigNumber operator*(const BigNumber& a, Ipp32u);
+  friend BigNumber operator%(const BigNumber& a, const BigNumber& b);
+  friend BigNumber operator%(const BigNumber& a, Ipp32u);
+  friend BigNumber operator/(const BigNumber& a, const BigNumber& b);
+  friend BigNumber operator/(const BigNumber& a, Ipp32u);
+
+  // modulo arithmetic, *this is the modulus (reference: bignum.cpp:318-350)
+  BigNumber Modulo(const BigNumber& a) const;
+  BigNumber ModAdd(const BigNumber& a, const BigNumber& b) const;
+  BigNumber ModSub(const BigNumber& a, const BigNumber& b) const;
+  BigNumber ModMul(const BigNumber& a, const BigNumber& b) const;
+  BigNumber InverseAdd(const BigNumber& a) const;
+  BigNumber InverseMul(const BigNumber& a) const;
+  BigNumber gcd(const BigNumber& q) const;
+  int compare(const BigNumber&) const;
+
+  friend bool operator<(const BigNumber& a, const BigNumber& b) { return a.compare(b) < 0; }
+  friend bool operator>(const BigNumber& a, const BigNumber& b) { return a.compare(b) > 0; }
+  friend bool operator==(const BigNumber& a, const BigNumber& b) { return a.compare(b) == 0; }
+  friend bool operator!=(const BigNumber& a, const BigNumber& b) { return a.compare(b) != 0; }
+  friend bool operator<=(const BigNumber& a, const BigNumber& b) { return !(a > b); }
+  friend bool operator>=(const BigNumber& a, const BigNumber& b) { return !(a < b); }
+
+  bool IsOdd() const;
+  bool IsEven() const { return !IsOdd(); }
+  bool TestBit(int index) const;
+
+  int MSB() const;
+  int LSB() const;
+  int BitSize() const { return MSB() + 1; }
+  int DwordSize() const { return (BitSize() + 31) >> 5; }
+  friend int Bit(const std::vector<Ipp32u>& v, int n);
+
+  void num2hex(std::string& s) const;
+  void num2vec(std::vector<Ipp32u>& v) const;
+  friend std::ostream& operator<<(std::ostream& os, const BigNumber& a);
+  void num2char(std::vector<Ipp8u>& dest) const;
+
+  // big-endian fixed-length octet strings (the reference's QAT wire format, bignum.cpp:511-565)
+  static bool fromBin(BigNumber& bn, const unsigned char* data, int len);
+  static bool toBin(unsigned char* data, int len, const BigNumber& bn);
+  static bool toBin(unsigned char** data, int* len, const BigNumber& bn);
+
+  // ---- GPU-side layout helpers (north_star: "bignum.cpp gains a GPU-side 64-bit-limb layout") ----
+  // Little-endian 64-bit limbs of |*this|, zero-padded/truncation-checked to exactly nlimbs.
+  // Returns false if the magnitude does not fit.
+  bool toLimbs64(uint64_t* out, std::size_t nlimbs) const;
+  static BigNumber fromLimbs64(const uint64_t* limbs, std::size_t nlimbs);
+  const std::vector<uint64_t>& limbs64() const { return m_mag; }
+  bool isNegative() const { return m_neg; }
+  bool isZero() const { return m_mag.empty(); }
+
+  // divide with remainder: *this = q*d + r, q truncated toward zero, r has the sign of *this
+  static void divmod(const BigNumber& a, const BigNumber& d, BigNumber* q, BigNumber* r);
+
+ protected:
+  std::vector<uint64_t> m_mag;  // magnitude, little-endian, no leading zero limbs; empty == 0
+  bool m_neg = false;           // sign; never set for zero
+  void trim();
+};
+
+constexpr int BITSIZE_WORD(int n) { return (((n) + 31) >> 5); }
+constexpr int BITSIZE_DWORD(int n) { return (((n) + 63) >> 6); }
+
+#endif  // PAILLIERCRYPTOLIB_AMD_IPCL_BIGNUM_H_
