@@ -1,0 +1,91 @@
+/* pgpu.h -- C-ABI of the MI355X (gfx950) batched modular-exponentiation engine.
+ *
+ * This is the drop-in boundary under the reference's `ipcl::` C++ API: every entry point takes
+ * plain pointers and sizes (no C++ types, no torch types) and replaces one call the reference
+ * makes into a third-party/accelerator primitive.  The precedent in the reference is its own
+ * accelerator seam, the HE-QAT C library (module/heqat/heqat/include/heqat/bnops.h:63-148,
+ * context.h:18-26) and the IPP-Crypto multi-buffer primitive mbx_exp_mb8 (call site
+ * ipcl/mod_exp.cpp:508-516).
+ *
+ * DATA LAYOUT.  A big integer is `words` little-endian 64-bit limbs (same as the `int64u`
+ * arrays handed to mbx_exp_mb8, mod_exp.cpp:486-506).  A batch is row-major
+ * [element][limb] with a fixed element stride given in 64-bit words; a stride of 0 means
+ * "one shared value for the whole batch" (every reference call site passes N copies of one
+ * modulus / one exponent / one base: pub_key.cpp:53-54,67-69, pri_key.cpp:119-120,
+ * ciphertext.cpp:151).  Values are zero padded to the stride.
+ *
+ * OWNERSHIP / THREADING.  The caller owns every buffer it passes.  Functions without the
+ * `_dev` suffix take HOST pointers and are synchronous (like release_bnModExp_buffer,
+ * bnops.h:134-148): on return the outputs are complete.  `_dev` functions take DEVICE
+ * pointers plus a hipStream_t (as void*) and only enqueue work on that stream.  All entry
+ * points may be called from several host threads (the reference's APPLEVEL_OMP test calls
+ * encrypt/decrypt from 4 threads, test/test_cryptography.cpp:45-57); calls on one process
+ * are serialised internally.  One process drives one GPU (pgpu_init selects it).
+ *
+ * ERRORS.  Every function returns PGPU_OK (0) or a negative pgpu_status; nothing calls
+ * exit().  pgpu_last_error() returns a thread-local description.  The C++ layer turns a
+ * non-zero status into the reference's ERROR_CHECK exception (utils/util.hpp:23-34).
+ * There is NO CPU fallback anywhere behind this interface: without a usable gfx950 device
+ * every compute entry point fails with PGPU_ERR_NO_DEVICE.
+ */
+#ifndef PGPU_H_
+#define PGPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pgpu_status {
+  PGPU_OK = 0,
+  PGPU_ERR_INVALID_PARAM = -1, /* null pointer, zero width, inconsistent sizes            */
+  PGPU_ERR_EVEN_MODULUS = -2,  /* Montgomery arithmetic needs an odd modulus               */
+  PGPU_ERR_UNSUPPORTED = -3,   /* operand width beyond the compiled kernel geometries      */
+  PGPU_ERR_NO_DEVICE = -4,     /* no HIP device / not initialised                          */
+  PGPU_ERR_HIP = -5,           /* a HIP runtime call failed (see pgpu_last_error)          */
+  PGPU_ERR_NOT_INVERTIBLE = -6 /* key material is inconsistent (e.g. p == q)               */
+} pgpu_status;
+
+/* ---- context: behind ipcl::initializeContext / terminateContext (utils/context.cpp:40-71);
+ *      replaces acquire_qat_devices / release_qat_devices (heqat/context.h:18-26) ---- */
+int pgpu_init(int device /* HIP ordinal; -1 = keep the current device */);
+void pgpu_shutdown(void);
+int pgpu_device_count(void);
+int pgpu_is_initialized(void);
+const char* pgpu_last_error(void);
+const char* pgpu_device_name(void);
+
+/* ---- generic batched modular exponentiation: out[i] = base[i]^exp[i] mod mod ----
+ * Replaces mbx_exp_mb8 (mod_exp.cpp:508-516) / ippsMontExp (mod_exp.cpp:549-579) under
+ * ipcl::modExp (mod_exp.hpp:72-83).  `exp_bits` is the maximum exponent bit length of the
+ * batch (the reference computes the same maximum, mod_exp.cpp:484); exponent words above
+ * exp_bits must be zero.  The modulus is shared and odd; bases may be any value that fits
+ * mod_words words (they are reduced).  out has stride mod_words. */
+int pgpu_modexp(const uint64_t* base, size_t base_stride, const uint64_t* exp, size_t exp_stride,
+                int exp_words, int exp_bits, const uint64_t* mod, int mod_words, uint64_t* out,
+                size_t count);
+int pgpu_modexp_dev(const uint64_t* d_base, size_t base_stride, const uint64_t* d_exp,
+                    size_t exp_stride, int exp_words, int exp_bits, const uint64_t* h_mod,
+                    int mod_words, uint64_t* d_out, size_t count, void* hip_stream);
+
+/* ---- batched modular multiplication: out[i] = a[i]*b[i] mod mod ----
+ * Replaces the per-element `a * b % sq` of CipherText::raw_add (ciphertext.cpp:135-141);
+ * b_stride == 0 is the reference's vector (+) scalar case (ciphertext.cpp:51-58). */
+int pgpu_modmul(const uint64_t* a, const uint64_t* b, size_t b_stride, const uint64_t* mod,
+                int mod_words, uint64_t* out, size_t count);
+int pgpu_modmul_dev(const uint64_t* d_a, const uint64_t* d_b, size_t b_stride,
+                    const uint64_t* h_mod, int mod_words, uint64_t* d_out, size_t count,
+                    void* hip_stream);
+
+/* ---- instrumentation used by bench.py (roofline): timing of the most recent kernel launch
+ *      of each kind, measured with hipEvents on the stream the kernel ran on ---- */
+int pgpu_set_timing(int enabled);
+double pgpu_last_kernel_ms(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PGPU_H_ */

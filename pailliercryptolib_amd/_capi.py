@@ -1,0 +1,67 @@
+"""ctypes binding of the C-ABI in include/pgpu.h (libpgpu.so, built in-tree by build.py).
+
+This module is plumbing only: it loads the HIP library and declares argument types.  There is
+deliberately no fallback: if the library is missing or no gfx950 device is present, every
+compute call raises.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p, POINTER, c_uint64
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpgpu.so")
+
+# every symbol include/pgpu.h declares (tests check the built library exports all of them)
+SYMBOLS = [
+    "pgpu_init", "pgpu_shutdown", "pgpu_device_count", "pgpu_is_initialized",
+    "pgpu_last_error", "pgpu_device_name",
+    "pgpu_modexp", "pgpu_modexp_dev", "pgpu_modmul", "pgpu_modmul_dev",
+    "pgpu_set_timing", "pgpu_last_kernel_ms",
+]
+
+_lib = None
+
+
+class PgpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"pgpu error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    """Load libpgpu.so (once).  Raises if the extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    u64p = POINTER(c_uint64)
+    L.pgpu_init.argtypes = [c_int]; L.pgpu_init.restype = c_int
+    L.pgpu_shutdown.argtypes = []; L.pgpu_shutdown.restype = None
+    L.pgpu_device_count.argtypes = []; L.pgpu_device_count.restype = c_int
+    L.pgpu_is_initialized.argtypes = []; L.pgpu_is_initialized.restype = c_int
+    L.pgpu_last_error.argtypes = []; L.pgpu_last_error.restype = c_char_p
+    L.pgpu_device_name.argtypes = []; L.pgpu_device_name.restype = c_char_p
+    L.pgpu_modexp.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_int, c_void_p, c_int,
+                              c_void_p, c_size_t]
+    L.pgpu_modexp.restype = c_int
+    L.pgpu_modexp_dev.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_int, c_void_p,
+                                  c_int, c_void_p, c_size_t, c_void_p]
+    L.pgpu_modexp_dev.restype = c_int
+    L.pgpu_modmul.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_size_t]
+    L.pgpu_modmul.restype = c_int
+    L.pgpu_modmul_dev.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_size_t,
+                                  c_void_p]
+    L.pgpu_modmul_dev.restype = c_int
+    L.pgpu_set_timing.argtypes = [c_int]; L.pgpu_set_timing.restype = c_int
+    L.pgpu_last_kernel_ms.argtypes = []; L.pgpu_last_kernel_ms.restype = c_double
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise PgpuError(rc, lib().pgpu_last_error().decode(errors="replace"))

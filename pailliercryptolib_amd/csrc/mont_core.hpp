@@ -1,0 +1,209 @@
+// pailliercryptolib_amd -- CDNA4 (gfx950) device core: distributed Montgomery multiplication.
+//
+// Replaces the arithmetic the reference obtains from IPP-Crypto's mbx_exp_mb8 / ippsMontExp
+// (call sites: ipcl/mod_exp.cpp:508-516, 549-579).  Design derived from measured gfx950 issue
+// rates (profiles/r01_ubench_valu_issue_rates.txt): v_mad_u64_u32 is a FULL-rate instruction
+// (~4.8 cyc per wave64 per SIMD, 32.7 T MAC32/s chip-wide) while every carry-chain instruction
+// (v_addc_co_u32) costs as much as a MAC and ds_bpermute_b32 costs 24 cyc.  Hence:
+//
+//   * reduced radix: a value is L = G*K limbs of LB = 29 bits, each held in a 32-bit VGPR;
+//     column sums live in 64-bit VGPR pairs, so  acc += a*b  is ONE v_mad_u64_u32 with no carry
+//     handling at all (2K products of < 2^58 per column lifetime < 2^64 for K <= 31);
+//   * G lanes (G in {2,4,8,16}, inside one 16-lane DPP row) co-operate on one exponentiation,
+//     64/G exponentiations per wavefront; lane x owns limbs [x*K, x*K+K);
+//   * word-serial Montgomery (operand scanning) in blocks of K rows: K*K MACs of a*b, then K*K
+//     MACs of q*n, the K quotient digits q_r broadcast from the group's lane 0 with one DPP
+//     move (row_newbcast / quad_perm), then the window slides down K columns with K DPP
+//     row_shl moves; the multiplier operand b is staged in LDS and read back as
+//     group-broadcast rows;
+//   * values stay in [0, 2N) between multiplications (R = 2^(29*L) >= 256*N), so there is no
+//     compare/subtract in the loop; canonical reduction happens once, at the very end.
+#ifndef PAILLIERCRYPTOLIB_AMD_CSRC_MONT_CORE_HPP_
+#define PAILLIERCRYPTOLIB_AMD_CSRC_MONT_CORE_HPP_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pgpu {
+
+constexpr int kWave = 64;
+constexpr int kLimbBits = 29;
+constexpr uint32_t kLimbMask = (1u << kLimbBits) - 1;
+
+template <int G_, int K_>
+struct Geo {
+  static constexpr int G = G_;            // lanes per exponentiation
+  static constexpr int K = K_;            // 29-bit limbs per lane
+  static constexpr int L = G_ * K_;       // limbs per value
+  static constexpr int RBITS = L * kLimbBits;      // Montgomery R = 2^RBITS
+  static constexpr int IPW = kWave / G_;           // exponentiations per wavefront
+  static constexpr int W64 = (RBITS + 63) / 64;    // 64-bit words that cover R
+  static_assert(G_ == 2 || G_ == 4 || G_ == 8 || G_ == 16, "group must sit inside a DPP row");
+  static_assert(2 * K_ < 64, "column accumulators would overflow 64 bits");
+};
+
+// ---- DPP cross-lane moves (VALU, no LDS traffic) ----
+// value of lane x+1 (same 16-lane row); 0 at the row end.
+__device__ __forceinline__ uint32_t dpp_from_next(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101 /*row_shl:1*/, 0xf, 0xf, true);
+}
+// value of lane x-1 (same 16-lane row); 0 at the row start.
+__device__ __forceinline__ uint32_t dpp_from_prev(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+}
+// broadcast the value held by lane 0 of every G-lane group to the whole group.
+template <int G>
+__device__ __forceinline__ uint32_t bcast_lane0(uint32_t v) {
+  if constexpr (G == 16) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 /*row_newbcast:0*/, 0xf, 0xf, true);
+  } else if constexpr (G == 8) {
+    int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x00 /*quad_perm:[0,0,0,0]*/, 0xf, 0xf, true);
+    // quads 1 and 3 take the value from 4 lanes below (quads 0 and 2 keep theirs)
+    return (uint32_t)__builtin_amdgcn_update_dpp(t, t, 0x114 /*row_shr:4*/, 0xf, 0xa, false);
+  } else if constexpr (G == 4) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00 /*quad_perm:[0,0,0,0]*/, 0xf, 0xf, true);
+  } else {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xa0 /*quad_perm:[0,0,2,2]*/, 0xf, 0xf, true);
+  }
+}
+
+// One K-row block of the word-serial Montgomery product.
+//   LOWC: the K columns this lane shares with nobody below it (get reduced / passed down)
+//   UPC : the next K columns (become LOWC of the next block; enter as zero)
+// On exit UPC holds the new low half (old UPC + the K normalised limbs received from lane x+1)
+// and LOWC is zero, i.e. the caller swaps the roles of the two arrays for the next block.
+template <class GEO>
+__device__ __forceinline__ void mont_block(uint64_t (&LOWC)[GEO::K], uint64_t (&UPC)[GEO::K],
+                                           const uint32_t (&a)[GEO::K], const uint32_t (&n)[GEO::K],
+                                           uint32_t n0inv, const uint32_t* __restrict__ brow) {
+  constexpr int K = GEO::K;
+  uint32_t b[K];
+#pragma unroll
+  for (int r = 0; r < K; ++r) b[r] = brow[r];
+  // phase A: acc += a_chunk * b_rows  (K*K v_mad_u64_u32, no carries)
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      if (r + j < K) LOWC[r + j] += (uint64_t)a[j] * b[r];
+      else UPC[r + j - K] += (uint64_t)a[j] * b[r];
+    }
+  }
+  // phase B: K quotient digits, each followed by acc += n_chunk * q
+  uint32_t low[K];
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    uint32_t q = ((uint32_t)LOWC[r] * n0inv) & kLimbMask;
+    q = bcast_lane0<GEO::G>(q);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      if (r + j < K) LOWC[r + j] += (uint64_t)n[j] * q;
+      else UPC[r + j - K] += (uint64_t)n[j] * q;
+    }
+    // column r is final: split into its 29-bit limb and the carry into column r+1.
+    // (in the group's lane 0 the limb is 0 by construction of q)
+    uint64_t c = LOWC[r] >> kLimbBits;
+    low[r] = (uint32_t)LOWC[r] & kLimbMask;
+    if (r + 1 < K) LOWC[r + 1] += c;
+    else UPC[0] += c;
+  }
+  // phase C: slide the window down K columns.  Lane x's low limbs are exactly the
+  // contribution lane x-1 is missing in its upper half.  The top lane of a group receives the
+  // low limbs of the NEXT group's lane 0, which are zero, so no masking is needed.
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    UPC[j] += dpp_from_next(low[j]);
+    LOWC[j] = 0;
+  }
+}
+
+// r = a * b * R^-1 mod N (lazy: inputs < 4N -> output < 2N), b read from LDS at bl[0..L).
+// Output limbs are < 2^29 except that limb 0 of a lane may equal 2^29 (deferred unit carry).
+template <class GEO>
+__device__ __forceinline__ void montmul(uint32_t (&r)[GEO::K], const uint32_t (&a)[GEO::K],
+                                        const uint32_t* __restrict__ bl,
+                                        const uint32_t (&n)[GEO::K], uint32_t n0inv) {
+  constexpr int K = GEO::K;
+  uint64_t c0[K], c1[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) { c0[j] = 0; c1[j] = 0; }
+#pragma unroll 1
+  for (int s = 0; s < GEO::G; s += 2) {
+    mont_block<GEO>(c0, c1, a, n, n0inv, bl + s * K);
+    mont_block<GEO>(c1, c0, a, n, n0inv, bl + (s + 1) * K);
+  }
+  // pass 1: local carry propagation
+  uint64_t c = 0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    uint64_t t = c0[j] + c;
+    r[j] = (uint32_t)t & kLimbMask;
+    c = t >> kLimbBits;
+  }
+  // pass 2: carry-out (< 2^36) of lane x-1 enters lane x and ripples locally.  The value is
+  // < R, so the top lane of a group never carries out and nothing leaks into the next group.
+  uint64_t cin = (uint64_t)dpp_from_prev((uint32_t)c) | ((uint64_t)dpp_from_prev((uint32_t)(c >> 32)) << 32);
+  uint64_t t0 = (uint64_t)r[0] + cin;
+  r[0] = (uint32_t)t0 & kLimbMask;
+  uint32_t cc = (uint32_t)(t0 >> kLimbBits);
+#pragma unroll
+  for (int j = 1; j < K; ++j) {
+    uint32_t u = r[j] + cc;
+    r[j] = u & kLimbMask;
+    cc = u >> kLimbBits;
+  }
+  // pass 3: the remaining carry is 0 or 1; park it in the next lane's limb 0 (may become 2^29).
+  r[0] += dpp_from_prev(cc);
+}
+
+// Fully canonical limbs (< 2^29 everywhere).  Data-dependent trip count (<= G+1); used only
+// outside the multiplication loop.  Values may carry a signed borrow in r[] limbs on entry?  No:
+// unsigned only.  x = lane index inside the group.
+template <class GEO>
+__device__ __forceinline__ void full_normalise(uint32_t (&r)[GEO::K], int x) {
+  constexpr int K = GEO::K;
+  for (;;) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      uint32_t u = r[j] + c;
+      r[j] = u & kLimbMask;
+      c = u >> kLimbBits;
+    }
+    uint32_t cin = dpp_from_prev(c);
+    if (x == 0) cin = 0;
+    r[0] += cin;
+    if (__ballot(cin != 0) == 0) break;
+  }
+}
+
+// limb i (29 bits at bit offset 29*i) of a little-endian u64 array that is zero-padded by one word.
+__device__ __forceinline__ uint32_t limb_from_words(const uint64_t* w, int i) {
+  int bit = i * kLimbBits;
+  int word = bit >> 6, sh = bit & 63;
+  uint64_t v = w[word] >> sh;
+  if (sh > 64 - kLimbBits) v |= w[word + 1] << (64 - sh);
+  return (uint32_t)v & kLimbMask;
+}
+
+// 64-bit word wi of the value whose canonical 29-bit limbs are limb[0..L).
+__device__ __forceinline__ uint64_t word_from_limbs(const uint32_t* limb, int L, int wi) {
+  int bit0 = wi * 64;
+  int i0 = bit0 / kLimbBits;
+  uint64_t v = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    int i = i0 + t;
+    if (i < L) {
+      int pos = i * kLimbBits - bit0;  // may be negative for t == 0
+      uint64_t lv = limb[i];
+      if (pos < 0) v |= lv >> (-pos);
+      else if (pos < 64) v |= lv << pos;
+    }
+  }
+  return v;
+}
+
+}  // namespace pgpu
+
+#endif  // PAILLIERCRYPTOLIB_AMD_CSRC_MONT_CORE_HPP_
