@@ -79,6 +79,38 @@ int pgpu_modmul_dev(const uint64_t* d_a, const uint64_t* d_b, size_t b_stride,
                     const uint64_t* h_mod, int mod_words, uint64_t* d_out, size_t count,
                     void* hip_stream);
 
+
+/* ---- Paillier public key: fused encrypt ----
+ * Replaces PublicKey::raw_encrypt + applyObfuscator (pub_key.cpp:82-110) for make_secure=true:
+ *   DJN key (hs != NULL):  c[i] = hs^r[i]      * (1 + n*m[i]) mod n^2   (pub_key.cpp:51-64)
+ *   plain   (hs == NULL):  c[i] = r[i]^n       * (1 + n*m[i]) mod n^2   (pub_key.cpp:66-80)
+ * n has n_words words (key bits / 64); hs and c have 2*n_words words.  r is the caller's
+ * randomness (the reference draws it on the host too, pub_key.cpp:59-61,74-76, or injects it
+ * with setRandom, pub_key.cpp:92-95); it is used as given: not reduced, not truncated. */
+typedef struct pgpu_pubkey pgpu_pubkey;
+int pgpu_pubkey_create(const uint64_t* n, int n_words, const uint64_t* hs_or_null,
+                       pgpu_pubkey** out);
+void pgpu_pubkey_destroy(pgpu_pubkey* key);
+int pgpu_paillier_encrypt(const pgpu_pubkey* key, const uint64_t* m, size_t m_stride, int m_words,
+                          const uint64_t* r, size_t r_stride, int r_words, int r_bits,
+                          uint64_t* c, size_t count);
+int pgpu_paillier_encrypt_dev(const pgpu_pubkey* key, const uint64_t* d_m, size_t m_stride,
+                              int m_words, const uint64_t* d_r, size_t r_stride, int r_words,
+                              int r_bits, uint64_t* d_c, size_t count, void* hip_stream);
+
+/* ---- Paillier private key: fused CRT decrypt ----
+ * Replaces PrivateKey::decryptCRT + computeLfun + computeCRT (pri_key.cpp:114-157): per
+ * ciphertext c (2*n_words words) two half-width exponentiations c^(p-1) mod p^2, c^(q-1) mod
+ * q^2, the L function, *hp / *hq, and the CRT recombination; m has n_words words.
+ * p and q have pq_words words each (either order: the smaller becomes p, pri_key.cpp:19-22). */
+typedef struct pgpu_privkey pgpu_privkey;
+int pgpu_privkey_create(const uint64_t* p, const uint64_t* q, int pq_words, pgpu_privkey** out);
+void pgpu_privkey_destroy(pgpu_privkey* key);
+int pgpu_paillier_decrypt_crt(const pgpu_privkey* key, const uint64_t* c, uint64_t* m,
+                              size_t count);
+int pgpu_paillier_decrypt_crt_dev(const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m,
+                                  size_t count, void* hip_stream);
+
 /* ---- instrumentation used by bench.py (roofline): timing of the most recent kernel launch
  *      of each kind, measured with hipEvents on the stream the kernel ran on ---- */
 int pgpu_set_timing(int enabled);

@@ -4,5 +4,6 @@
 ``include/ipcl``; this Python package is the thin host-side binding used by tests and bench.
 """
 from . import _capi  # noqa: F401
-from .engine import initialize, terminate, mod_exp, mod_exp_limbs, mod_mul, mod_mul_limbs  # noqa: F401
+from .engine import (initialize, terminate, mod_exp, mod_exp_limbs, mod_mul, mod_mul_limbs,  # noqa: F401
+                     PublicKey, PrivateKey)
 from .limbs import ints_to_limbs, limbs_to_ints  # noqa: F401

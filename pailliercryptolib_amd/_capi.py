@@ -16,6 +16,9 @@ SYMBOLS = [
     "pgpu_init", "pgpu_shutdown", "pgpu_device_count", "pgpu_is_initialized",
     "pgpu_last_error", "pgpu_device_name",
     "pgpu_modexp", "pgpu_modexp_dev", "pgpu_modmul", "pgpu_modmul_dev",
+    "pgpu_pubkey_create", "pgpu_pubkey_destroy", "pgpu_paillier_encrypt", "pgpu_paillier_encrypt_dev",
+    "pgpu_privkey_create", "pgpu_privkey_destroy", "pgpu_paillier_decrypt_crt",
+    "pgpu_paillier_decrypt_crt_dev",
     "pgpu_set_timing", "pgpu_last_kernel_ms",
 ]
 
@@ -56,6 +59,22 @@ def lib():
     L.pgpu_modmul_dev.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_size_t,
                                   c_void_p]
     L.pgpu_modmul_dev.restype = c_int
+    L.pgpu_pubkey_create.argtypes = [c_void_p, c_int, c_void_p, POINTER(c_void_p)]
+    L.pgpu_pubkey_create.restype = c_int
+    L.pgpu_pubkey_destroy.argtypes = [c_void_p]; L.pgpu_pubkey_destroy.restype = None
+    L.pgpu_paillier_encrypt.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_int,
+                                        c_int, c_void_p, c_size_t]
+    L.pgpu_paillier_encrypt.restype = c_int
+    L.pgpu_paillier_encrypt_dev.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t,
+                                            c_int, c_int, c_void_p, c_size_t, c_void_p]
+    L.pgpu_paillier_encrypt_dev.restype = c_int
+    L.pgpu_privkey_create.argtypes = [c_void_p, c_void_p, c_int, POINTER(c_void_p)]
+    L.pgpu_privkey_create.restype = c_int
+    L.pgpu_privkey_destroy.argtypes = [c_void_p]; L.pgpu_privkey_destroy.restype = None
+    L.pgpu_paillier_decrypt_crt.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
+    L.pgpu_paillier_decrypt_crt.restype = c_int
+    L.pgpu_paillier_decrypt_crt_dev.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    L.pgpu_paillier_decrypt_crt_dev.restype = c_int
     L.pgpu_set_timing.argtypes = [c_int]; L.pgpu_set_timing.restype = c_int
     L.pgpu_last_kernel_ms.argtypes = []; L.pgpu_last_kernel_ms.restype = c_double
     _lib = L

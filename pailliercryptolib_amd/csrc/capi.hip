@@ -38,36 +38,41 @@ int fail(int code, const std::string& msg) {
     if (e_ != hipSuccess)                                                                      \
       return fail(PGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
   } while (0)
+#define RC_TRY(expr)          \
+  do {                        \
+    int rc_ = (expr);         \
+    if (rc_) return rc_;      \
+  } while (0)
 
 // ---------- geometry table ----------
-struct GeoInfo { int G, K; };
+struct GeoInfo {
+  int G, K;
+  int L() const { return G * K; }
+  int rbits() const { return pgpu::kLimbBits * G * K; }
+  int w64() const { return (rbits() + 63) / 64; }
+  int ipw() const { return pgpu::kWave / G; }
+};
 const GeoInfo kGeos[] = {{2, 9}, {4, 9}, {4, 14}, {8, 9}, {8, 14}, {16, 9}, {16, 14}, {16, 18}};
 
-// smallest geometry with R = 2^(29*G*K) >= 2^(64*mod_words) and R >= 256*N
-const GeoInfo* pick_geo(int mod_words, int mod_bits) {
-  for (const GeoInfo& g : kGeos) {
-    int rbits = pgpu::kLimbBits * g.G * g.K;
-    if (rbits >= 64 * mod_words && rbits >= mod_bits + 8) return &g;
-  }
+// smallest geometry with R = 2^(29*G*K) >= 2^(64*in_words) (any input row fits) and R >= 256*N
+const GeoInfo* pick_geo(int in_words, int mod_bits) {
+  for (const GeoInfo& g : kGeos)
+    if (g.rbits() >= 64 * in_words && g.rbits() >= mod_bits + 8) return &g;
   return nullptr;
 }
 
-// ---------- modulus context ----------
-struct ModCtx {
-  GeoInfo geo;
-  int mod_words = 0;
-  void* d_blob = nullptr;  // one allocation: n | r2 | one | n64
-  pgpu::ModCtxDev dev{};
-  ~ModCtx() {
-    if (d_blob) (void)hipFree(d_blob);
+// ---------- device blobs ----------
+struct DevBlob {
+  void* p = nullptr;
+  ~DevBlob() {
+    if (p) (void)hipFree(p);
+  }
+  int upload(const void* src, size_t bytes) {
+    HIP_TRY(hipMalloc(&p, bytes));
+    HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    return PGPU_OK;
   }
 };
-
-std::map<std::vector<uint64_t>, std::shared_ptr<ModCtx>> g_ctx_cache;
-
-// workspace for window tables (grow-only)
-void* g_table = nullptr;
-size_t g_table_bytes = 0;
 
 void to_limbs29(const BigNumber& v, int L, uint32_t* out) {
   const std::vector<uint64_t>& w = v.limbs64();
@@ -87,6 +92,77 @@ BigNumber pow2(int bits) {
   return BigNumber::fromLimbs64(w.data(), w.size());
 }
 
+// ---------- modulus context ----------
+// Host description of what goes into a pgpu::ModCtxDev; every BigNumber is a plain integer,
+// the builder converts to the Montgomery constants of the chosen geometry.
+struct ModCtx {
+  GeoInfo geo{};
+  int mod_words = 0;
+  BigNumber N;
+  DevBlob blob;
+  pgpu::ModCtxDev dev{};
+};
+
+// extras: optional constants appended to the context blob
+struct CtxExtras {
+  bool want_r2s = false;     // R^2 * 2^(64*mod_words) mod N
+  const BigNumber* fc = nullptr;   // plain final multiplier
+  const BigNumber* nr_n = nullptr; // n  ->  n*R mod N
+};
+
+int build_modctx(const BigNumber& N, int mod_words, const GeoInfo& geo, const CtxExtras& ex,
+                 std::shared_ptr<ModCtx>* out) {
+  if (N.isZero() || N.isNegative() || N == BigNumber::One())
+    return fail(PGPU_ERR_INVALID_PARAM, "modulus must be > 1");
+  if (!N.IsOdd()) return fail(PGPU_ERR_EVEN_MODULUS, "modulus must be odd");
+  if (geo.rbits() < N.BitSize() + 8)
+    return fail(PGPU_ERR_UNSUPPORTED, "geometry too small for modulus");
+  const int L = geo.L(), W64 = geo.w64();
+  BigNumber R = pow2(geo.rbits());
+  BigNumber Rm = R % N;
+  BigNumber R2 = (Rm * Rm) % N;
+  uint32_t n0 = (uint32_t)(N.limbs64()[0] & pgpu::kLimbMask);
+  uint32_t inv = n0;  // Newton iteration for n0^-1 mod 2^32 (n0 odd: correct to 3 bits)
+  for (int i = 0; i < 5; ++i) inv *= 2u - n0 * inv;
+  uint32_t n0inv = (0u - inv) & pgpu::kLimbMask;
+
+  std::vector<uint32_t> h((size_t)6 * L, 0);
+  to_limbs29(N, L, h.data());
+  to_limbs29(R2, L, h.data() + L);
+  to_limbs29(Rm, L, h.data() + 2 * L);
+  if (ex.want_r2s) to_limbs29((R2 * (pow2(64 * mod_words) % N)) % N, L, h.data() + 3 * L);
+  if (ex.fc) to_limbs29(*ex.fc % N, L, h.data() + 4 * L);
+  if (ex.nr_n) to_limbs29((*ex.nr_n * Rm) % N, L, h.data() + 5 * L);
+  std::vector<uint64_t> n64((size_t)W64 + 1, 0);
+  N.toLimbs64(n64.data(), n64.size());
+
+  auto ctx = std::make_shared<ModCtx>();
+  ctx->geo = geo;
+  ctx->mod_words = mod_words;
+  ctx->N = N;
+  size_t bytes32 = h.size() * sizeof(uint32_t);
+  size_t off64 = (bytes32 + 15) & ~(size_t)15;
+  std::vector<uint8_t> host(off64 + n64.size() * 8, 0);
+  std::memcpy(host.data(), h.data(), bytes32);
+  std::memcpy(host.data() + off64, n64.data(), n64.size() * 8);
+  RC_TRY(ctx->blob.upload(host.data(), host.size()));
+  uint32_t* d32 = (uint32_t*)ctx->blob.p;
+  ctx->dev.n = d32;
+  ctx->dev.r2 = d32 + L;
+  ctx->dev.one = d32 + 2 * L;
+  ctx->dev.r2s = ex.want_r2s ? d32 + 3 * L : nullptr;
+  ctx->dev.fc = ex.fc ? d32 + 4 * L : nullptr;
+  ctx->dev.nr = ex.nr_n ? d32 + 5 * L : nullptr;
+  ctx->dev.n64 = (const uint64_t*)((char*)ctx->blob.p + off64);
+  ctx->dev.n0inv = n0inv;
+  ctx->dev.mod_words = mod_words;
+  *out = ctx;
+  return PGPU_OK;
+}
+
+std::map<std::vector<uint64_t>, std::shared_ptr<ModCtx>> g_ctx_cache;
+
+// cached plain context for the generic seam (pgpu_modexp / pgpu_modmul)
 int get_modctx(const uint64_t* mod, int mod_words, std::shared_ptr<ModCtx>* out) {
   if (!mod || mod_words <= 0) return fail(PGPU_ERR_INVALID_PARAM, "modulus is null/empty");
   if (!(mod[0] & 1)) return fail(PGPU_ERR_EVEN_MODULUS, "modulus must be odd");
@@ -101,63 +177,38 @@ int get_modctx(const uint64_t* mod, int mod_words, std::shared_ptr<ModCtx>* out)
     return fail(PGPU_ERR_INVALID_PARAM, "modulus must be > 1");
   const GeoInfo* geo = pick_geo(mod_words, N.BitSize());
   if (!geo) return fail(PGPU_ERR_UNSUPPORTED, "modulus wider than the compiled kernel geometries");
-  const int L = geo->G * geo->K;
-  const int rbits = pgpu::kLimbBits * L;
-  const int W64 = (rbits + 63) / 64;
-
-  BigNumber R = pow2(rbits);
-  BigNumber Rm = R % N;
-  BigNumber R2 = (Rm * Rm) % N;
-  // n0inv = -N^-1 mod 2^29 by Newton iteration on the low word
-  uint32_t n0 = (uint32_t)(mod[0] & pgpu::kLimbMask);
-  uint32_t inv = n0;                       // correct to 3 bits (n0 odd)
-  for (int i = 0; i < 5; ++i) inv *= 2u - n0 * inv;
-  uint32_t n0inv = (0u - inv) & pgpu::kLimbMask;
-
-  std::vector<uint32_t> h((size_t)3 * L);
-  to_limbs29(N, L, h.data());
-  to_limbs29(R2, L, h.data() + L);
-  to_limbs29(Rm, L, h.data() + 2 * L);
-  std::vector<uint64_t> n64((size_t)W64 + 1, 0);
-  for (int i = 0; i < mod_words && i <= W64; ++i) n64[i] = mod[i];
-
-  auto ctx = std::make_shared<ModCtx>();
-  ctx->geo = *geo;
-  ctx->mod_words = mod_words;
-  size_t bytes32 = h.size() * sizeof(uint32_t);
-  size_t off64 = (bytes32 + 15) & ~(size_t)15;
-  size_t total = off64 + n64.size() * sizeof(uint64_t);
-  HIP_TRY(hipMalloc(&ctx->d_blob, total));
-  HIP_TRY(hipMemcpy(ctx->d_blob, h.data(), bytes32, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy((char*)ctx->d_blob + off64, n64.data(), n64.size() * sizeof(uint64_t),
-                    hipMemcpyHostToDevice));
-  uint32_t* d32 = (uint32_t*)ctx->d_blob;
-  ctx->dev.n = d32;
-  ctx->dev.r2 = d32 + L;
-  ctx->dev.one = d32 + 2 * L;
-  ctx->dev.n64 = (const uint64_t*)((char*)ctx->d_blob + off64);
-  ctx->dev.n0inv = n0inv;
-  ctx->dev.mod_words = mod_words;
-  g_ctx_cache[key] = ctx;
-  *out = ctx;
+  RC_TRY(build_modctx(N, mod_words, *geo, CtxExtras(), out));
+  if (g_ctx_cache.size() > 64) g_ctx_cache.clear();
+  g_ctx_cache[key] = *out;
   return PGPU_OK;
 }
 
-int ensure_table(size_t bytes) {
-  if (bytes <= g_table_bytes) return PGPU_OK;
-  if (g_table) {
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipFree(g_table));
-    g_table = nullptr;
-    g_table_bytes = 0;
+// ---------- grow-only device workspaces ----------
+struct Workspace {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return PGPU_OK;
+    if (p) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(p));
+      p = nullptr;
+      bytes = 0;
+    }
+    HIP_TRY(hipMalloc(&p, need));
+    bytes = need;
+    return PGPU_OK;
   }
-  HIP_TRY(hipMalloc(&g_table, bytes));
-  g_table_bytes = bytes;
-  return PGPU_OK;
-}
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+Workspace g_table, g_vbuf;
 
-// fixed-window width: canonical w = 5 for long exponents; shorter exponents pick the w that
-// minimises (2^w - 2) table multiplications + ceil(e/w) window multiplications.
+// fixed-window width: the w in 1..5 that minimises (2^w - 2) table multiplications +
+// ceil(e/w) window multiplications (w = 5 for e >= ~240 bits).
 int pick_window(int exp_bits) {
   int best = 1;
   long best_cost = 1L << 60;
@@ -196,6 +247,12 @@ void launch_modmul(const pgpu::ModmulArgs& a, hipStream_t s) {
   unsigned blocks = (unsigned)((a.count + GEO::IPW - 1) / GEO::IPW);
   hipLaunchKernelGGL((pgpu::modmul_kernel<GEO>), dim3(blocks), dim3(pgpu::kWave), 0, s, a);
 }
+template <int G, int K>
+void launch_crt(const pgpu::CrtArgs& a, hipStream_t s) {
+  typedef pgpu::Geo<G, K> GEO;
+  unsigned blocks = (unsigned)((a.count + GEO::IPW - 1) / GEO::IPW);
+  hipLaunchKernelGGL((pgpu::crt_kernel<GEO>), dim3(blocks), dim3(pgpu::kWave), 0, s, a);
+}
 
 #define GEO_DISPATCH(FN, geo, ...)                                  \
   do {                                                              \
@@ -214,7 +271,66 @@ int check_ready() {
   return PGPU_OK;
 }
 
+// common launcher of modexp_kernel: sizes the window table and fills the shared fields
+int run_modexp(pgpu::ModexpArgs& a, const GeoInfo& geo, hipStream_t s) {
+  a.window = pick_window(a.exp_bits);
+  size_t padded = (a.count + geo.ipw() - 1) / geo.ipw() * geo.ipw();
+  RC_TRY(g_table.ensure(padded * ((size_t)1 << a.window) * geo.L() * sizeof(uint32_t)));
+  a.table = (uint32_t*)g_table.p;
+  TimerScope t(s);
+  GEO_DISPATCH(launch_modexp, geo, a, s);
+  HIP_TRY(hipGetLastError());
+  t.stop();
+  return PGPU_OK;
+}
+
+// staging helper for the synchronous host-pointer entry points
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(size_t bytes) {
+    HIP_TRY(hipMalloc(&p, bytes ? bytes : 8));
+    return PGPU_OK;
+  }
+  int from_host(const void* src, size_t bytes) {
+    RC_TRY(alloc(bytes));
+    HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    return PGPU_OK;
+  }
+  int to_host(void* dst, size_t bytes) {
+    hipError_t e = hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+      return fail(PGPU_ERR_HIP, std::string("kernel / D2H copy failed: ") + hipGetErrorString(e));
+    return PGPU_OK;
+  }
+};
+
 }  // namespace
+
+// ---------- Paillier key objects ----------
+struct pgpu_pubkey {
+  int n_words = 0;
+  BigNumber n;
+  bool djn = false;
+  std::shared_ptr<ModCtx> nsq;  // modulus n^2, with nr = n*R mod n^2
+  DevBlob d_hs;                 // DJN: hs, 2*n_words words
+  DevBlob d_n;                  // plain: the exponent n, n_words words
+};
+
+struct pgpu_privkey {
+  int n_words = 0;              // words of n (= words of p^2, q^2 rows)
+  int pq_words = 0;
+  GeoInfo geo_exp{};            // geometry of the two half-width exponentiations
+  GeoInfo geo_crt{};            // geometry of the recombination kernel
+  std::shared_ptr<ModCtx> p2, q2;   // moduli p^2, q^2 (fc = hp / hq, r2s set)
+  std::shared_ptr<ModCtx> cM, cQ;   // auxiliary modulus M, modulus q (CRT geometry)
+  DevBlob d_exps;               // [2][pq_words]: p-1, q-1
+  int exp_bits = 0;
+  DevBlob d_crt32;              // cp | cq | pinvR | pRM  (29-bit limbs, CRT geometry)
+  DevBlob d_crt64;              // hp | hq | p^2 | q^2 | q   (n_words words each)
+};
 
 extern "C" {
 
@@ -249,10 +365,13 @@ void pgpu_shutdown(void) {
   if (!g_init) return;
   (void)hipDeviceSynchronize();
   g_ctx_cache.clear();
-  if (g_table) (void)hipFree(g_table);
-  g_table = nullptr;
-  g_table_bytes = 0;
-  if (g_ev0) { (void)hipEventDestroy(g_ev0); (void)hipEventDestroy(g_ev1); g_ev0 = g_ev1 = nullptr; }
+  g_table.release();
+  g_vbuf.release();
+  if (g_ev0) {
+    (void)hipEventDestroy(g_ev0);
+    (void)hipEventDestroy(g_ev1);
+    g_ev0 = g_ev1 = nullptr;
+  }
   g_init = false;
 }
 
@@ -266,12 +385,12 @@ int pgpu_set_timing(int enabled) {
 }
 double pgpu_last_kernel_ms(void) { return g_last_ms; }
 
+// ===================== generic modexp =====================
 int pgpu_modexp_dev(const uint64_t* d_base, size_t base_stride, const uint64_t* d_exp,
                     size_t exp_stride, int exp_words, int exp_bits, const uint64_t* h_mod,
                     int mod_words, uint64_t* d_out, size_t count, void* hip_stream) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
-  int rc = check_ready();
-  if (rc) return rc;
+  RC_TRY(check_ready());
   if (count == 0) return PGPU_OK;
   if (!d_base || !d_exp || !d_out) return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer");
   if (exp_words <= 0 || exp_bits < 0 || exp_bits > 64 * exp_words)
@@ -281,79 +400,58 @@ int pgpu_modexp_dev(const uint64_t* d_base, size_t base_stride, const uint64_t* 
   if (exp_stride != 0 && exp_stride < (size_t)exp_words)
     return fail(PGPU_ERR_INVALID_PARAM, "exponent stride smaller than exp_words");
   std::shared_ptr<ModCtx> ctx;
-  rc = get_modctx(h_mod, mod_words, &ctx);
-  if (rc) return rc;
-  const int L = ctx->geo.G * ctx->geo.K, ipw = pgpu::kWave / ctx->geo.G;
-  const int w = pick_window(exp_bits);
-  size_t padded = (count + ipw - 1) / ipw * ipw;
-  rc = ensure_table(padded * ((size_t)1 << w) * L * sizeof(uint32_t));
-  if (rc) return rc;
-  pgpu::ModexpArgs a;
-  a.ctx = ctx->dev;
+  RC_TRY(get_modctx(h_mod, mod_words, &ctx));
+  pgpu::ModexpArgs a{};
+  a.ctx[0] = a.ctx[1] = ctx->dev;
+  a.nctx = 1;
   a.base = d_base;
   a.base_stride = base_stride;
   a.base_words = mod_words;
   a.exp = d_exp;
   a.exp_stride = exp_stride;
+  a.exp_per_ctx = 0;
   a.exp_words = exp_words;
   a.exp_bits = exp_bits;
-  a.window = w;
+  a.final_mul = pgpu::FM_UNIT;
   a.out = d_out;
-  a.table = (uint32_t*)g_table;
+  a.out_stride = (size_t)mod_words;
   a.count = count;
-  hipStream_t s = (hipStream_t)hip_stream;
-  TimerScope t(s);
-  GEO_DISPATCH(launch_modexp, ctx->geo, a, s);
-  HIP_TRY(hipGetLastError());
-  t.stop();
-  return PGPU_OK;
+  return run_modexp(a, ctx->geo, (hipStream_t)hip_stream);
 }
 
 int pgpu_modexp(const uint64_t* base, size_t base_stride, const uint64_t* exp, size_t exp_stride,
                 int exp_words, int exp_bits, const uint64_t* mod, int mod_words, uint64_t* out,
                 size_t count) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
-  int rc = check_ready();
-  if (rc) return rc;
+  RC_TRY(check_ready());
   if (count == 0) return PGPU_OK;
   if (!base || !exp || !out || mod_words <= 0 || exp_words <= 0)
     return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer or zero width");
   size_t nb = (base_stride ? count * base_stride : (size_t)mod_words) * 8;
   size_t ne = (exp_stride ? count * exp_stride : (size_t)exp_words) * 8;
   size_t no = count * (size_t)mod_words * 8;
-  void *db = nullptr, *de = nullptr, *dout = nullptr;
-  HIP_TRY(hipMalloc(&db, nb));
-  HIP_TRY(hipMalloc(&de, ne));
-  HIP_TRY(hipMalloc(&dout, no));
-  rc = PGPU_OK;
-  if (hipMemcpy(db, base, nb, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(de, exp, ne, hipMemcpyHostToDevice) != hipSuccess)
-    rc = fail(PGPU_ERR_HIP, "H2D copy failed");
-  if (!rc)
-    rc = pgpu_modexp_dev((const uint64_t*)db, base_stride, (const uint64_t*)de, exp_stride,
-                         exp_words, exp_bits, mod, mod_words, (uint64_t*)dout, count, nullptr);
-  if (!rc && hipMemcpy(out, dout, no, hipMemcpyDeviceToHost) != hipSuccess)
-    rc = fail(PGPU_ERR_HIP, std::string("D2H copy / kernel failed: ") + hipGetErrorString(hipGetLastError()));
-  (void)hipFree(db);
-  (void)hipFree(de);
-  (void)hipFree(dout);
-  return rc;
+  DevBuf db, de, dout;
+  RC_TRY(db.from_host(base, nb));
+  RC_TRY(de.from_host(exp, ne));
+  RC_TRY(dout.alloc(no));
+  RC_TRY(pgpu_modexp_dev((const uint64_t*)db.p, base_stride, (const uint64_t*)de.p, exp_stride,
+                         exp_words, exp_bits, mod, mod_words, (uint64_t*)dout.p, count, nullptr));
+  return dout.to_host(out, no);
 }
 
+// ===================== modmul =====================
 int pgpu_modmul_dev(const uint64_t* d_a, const uint64_t* d_b, size_t b_stride,
                     const uint64_t* h_mod, int mod_words, uint64_t* d_out, size_t count,
                     void* hip_stream) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
-  int rc = check_ready();
-  if (rc) return rc;
+  RC_TRY(check_ready());
   if (count == 0) return PGPU_OK;
   if (!d_a || !d_b || !d_out) return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer");
   if (b_stride != 0 && b_stride < (size_t)mod_words)
     return fail(PGPU_ERR_INVALID_PARAM, "b stride smaller than the modulus width");
   std::shared_ptr<ModCtx> ctx;
-  rc = get_modctx(h_mod, mod_words, &ctx);
-  if (rc) return rc;
-  pgpu::ModmulArgs a;
+  RC_TRY(get_modctx(h_mod, mod_words, &ctx));
+  pgpu::ModmulArgs a{};
   a.ctx = ctx->dev;
   a.a = d_a;
   a.a_stride = (size_t)mod_words;
@@ -373,30 +471,284 @@ int pgpu_modmul_dev(const uint64_t* d_a, const uint64_t* d_b, size_t b_stride,
 int pgpu_modmul(const uint64_t* a, const uint64_t* b, size_t b_stride, const uint64_t* mod,
                 int mod_words, uint64_t* out, size_t count) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
-  int rc = check_ready();
-  if (rc) return rc;
+  RC_TRY(check_ready());
   if (count == 0) return PGPU_OK;
   if (!a || !b || !out || mod_words <= 0)
     return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer or zero width");
   size_t na = count * (size_t)mod_words * 8;
   size_t nb = (b_stride ? count * b_stride : (size_t)mod_words) * 8;
-  void *da = nullptr, *db = nullptr, *dout = nullptr;
-  HIP_TRY(hipMalloc(&da, na));
-  HIP_TRY(hipMalloc(&db, nb));
-  HIP_TRY(hipMalloc(&dout, na));
-  rc = PGPU_OK;
-  if (hipMemcpy(da, a, na, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(db, b, nb, hipMemcpyHostToDevice) != hipSuccess)
-    rc = fail(PGPU_ERR_HIP, "H2D copy failed");
-  if (!rc)
-    rc = pgpu_modmul_dev((const uint64_t*)da, (const uint64_t*)db, b_stride, mod, mod_words,
-                         (uint64_t*)dout, count, nullptr);
-  if (!rc && hipMemcpy(out, dout, na, hipMemcpyDeviceToHost) != hipSuccess)
-    rc = fail(PGPU_ERR_HIP, std::string("D2H copy / kernel failed: ") + hipGetErrorString(hipGetLastError()));
-  (void)hipFree(da);
-  (void)hipFree(db);
-  (void)hipFree(dout);
-  return rc;
+  DevBuf da, db, dout;
+  RC_TRY(da.from_host(a, na));
+  RC_TRY(db.from_host(b, nb));
+  RC_TRY(dout.alloc(na));
+  RC_TRY(pgpu_modmul_dev((const uint64_t*)da.p, (const uint64_t*)db.p, b_stride, mod, mod_words,
+                         (uint64_t*)dout.p, count, nullptr));
+  return dout.to_host(out, na);
+}
+
+// ===================== Paillier public key / encrypt =====================
+int pgpu_pubkey_create(const uint64_t* n, int n_words, const uint64_t* hs_or_null,
+                       pgpu_pubkey** out) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  RC_TRY(check_ready());
+  if (!n || n_words <= 0 || !out) return fail(PGPU_ERR_INVALID_PARAM, "null key material");
+  std::unique_ptr<pgpu_pubkey> k(new pgpu_pubkey);
+  k->n_words = n_words;
+  k->n = BigNumber::fromLimbs64(n, (size_t)n_words);
+  if (!k->n.IsOdd()) return fail(PGPU_ERR_EVEN_MODULUS, "n must be odd");
+  BigNumber nsq = k->n * k->n;
+  const GeoInfo* geo = pick_geo(2 * n_words, nsq.BitSize());
+  if (!geo) return fail(PGPU_ERR_UNSUPPORTED, "key wider than the compiled kernel geometries");
+  CtxExtras ex;
+  ex.nr_n = &k->n;
+  RC_TRY(build_modctx(nsq, 2 * n_words, *geo, ex, &k->nsq));
+  if (hs_or_null) {
+    k->djn = true;
+    RC_TRY(k->d_hs.upload(hs_or_null, (size_t)2 * n_words * 8));
+  }
+  RC_TRY(k->d_n.upload(n, (size_t)n_words * 8));
+  *out = k.release();
+  return PGPU_OK;
+}
+
+void pgpu_pubkey_destroy(pgpu_pubkey* key) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  delete key;
+}
+
+int pgpu_paillier_encrypt_dev(const pgpu_pubkey* key, const uint64_t* d_m, size_t m_stride,
+                              int m_words, const uint64_t* d_r, size_t r_stride, int r_words,
+                              int r_bits, uint64_t* d_c, size_t count, void* hip_stream) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  RC_TRY(check_ready());
+  if (!key) return fail(PGPU_ERR_INVALID_PARAM, "null key");
+  if (count == 0) return PGPU_OK;
+  if (!d_m || !d_r || !d_c) return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer");
+  const int W = 2 * key->n_words;
+  if (m_words <= 0 || m_words > W || m_stride < (size_t)m_words)
+    return fail(PGPU_ERR_INVALID_PARAM, "plaintext width/stride invalid");
+  if (r_words <= 0 || r_stride < (size_t)r_words)
+    return fail(PGPU_ERR_INVALID_PARAM, "random width/stride invalid");
+  pgpu::ModexpArgs a{};
+  a.ctx[0] = a.ctx[1] = key->nsq->dev;
+  a.nctx = 1;
+  if (key->djn) {  // hs^r: shared base, per-element exponent (pub_key.cpp:51-64)
+    if (r_bits < 0 || r_bits > 64 * r_words)
+      return fail(PGPU_ERR_INVALID_PARAM, "r_bits/r_words inconsistent");
+    a.base = (const uint64_t*)key->d_hs.p;
+    a.base_stride = 0;
+    a.base_words = W;
+    a.exp = d_r;
+    a.exp_stride = r_stride;
+    a.exp_words = r_words;
+    a.exp_bits = r_bits;
+  } else {         // r^n: per-element base, shared exponent n (pub_key.cpp:66-80)
+    if (r_words > W) return fail(PGPU_ERR_INVALID_PARAM, "random wider than n^2");
+    a.base = d_r;
+    a.base_stride = r_stride;
+    a.base_words = r_words;
+    a.exp = (const uint64_t*)key->d_n.p;
+    a.exp_stride = 0;
+    a.exp_words = key->n_words;
+    a.exp_bits = key->n.BitSize();
+  }
+  a.exp_per_ctx = 0;
+  a.final_mul = pgpu::FM_PAILLIER_G;
+  a.fm_words = d_m;
+  a.fm_stride = m_stride;
+  a.fm_nwords = m_words;
+  a.out = d_c;
+  a.out_stride = (size_t)W;
+  a.count = count;
+  return run_modexp(a, key->nsq->geo, (hipStream_t)hip_stream);
+}
+
+int pgpu_paillier_encrypt(const pgpu_pubkey* key, const uint64_t* m, size_t m_stride, int m_words,
+                          const uint64_t* r, size_t r_stride, int r_words, int r_bits,
+                          uint64_t* c, size_t count) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  RC_TRY(check_ready());
+  if (!key) return fail(PGPU_ERR_INVALID_PARAM, "null key");
+  if (count == 0) return PGPU_OK;
+  if (!m || !r || !c) return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer");
+  size_t no = count * (size_t)2 * key->n_words * 8;
+  DevBuf dm, dr, dc;
+  RC_TRY(dm.from_host(m, count * m_stride * 8));
+  RC_TRY(dr.from_host(r, count * r_stride * 8));
+  RC_TRY(dc.alloc(no));
+  RC_TRY(pgpu_paillier_encrypt_dev(key, (const uint64_t*)dm.p, m_stride, m_words,
+                                   (const uint64_t*)dr.p, r_stride, r_words, r_bits,
+                                   (uint64_t*)dc.p, count, nullptr));
+  return dc.to_host(c, no);
+}
+
+// ===================== Paillier private key / CRT decrypt =====================
+// host-side single modexp through the GPU engine (key precomputation, pri_key.cpp:159-167)
+static int host_modexp(const BigNumber& base, const BigNumber& exp, const BigNumber& mod,
+                       BigNumber* out) {
+  int mw = (mod.BitSize() + 63) / 64, ew = std::max(1, (exp.BitSize() + 63) / 64);
+  std::vector<uint64_t> b(mw), e(ew), m(mw), o(mw);
+  (base % mod).toLimbs64(b.data(), mw);
+  exp.toLimbs64(e.data(), ew);
+  mod.toLimbs64(m.data(), mw);
+  RC_TRY(pgpu_modexp(b.data(), mw, e.data(), ew, ew, exp.isZero() ? 0 : exp.BitSize(), m.data(), mw,
+                     o.data(), 1));
+  *out = BigNumber::fromLimbs64(o.data(), mw);
+  return PGPU_OK;
+}
+
+int pgpu_privkey_create(const uint64_t* p_in, const uint64_t* q_in, int pq_words,
+                        pgpu_privkey** out) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  RC_TRY(check_ready());
+  if (!p_in || !q_in || pq_words <= 0 || !out) return fail(PGPU_ERR_INVALID_PARAM, "null key material");
+  BigNumber p = BigNumber::fromLimbs64(p_in, (size_t)pq_words);
+  BigNumber q = BigNumber::fromLimbs64(q_in, (size_t)pq_words);
+  if (q < p) std::swap(p, q);  // pri_key.cpp:19-22
+  if (p == q) return fail(PGPU_ERR_NOT_INVERTIBLE, "PrivateKey: p and q are same");
+  if (!p.IsOdd() || !q.IsOdd() || p <= BigNumber::Two())
+    return fail(PGPU_ERR_EVEN_MODULUS, "p and q must be odd primes");
+  std::unique_ptr<pgpu_privkey> k(new pgpu_privkey);
+  const BigNumber n = p * q, g = n + 1;
+  const int nw = (n.BitSize() + 63) / 64;  // words of n; p^2, q^2 rows use the same width
+  k->n_words = nw;
+  k->pq_words = pq_words;
+  const BigNumber psq = p * p, qsq = q * q;
+  const BigNumber pm1 = p - 1, qm1 = q - 1;
+  if (psq.BitSize() > 64 * nw || qsq.BitSize() > 64 * nw)
+    return fail(PGPU_ERR_INVALID_PARAM, "p and q differ too much in size");
+  // hp = L_p(g^(p-1) mod p^2)^-1 mod p   (computeHfun, pri_key.cpp:159-167)
+  BigNumber hp, hq;
+  try {
+    BigNumber t;
+    RC_TRY(host_modexp(g % psq, pm1, psq, &t));
+    hp = p.InverseMul((t - 1) / p);
+    RC_TRY(host_modexp(g % qsq, qm1, qsq, &t));
+    hq = q.InverseMul((t - 1) / q);
+  } catch (const std::exception& e) {
+    return fail(PGPU_ERR_NOT_INVERTIBLE, std::string("PrivateKey precompute: ") + e.what());
+  }
+  // half-width exponentiation contexts: inputs are 2*nw-word ciphertexts reduced on load
+  const GeoInfo* ge = pick_geo(nw, std::max(psq.BitSize(), qsq.BitSize()));
+  if (!ge) return fail(PGPU_ERR_UNSUPPORTED, "key wider than the compiled kernel geometries");
+  k->geo_exp = *ge;
+  CtxExtras exp_p, exp_q;
+  exp_p.want_r2s = exp_q.want_r2s = true;
+  exp_p.fc = &hp;
+  exp_q.fc = &hq;
+  RC_TRY(build_modctx(psq, nw, *ge, exp_p, &k->p2));
+  RC_TRY(build_modctx(qsq, nw, *ge, exp_q, &k->q2));
+  std::vector<uint64_t> exps((size_t)2 * pq_words, 0);
+  pm1.toLimbs64(exps.data(), pq_words);
+  qm1.toLimbs64(exps.data() + pq_words, pq_words);
+  RC_TRY(k->d_exps.upload(exps.data(), exps.size() * 8));
+  k->exp_bits = std::max(pm1.BitSize(), qm1.BitSize());
+
+  // recombination: auxiliary modulus M = 2^(29*(L-1)) - 1 must exceed n (exact u*p product)
+  const GeoInfo* gc = nullptr;
+  for (const GeoInfo& gg : kGeos)
+    if (pgpu::kLimbBits * (gg.L() - 1) >= n.BitSize() + 2 && gg.rbits() >= 64 * nw) { gc = &gg; break; }
+  if (!gc) return fail(PGPU_ERR_UNSUPPORTED, "key wider than the compiled kernel geometries");
+  k->geo_crt = *gc;
+  const int Lc = gc->L();
+  const BigNumber M = pow2(pgpu::kLimbBits * (Lc - 1)) - 1;
+  if (M.gcd(p) != BigNumber::One() || M.gcd(q) != BigNumber::One())
+    return fail(PGPU_ERR_NOT_INVERTIBLE, "auxiliary modulus shares a factor with the key");
+  const int mwM = (M.BitSize() + 63) / 64;
+  RC_TRY(build_modctx(M, mwM, *gc, CtxExtras(), &k->cM));
+  RC_TRY(build_modctx(q, nw, *gc, CtxExtras(), &k->cQ));
+  const BigNumber Rc = pow2(gc->rbits());
+  const BigNumber pinv_q = q.InverseMul(p);  // p^-1 mod q (pri_key.cpp:27)
+  std::vector<uint32_t> c32((size_t)4 * Lc);
+  to_limbs29((M.InverseMul(p) * Rc) % M, Lc, c32.data());
+  to_limbs29((M.InverseMul(q) * Rc) % M, Lc, c32.data() + Lc);
+  to_limbs29((pinv_q * Rc) % q, Lc, c32.data() + 2 * Lc);
+  to_limbs29((p * Rc) % M, Lc, c32.data() + 3 * Lc);
+  RC_TRY(k->d_crt32.upload(c32.data(), c32.size() * 4));
+  const int pad = gc->w64() + 1;  // rows padded so word helpers can run over W64 words
+  std::vector<uint64_t> c64((size_t)5 * pad, 0);
+  hp.toLimbs64(c64.data(), pad);
+  hq.toLimbs64(c64.data() + pad, pad);
+  psq.toLimbs64(c64.data() + 2 * pad, pad);
+  qsq.toLimbs64(c64.data() + 3 * pad, pad);
+  q.toLimbs64(c64.data() + 4 * pad, pad);
+  RC_TRY(k->d_crt64.upload(c64.data(), c64.size() * 8));
+  *out = k.release();
+  return PGPU_OK;
+}
+
+void pgpu_privkey_destroy(pgpu_privkey* key) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  delete key;
+}
+
+int pgpu_paillier_decrypt_crt_dev(const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m,
+                                  size_t count, void* hip_stream) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  RC_TRY(check_ready());
+  if (!key) return fail(PGPU_ERR_INVALID_PARAM, "null key");
+  if (count == 0) return PGPU_OK;
+  if (!d_c || !d_m) return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer");
+  const int nw = key->n_words;
+  hipStream_t s = (hipStream_t)hip_stream;
+  RC_TRY(g_vbuf.ensure(2 * count * (size_t)nw * 8));
+  // stage 1: V[2i] = c^(p-1)*hp mod p^2, V[2i+1] = c^(q-1)*hq mod q^2   (2*count instances)
+  pgpu::ModexpArgs a{};
+  a.ctx[0] = key->p2->dev;
+  a.ctx[1] = key->q2->dev;
+  a.nctx = 2;
+  a.base = d_c;
+  a.base_stride = (size_t)2 * nw;
+  a.base_words = 2 * nw;
+  a.exp = (const uint64_t*)key->d_exps.p;
+  a.exp_stride = (size_t)key->pq_words;
+  a.exp_per_ctx = 1;
+  a.exp_words = key->pq_words;
+  a.exp_bits = key->exp_bits;
+  a.final_mul = pgpu::FM_CTX_CONST;
+  a.out = (uint64_t*)g_vbuf.p;
+  a.out_stride = (size_t)nw;
+  a.count = 2 * count;
+  RC_TRY(run_modexp(a, key->geo_exp, s));
+  // stage 2: L function, CRT
+  const int Lc = key->geo_crt.L(), pad = key->geo_crt.w64() + 1;
+  pgpu::CrtArgs c{};
+  c.ctxM = key->cM->dev;
+  c.ctxQ = key->cQ->dev;
+  const uint32_t* c32 = (const uint32_t*)key->d_crt32.p;
+  c.cp = c32;
+  c.cq = c32 + Lc;
+  c.pinvR = c32 + 2 * Lc;
+  c.pRM = c32 + 3 * Lc;
+  const uint64_t* c64 = (const uint64_t*)key->d_crt64.p;
+  c.hp64 = c64;
+  c.hq64 = c64 + pad;
+  c.p2_64 = c64 + 2 * pad;
+  c.q2_64 = c64 + 3 * pad;
+  c.q64 = c64 + 4 * pad;
+  c.v = (const uint64_t*)g_vbuf.p;
+  c.vw = nw;
+  c.out = d_m;
+  c.out_words = nw;
+  c.count = count;
+  GEO_DISPATCH(launch_crt, key->geo_crt, c, s);
+  HIP_TRY(hipGetLastError());
+  return PGPU_OK;
+}
+
+int pgpu_paillier_decrypt_crt(const pgpu_privkey* key, const uint64_t* c, uint64_t* m,
+                              size_t count) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  RC_TRY(check_ready());
+  if (!key) return fail(PGPU_ERR_INVALID_PARAM, "null key");
+  if (count == 0) return PGPU_OK;
+  if (!c || !m) return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer");
+  size_t nc = count * (size_t)2 * key->n_words * 8, nm = count * (size_t)key->n_words * 8;
+  DevBuf dc, dm;
+  RC_TRY(dc.from_host(c, nc));
+  RC_TRY(dm.alloc(nm));
+  RC_TRY(pgpu_paillier_decrypt_crt_dev(key, (const uint64_t*)dc.p, (uint64_t*)dm.p, count, nullptr));
+  return dm.to_host(m, nm);
 }
 
 }  // extern "C"

@@ -1,10 +1,19 @@
 // pailliercryptolib_amd -- gfx950 kernels of the batched-modexp hot path.
 //
-//   modexp_kernel : out[i] = base[i]^exp[i] mod N          (ipcl::modExp, mod_exp.cpp:680-737)
-//   modmul_kernel : out[i] = a[i]*b[i] mod N               (CipherText::raw_add, ciphertext.cpp:135-141)
+//   modexp_kernel : out[i] = F_i * base[i]^exp[i] mod N_i
+//        plain form  -> ipcl::modExp (mod_exp.cpp:680-737, replaces mbx_exp_mb8 :508-516)
+//        encrypt form-> PublicKey::raw_encrypt + applyObfuscator (pub_key.cpp:82-110):
+//                       F_i = (1 + n*m_i) mod n^2 is computed in-kernel and becomes the
+//                       multiplication that leaves the Montgomery domain (zero extra cost)
+//        decrypt form-> first half of PrivateKey::decryptCRT (pri_key.cpp:119-134): two
+//                       interleaved contexts (p^2, q^2), the 2k-bit ciphertext is reduced on load
+//                       (c mod p^2 / q^2, pri_key.cpp:128-129), F = hp / hq
+//   crt_kernel    : second half of decryptCRT (pri_key.cpp:136-157): L-function by exact
+//                   division, *hp mod p, CRT recombination
+//   modmul_kernel : out[i] = a[i]*b[i] mod N     (CipherText::raw_add, ciphertext.cpp:135-141)
 //
 // One wavefront (= one 64-thread workgroup) handles 64/G exponentiations; nothing is shared
-// between wavefronts, so there are no workgroup barriers beyond the single-wave LDS hand-offs.
+// between wavefronts, so the only synchronisation is the single-wave LDS hand-off.
 #ifndef PAILLIERCRYPTOLIB_AMD_CSRC_KERNELS_HPP_
 #define PAILLIERCRYPTOLIB_AMD_CSRC_KERNELS_HPP_
 
@@ -13,29 +22,45 @@
 namespace pgpu {
 
 // Montgomery context of one odd modulus N, resident in device memory (built by the host,
-// see capi.hip: build_modctx).  R = 2^(29*L) for the geometry the context was built for.
+// capi.hip: build_modctx).  R = 2^(29*L) for the geometry the context was built for.
 struct ModCtxDev {
   const uint32_t* n;    // [L]   N, 29-bit limbs
   const uint32_t* r2;   // [L]   R^2 mod N
   const uint32_t* one;  // [L]   R mod N
+  const uint32_t* r2s;  // [L]   R^2 * 2^(64*mod_words) mod N   (wide-base reduction)   | may be null
+  const uint32_t* fc;   // [L]   constant final multiplier, plain domain (hp, hq)       | may be null
+  const uint32_t* nr;   // [L]   n*R mod N for N = n^2 (Paillier g^m = 1 + n*m)          | may be null
   const uint64_t* n64;  // [W64+1] N as little-endian 64-bit words, zero padded
   uint32_t n0inv;       // -N^-1 mod 2^29
-  int mod_words;        // 64-bit words per element in the C-ABI layout (ceil(mod_bits/64))
+  int mod_words;        // 64-bit words per element of this modulus in the C-ABI layout
+};
+
+enum FinalMul : int {
+  FM_UNIT = 0,       // multiply by 1: plain modexp
+  FM_CTX_CONST = 1,  // multiply by ctx.fc
+  FM_PAILLIER_G = 2  // multiply by (1 + n*m) mod n^2, m read from fm_words
 };
 
 struct ModexpArgs {
-  ModCtxDev ctx;
-  const uint64_t* base;  // [count][base_stride] (base_stride == 0: one shared base)
+  ModCtxDev ctx[2];
+  int nctx;              // 1, or 2: instance i uses ctx[i % 2] and base element i / 2
+  const uint64_t* base;  // [.][base_stride] (0: one shared base)
   size_t base_stride;
-  int base_words;        // valid words per base
-  const uint64_t* exp;   // [count][exp_stride]  (exp_stride == 0: one shared exponent)
+  int base_words;        // valid words per base; may be 2*mod_words (reduced on load) if ctx.r2s
+  const uint64_t* exp;   // [.][exp_stride]; exp_per_ctx: row (i % nctx), else row i (0: shared)
   size_t exp_stride;
+  int exp_per_ctx;
   int exp_words;
   int exp_bits;          // max exponent bit length over the batch (mod_exp.cpp:484)
   int window;            // fixed window width w, 1..5
-  uint64_t* out;         // [count][ctx.mod_words]
+  int final_mul;         // FinalMul
+  const uint64_t* fm_words;  // FM_PAILLIER_G: plaintexts [count][fm_stride]
+  size_t fm_stride;
+  int fm_nwords;
+  uint64_t* out;         // [count][out_stride]
+  size_t out_stride;
   uint32_t* table;       // [count rounded up to IPW][2^w][L] workspace
-  size_t count;
+  size_t count;          // number of instances (= 2 * ciphertexts when nctx == 2)
 };
 
 struct ModmulArgs {
@@ -49,31 +74,35 @@ struct ModmulArgs {
   size_t count;
 };
 
-// wave-level LDS hand-off: all lanes of the (single-wave) workgroup have finished their LDS
-// writes before any lane reads.
+// Second half of CRT decryption.  All constants are host-precomputed for the geometry of this
+// launch (R = 2^(29*L)); M is the auxiliary modulus 2^(29*(L-1)) - 1 (odd, coprime to p and q)
+// under which "multiply by p^-1" is an exact division and "multiply by p" an exact product.
+struct CrtArgs {
+  ModCtxDev ctxM;        // modulus M
+  ModCtxDev ctxQ;        // modulus q
+  const uint32_t* cp;    // [L] p^-1 * R mod M
+  const uint32_t* cq;    // [L] q^-1 * R mod M
+  const uint32_t* pinvR; // [L] (p^-1 mod q) * R mod q
+  const uint32_t* pRM;   // [L] p * R mod M
+  const uint64_t* hp64;  // [vw] hp
+  const uint64_t* hq64;  // [vw] hq
+  const uint64_t* p2_64; // [vw] p^2
+  const uint64_t* q2_64; // [vw] q^2
+  const uint64_t* q64;   // [vw] q (zero padded)
+  const uint64_t* v;     // [2*count][vw]: row 2i = xp*hp mod p^2, row 2i+1 = xq*hq mod q^2
+  int vw;                // words per row of v (= words of p^2)
+  uint64_t* out;         // [count][out_words]  plaintexts (< n)
+  int out_words;
+  size_t count;
+};
+
+// wave-level LDS hand-off (workgroup == one wavefront)
 __device__ __forceinline__ void wave_lds_sync() { __syncthreads(); }
 
-// Load one element per group (64-bit words, C-ABI layout) into LDS, zero padded to W64+1.
+// limbs (any lazy form) -> canonical 64-bit words in io[g][0..W64], zero padded
 template <class GEO>
-__device__ __forceinline__ void stage_words(uint64_t (*io)[GEO::W64 + 1], const uint64_t* src,
-                                            size_t stride, int words, size_t first_inst,
-                                            size_t count, int lane) {
-  constexpr int WW = GEO::W64 + 1;
-  for (int t = lane; t < GEO::IPW * WW; t += kWave) {
-    int g = t / WW, w = t % WW;
-    size_t inst = first_inst + g;
-    if (inst >= count) inst = count - 1;
-    io[g][w] = (w < words) ? src[inst * stride + w] : 0;
-  }
-}
-
-// Canonicalise r (value in [0, 2N) -> [0, N)) and store it as 64-bit words.
-// Uses bl (limb scratch, [IPW][L]) and io ([IPW][W64+1]).
-template <class GEO>
-__device__ __forceinline__ void store_canonical(uint32_t (&r)[GEO::K], const ModCtxDev& ctx,
-                                                uint32_t (*bl)[GEO::L], uint64_t (*io)[GEO::W64 + 1],
-                                                uint64_t* out, size_t first_inst, size_t count,
-                                                int lane, int g, int x) {
+__device__ __forceinline__ void limbs_to_words(uint32_t (&r)[GEO::K], uint32_t (*bl)[GEO::L],
+                                               uint64_t (*io)[GEO::W64 + 1], int lane, int g, int x) {
   constexpr int K = GEO::K, L = GEO::L, W64 = GEO::W64;
   full_normalise<GEO>(r, x);
   wave_lds_sync();
@@ -85,34 +114,102 @@ __device__ __forceinline__ void store_canonical(uint32_t (&r)[GEO::K], const Mod
     io[gg][w] = (w < W64) ? word_from_limbs(bl[gg], L, w) : 0;
   }
   wave_lds_sync();
-  // canonical reduction on the 64-bit words, one lane per group: while (V >= N) V -= N.
-  // V < 3N on every path that reaches here, so two rounds suffice; loops stay rolled.
-  if (x == 0) {
-    uint64_t* v = io[g];
+}
+
+// one lane: while (v >= mod) v -= mod, at most `rounds` times.  tmp: W scratch words.
+__device__ __forceinline__ void words_reduce(uint64_t* v, const uint64_t* mod, uint64_t* tmp, int W,
+                                             int rounds) {
 #pragma unroll 1
-    for (int round = 0; round < 2; ++round) {
-      // D = V - N into the spare half of the limb scratch; the final borrow says V < N
-      uint64_t* dtmp = reinterpret_cast<uint64_t*>(bl[g]);
-      uint64_t borrow = 0;
+  for (int round = 0; round < rounds; ++round) {
+    uint64_t borrow = 0;
 #pragma unroll 1
-      for (int w = 0; w < W64; ++w) {
-        uint64_t vw = v[w], nw = ctx.n64[w];
-        uint64_t d = vw - nw - borrow;
-        borrow = ((vw < nw) | ((vw == nw) & (borrow != 0))) ? 1 : 0;
-        dtmp[w] = d;
-      }
-      if (borrow) break;
+    for (int w = 0; w < W; ++w) {
+      uint64_t vw = v[w], nw = mod[w];
+      uint64_t d = vw - nw - borrow;
+      borrow = ((vw < nw) | ((vw == nw) & (borrow != 0))) ? 1 : 0;
+      tmp[w] = d;
+    }
+    if (borrow) break;
 #pragma unroll 1
-      for (int w = 0; w < W64; ++w) v[w] = dtmp[w];
+    for (int w = 0; w < W; ++w) v[w] = tmp[w];
+  }
+}
+
+// one lane: v = (a - b) mod m for canonical a, b in [0, m)
+__device__ __forceinline__ void words_submod(uint64_t* v, const uint64_t* a, const uint64_t* b,
+                                             const uint64_t* m, int W) {
+  uint64_t borrow = 0;
+#pragma unroll 1
+  for (int w = 0; w < W; ++w) {
+    uint64_t aw = a[w], bw = b[w];
+    uint64_t d = aw - bw - borrow;
+    borrow = ((aw < bw) | ((aw == bw) & (borrow != 0))) ? 1 : 0;
+    v[w] = d;
+  }
+  if (borrow) {
+    uint64_t carry = 0;
+#pragma unroll 1
+    for (int w = 0; w < W; ++w) {
+      uint64_t s = v[w] + m[w];
+      uint64_t c1 = s < v[w];
+      uint64_t s2 = s + carry;
+      carry = c1 | (s2 < s);
+      v[w] = s2;
     }
   }
+}
+
+// Load one element per group (64-bit words, C-ABI layout) into LDS, zero padded to W64+1.
+// Instance i reads source row (i / div); words [first, first+words) of that row.
+template <class GEO>
+__device__ __forceinline__ void stage_words(uint64_t (*io)[GEO::W64 + 1], const uint64_t* src,
+                                            size_t stride, int first, int words, size_t first_inst,
+                                            size_t count, int div, int lane) {
+  constexpr int WW = GEO::W64 + 1;
+  for (int t = lane; t < GEO::IPW * WW; t += kWave) {
+    int g = t / WW, w = t % WW;
+    size_t inst = first_inst + g;
+    if (inst >= count) inst = count - 1;
+    io[g][w] = (w < words) ? src[(inst / div) * stride + first + w] : 0;
+  }
+}
+
+// Canonicalise r (value < 3N -> [0, N)) and store it as 64-bit words.
+template <class GEO>
+__device__ __forceinline__ void store_canonical(uint32_t (&r)[GEO::K], const ModCtxDev& ctx,
+                                                uint32_t (*bl)[GEO::L], uint64_t (*io)[GEO::W64 + 1],
+                                                uint64_t* out, size_t out_stride, size_t first_inst,
+                                                size_t count, int lane, int g, int x) {
+  limbs_to_words<GEO>(r, bl, io, lane, g, x);
+  if (x == 0) words_reduce(io[g], ctx.n64, reinterpret_cast<uint64_t*>(bl[g]), GEO::W64, 2);
   wave_lds_sync();
   const int mw = ctx.mod_words;
   for (int t = lane; t < GEO::IPW * mw; t += kWave) {
     int gg = t / mw, w = t % mw;
     size_t inst = first_inst + gg;
-    if (inst < count) out[inst * (size_t)mw + w] = io[gg][w];
+    if (inst < count) out[inst * out_stride + w] = io[gg][w];
   }
+}
+
+// a[j] += k[j], then relaxed normalisation (limbs <= 2^29).  Value must stay < R.
+template <class GEO>
+__device__ __forceinline__ void add_normalise(uint32_t (&a)[GEO::K], const uint32_t (&k)[GEO::K]) {
+  constexpr int K = GEO::K;
+  uint32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    uint32_t u = a[j] + k[j] + c;
+    a[j] = u & kLimbMask;
+    c = u >> kLimbBits;
+  }
+  uint32_t cc = dpp_from_prev(c);
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    uint32_t u = a[j] + cc;
+    a[j] = u & kLimbMask;
+    cc = u >> kLimbBits;
+  }
+  a[0] += dpp_from_prev(cc);
 }
 
 template <class GEO>
@@ -127,24 +224,30 @@ __global__ __launch_bounds__(kWave) void modexp_kernel(ModexpArgs A) {
   size_t inst = first_inst + g;
   const size_t tinst = inst;                 // table slot (padded instances own a slot too)
   if (inst >= A.count) inst = A.count - 1;   // padded lanes recompute the last element
+  const int nctx = A.nctx;
+  const bool second = (nctx == 2) && (inst & 1);   // explicit selects: no dynamic arg indexing
+  ModCtxDev C;
+  C.n = second ? A.ctx[1].n : A.ctx[0].n;
+  C.r2 = second ? A.ctx[1].r2 : A.ctx[0].r2;
+  C.one = second ? A.ctx[1].one : A.ctx[0].one;
+  C.r2s = second ? A.ctx[1].r2s : A.ctx[0].r2s;
+  C.fc = second ? A.ctx[1].fc : A.ctx[0].fc;
+  C.nr = second ? A.ctx[1].nr : A.ctx[0].nr;
+  C.n64 = second ? A.ctx[1].n64 : A.ctx[0].n64;
+  C.n0inv = second ? A.ctx[1].n0inv : A.ctx[0].n0inv;
+  C.mod_words = A.ctx[0].mod_words;                // both contexts share the row width
 
-  uint32_t n[K], a[K];
+  uint32_t n[K], a[K], keep[K];
 #pragma unroll
-  for (int j = 0; j < K; ++j) n[j] = A.ctx.n[x * K + j];
-  const uint32_t n0inv = A.ctx.n0inv;
-
-  // ---- base -> limbs, R^2 -> LDS ----
-  stage_words<GEO>(io, A.base, A.base_stride, A.base_words, first_inst, A.count, lane);
-#pragma unroll
-  for (int j = 0; j < K; ++j) bl[g][x * K + j] = A.ctx.r2[x * K + j];
-  wave_lds_sync();
-#pragma unroll
-  for (int j = 0; j < K; ++j) a[j] = limb_from_words(io[g], x * K + j);
+  for (int j = 0; j < K; ++j) { n[j] = C.n[x * K + j]; keep[j] = 0; }
+  const uint32_t n0inv = C.n0inv;
+  const int mw = C.mod_words;
+  const bool wide = A.base_words > mw;
 
   const int w = A.window;
   const int tsize = 1 << w;
   uint32_t* tbl = A.table + tinst * (size_t)tsize * L + x * K;   // this lane's slice of entry 0
-  const uint64_t* ep = A.exp + inst * A.exp_stride;
+  const uint64_t* ep = A.exp + (A.exp_per_ctx ? (inst % nctx) : inst) * A.exp_stride;
   const int nwin = (A.exp_bits + w - 1) / w;
 
   auto digit = [&](int i) -> int {
@@ -157,23 +260,62 @@ __global__ __launch_bounds__(kWave) void modexp_kernel(ModexpArgs A) {
 
   // The whole exponentiation is one loop around a single montmul call site; the wave-uniform
   // phase variable selects how the multiplier operand is staged and what happens to the result.
-  enum { TOMONT, TABLE, SQR, MUL, FINAL };
-  int phase = TOMONT;
+  enum { GMUL, TOMONT_HI, TOMONT, TABLE, SQR, MUL, FINAL };
+  int phase;
   int e = 2;         // next table entry to build
   int win = 0;       // current window index
   int sq = 0;        // squarings left in the current window
+
+  // ---- first multiplication: operand a from global words, multiplier from the context ----
+  if (A.final_mul == FM_PAILLIER_G) {
+    phase = GMUL;    // keep = m * (n*R) * R^-1 = n*m mod n^2 (plain domain, lazy)
+    stage_words<GEO>(io, A.fm_words, A.fm_stride, 0, A.fm_nwords, first_inst, A.count, 1, lane);
+#pragma unroll
+    for (int j = 0; j < K; ++j) bl[g][x * K + j] = C.nr[x * K + j];
+  } else if (wide) {
+    phase = TOMONT_HI;  // keep = hi(base) * 2^(64 mw) * R mod N
+    stage_words<GEO>(io, A.base, A.base_stride, mw, A.base_words - mw, first_inst, A.count, nctx, lane);
+#pragma unroll
+    for (int j = 0; j < K; ++j) bl[g][x * K + j] = C.r2s[x * K + j];
+  } else {
+    phase = TOMONT;
+    stage_words<GEO>(io, A.base, A.base_stride, 0, A.base_words, first_inst, A.count, nctx, lane);
+#pragma unroll
+    for (int j = 0; j < K; ++j) bl[g][x * K + j] = C.r2[x * K + j];
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int j = 0; j < K; ++j) a[j] = limb_from_words(io[g], x * K + j);
+
   for (;;) {
     montmul<GEO>(a, a, bl[g], n, n0inv);
     if (phase == FINAL) break;
 
     bool start_main = false;
+    if (phase == GMUL || phase == TOMONT_HI) {
+      // park the result, then run the (low-part) to-Montgomery multiplication of the base
+#pragma unroll
+      for (int j = 0; j < K; ++j) keep[j] = a[j];
+      if (phase == GMUL && x == 0) keep[0] += 1;          // g^m = 1 + n*m
+      wave_lds_sync();
+      stage_words<GEO>(io, A.base, A.base_stride, 0, wide ? mw : A.base_words, first_inst, A.count,
+                       nctx, lane);
+#pragma unroll
+      for (int j = 0; j < K; ++j) bl[g][x * K + j] = C.r2[x * K + j];
+      wave_lds_sync();
+#pragma unroll
+      for (int j = 0; j < K; ++j) a[j] = limb_from_words(io[g], x * K + j);
+      phase = TOMONT;
+      continue;
+    }
     if (phase == TOMONT) {
+      if (wide) add_normalise<GEO>(a, keep);               // (lo + hi*2^S) * R, lazy < 4N
       // a = base*R.  table[1] = a, table[0] = R mod N; multiplier for the table build = a.
       wave_lds_sync();
 #pragma unroll
       for (int j = 0; j < K; ++j) {
         tbl[L + j] = a[j];
-        tbl[j] = A.ctx.one[x * K + j];
+        tbl[j] = C.one[x * K + j];
         bl[g][x * K + j] = a[j];
       }
       wave_lds_sync();
@@ -189,15 +331,12 @@ __global__ __launch_bounds__(kWave) void modexp_kernel(ModexpArgs A) {
     }
 
     if (start_main) {
-      // top window: a = table[d]
       if (nwin == 0) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) a[j] = A.ctx.one[x * K + j];
+        for (int j = 0; j < K; ++j) a[j] = C.one[x * K + j];
         phase = FINAL;
       } else {
-        // make this lane's table stores visible to its own loads (same lane wrote them)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        int d = digit(nwin - 1);
+        int d = digit(nwin - 1);   // top window: a = table[d] (this lane's own earlier stores)
 #pragma unroll
         for (int j = 0; j < K; ++j) a[j] = tbl[(size_t)d * L + j];
         win = nwin - 2;
@@ -221,15 +360,31 @@ __global__ __launch_bounds__(kWave) void modexp_kernel(ModexpArgs A) {
       for (int j = 0; j < K; ++j) bl[g][x * K + j] = t[j];
       wave_lds_sync();
     } else if (phase == FINAL) {
-      // leave the Montgomery domain: multiply by 1
+      // leave the Montgomery domain: multiply by 1, by the context constant, or by g^m
       wave_lds_sync();
+      if (A.final_mul == FM_UNIT) {
 #pragma unroll
-      for (int j = 0; j < K; ++j) bl[g][x * K + j] = (x == 0 && j == 0) ? 1u : 0u;
+        for (int j = 0; j < K; ++j) bl[g][x * K + j] = (x == 0 && j == 0) ? 1u : 0u;
+      } else if (A.final_mul == FM_CTX_CONST) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) bl[g][x * K + j] = C.fc[x * K + j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) bl[g][x * K + j] = keep[j];
+      }
       wave_lds_sync();
     }
     // phase == TABLE: multiplier (base*R) is already staged
   }
-  store_canonical<GEO>(a, A.ctx, bl, io, A.out, first_inst, A.count, lane, g, x);
+  // per-group modulus for the canonical reduction: contexts may differ between groups
+  limbs_to_words<GEO>(a, bl, io, lane, g, x);
+  if (x == 0) words_reduce(io[g], C.n64, reinterpret_cast<uint64_t*>(bl[g]), GEO::W64, 2);
+  wave_lds_sync();
+  for (int t = lane; t < IPW * mw; t += kWave) {
+    int gg = t / mw, ww = t % mw;
+    size_t oi = first_inst + gg;
+    if (oi < A.count) A.out[oi * A.out_stride + ww] = io[gg][ww];
+  }
 }
 
 // out = a*b mod N: montmul(montmul(a, R^2), b) -- two Montgomery multiplications.
@@ -247,22 +402,103 @@ __global__ __launch_bounds__(kWave) void modmul_kernel(ModmulArgs A) {
   for (int j = 0; j < K; ++j) n[j] = A.ctx.n[x * K + j];
   const uint32_t n0inv = A.ctx.n0inv;
 
-  stage_words<GEO>(io, A.a, A.a_stride, A.in_words, first_inst, A.count, lane);
+  stage_words<GEO>(io, A.a, A.a_stride, 0, A.in_words, first_inst, A.count, 1, lane);
 #pragma unroll
   for (int j = 0; j < K; ++j) bl[g][x * K + j] = A.ctx.r2[x * K + j];
   wave_lds_sync();
 #pragma unroll
   for (int j = 0; j < K; ++j) a[j] = limb_from_words(io[g], x * K + j);
-  montmul<GEO>(a, a, bl[g], n, n0inv);      // a*R  (any a < R is fine)
-
-  wave_lds_sync();
-  stage_words<GEO>(io, A.b, A.b_stride, A.in_words, first_inst, A.count, lane);
-  wave_lds_sync();
+#pragma unroll 1
+  for (int step = 0; step < 2; ++step) {
+    montmul<GEO>(a, a, bl[g], n, n0inv);      // step 0: a*R (any a < R); step 1: a*b mod N, lazy
+    if (step == 0) {
+      wave_lds_sync();
+      stage_words<GEO>(io, A.b, A.b_stride, 0, A.in_words, first_inst, A.count, 1, lane);
+      wave_lds_sync();
 #pragma unroll
-  for (int j = 0; j < K; ++j) bl[g][x * K + j] = limb_from_words(io[g], x * K + j);
+      for (int j = 0; j < K; ++j) bl[g][x * K + j] = limb_from_words(io[g], x * K + j);
+      wave_lds_sync();
+    }
+  }
+  store_canonical<GEO>(a, A.ctx, bl, io, A.out, (size_t)A.ctx.mod_words, first_inst, A.count, lane, g, x);
+}
+
+// CRT recombination, one G-lane group per ciphertext (pri_key.cpp:136-157):
+//   Zp = (Vp - hp) mod p^2 = p * mp           (Vp = xp*hp mod p^2, xp = c^(p-1) mod p^2;
+//                                              L(xp)*hp mod p == mp  <=>  (xp-1)*hp mod p^2 == p*mp)
+//   mp = Zp * p^-1 mod M  (exact division, M coprime to p, M > p)         likewise mq
+//   u  = (mq - mp) * (p^-1 mod q) mod q,  m = mp + u*p  (u*p as an exact product mod M > n)
+template <class GEO>
+__global__ __launch_bounds__(kWave) void crt_kernel(CrtArgs A) {
+  constexpr int K = GEO::K, L = GEO::L, G = GEO::G, IPW = GEO::IPW, W64 = GEO::W64;
+  __shared__ uint32_t bl[IPW][L];
+  __shared__ uint64_t io[IPW][W64 + 1];    // working value
+  __shared__ uint64_t ymp[IPW][W64 + 1];   // mp
+  __shared__ uint64_t tmp[IPW][W64 + 1];   // scratch / mq
+  const int lane = threadIdx.x;
+  const int g = lane / G, x = lane % G;
+  const size_t first_inst = (size_t)blockIdx.x * IPW;
+  size_t inst = first_inst + g;
+  if (inst >= A.count) inst = A.count - 1;
+  const int vw = A.vw;
+
+  uint32_t n[K], a[K];
+  // steps: 0: mp = (Vp-hp)/p   1: mq = (Vq-hq)/q   2: u = (mq-mp)*pinv mod q   3: t = u*p
+#pragma unroll 1
+  for (int step = 0; step < 4; ++step) {
+    const ModCtxDev& C = (step == 2) ? A.ctxQ : A.ctxM;
+    const uint32_t* mulc = (step == 0) ? A.cp : (step == 1) ? A.cq : (step == 2) ? A.pinvR : A.pRM;
+    wave_lds_sync();
+    if (step < 2) {
+      // io = (V - h) mod sq, exactly divisible by the prime
+      const uint64_t* V = A.v + (2 * inst + step) * (size_t)vw;
+      for (int t = x; t <= W64; t += G) io[g][t] = (t < vw) ? V[t] : 0;
+      wave_lds_sync();
+      if (x == 0) {
+        const uint64_t* h = step ? A.hq64 : A.hp64;
+        const uint64_t* sq = step ? A.q2_64 : A.p2_64;
+        words_submod(io[g], io[g], h, sq, vw);
+      }
+    } else if (step == 2) {
+      // io = (mq - mp) mod q    (mq sits in tmp, mp in ymp; both canonical, mp < p < q)
+      if (x == 0) words_submod(io[g], tmp[g], ymp[g], A.q64, vw);
+    }
+    // step 3: io already holds u
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      a[j] = limb_from_words(io[g], x * K + j);
+      n[j] = C.n[x * K + j];
+      bl[g][x * K + j] = mulc[x * K + j];
+    }
+    wave_lds_sync();
+    montmul<GEO>(a, a, bl[g], n, C.n0inv);
+    limbs_to_words<GEO>(a, bl, io, lane, g, x);
+    if (x == 0) {
+      words_reduce(io[g], C.n64, reinterpret_cast<uint64_t*>(bl[g]), W64, 2);
+      if (step == 0) { for (int t = 0; t <= W64; ++t) ymp[g][t] = io[g][t]; }
+      if (step == 1) { for (int t = 0; t <= W64; ++t) tmp[g][t] = io[g][t]; }
+      if (step == 3) {
+        // m = mp + u*p  (< n, no reduction needed)
+        uint64_t carry = 0;
+#pragma unroll 1
+        for (int t = 0; t < W64; ++t) {
+          uint64_t s = io[g][t] + ymp[g][t];
+          uint64_t c1 = s < io[g][t];
+          uint64_t s2 = s + carry;
+          carry = c1 | (s2 < s);
+          io[g][t] = s2;
+        }
+      }
+    }
+  }
   wave_lds_sync();
-  montmul<GEO>(a, a, bl[g], n, n0inv);      // a*b mod N, lazy
-  store_canonical<GEO>(a, A.ctx, bl, io, A.out, first_inst, A.count, lane, g, x);
+  const int ow = A.out_words;
+  for (int t = lane; t < IPW * ow; t += kWave) {
+    int gg = t / ow, ww = t % ow;
+    size_t oi = first_inst + gg;
+    if (oi < A.count) A.out[oi * (size_t)ow + ww] = io[gg][ww];
+  }
 }
 
 }  // namespace pgpu

@@ -89,3 +89,88 @@ def mod_mul(a, b, mod):
     W = (int(mod).bit_length() + 63) // 64
     out = mod_mul_limbs(ints_to_limbs(a, W), ints_to_limbs(b, W), ints_to_limbs([mod], W)[0])
     return limbs_to_ints(out)
+
+
+class PublicKey:
+    """Host-side mirror of ipcl::PublicKey's encrypt path (reference ipcl/pub_key.cpp:82-129).
+
+    ``hs`` set -> DJN scheme (obfuscator hs^r); otherwise r^n.  Randomness is supplied by the
+    caller (like ``setRandom``, pub_key.cpp:92-95) so results are reproducible.
+    """
+
+    def __init__(self, n, bits=None, hs=None):
+        _ensure()
+        self.n = int(n)
+        self.bits = int(bits) if bits is not None else self.n.bit_length()
+        self.n_words = (self.n.bit_length() + 63) // 64
+        self.hs = None if hs is None else int(hs)
+        self.nsq = self.n * self.n
+        self._h = ctypes.c_void_p()
+        n_l = ints_to_limbs([self.n], self.n_words)
+        hs_l = None if hs is None else ints_to_limbs([self.hs], 2 * self.n_words)
+        _capi.check(_capi.lib().pgpu_pubkey_create(_ptr(n_l), self.n_words,
+                                                   None if hs_l is None else _ptr(hs_l),
+                                                   ctypes.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _capi._lib is not None:
+            _capi._lib.pgpu_pubkey_destroy(self._h)
+            self._h = None
+
+    def encrypt_limbs(self, m, r, r_bits=None):
+        """m: [n, Wm] uint64, r: [n, Wr] uint64 -> ciphertexts [n, 2*n_words]."""
+        m = np.ascontiguousarray(m, dtype=np.uint64)
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        if m.shape[0] == 0:
+            raise RuntimeError("encrypt: Cannot encrypt empty PlainText")     # pub_key.cpp:116
+        if r.shape[0] != m.shape[0]:
+            raise RuntimeError("modExp: input vector size error")             # mod_exp.cpp:452-454
+        if r_bits is None:
+            r_bits = max(int(v).bit_length() for v in limbs_to_ints(r))
+        out = np.empty((m.shape[0], 2 * self.n_words), dtype=np.uint64)
+        _capi.check(_capi.lib().pgpu_paillier_encrypt(self._h, _ptr(m), m.shape[1], m.shape[1], _ptr(r),
+                                                      r.shape[1], r.shape[1], int(r_bits), _ptr(out),
+                                                      m.shape[0]))
+        return out
+
+    def encrypt(self, m, r):
+        mw = max(1, (max(int(v).bit_length() for v in m) + 63) // 64) if len(m) else 1
+        rw = max(1, (max(int(v).bit_length() for v in r) + 63) // 64) if len(r) else 1
+        if len(m) == 0:
+            raise RuntimeError("encrypt: Cannot encrypt empty PlainText")
+        return limbs_to_ints(self.encrypt_limbs(ints_to_limbs(m, mw), ints_to_limbs(r, rw)))
+
+
+class PrivateKey:
+    """Host-side mirror of ipcl::PrivateKey::decrypt (CRT path, pri_key.cpp:65-90,114-157)."""
+
+    def __init__(self, p, q):
+        _ensure()
+        self.p, self.q = (int(p), int(q)) if int(p) < int(q) else (int(q), int(p))
+        self.n = self.p * self.q
+        self.n_words = (self.n.bit_length() + 63) // 64
+        pw = (max(self.p.bit_length(), self.q.bit_length()) + 63) // 64
+        self._h = ctypes.c_void_p()
+        _capi.check(_capi.lib().pgpu_privkey_create(_ptr(ints_to_limbs([self.p], pw)),
+                                                    _ptr(ints_to_limbs([self.q], pw)), pw,
+                                                    ctypes.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _capi._lib is not None:
+            _capi._lib.pgpu_privkey_destroy(self._h)
+            self._h = None
+
+    def decrypt_limbs(self, c):
+        c = np.ascontiguousarray(c, dtype=np.uint64)
+        if c.shape[0] == 0:
+            raise RuntimeError("decrypt: Cannot decrypt empty CipherText")     # pri_key.cpp:71
+        if c.shape[1] != 2 * self.n_words:
+            raise RuntimeError("decrypt: ciphertext width mismatch")
+        out = np.empty((c.shape[0], self.n_words), dtype=np.uint64)
+        _capi.check(_capi.lib().pgpu_paillier_decrypt_crt(self._h, _ptr(c), _ptr(out), c.shape[0]))
+        return out
+
+    def decrypt(self, c):
+        if len(c) == 0:
+            raise RuntimeError("decrypt: Cannot decrypt empty CipherText")
+        return limbs_to_ints(self.decrypt_limbs(ints_to_limbs(c, 2 * self.n_words)))
