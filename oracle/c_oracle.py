@@ -1,0 +1,92 @@
+"""ctypes loader of the C oracle (oracle/modexp_oracle.c).  TEST INFRASTRUCTURE ONLY."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def _cpu_has(flag):
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return flag in line.split()
+    except OSError:
+        pass
+    return False
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        name = "libmodexp_oracle_v3.so" if (_cpu_has("bmi2") and _cpu_has("avx2")) else "libmodexp_oracle.so"
+        path = os.path.join(_HERE, name)
+        if not os.path.exists(path):
+            path = os.path.join(_HERE, "libmodexp_oracle.so")
+        if not os.path.exists(path):
+            raise ImportError(f"{path} not built: run `make -C oracle`")
+        L = ctypes.CDLL(path)
+        vp, sz, i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        L.orc_modexp_batch.argtypes = [vp, sz, vp, sz, i, vp, i, vp, sz]
+        L.orc_modmul_batch.argtypes = [vp, vp, sz, vp, i, vp, sz]
+        L.orc_paillier_encrypt.argtypes = [vp, i, vp, vp, i, vp, i, vp, sz]
+        L.orc_paillier_decrypt_crt.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, sz]
+        L.orc_max_threads.restype = i
+        _lib = L
+        _lib._path = path
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def modexp_batch(base, exp, mod):
+    """base [n,W], exp [n,E], mod [W] (uint64) -> [n,W]"""
+    base = np.ascontiguousarray(base, dtype=np.uint64)
+    exp = np.ascontiguousarray(exp, dtype=np.uint64)
+    mod = np.ascontiguousarray(mod, dtype=np.uint64)
+    out = np.empty_like(base)
+    rc = lib().orc_modexp_batch(_p(base), base.shape[1], _p(exp), exp.shape[1], exp.shape[1], _p(mod),
+                                mod.shape[0], _p(out), base.shape[0])
+    assert rc == 0
+    return out
+
+
+def modmul_batch(a, b, mod):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    mod = np.ascontiguousarray(mod, dtype=np.uint64)
+    out = np.empty_like(a)
+    rc = lib().orc_modmul_batch(_p(a), _p(b), b.shape[1] if b.shape[0] == a.shape[0] else 0, _p(mod),
+                                mod.shape[0], _p(out), a.shape[0])
+    assert rc == 0
+    return out
+
+
+def paillier_encrypt(n, hs, m, r):
+    """n [nw], hs [2nw] or None, m [cnt, mw], r [cnt, rw] -> c [cnt, 2nw]"""
+    n = np.ascontiguousarray(n, dtype=np.uint64)
+    m = np.ascontiguousarray(m, dtype=np.uint64)
+    r = np.ascontiguousarray(r, dtype=np.uint64)
+    out = np.empty((m.shape[0], 2 * n.shape[0]), dtype=np.uint64)
+    hsp = None if hs is None else _p(np.ascontiguousarray(hs, dtype=np.uint64))
+    rc = lib().orc_paillier_encrypt(_p(n), n.shape[0], hsp, _p(m), m.shape[1], _p(r), r.shape[1], _p(out),
+                                    m.shape[0])
+    assert rc == 0
+    return out
+
+
+def paillier_decrypt_crt(p, q, hp, hq, pinv, c):
+    """p<q [pw]; hp,hq,pinv [pw]; c [cnt, 4pw] -> m [cnt, 2pw]"""
+    arrs = [np.ascontiguousarray(v, dtype=np.uint64) for v in (p, q, hp, hq, pinv)]
+    c = np.ascontiguousarray(c, dtype=np.uint64)
+    pw = arrs[0].shape[0]
+    out = np.empty((c.shape[0], 2 * pw), dtype=np.uint64)
+    rc = lib().orc_paillier_decrypt_crt(_p(arrs[0]), _p(arrs[1]), pw, _p(arrs[2]), _p(arrs[3]), _p(arrs[4]),
+                                        _p(c), _p(out), c.shape[0])
+    assert rc == 0
+    return out
