@@ -213,7 +213,7 @@ __device__ __forceinline__ void add_normalise(uint32_t (&a)[GEO::K], const uint3
 }
 
 template <class GEO>
-__global__ __launch_bounds__(kWave) void modexp_kernel(ModexpArgs A) {
+__global__ __launch_bounds__(kWave, GEO::K <= 9 ? 4 : 2) void modexp_kernel(ModexpArgs A) {
   constexpr int K = GEO::K, L = GEO::L, G = GEO::G, IPW = GEO::IPW;
   __shared__ uint32_t bl[IPW][L];
   __shared__ uint64_t io[IPW][GEO::W64 + 1];

@@ -90,29 +90,28 @@ __device__ __forceinline__ void mont_block(uint64_t (&LOWC)[GEO::K], uint64_t (&
     }
   }
   // phase B: K quotient digits, each followed by acc += n_chunk * q
-  uint32_t low[K];
+  uint32_t recv[K];
 #pragma unroll
   for (int r = 0; r < K; ++r) {
-    uint32_t q = ((uint32_t)LOWC[r] * n0inv) & kLimbMask;
-    q = bcast_lane0<GEO::G>(q);
+    // the 29-bit mask is applied after the DPP move so that both fuse into one v_and_b32_dpp
+    uint32_t q = bcast_lane0<GEO::G>((uint32_t)LOWC[r] * n0inv) & kLimbMask;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       if (r + j < K) LOWC[r + j] += (uint64_t)n[j] * q;
       else UPC[r + j - K] += (uint64_t)n[j] * q;
     }
-    // column r is final: split into its 29-bit limb and the carry into column r+1.
-    // (in the group's lane 0 the limb is 0 by construction of q)
+    // column r is final: its 29-bit limb goes down to lane x-1 (whose window overlaps it), the
+    // rest carries into column r+1.  In the group's lane 0 the limb is 0 by construction of q,
+    // so the top lane of the group below receives 0 and no masking is needed.
     uint64_t c = LOWC[r] >> kLimbBits;
-    low[r] = (uint32_t)LOWC[r] & kLimbMask;
+    recv[r] = dpp_from_next((uint32_t)LOWC[r]) & kLimbMask;
     if (r + 1 < K) LOWC[r + 1] += c;
     else UPC[0] += c;
   }
-  // phase C: slide the window down K columns.  Lane x's low limbs are exactly the
-  // contribution lane x-1 is missing in its upper half.  The top lane of a group receives the
-  // low limbs of the NEXT group's lane 0, which are zero, so no masking is needed.
+  // phase C: slide the window down K columns
 #pragma unroll
   for (int j = 0; j < K; ++j) {
-    UPC[j] += dpp_from_next(low[j]);
+    UPC[j] += recv[j];
     LOWC[j] = 0;
   }
 }

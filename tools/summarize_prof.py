@@ -1,0 +1,47 @@
+"""Summarise a tools/profile_r01.sh run (gpurun_out/prof_<tag>) into profiles/<tag>_*.{csv,json,txt}."""
+import csv, glob, json, os, sys, collections
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+
+def short(name):
+    for k in ("modexp_kernel", "crt_kernel", "modmul_kernel", "fixedbase", "fb_"):
+        if k in name:
+            return name.split("(")[0].replace("void pgpu::", "")
+    return None
+
+rows = list(csv.DictReader(open(glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0])))
+with open(f"profiles/{tag}_rocprofv3_kernel_stats.csv", "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for r in rows:
+        w.writerow([r["Name"][:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+
+# counters: average per dispatch per kernel (only full-batch dispatches: >= 1000 workgroups)
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+meta = {}
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    for fn in glob.glob(f"{src}/{d}/*/*_counter_collection.csv"):
+        for r in csv.DictReader(open(fn)):
+            s = short(r["Kernel_Name"])
+            if not s or int(r["Grid_Size"]) < 64 * 1000:
+                continue
+            agg[s][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta[s] = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
+out = {}
+for s, cs in agg.items():
+    out[s] = {"dispatch": meta[s], "counters_avg_per_dispatch": {c: sum(v) / len(v) for c, v in cs.items()}}
+    c = out[s]["counters_avg_per_dispatch"]
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # rocprofv3 reports KiB; gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide reads (MI355X_MICROARCH.md, HBM)
+        out[s]["hbm_bytes_raw"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+        out[s]["hbm_bytes_fetch_x2_corrected"] = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+    if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c:
+        out[s]["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / max(c["SQ_WAVES"], 1)
+json.dump(out, open(f"profiles/{tag}_pmc_counters.json", "w"), indent=1)
+enc = out.get("modexp_kernel<pgpu::Geo<16, 9> >")
+if enc and "hbm_bytes_fetch_x2_corrected" in enc:
+    json.dump({"source": f"profiles/{tag}_pmc_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x2 per MI355X_MICROARCH.md)",
+               "modexp_encrypt_hbm_bytes_per_launch": enc["hbm_bytes_fetch_x2_corrected"],
+               "modexp_encrypt_hbm_bytes_per_launch_raw": enc["hbm_bytes_raw"]}, open("profiles/pmc_summary.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
