@@ -1,0 +1,118 @@
+// BaseText / PlainText containers (reference ipcl/base_text.cpp, ipcl/plaintext.cpp).
+#include "ipcl/base_text.hpp"
+
+#include <algorithm>
+
+#include "ipcl/ciphertext.hpp"
+#include "ipcl/plaintext.hpp"
+#include "ipcl/utils/util.hpp"
+
+namespace ipcl {
+
+BaseText::BaseText(const uint32_t& n) : m_texts(1, BigNumber((Ipp32u)n)), m_size(1) {}
+
+BaseText::BaseText(const std::vector<uint32_t>& n_v) {
+  m_texts.reserve(n_v.size());
+  for (uint32_t n : n_v) m_texts.emplace_back((Ipp32u)n);
+  m_size = m_texts.size();
+}
+
+BaseText::BaseText(const BigNumber& bn) : m_texts(1, bn), m_size(1) {}
+
+BaseText::BaseText(const std::vector<BigNumber>& bn_v) : m_texts(bn_v), m_size(bn_v.size()) {}
+
+BigNumber& BaseText::operator[](const std::size_t idx) {
+  ERROR_CHECK(idx < m_size, "BaseText:operator[] index is out of range");
+  return m_texts[idx];
+}
+
+void BaseText::insert(const std::size_t pos, BigNumber& bn) {
+  ERROR_CHECK(pos <= m_size, "BaseText: insert position is out of range");
+  m_texts.insert(m_texts.begin() + (std::ptrdiff_t)pos, bn);
+  m_size++;
+}
+
+void BaseText::clear() {
+  m_texts.clear();
+  m_size = 0;
+}
+
+// strict '<' as in the reference (base_text.cpp:58): the last element cannot be removed this way
+void BaseText::remove(const std::size_t pos, const std::size_t length) {
+  ERROR_CHECK(pos + length < m_size, "BaseText: remove position is out of range");
+  m_texts.erase(m_texts.begin() + (std::ptrdiff_t)pos, m_texts.begin() + (std::ptrdiff_t)(pos + length));
+  m_size -= length;
+}
+
+BigNumber BaseText::getElement(const std::size_t& idx) const {
+  ERROR_CHECK(idx < m_size, "BaseText: getElement index is out of range");
+  return m_texts[idx];
+}
+
+std::vector<uint32_t> BaseText::getElementVec(const std::size_t& idx) const {
+  ERROR_CHECK(idx < m_size, "BaseText: getElementVec index is out of range");
+  std::vector<uint32_t> v;
+  m_texts[idx].num2vec(v);
+  return v;
+}
+
+std::string BaseText::getElementHex(const std::size_t& idx) const {
+  ERROR_CHECK(idx < m_size, "BaseText: getElementHex index is out of range");
+  std::string s;
+  m_texts[idx].num2hex(s);
+  return s;
+}
+
+std::vector<BigNumber> BaseText::getChunk(const std::size_t& start, const std::size_t& size) const {
+  ERROR_CHECK(start + size <= m_size, "BaseText: getChunk parameter is incorrect");
+  return std::vector<BigNumber>(m_texts.begin() + (std::ptrdiff_t)start,
+                                m_texts.begin() + (std::ptrdiff_t)(start + size));
+}
+
+std::vector<BigNumber> BaseText::getTexts() const { return m_texts; }
+std::size_t BaseText::getSize() const { return m_size; }
+
+// ---- PlainText ----
+PlainText::PlainText(const uint32_t& n) : BaseText(n) {}
+PlainText::PlainText(const std::vector<uint32_t>& n_v) : BaseText(n_v) {}
+PlainText::PlainText(const BigNumber& bn) : BaseText(bn) {}
+PlainText::PlainText(const std::vector<BigNumber>& bn_v) : BaseText(bn_v) {}
+
+CipherText PlainText::operator+(const CipherText& other) const { return other + *this; }
+CipherText PlainText::operator*(const CipherText& other) const { return other * *this; }
+
+PlainText::operator std::vector<uint32_t>() const {
+  ERROR_CHECK(m_size > 0, "PlainText: type conversion to uint32_t vector error");
+  std::vector<uint32_t> v;
+  m_texts[0].num2vec(v);
+  return v;
+}
+
+PlainText::operator BigNumber() const {
+  ERROR_CHECK(m_size > 0, "PlainText: type conversion to BigNumber error");
+  return m_texts[0];
+}
+
+PlainText::operator std::vector<BigNumber>() const {
+  ERROR_CHECK(m_size > 0, "PlainText: type conversion to BigNumber vector error");
+  return m_texts;
+}
+
+namespace detail {
+// shared by PlainText::rotate and CipherText::rotate (plaintext.cpp:57-73, ciphertext.cpp:117-133):
+// positive shift moves elements towards higher indices
+std::vector<BigNumber> rotated(const std::vector<BigNumber>& v, int shift) {
+  const int size = (int)v.size();
+  ERROR_CHECK(size != 1, "rotate: Cannot rotate single CipherText");
+  ERROR_CHECK(shift >= -size && shift <= size, "rotate: Cannot shift more than the test size");
+  std::vector<BigNumber> out(v);
+  if (size == 0 || shift == 0 || shift == size || shift == -size) return out;
+  int left = shift > 0 ? size - shift : -shift;
+  std::rotate(out.begin(), out.begin() + left, out.end());
+  return out;
+}
+}  // namespace detail
+
+PlainText PlainText::rotate(int shift) const { return PlainText(detail::rotated(m_texts, shift)); }
+
+}  // namespace ipcl

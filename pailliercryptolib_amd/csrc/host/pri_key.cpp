@@ -1,0 +1,96 @@
+// ipcl::PrivateKey -- decrypt path (reference ipcl/pri_key.cpp).
+// The reference reduces c mod p^2 / q^2 on the host under OpenMP, calls modExp twice and runs the
+// L function + CRT in another host loop (pri_key.cpp:114-157); here ONE GPU pipeline does all of it.
+#include "ipcl/pri_key.hpp"
+
+#include "detail.hpp"
+#include "ipcl/utils/util.hpp"
+
+namespace ipcl {
+
+BigNumber lcm(const BigNumber& p, const BigNumber& q) { return p * q / p.gcd(q); }
+
+PrivateKey::PrivateKey(const PublicKey& pk, const BigNumber& p, const BigNumber& q)
+    : m_n(pk.getN()), m_nsquare(pk.getNSQ()), m_g(pk.getG()) {
+  ERROR_CHECK(m_n != nullptr, "PrivateKey ctor: Public key is NOT initialized.");
+  precompute(p, q);
+}
+
+PrivateKey::PrivateKey(const BigNumber& n, const BigNumber& p, const BigNumber& q)
+    : m_n(std::make_shared<BigNumber>(n)),
+      m_nsquare(std::make_shared<BigNumber>(n * n)),
+      m_g(std::make_shared<BigNumber>(n + 1)) {
+  precompute(p, q);
+}
+
+// key constants (reference pri_key.cpp:13-37): p < q, p^-1 mod q, hp, hq, lambda, x
+void PrivateKey::precompute(const BigNumber& p_in, const BigNumber& q_in) {
+  const bool swap = q_in < p_in;
+  m_p = std::make_shared<BigNumber>(swap ? q_in : p_in);
+  m_q = std::make_shared<BigNumber>(swap ? p_in : q_in);
+  const BigNumber &p = *m_p, &q = *m_q;
+  ERROR_CHECK(p * q == *m_n, "PrivateKey ctor: Public key does not match p * q.");
+  ERROR_CHECK(p != q, "PrivateKey ctor: p and q are same");
+  m_enable_crt = true;
+  m_pminusone = p - 1;
+  m_qminusone = q - 1;
+  m_psquare = p * p;
+  m_qsquare = q * q;
+  m_pinverse = q.InverseMul(p);
+  m_hp = computeHfun(p, m_psquare);
+  m_hq = computeHfun(q, m_qsquare);
+  m_lambda = lcm(m_pminusone, m_qminusone);
+  m_x = m_n->InverseMul((modExp(*m_g, m_lambda, *m_nsquare) - 1) / *m_n);
+  // device-side key: Montgomery contexts mod p^2, q^2, recombination constants
+  detail::ensure_context();
+  auto d = std::make_shared<detail::PrivKeyDevice>();
+  const int pw = detail::words_for_bits(q.BitSize());
+  std::vector<uint64_t> pl((size_t)pw), ql((size_t)pw);
+  p.toLimbs64(pl.data(), (size_t)pw);
+  q.toLimbs64(ql.data(), (size_t)pw);
+  IPCL_GPU_CHECK(pgpu_privkey_create(pl.data(), ql.data(), pw, &d->h), "PrivateKey");
+  m_dev = d;
+  m_isInitialized = true;
+}
+
+BigNumber PrivateKey::computeLfun(const BigNumber& a, const BigNumber& b) const { return (a - 1) / b; }
+
+// h = L_a(g^(a-1) mod a^2)^-1 mod a  (reference pri_key.cpp:159-167)
+BigNumber PrivateKey::computeHfun(const BigNumber& a, const BigNumber& b) const {
+  BigNumber pm = modExp(*m_g % b, a - 1, b);
+  return a.InverseMul(computeLfun(pm, a));
+}
+
+PlainText PrivateKey::decrypt(const CipherText& ct) const {
+  ERROR_CHECK(m_isInitialized, "decrypt: Private key is NOT initialized.");
+  ERROR_CHECK(*(ct.getPubKey()->getN()) == *(this->getN()),
+              "decrypt: The value of N in public key mismatch.");
+  std::size_t ct_size = ct.getSize();
+  ERROR_CHECK(ct_size > 0, "decrypt: Cannot decrypt empty CipherText");
+  std::vector<BigNumber> pt_bn(ct_size);
+  std::vector<BigNumber> ct_bn = ct.getTexts();
+  if (m_enable_crt) decryptCRT(pt_bn, ct_bn);
+  else decryptRAW(pt_bn, ct_bn);
+  return PlainText(pt_bn);
+}
+
+// m = L(c^lambda mod n^2) * x mod n   (reference pri_key.cpp:92-111); modexp on the GPU
+void PrivateKey::decryptRAW(std::vector<BigNumber>& plaintext, const std::vector<BigNumber>& ciphertext) const {
+  const std::size_t sz = ciphertext.size();
+  std::vector<BigNumber> res = modExp(ciphertext, std::vector<BigNumber>(sz, m_lambda),
+                                      std::vector<BigNumber>(sz, *m_nsquare));
+  for (std::size_t i = 0; i < sz; ++i) plaintext[i] = (computeLfun(res[i], *m_n) * m_x) % *m_n;
+}
+
+void PrivateKey::decryptCRT(std::vector<BigNumber>& plaintext, const std::vector<BigNumber>& ciphertext) const {
+  const std::size_t sz = ciphertext.size();
+  const int nw = detail::words_for_bits(m_n->BitSize());
+  std::vector<BigNumber> c(ciphertext);
+  for (auto& x : c)
+    if (x.isNegative() || x.BitSize() > 64 * 2 * nw) x = x % *m_nsquare;
+  std::vector<uint64_t> fc = detail::pack(c, 2 * nw), fm(sz * (size_t)nw);
+  IPCL_GPU_CHECK(pgpu_paillier_decrypt_crt(m_dev->h, fc.data(), fm.data(), sz), "decrypt");
+  plaintext = detail::unpack(fm, sz, nw);
+}
+
+}  // namespace ipcl

@@ -1,0 +1,158 @@
+// ipcl::PublicKey -- encrypt path (reference ipcl/pub_key.cpp).
+// The reference computes (n*m+1) % n^2 in a serial host loop, builds N-element vectors of hs and
+// n^2, calls modExp, then multiplies in another serial host loop (pub_key.cpp:51-110).  Here the
+// plaintexts and the randomness are marshalled once and ONE fused GPU call returns the ciphertexts.
+#include "ipcl/pub_key.hpp"
+
+#include "detail.hpp"
+#include "ipcl/ciphertext.hpp"
+#include "ipcl/mod_exp.hpp"
+#include "ipcl/utils/util.hpp"
+
+namespace ipcl {
+
+PublicKey::PublicKey(const BigNumber& n, int bits, bool enableDJN_) { create(n, bits, enableDJN_); }
+
+void PublicKey::create(const BigNumber& n, int bits, bool enableDJN_) {
+  m_n = std::make_shared<BigNumber>(n);
+  m_g = std::make_shared<BigNumber>(n + 1);
+  m_nsquare = std::make_shared<BigNumber>(n * n);
+  m_bits = bits;
+  m_dwords = BITSIZE_DWORD(bits * 2);
+  m_enable_DJN = false;
+  m_hs = BigNumber::Zero();
+  m_randbits = 0;
+  m_testv = false;
+  m_r.clear();
+  m_dev.reset();
+  if (enableDJN_) enableDJN();
+  m_isInitialized = true;
+}
+
+void PublicKey::create(const BigNumber& n, int bits, const BigNumber& hs, int randbits) {
+  create(n, bits, false);
+  m_enable_DJN = true;
+  m_hs = hs;
+  m_randbits = randbits;
+  m_dev.reset();
+}
+
+// hs = (-x^2 mod n)^n mod n^2 for a random x coprime to n (reference pub_key.cpp:29-49)
+void PublicKey::enableDJN() {
+  const BigNumber& n = *m_n;
+  BigNumber x;
+  do {
+    x = getRandomBN(n.BitSize() + 128);
+  } while (x.gcd(n) != BigNumber::One());
+  BigNumber xm = x % n;
+  BigNumber h = (BigNumber::Zero() - xm * xm) % n;  // non-negative residue
+  m_hs = modExp(h, n, *m_nsquare);
+  m_randbits = m_bits >> 1;
+  m_enable_DJN = true;
+  m_dev.reset();
+}
+
+void PublicKey::setDJN(const BigNumber& hs, int randbit) {
+  if (m_enable_DJN) return;
+  m_hs = hs;
+  m_randbits = randbit;
+  m_enable_DJN = true;
+  m_dev.reset();
+}
+
+void PublicKey::setRandom(const std::vector<BigNumber>& r) {
+  m_r.insert(m_r.end(), r.begin(), r.end());
+  m_testv = true;
+}
+
+void PublicKey::setHS(const BigNumber& hs) {
+  m_hs = hs;
+  m_dev.reset();
+}
+
+std::shared_ptr<detail::PubKeyDevice> PublicKey::device() const {
+  if (m_dev && m_dev->n == *m_n && m_dev->djn == m_enable_DJN && (!m_enable_DJN || m_dev->hs == m_hs))
+    return m_dev;
+  detail::ensure_context();
+  auto d = std::make_shared<detail::PubKeyDevice>();
+  d->n = *m_n;
+  d->hs = m_hs;
+  d->djn = m_enable_DJN;
+  const int nw = detail::words_for_bits(m_n->BitSize());
+  std::vector<uint64_t> n_l((size_t)nw), hs_l((size_t)2 * nw);
+  m_n->toLimbs64(n_l.data(), (size_t)nw);
+  if (m_enable_DJN)
+    ERROR_CHECK((m_hs % *m_nsquare).toLimbs64(hs_l.data(), hs_l.size()), "PublicKey: hs does not fit n^2");
+  IPCL_GPU_CHECK(pgpu_pubkey_create(n_l.data(), nw, m_enable_DJN ? hs_l.data() : nullptr, &d->h),
+                 "PublicKey");
+  m_dev = d;
+  return d;
+}
+
+// the per-element randomness: injected (setRandom) or drawn on the host like the reference
+// (DJN: randbits random bits, pub_key.cpp:59-61; otherwise uniform in [1, n-1], pub_key.cpp:74-76)
+std::vector<BigNumber> PublicKey::drawRandom(std::size_t sz) const {
+  if (m_testv) return m_r;  // used as is: size is checked by the caller like ippMBModExp does
+  std::vector<BigNumber> r(sz);
+  if (m_enable_DJN) {
+    for (auto& x : r) x = getRandomBN(m_randbits);
+  } else {
+    const BigNumber nm1 = *m_n - 1;
+    for (auto& x : r) x = getRandomBN(m_bits) % nm1 + 1;
+  }
+  return r;
+}
+
+std::vector<BigNumber> PublicKey::raw_encrypt(const std::vector<BigNumber>& pt, bool make_secure) const {
+  const BigNumber& n = *m_n;
+  const BigNumber& nsq = *m_nsquare;
+  const std::size_t sz = pt.size();
+  if (!make_secure) {  // g^m only (used by CT+PT): cheap, stays on the host
+    std::vector<BigNumber> ct(sz);
+    for (std::size_t i = 0; i < sz; ++i) ct[i] = (n * pt[i] + 1) % nsq;
+    return ct;
+  }
+  std::vector<BigNumber> r = drawRandom(sz);
+  ERROR_CHECK(r.size() == sz, "ippMBModExp: input vector size error");  // reference mod_exp.cpp:452-454
+  auto dev = device();
+  const int nw = detail::words_for_bits(n.BitSize());
+  // plaintexts: any non-negative value; wider than n^2 is reduced first ((n*m+1) % n^2 only
+  // depends on m mod n)
+  std::vector<BigNumber> m(pt);
+  for (auto& x : m)
+    if (x.isNegative() || x.BitSize() > 64 * 2 * nw) x = x % n;
+  for (auto& x : r) ERROR_CHECK(!x.isNegative(), "encrypt: negative random value");
+  const int mw = detail::words_for_bits(detail::max_bits(m));
+  const int rbits = detail::max_bits(r);
+  int rw = detail::words_for_bits(rbits);
+  if (!m_enable_DJN) {
+    for (auto& x : r)
+      if (x.BitSize() > 64 * 2 * nw) x = x % nsq;  // base wider than n^2
+    rw = detail::words_for_bits(detail::max_bits(r));
+  }
+  std::vector<uint64_t> fm = detail::pack(m, mw), fr = detail::pack(r, rw), fc(sz * (size_t)2 * nw);
+  IPCL_GPU_CHECK(pgpu_paillier_encrypt(dev->h, fm.data(), (size_t)mw, mw, fr.data(), (size_t)rw, rw,
+                                       detail::max_bits(r), fc.data(), sz),
+                 "encrypt");
+  return detail::unpack(fc, sz, 2 * nw);
+}
+
+// kept for API compatibility: multiplies the given values by fresh obfuscators in place
+void PublicKey::applyObfuscator(std::vector<BigNumber>& ciphertext) const {
+  const std::size_t sz = ciphertext.size();
+  std::vector<BigNumber> r = drawRandom(sz);
+  ERROR_CHECK(r.size() == sz, "ippMBModExp: input vector size error");
+  std::vector<BigNumber> sq(sz, *m_nsquare), obf;
+  if (m_enable_DJN) obf = modExp(std::vector<BigNumber>(sz, m_hs), r, sq);
+  else obf = modExp(r, std::vector<BigNumber>(sz, *m_n), sq);
+  ciphertext = modMul(ciphertext, obf, *m_nsquare);
+}
+
+CipherText PublicKey::encrypt(const PlainText& pt, bool make_secure) const {
+  ERROR_CHECK(m_isInitialized, "encrypt: Public key is NOT initialized.");
+  std::size_t pt_size = pt.getSize();
+  ERROR_CHECK(pt_size > 0, "encrypt: Cannot encrypt empty PlainText");
+  return CipherText(*this, raw_encrypt(pt.getTexts(), make_secure));
+}
+
+}  // namespace ipcl

@@ -1,0 +1,300 @@
+// C++ API parity tests of the ipcl:: mirror, run on a real MI355X by tests/test_gpu_cpp_api.py.
+// Coverage follows the reference's gtest suites (gtest itself is not available offline):
+//   test/test_cryptography.cpp  -- random round trip, application-level OpenMP, ISO/IEC 18033-6 KAT
+//   test/test_ops.cpp           -- CT+CT, CT+PT, CT*PT (array / scalar), PT+CT, PT*CT,
+//                                  multiply by zero, a + b*2 + b
+// plus the error behaviour and container quirks listed in SURVEY.md section 4 / Appendix A.
+#include <omp.h>
+
+#include <climits>
+#include <cstdio>
+#include <functional>
+#include <iostream>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "ipcl/ipcl.hpp"
+#include "kat_vectors.inc"  // generated from tests/golden/iso_kat.json by the pytest wrapper
+
+static int g_failed = 0, g_checks = 0;
+#define EXPECT_TRUE(c)                                                                 \
+  do {                                                                                 \
+    ++g_checks;                                                                        \
+    if (!(c)) { ++g_failed; std::printf("  FAIL %s:%d  %s\n", __FILE__, __LINE__, #c); } \
+  } while (0)
+#define EXPECT_EQ(a, b) EXPECT_TRUE((a) == (b))
+#define EXPECT_THROW(stmt)                                        \
+  do {                                                            \
+    bool thrown_ = false;                                         \
+    try { stmt; } catch (const std::runtime_error&) { thrown_ = true; } \
+    EXPECT_TRUE(thrown_);                                         \
+  } while (0)
+
+struct Case { const char* name; std::function<void()> fn; };
+static std::vector<Case>& cases() { static std::vector<Case> c; return c; }
+struct Reg { Reg(const char* n, std::function<void()> f) { cases().push_back({n, f}); } };
+#define TEST(name) static void name(); static Reg reg_##name(#name, name); static void name()
+
+static std::vector<uint32_t> random_u32(size_t n, uint32_t seed) {
+  std::mt19937 rng(seed);
+  std::vector<uint32_t> v(n);
+  for (auto& x : v) x = rng();
+  return v;
+}
+
+static ipcl::KeyPair& shared_key() {  // 2048-bit DJN key as in the reference's fixtures
+  static ipcl::KeyPair key = ipcl::generateKeypair(2048, true);
+  return key;
+}
+
+// ---------------- cryptography ----------------
+TEST(roundtrip_random_u32) {
+  ipcl::KeyPair& key = shared_key();
+  std::vector<uint32_t> expect = random_u32(20, 1);
+  ipcl::PlainText pt(expect);
+  ipcl::setHybridRatio(0.5f);
+  ipcl::CipherText ct = key.pub_key.encrypt(pt);
+  ipcl::PlainText dt = key.priv_key.decrypt(ct);
+  for (size_t i = 0; i < expect.size(); ++i) EXPECT_EQ(dt.getElementVec(i)[0], expect[i]);
+  // fresh randomness: encrypting twice gives different ciphertexts that decrypt alike
+  ipcl::CipherText ct2 = key.pub_key.encrypt(pt);
+  EXPECT_TRUE(ct.getElement(0) != ct2.getElement(0));
+  EXPECT_EQ(key.priv_key.decrypt(ct2).getElement(0), pt.getElement(0));
+}
+
+TEST(roundtrip_application_level_openmp) {
+  ipcl::KeyPair& key = shared_key();
+  const int vec_size = 10;
+  std::vector<uint32_t> expect = random_u32(20, 2);
+  std::vector<ipcl::PlainText> pt(vec_size, ipcl::PlainText(expect)), dt(vec_size);
+  std::vector<ipcl::CipherText> ct(vec_size);
+#pragma omp parallel for num_threads(4)
+  for (int i = 0; i < vec_size; i++) ct[i] = key.pub_key.encrypt(pt[i]);
+#pragma omp parallel for num_threads(4)
+  for (int i = 0; i < vec_size; i++) dt[i] = key.priv_key.decrypt(ct[i]);
+  for (int j = 0; j < vec_size; j++)
+    for (size_t i = 0; i < expect.size(); ++i) EXPECT_EQ(dt[j].getElementVec(i)[0], expect[i]);
+}
+
+TEST(iso_iec_18033_6_known_answer) {
+  BigNumber p(KAT_P), q(KAT_Q);
+  BigNumber n = p * q;
+  int n_length = n.BitSize();
+  EXPECT_EQ(n_length, 2048);
+  ipcl::PublicKey pk(n, n_length);  // non-DJN
+  ipcl::PrivateKey sk(pk, p, q);
+  const int num_values = 21;
+  std::vector<BigNumber> pt_bn(num_values, BigNumber(KAT_M0)), r_bn(num_values, BigNumber(KAT_R0));
+  pt_bn[1] = BigNumber(KAT_M1);
+  r_bn[1] = BigNumber(KAT_R1);
+  ipcl::setHybridOff();
+  pk.setRandom(r_bn);
+  ipcl::CipherText ct = pk.encrypt(ipcl::PlainText(pt_bn));
+  ipcl::PlainText dt = sk.decrypt(ct);
+  for (int i = 0; i < num_values; i++) EXPECT_EQ(dt.getElement(i), pt_bn[i]);
+  std::string s1, s2, s3, s4;
+  BigNumber(KAT_C1).num2hex(s1);
+  BigNumber(KAT_C2).num2hex(s2);
+  EXPECT_EQ(s1, ct.getElementHex(0));
+  EXPECT_EQ(s2, ct.getElementHex(1));
+  ipcl::CipherText a(pk, ct.getElement(0)), b(pk, ct.getElement(1));
+  ipcl::CipherText sum = a + b;
+  BigNumber(KAT_C1C2).num2hex(s3);
+  EXPECT_EQ(s3, sum.getElementHex(0));
+  BigNumber(KAT_M1M2).num2hex(s4);
+  EXPECT_EQ(s4, sk.decrypt(sum).getElementHex(0));
+  // the non-CRT path gives the same plaintexts (pri_key.cpp:92-111)
+  sk.enableCRT(false);
+  ipcl::PlainText dr = sk.decrypt(ct);
+  for (int i = 0; i < num_values; i++) EXPECT_EQ(dr.getElement(i), pt_bn[i]);
+  // a batch whose size differs from the injected randomness is rejected (mod_exp.cpp:452-454)
+  EXPECT_THROW(pk.encrypt(ipcl::PlainText(std::vector<uint32_t>{1, 2, 3})));
+}
+
+TEST(benchmark_key_with_injected_hs) {  // BM_Encrypt / BM_Decrypt configuration
+  BigNumber p(KAT_P), q(KAT_Q), n = p * q;
+  ipcl::PublicKey pk(n, 2048, true);
+  ipcl::PrivateKey sk(pk, p, q);
+  const size_t dsize = 16;
+  pk.setRandom(std::vector<BigNumber>(dsize, BigNumber(KAT_BENCH_R)));
+  pk.setHS(BigNumber(KAT_BENCH_HS));
+  std::vector<BigNumber> m(dsize);
+  for (size_t i = 0; i < dsize; i++) m[i] = p - BigNumber((unsigned int)(i * 1024));
+  ipcl::CipherText ct = pk.encrypt(ipcl::PlainText(m));
+  ipcl::PlainText dt = sk.decrypt(ct);
+  for (size_t i = 0; i < dsize; i++) EXPECT_EQ(dt.getElement(i), m[i]);
+  // bit-exact against the definition, with the obfuscator from the generic seam
+  BigNumber nsq = n * n;
+  BigNumber obf = ipcl::modExp(BigNumber(KAT_BENCH_HS), BigNumber(KAT_BENCH_R), nsq);
+  EXPECT_EQ(ct.getElement(3), nsq.ModMul((n * m[3] + 1) % nsq, obf));
+}
+
+// ---------------- homomorphic operations ----------------
+static void check_sum64(const ipcl::PlainText& dt, const std::vector<uint32_t>& a, const std::vector<uint32_t>& b,
+                        uint64_t mul_b = 1) {
+  for (size_t i = 0; i < a.size(); i++) {
+    std::vector<uint32_t> v = dt.getElementVec(i);
+    uint64_t got = v[0] | (v.size() > 1 ? (uint64_t)v[1] << 32 : 0);
+    uint64_t want = (uint64_t)a[i] + (uint64_t)(b.size() == 1 ? b[0] : b[i]) * mul_b;
+    EXPECT_EQ(got, want);
+  }
+}
+static void check_prod64(const ipcl::PlainText& dt, const std::vector<uint32_t>& a, const std::vector<uint32_t>& b) {
+  for (size_t i = 0; i < a.size(); i++) {
+    std::vector<uint32_t> v = dt.getElementVec(i);
+    uint64_t got = v[0] | (v.size() > 1 ? (uint64_t)v[1] << 32 : 0);
+    EXPECT_EQ(got, (uint64_t)a[i] * (uint64_t)(b.size() == 1 ? b[0] : b[i]));
+  }
+}
+
+TEST(ct_plus_ct) {
+  ipcl::KeyPair& key = shared_key();
+  auto a = random_u32(14, 3), b = random_u32(14, 4);
+  ipcl::CipherText ca = key.pub_key.encrypt(ipcl::PlainText(a)), cb = key.pub_key.encrypt(ipcl::PlainText(b));
+  check_sum64(key.priv_key.decrypt(ca + cb), a, b);
+  // vector (+) scalar ciphertext
+  ipcl::CipherText c1 = key.pub_key.encrypt(ipcl::PlainText(b[0]));
+  check_sum64(key.priv_key.decrypt(ca + c1), a, {b[0]});
+  // element-by-element
+  for (size_t i = 0; i < 3; i++) {
+    ipcl::CipherText s = ca.getCipherText(i) + cb.getCipherText(i);
+    check_sum64(key.priv_key.decrypt(s), {a[i]}, {b[i]});
+  }
+}
+
+TEST(ct_plus_pt_and_pt_plus_ct) {
+  ipcl::KeyPair& key = shared_key();
+  auto a = random_u32(14, 5), b = random_u32(14, 6);
+  ipcl::PlainText pb(b);
+  ipcl::CipherText ca = key.pub_key.encrypt(ipcl::PlainText(a));
+  check_sum64(key.priv_key.decrypt(ca + pb), a, b);
+  check_sum64(key.priv_key.decrypt(pb + ca), a, b);
+  check_sum64(key.priv_key.decrypt(ca + ipcl::PlainText(b[0])), a, {b[0]});
+}
+
+TEST(ct_times_pt_and_pt_times_ct) {
+  ipcl::KeyPair& key = shared_key();
+  auto a = random_u32(14, 7), b = random_u32(14, 8);
+  ipcl::PlainText pb(b);
+  ipcl::CipherText ca = key.pub_key.encrypt(ipcl::PlainText(a));
+  check_prod64(key.priv_key.decrypt(ca * pb), a, b);
+  check_prod64(key.priv_key.decrypt(pb * ca), a, b);
+  check_prod64(key.priv_key.decrypt(ca * ipcl::PlainText(b[0])), a, {b[0]});
+  ipcl::CipherText one = ca.getCipherText(2) * ipcl::PlainText(b[2]);  // size-1 path
+  check_prod64(key.priv_key.decrypt(one), {a[2]}, {b[2]});
+}
+
+TEST(ct_times_zero_pt) {
+  ipcl::KeyPair& key = shared_key();
+  auto a = random_u32(14, 9);
+  std::vector<uint32_t> zeros(14, 0);
+  ipcl::CipherText ca = key.pub_key.encrypt(ipcl::PlainText(a));
+  ipcl::PlainText dt = key.priv_key.decrypt(ca * ipcl::PlainText(zeros));
+  for (size_t i = 0; i < a.size(); i++) {
+    std::vector<uint32_t> v = dt.getElementVec(i);  // must have >= 1 word for the value 0 (Q8)
+    EXPECT_TRUE(v.size() >= 1);
+    EXPECT_EQ(v[0], 0u);
+  }
+}
+
+TEST(add_sub_expression) {  // a + b*2 + b
+  ipcl::KeyPair& key = shared_key();
+  auto a = random_u32(14, 10), b = random_u32(14, 11);
+  ipcl::CipherText ca = key.pub_key.encrypt(ipcl::PlainText(a)), cb = key.pub_key.encrypt(ipcl::PlainText(b));
+  ipcl::CipherText r = ca + cb * ipcl::PlainText(std::vector<uint32_t>(14, 2)) + cb;
+  check_sum64(key.priv_key.decrypt(r), a, b, 3);
+}
+
+// ---------------- seam, containers, errors ----------------
+TEST(modexp_seam_mixed_moduli) {
+  std::vector<BigNumber> base, exp, mod;
+  std::mt19937_64 rng(5);
+  for (int i = 0; i < 6; i++) {
+    Ipp32u w[8];
+    for (auto& x : w) x = (Ipp32u)rng();
+    BigNumber m(w, (i % 2) ? 8 : 4);
+    mod.push_back(m * 2 + 1);  // odd
+    base.push_back(BigNumber((Ipp32u)rng()) * BigNumber((Ipp32u)rng()));
+    exp.push_back(BigNumber((Ipp32u)(i * 977)));
+  }
+  std::vector<BigNumber> got = ipcl::modExp(base, exp, mod);
+  for (int i = 0; i < 6; i++) {
+    BigNumber want = BigNumber::One(), b = base[i] % mod[i];
+    for (int bit = exp[i].BitSize() - 1; bit >= 0; --bit) {
+      want = (want * want) % mod[i];
+      if (exp[i].TestBit(bit)) want = (want * b) % mod[i];
+    }
+    if (exp[i] == BigNumber::Zero()) want = BigNumber::One() % mod[i];
+    EXPECT_EQ(got[i], want);
+  }
+  EXPECT_THROW(ipcl::modExp(base, std::vector<BigNumber>(2), mod));
+  EXPECT_THROW(ipcl::qatModExp(base, exp, mod));
+}
+
+TEST(containers_and_errors) {
+  ipcl::KeyPair& key = shared_key();
+  ipcl::PlainText empty;
+  EXPECT_THROW(key.pub_key.encrypt(empty));                 // pub_key.cpp:116
+  ipcl::PublicKey uninit;
+  EXPECT_THROW(uninit.encrypt(ipcl::PlainText(1u)));        // pub_key.cpp:113
+  ipcl::PlainText pt(std::vector<uint32_t>{1, 2, 3, 4});
+  EXPECT_EQ(pt.getSize(), (size_t)4);
+  EXPECT_EQ(pt.rotate(1).getElementVec(0)[0], 4u);
+  EXPECT_EQ(pt.rotate(-1).getElementVec(0)[0], 2u);
+  EXPECT_THROW(ipcl::PlainText(7u).rotate(1));
+  EXPECT_THROW(pt.getElement(4));
+  EXPECT_THROW(pt.remove(3, 1));                            // strict '<' quirk (Q12)
+  pt.remove(0, 1);
+  EXPECT_EQ(pt.getSize(), (size_t)3);
+  std::string z;
+  BigNumber::Zero().num2hex(z);
+  EXPECT_EQ(z, std::string("0x"));                          // Q7
+  ipcl::CipherText ca = key.pub_key.encrypt(ipcl::PlainText(std::vector<uint32_t>{1, 2, 3}));
+  ipcl::CipherText cb = key.pub_key.encrypt(ipcl::PlainText(std::vector<uint32_t>{1, 2}));
+  EXPECT_THROW(ca + cb);                                    // ciphertext.cpp:37-38
+  EXPECT_THROW(ca * ipcl::PlainText(std::vector<uint32_t>{1, 2}));
+  // a different key is rejected by decrypt and by CT+CT (pri_key.cpp:67-68, ciphertext.cpp:39-40)
+  ipcl::KeyPair other = ipcl::generateKeypair(1024, true);
+  EXPECT_THROW(other.priv_key.decrypt(ca));
+  ipcl::CipherText cc = other.pub_key.encrypt(ipcl::PlainText(std::vector<uint32_t>{1, 2, 3}));
+  EXPECT_THROW(ca + cc);
+  EXPECT_EQ(other.priv_key.decrypt(cc).getElementVec(2)[0], 3u);
+  EXPECT_THROW(ipcl::generateKeypair(100, true));           // keygen.cpp:101-102
+  EXPECT_THROW(ipcl::PrivateKey(BigNumber(15u), BigNumber(3u), BigNumber(3u)));
+}
+
+TEST(keygen_non_djn_and_3072_bit) {
+  ipcl::KeyPair k = ipcl::generateKeypair(1024, false);
+  EXPECT_TRUE(!k.pub_key.isDJN());
+  auto a = random_u32(9, 12);
+  ipcl::PlainText dt = k.priv_key.decrypt(k.pub_key.encrypt(ipcl::PlainText(a)));
+  for (size_t i = 0; i < a.size(); i++) EXPECT_EQ(dt.getElementVec(i)[0], a[i]);
+  // beyond the reference's 2048-bit cap (BASELINE config 4): 3072-bit key, 6144-bit n^2
+  ipcl::KeyPair k3 = ipcl::generateKeypair(3072, true);
+  EXPECT_EQ(k3.pub_key.getN()->BitSize(), 3072);
+  ipcl::PlainText d3 = k3.priv_key.decrypt(k3.pub_key.encrypt(ipcl::PlainText(a)));
+  for (size_t i = 0; i < a.size(); i++) EXPECT_EQ(d3.getElementVec(i)[0], a[i]);
+}
+
+int main(int argc, char** argv) {
+  ipcl::initializeContext("default");
+  std::string filter = argc > 1 ? argv[1] : "";
+  int ran = 0;
+  for (auto& c : cases()) {
+    if (!filter.empty() && std::string(c.name).find(filter) == std::string::npos) continue;
+    int before = g_failed;
+    std::printf("[ RUN  ] %s\n", c.name);
+    try {
+      c.fn();
+    } catch (const std::exception& e) {
+      ++g_failed;
+      std::printf("  EXCEPTION: %s\n", e.what());
+    }
+    std::printf("[ %s ] %s\n", g_failed == before ? " OK " : "FAIL", c.name);
+    ++ran;
+  }
+  ipcl::terminateContext();
+  std::printf("%d tests, %d checks, %d failed\n", ran, g_checks, g_failed);
+  return g_failed ? 1 : 0;
+}
