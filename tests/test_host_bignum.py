@@ -1,0 +1,73 @@
+"""CPU suite: the IPP-free host BigNumber (include/ipcl/bignum.h) fuzzed against Python integers
+through a tiny driver program (tests/cpp/bignum_driver.cpp)."""
+import math
+import os
+import random
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("bn") / "bn_driver")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "bignum_driver.cpp"),
+                    os.path.join(ROOT, "pailliercryptolib_amd", "csrc", "host", "bignum.cpp"), "-o", exe], check=True)
+    return exe
+
+
+def hx(x):
+    return ("-" if x < 0 else "") + hex(abs(x))
+
+
+def num2hex(x):      # reference num2hex: lowercase, 0x prefix, no leading zeros, zero -> "0x" (Q7)
+    return ("-" if x < 0 else "") + "0x" + (format(abs(x), "x") if x else "")
+
+
+def test_bignum_fuzz(driver):
+    rng = random.Random(2024)
+    cases, expect = [], []
+    sizes = [1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 500, 1024, 2048, 4096]
+    for _ in range(1500):
+        a = rng.getrandbits(rng.choice(sizes))
+        b = rng.getrandbits(rng.choice(sizes[:-1]))
+        A, B = a * rng.choice([1, 1, -1]), b * rng.choice([1, 1, -1])
+        op = rng.choice(["add", "sub", "mul", "div", "mod", "gcd", "inv", "modmul", "modsub", "cmp", "bits", "vec"])
+        if op == "add":
+            cases.append(f"add {hx(A)} {hx(B)}"); expect.append(num2hex(A + B))
+        elif op == "sub":
+            cases.append(f"sub {hx(A)} {hx(B)}"); expect.append(num2hex(A - B))
+        elif op == "mul":
+            cases.append(f"mul {hx(A)} {hx(B)}"); expect.append(num2hex(A * B))
+        elif op == "div" and b:
+            q = abs(A) // abs(B)
+            cases.append(f"div {hx(A)} {hx(B)}"); expect.append(num2hex(-q if (A < 0) != (B < 0) else q))
+        elif op == "mod" and b:      # non-negative residue for a negative left operand (Q1)
+            cases.append(f"mod {hx(A)} {hx(b)}"); expect.append(num2hex(A % b))
+        elif op == "gcd":
+            cases.append(f"gcd {hx(a)} {hx(b)}"); expect.append(num2hex(math.gcd(a, b)))
+        elif op == "inv" and b > 1 and math.gcd(a, b) == 1:
+            cases.append(f"inv {hx(a)} {hx(b)}"); expect.append(num2hex(pow(a, -1, b)))
+        elif op in ("modmul", "modsub"):
+            c = rng.getrandbits(rng.choice(sizes[3:])) | 1
+            cases.append(f"{op} {hx(a)} {hx(b)} {hx(c)}")
+            expect.append(num2hex(a * b % c if op == "modmul" else (a - b) % c))
+        elif op == "cmp":
+            cases.append(f"cmp {hx(A)} {hx(B)}"); expect.append(str((A > B) - (A < B)))
+        elif op == "bits":
+            bs = a.bit_length() if a else 1
+            lsb = (a & -a).bit_length() - 1 if a else 0
+            cases.append(f"bits {hx(a)}"); expect.append(f"{bs} {lsb} {(bs + 31) // 32}")
+        elif op == "vec":            # >= 1 word also for zero (Q8)
+            n = max(1, (a.bit_length() + 31) // 32)
+            cases.append(f"vec {hx(a)}")
+            expect.append(" ".join([str(n)] + [str((a >> (32 * i)) & 0xFFFFFFFF) for i in range(n)]))
+    cases += ["dec 123456789012345678901234567890", "dec -42", "bin 0x1234567890abcdef1122", "vec 0x0", "add 0x0 0x0"]
+    expect += [num2hex(123456789012345678901234567890), "-0x2a", "0x1234567890abcdef1122", "1 0", "0x"]
+    out = subprocess.run([driver], input="\n".join(cases) + "\n", capture_output=True, text=True).stdout.split("\n")
+    bad = [(c, e, o) for c, e, o in zip(cases, expect, out) if e != o]
+    assert not bad, bad[:3]
+    assert len(out) >= len(cases)
