@@ -98,6 +98,12 @@ int pgpu_paillier_encrypt_dev(const pgpu_pubkey* key, const uint64_t* d_m, size_
                               int m_words, const uint64_t* d_r, size_t r_stride, int r_words,
                               int r_bits, uint64_t* d_c, size_t count, void* hip_stream);
 
+/* DJN keys: hs is a key constant, so hs^r runs as a fixed-base product over a per-key table of
+ * hs^(d*2^(w*i)) (built on the GPU at the first encrypt, no squarings afterwards).  w = 0 selects
+ * the generic square-and-multiply kernel instead; default 8 (env PGPU_FB_WINDOW).  Results are
+ * identical either way. */
+int pgpu_set_fixed_base_window(int w);
+
 /* ---- Paillier private key: fused CRT decrypt ----
  * Replaces PrivateKey::decryptCRT + computeLfun + computeCRT (pri_key.cpp:114-157): per
  * ciphertext c (2*n_words words) two half-width exponentiations c^(p-1) mod p^2, c^(q-1) mod

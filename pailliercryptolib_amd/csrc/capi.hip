@@ -5,7 +5,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -219,6 +221,18 @@ int pick_window(int exp_bits) {
   return best;
 }
 
+// window width of the fixed-base table for the DJN obfuscator; PGPU_FB_WINDOW=0 selects the
+// generic (per-instance table, square-and-multiply) kernel instead.
+int g_fb_window = -1;
+int fixed_base_window() {
+  if (g_fb_window < 0) {
+    const char* e = std::getenv("PGPU_FB_WINDOW");
+    int v = e ? std::atoi(e) : 8;
+    g_fb_window = (v < 0 || v > 12) ? 8 : v;
+  }
+  return g_fb_window;
+}
+
 struct TimerScope {
   hipStream_t s;
   bool on;
@@ -252,6 +266,19 @@ void launch_crt(const pgpu::CrtArgs& a, hipStream_t s) {
   typedef pgpu::Geo<G, K> GEO;
   unsigned blocks = (unsigned)((a.count + GEO::IPW - 1) / GEO::IPW);
   hipLaunchKernelGGL((pgpu::crt_kernel<GEO>), dim3(blocks), dim3(pgpu::kWave), 0, s, a);
+}
+
+template <int G, int K>
+void launch_fb_build(const pgpu::FixedBaseBuildArgs& a, hipStream_t s) {
+  typedef pgpu::Geo<G, K> GEO;
+  unsigned blocks = (unsigned)((a.nwin + GEO::IPW - 1) / GEO::IPW);
+  hipLaunchKernelGGL((pgpu::fb_build_kernel<GEO>), dim3(blocks), dim3(pgpu::kWave), 0, s, a);
+}
+template <int G, int K>
+void launch_fb_encrypt(const pgpu::FixedBaseArgs& a, hipStream_t s) {
+  typedef pgpu::Geo<G, K> GEO;
+  unsigned blocks = (unsigned)((a.count + GEO::IPW - 1) / GEO::IPW);
+  hipLaunchKernelGGL((pgpu::fb_encrypt_kernel<GEO>), dim3(blocks), dim3(pgpu::kWave), 0, s, a);
 }
 
 #define GEO_DISPATCH(FN, geo, ...)                                  \
@@ -317,6 +344,11 @@ struct pgpu_pubkey {
   std::shared_ptr<ModCtx> nsq;  // modulus n^2, with nr = n*R mod n^2
   DevBlob d_hs;                 // DJN: hs, 2*n_words words
   DevBlob d_n;                  // plain: the exponent n, n_words words
+  // fixed-base table for hs^r (built lazily, grown when a longer exponent shows up)
+  mutable Workspace fb_table;
+  mutable int fb_nwin = 0;
+  mutable int fb_w = 0;
+  ~pgpu_pubkey() { fb_table.release(); }
 };
 
 struct pgpu_privkey {
@@ -378,6 +410,13 @@ void pgpu_shutdown(void) {
 int pgpu_is_initialized(void) { return g_init ? 1 : 0; }
 const char* pgpu_last_error(void) { return g_err.c_str(); }
 const char* pgpu_device_name(void) { return g_devname.c_str(); }
+
+int pgpu_set_fixed_base_window(int w) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  if (w < 0 || w > 12) return fail(PGPU_ERR_INVALID_PARAM, "fixed-base window must be 0..12");
+  g_fb_window = w;
+  return PGPU_OK;
+}
 
 int pgpu_set_timing(int enabled) {
   g_timing = enabled != 0;
@@ -529,12 +568,51 @@ int pgpu_paillier_encrypt_dev(const pgpu_pubkey* key, const uint64_t* d_m, size_
     return fail(PGPU_ERR_INVALID_PARAM, "plaintext width/stride invalid");
   if (r_words <= 0 || r_stride < (size_t)r_words)
     return fail(PGPU_ERR_INVALID_PARAM, "random width/stride invalid");
+  if (key->djn && (r_bits < 0 || r_bits > 64 * r_words))
+    return fail(PGPU_ERR_INVALID_PARAM, "r_bits/r_words inconsistent");
+  const int fbw = fixed_base_window();
+  if (key->djn && fbw > 0) {
+    // hs is a key constant: fixed-base windowing, no squarings (kernels.hpp: fb_encrypt_kernel)
+    hipStream_t s = (hipStream_t)hip_stream;
+    const GeoInfo& geo = key->nsq->geo;
+    const int nwin = std::max(1, (r_bits + fbw - 1) / fbw);
+    if (key->fb_w != fbw || key->fb_nwin < nwin) {
+      RC_TRY(key->fb_table.ensure((size_t)nwin * ((size_t)1 << fbw) * geo.L() * sizeof(uint32_t)));
+      pgpu::FixedBaseBuildArgs b{};
+      b.ctx = key->nsq->dev;
+      b.base = (const uint64_t*)key->d_hs.p;
+      b.table = (uint32_t*)key->fb_table.p;
+      b.nwin = nwin;
+      b.w = fbw;
+      GEO_DISPATCH(launch_fb_build, geo, b, s);
+      HIP_TRY(hipGetLastError());
+      key->fb_nwin = nwin;
+      key->fb_w = fbw;
+    }
+    pgpu::FixedBaseArgs f{};
+    f.ctx = key->nsq->dev;
+    f.table = (const uint32_t*)key->fb_table.p;
+    f.nwin = nwin;
+    f.w = fbw;
+    f.exp = d_r;
+    f.exp_stride = r_stride;
+    f.exp_words = r_words;
+    f.fm_words = d_m;
+    f.fm_stride = m_stride;
+    f.fm_nwords = m_words;
+    f.out = d_c;
+    f.out_stride = (size_t)W;
+    f.count = count;
+    TimerScope t(s);
+    GEO_DISPATCH(launch_fb_encrypt, geo, f, s);
+    HIP_TRY(hipGetLastError());
+    t.stop();
+    return PGPU_OK;
+  }
   pgpu::ModexpArgs a{};
   a.ctx[0] = a.ctx[1] = key->nsq->dev;
   a.nctx = 1;
   if (key->djn) {  // hs^r: shared base, per-element exponent (pub_key.cpp:51-64)
-    if (r_bits < 0 || r_bits > 64 * r_words)
-      return fail(PGPU_ERR_INVALID_PARAM, "r_bits/r_words inconsistent");
     a.base = (const uint64_t*)key->d_hs.p;
     a.base_stride = 0;
     a.base_words = W;

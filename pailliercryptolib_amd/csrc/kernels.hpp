@@ -387,6 +387,170 @@ __global__ __launch_bounds__(kWave, GEO::K <= 9 ? 4 : 2) void modexp_kernel(Mode
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fixed-base exponentiation for the DJN obfuscator hs^r (pub_key.cpp:51-64): the base hs is a key
+// constant, so   hs^r = prod_i T[i][d_i],   T[i][d] = hs^(d * 2^(w*i)) * R mod N,   d_i = i-th
+// w-bit digit of r   -- nwin-1 multiplications and NO squarings (1024-bit r, w = 8: 127 instead
+// of 1259).  The table (nwin * 2^w entries of L limbs) is built once per key by fb_build_kernel and
+// lives in HBM / Infinity Cache; an entry is loaded straight into the lane-resident operand.
+struct FixedBaseArgs {
+  ModCtxDev ctx;         // modulus n^2 (nr set)
+  const uint32_t* table; // [nwin][2^w][L]
+  int nwin;
+  int w;
+  const uint64_t* exp;   // [count][exp_stride] the randomness r
+  size_t exp_stride;
+  int exp_words;
+  const uint64_t* fm_words;  // plaintexts [count][fm_stride]
+  size_t fm_stride;
+  int fm_nwords;
+  uint64_t* out;         // [count][out_stride]
+  size_t out_stride;
+  size_t count;
+};
+
+struct FixedBaseBuildArgs {
+  ModCtxDev ctx;
+  const uint64_t* base;  // hs, ctx.mod_words words
+  uint32_t* table;       // [nwin][2^w][L]
+  int nwin;
+  int w;
+};
+
+// instance i builds row i of the table: B = hs^(2^(w*i)) by w*i squarings, then T[i][d] = T[i][d-1]*B
+template <class GEO>
+__global__ __launch_bounds__(kWave) void fb_build_kernel(FixedBaseBuildArgs A) {
+  constexpr int K = GEO::K, L = GEO::L, G = GEO::G, IPW = GEO::IPW;
+  __shared__ uint32_t bl[IPW][L];
+  __shared__ uint64_t io[IPW][GEO::W64 + 1];
+  const int lane = threadIdx.x;
+  const int g = lane / G, x = lane % G;
+  const size_t first_inst = (size_t)blockIdx.x * IPW;
+  size_t inst = first_inst + g;
+  const bool live = inst < (size_t)A.nwin;
+  if (!live) inst = (size_t)A.nwin - 1;
+  uint32_t n[K], a[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) n[j] = A.ctx.n[x * K + j];
+  const uint32_t n0inv = A.ctx.n0inv;
+  stage_words<GEO>(io, A.base, 0, 0, A.ctx.mod_words, 0, 1, 1, lane);
+#pragma unroll
+  for (int j = 0; j < K; ++j) bl[g][x * K + j] = A.ctx.r2[x * K + j];
+  wave_lds_sync();
+#pragma unroll
+  for (int j = 0; j < K; ++j) a[j] = limb_from_words(io[g], x * K + j);
+  const int tsize = 1 << A.w;
+  // every group runs the squaring count of the LAST live instance of its wave so that control
+  // flow stays wave-uniform; a group stops updating once its own count is reached
+  const int my_sq = A.w * (int)inst;
+  size_t last = first_inst + IPW - 1;
+  if (last >= (size_t)A.nwin) last = (size_t)A.nwin - 1;
+  const int wave_sq = A.w * (int)last;
+  uint32_t* row = A.table + inst * (size_t)tsize * L + x * K;
+  // step 0: to Montgomery form; steps 1..wave_sq: squarings; then tsize-2 table multiplications
+  const int total = 1 + wave_sq + (tsize - 2);
+#pragma unroll 1
+  for (int step = 0; step < total; ++step) {
+    uint32_t r[K];
+    montmul<GEO>(r, a, bl[g], n, n0inv);
+    const bool squaring_phase = step <= wave_sq;   // result of step is hs*R (0) or a square
+    if (squaring_phase) {
+      if (step <= my_sq) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) a[j] = r[j];
+      }
+      if (step == wave_sq) {
+        // a = B_i * R: table entries 0 and 1, multiplier for the rest of the row
+        if (live) {
+#pragma unroll
+          for (int j = 0; j < K; ++j) { row[j] = A.ctx.one[x * K + j]; row[L + j] = a[j]; }
+        }
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int j = 0; j < K; ++j) bl[g][x * K + j] = a[j];
+      wave_lds_sync();
+    } else {
+      const int d = step - wave_sq + 1;   // entry index 2..tsize-1
+#pragma unroll
+      for (int j = 0; j < K; ++j) a[j] = r[j];
+      if (live) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) row[(size_t)d * L + j] = a[j];
+      }
+    }
+  }
+}
+
+template <class GEO>
+__global__ __launch_bounds__(kWave, GEO::K <= 9 ? 4 : 2) void fb_encrypt_kernel(FixedBaseArgs A) {
+  constexpr int K = GEO::K, L = GEO::L, G = GEO::G, IPW = GEO::IPW;
+  __shared__ uint32_t bl[IPW][L];
+  __shared__ uint64_t io[IPW][GEO::W64 + 1];
+  const int lane = threadIdx.x;
+  const int g = lane / G, x = lane % G;
+  const size_t first_inst = (size_t)blockIdx.x * IPW;
+  size_t inst = first_inst + g;
+  if (inst >= A.count) inst = A.count - 1;
+  uint32_t n[K], a[K], acc[K], nxt[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) n[j] = A.ctx.n[x * K + j];
+  const uint32_t n0inv = A.ctx.n0inv;
+  const int w = A.w, tsize = 1 << w;
+  const uint64_t* ep = A.exp + inst * A.exp_stride;
+  auto digit = [&](int i) -> int {
+    int bit = i * w;
+    int word = bit >> 6, sh = bit & 63;
+    uint64_t v = (word < A.exp_words) ? ep[word] >> sh : 0;
+    if (sh + w > 64 && word + 1 < A.exp_words) v |= ep[word + 1] << (64 - sh);
+    return (int)(v & (uint64_t)(tsize - 1));
+  };
+  auto load_entry = [&](uint32_t (&dst)[K], int i) {
+    const uint32_t* e = A.table + ((size_t)i * tsize + digit(i)) * L + x * K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) dst[j] = e[j];
+  };
+  // step 0: acc = m * (n*R) * R^-1 + 1 = g^m (plain domain, lazy); multiplier staged = n*R
+  stage_words<GEO>(io, A.fm_words, A.fm_stride, 0, A.fm_nwords, first_inst, A.count, 1, lane);
+#pragma unroll
+  for (int j = 0; j < K; ++j) bl[g][x * K + j] = A.ctx.nr[x * K + j];
+  wave_lds_sync();
+#pragma unroll
+  for (int j = 0; j < K; ++j) a[j] = limb_from_words(io[g], x * K + j);
+  load_entry(acc, 0);   // T[0][d_0]: the running product starts here
+  uint32_t gm[K];
+  const int nwin = A.nwin;
+  // steps: 0 (g^m), 1..nwin-1 (acc *= T[i][d_i]), nwin (acc *= g^m, leaves Montgomery form).
+  // The table entry of step+1 is fetched before the multiplication of step (latency hidden).
+#pragma unroll 1
+  for (int step = 0; step <= nwin; ++step) {
+    if (step + 1 < nwin) load_entry(nxt, step + 1);
+    uint32_t r[K];
+    montmul<GEO>(r, a, bl[g], n, n0inv);
+    if (step == nwin) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) a[j] = r[j];
+      break;
+    }
+    if (step == 0) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) gm[j] = r[j];
+      if (x == 0) gm[0] += 1;
+    } else {
+#pragma unroll
+      for (int j = 0; j < K; ++j) acc[j] = r[j];
+    }
+    // next multiplication: lane-resident operand = table entry (g^m at the end), row operand = acc
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < K; ++j) bl[g][x * K + j] = acc[j];
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = (step + 1 < nwin) ? nxt[j] : gm[j];
+  }
+  store_canonical<GEO>(a, A.ctx, bl, io, A.out, A.out_stride, first_inst, A.count, lane, g, x);
+}
+
 // out = a*b mod N: montmul(montmul(a, R^2), b) -- two Montgomery multiplications.
 template <class GEO>
 __global__ __launch_bounds__(kWave) void modmul_kernel(ModmulArgs A) {

@@ -54,6 +54,30 @@ def test_bench_key_djn(engine, kat):
     assert sk.decrypt(ct) == m
 
 
+@pytest.mark.parametrize("fbw", [0, 4, 8, 11])
+def test_djn_encrypt_generic_vs_fixed_base(engine, kat, fbw):
+    """The DJN obfuscator hs^r through the generic kernel (w=0) and through fixed-base tables of
+    several window widths must give the same bits, incl. r = 0, r = 1, short and full-width r."""
+    from pailliercryptolib_amd import _capi
+    p, q = kat["p"], kat["q"]
+    n = p * q
+    hs = kat["bench_hs"]
+    rng = random.Random(fbw)
+    r = [0, 1, (1 << 1024) - 1, kat["bench_r"], rng.getrandbits(7)] + [rng.getrandbits(1024) for _ in range(12)]
+    m = [0, n - 1] + [rng.randrange(n) for _ in range(len(r) - 2)]
+    opk = orc.PublicKey(n, 2048)
+    opk.set_djn(hs)
+    want = opk.encrypt(m, r)
+    _capi.check(_capi.lib().pgpu_set_fixed_base_window(fbw))
+    try:
+        pk = engine.PublicKey(n, 2048, hs=hs)
+        assert pk.encrypt(m[4:], r[4:]) == want[4:]          # table sized for 1024-bit r ...
+        assert pk.encrypt(m, r) == want                      # ... and regrown for the 2047-bit R_BN
+        assert pk.encrypt(m[:2], r[:2]) == want[:2]          # r in {0, 1}
+    finally:
+        _capi.check(_capi.lib().pgpu_set_fixed_base_window(8))
+
+
 def test_seeded_fixtures(engine):
     data = json.load(open(os.path.join(GOLD, "seeded_vectors.json")))
     for case in data["cases"]:
