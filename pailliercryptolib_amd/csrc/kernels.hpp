@@ -213,9 +213,10 @@ __device__ __forceinline__ void add_normalise(uint32_t (&a)[GEO::K], const uint3
 }
 
 template <class GEO>
-__global__ __launch_bounds__(kWave, GEO::K <= 9 ? 4 : 2) void modexp_kernel(ModexpArgs A) {
+__global__ __launch_bounds__(kWave, 2) void modexp_kernel(ModexpArgs A) {
   constexpr int K = GEO::K, L = GEO::L, G = GEO::G, IPW = GEO::IPW;
   __shared__ uint32_t bl[IPW][L];
+  __shared__ uint32_t bl2[IPW][L];   // doubled limbs of the operand being squared
   __shared__ uint64_t io[IPW][GEO::W64 + 1];
 
   const int lane = threadIdx.x;
@@ -288,7 +289,8 @@ __global__ __launch_bounds__(kWave, GEO::K <= 9 ? 4 : 2) void modexp_kernel(Mode
   for (int j = 0; j < K; ++j) a[j] = limb_from_words(io[g], x * K + j);
 
   for (;;) {
-    montmul<GEO>(a, a, bl[g], n, n0inv);
+    if (phase == SQR) montmul<GEO, true>(a, a, bl[g], n, n0inv, bl2[g]);
+    else montmul<GEO, false>(a, a, bl[g], n, n0inv);
     if (phase == FINAL) break;
 
     bool start_main = false;
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(kWave, GEO::K <= 9 ? 4 : 2) void modexp_kernel(Mode
     if (phase == SQR) {
       wave_lds_sync();
 #pragma unroll
-      for (int j = 0; j < K; ++j) bl[g][x * K + j] = a[j];
+      for (int j = 0; j < K; ++j) { bl[g][x * K + j] = a[j]; bl2[g][x * K + j] = a[j] << 1; }
       wave_lds_sync();
     } else if (phase == MUL) {
       int d = digit(win);
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(kWave) void fb_build_kernel(FixedBaseBuildArgs A) {
 }
 
 template <class GEO>
-__global__ __launch_bounds__(kWave, GEO::K <= 9 ? 4 : 2) void fb_encrypt_kernel(FixedBaseArgs A) {
+__global__ __launch_bounds__(kWave, 2) void fb_encrypt_kernel(FixedBaseArgs A) {
   constexpr int K = GEO::K, L = GEO::L, G = GEO::G, IPW = GEO::IPW;
   __shared__ uint32_t bl[IPW][L];
   __shared__ uint64_t io[IPW][GEO::W64 + 1];

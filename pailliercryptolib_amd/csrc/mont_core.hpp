@@ -72,21 +72,38 @@ __device__ __forceinline__ uint32_t bcast_lane0(uint32_t v) {
 //   UPC : the next K columns (become LOWC of the next block; enter as zero)
 // On exit UPC holds the new low half (old UPC + the K normalised limbs received from lane x+1)
 // and LOWC is zero, i.e. the caller swaps the roles of the two arrays for the next block.
-template <class GEO>
+// SQR = true: the multiplier rows ARE the multiplicand (a squaring).  Every cross product
+// a_X[j]*a_S[r] (lane chunk X, row block S) then occurs twice in the full square -- once in block
+// (X,S), once in block (S,X) at the same column -- so each block computes only the pairs with
+// j < r, against the doubled row limb (brow2 = 2*brow), plus the diagonal j == r once:
+//   sum_{X,S} [ sum_{j<r} 2 a_X[j] a_S[r] + sum_r a_X[r] a_S[r] ] = a^2   (rename X<->S, j<->r)
+// K(K+1)/2 MACs instead of K^2, identical instruction stream in every lane and block.
+template <class GEO, bool SQR>
 __device__ __forceinline__ void mont_block(uint64_t (&LOWC)[GEO::K], uint64_t (&UPC)[GEO::K],
                                            const uint32_t (&a)[GEO::K], const uint32_t (&n)[GEO::K],
-                                           uint32_t n0inv, const uint32_t* __restrict__ brow) {
+                                           uint32_t n0inv, const uint32_t* __restrict__ brow,
+                                           const uint32_t* __restrict__ brow2) {
   constexpr int K = GEO::K;
-  uint32_t b[K];
+  uint32_t b[K], b2[K];
 #pragma unroll
-  for (int r = 0; r < K; ++r) b[r] = brow[r];
-  // phase A: acc += a_chunk * b_rows  (K*K v_mad_u64_u32, no carries)
+  for (int r = 0; r < K; ++r) {
+    b[r] = brow[r];
+    if constexpr (SQR) b2[r] = brow2[r]; else b2[r] = 0;
+  }
+  // phase A: acc += a_chunk * b_rows  (v_mad_u64_u32 only, no carries)
 #pragma unroll
   for (int r = 0; r < K; ++r) {
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      if (r + j < K) LOWC[r + j] += (uint64_t)a[j] * b[r];
-      else UPC[r + j - K] += (uint64_t)a[j] * b[r];
+      uint64_t p;
+      if constexpr (SQR) {
+        if (j > r) continue;
+        p = (uint64_t)a[j] * (j < r ? b2[r] : b[r]);
+      } else {
+        p = (uint64_t)a[j] * b[r];
+      }
+      if (r + j < K) LOWC[r + j] += p;
+      else UPC[r + j - K] += p;
     }
   }
   // phase B: K quotient digits, each followed by acc += n_chunk * q
@@ -118,18 +135,19 @@ __device__ __forceinline__ void mont_block(uint64_t (&LOWC)[GEO::K], uint64_t (&
 
 // r = a * b * R^-1 mod N (lazy: inputs < 4N -> output < 2N), b read from LDS at bl[0..L).
 // Output limbs are < 2^29 except that limb 0 of a lane may equal 2^29 (deferred unit carry).
-template <class GEO>
+template <class GEO, bool SQR = false>
 __device__ __forceinline__ void montmul(uint32_t (&r)[GEO::K], const uint32_t (&a)[GEO::K],
                                         const uint32_t* __restrict__ bl,
-                                        const uint32_t (&n)[GEO::K], uint32_t n0inv) {
+                                        const uint32_t (&n)[GEO::K], uint32_t n0inv,
+                                        const uint32_t* __restrict__ bl2 = nullptr) {
   constexpr int K = GEO::K;
   uint64_t c0[K], c1[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) { c0[j] = 0; c1[j] = 0; }
 #pragma unroll 1
   for (int s = 0; s < GEO::G; s += 2) {
-    mont_block<GEO>(c0, c1, a, n, n0inv, bl + s * K);
-    mont_block<GEO>(c1, c0, a, n, n0inv, bl + (s + 1) * K);
+    mont_block<GEO, SQR>(c0, c1, a, n, n0inv, bl + s * K, bl2 + s * K);
+    mont_block<GEO, SQR>(c1, c0, a, n, n0inv, bl + (s + 1) * K, bl2 + (s + 1) * K);
   }
   // pass 1: local carry propagation
   uint64_t c = 0;
