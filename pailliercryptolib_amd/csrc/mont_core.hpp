@@ -67,6 +67,39 @@ __device__ __forceinline__ uint32_t bcast_lane0(uint32_t v) {
   }
 }
 
+// ---- fused DPP + mask (one VALU slot instead of v_mov_b32_dpp + v_and_b32) ----
+// hipcc does not fold a v_and into the DPP move, so these are written as v_and_b32_dpp by hand.
+// The leading s_nop 1 covers the "VALU write -> DPP read of the same VGPR" hazard (2 wait states),
+// which the compiler cannot see inside an asm statement.
+// (value of lane x+1) & m; 0 at the row end
+__device__ __forceinline__ uint32_t and_from_next(uint32_t v, uint32_t m) {
+  uint32_t r;
+  asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "=v"(r) : "v"(v), "v"(m));
+  return r;
+}
+// (value held by lane 0 of the G-lane group) & m, in every lane of the group
+template <int G>
+__device__ __forceinline__ uint32_t and_bcast_lane0(uint32_t v, uint32_t m) {
+  uint32_t r;
+  if constexpr (G == 16) {
+    asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=v"(r) : "v"(v), "v"(m));
+  } else if constexpr (G == 8) {
+    // lanes 0-7 take lane 0, lanes 8-15 take lane 8: two bank-masked broadcasts into one VGPR
+    asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_and_b32_dpp %0, %1, %2 row_newbcast:8 row_mask:0xf bank_mask:0xc bound_ctrl:1"
+        : "=&v"(r) : "v"(v), "v"(m));
+  } else if constexpr (G == 4) {
+    asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=v"(r) : "v"(v), "v"(m));
+  } else {
+    asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=v"(r) : "v"(v), "v"(m));
+  }
+  return r;
+}
+
 // One K-row block of the word-serial Montgomery product.
 //   LOWC: the K columns this lane shares with nobody below it (get reduced / passed down)
 //   UPC : the next K columns (become LOWC of the next block; enter as zero)
@@ -108,10 +141,11 @@ __device__ __forceinline__ void mont_block(uint64_t (&LOWC)[GEO::K], uint64_t (&
   }
   // phase B: K quotient digits, each followed by acc += n_chunk * q
   uint32_t recv[K];
+  uint32_t maskv = kLimbMask;
+  asm("" : "+v"(maskv));   // keep the mask in a VGPR (v_and_b32_dpp takes no literal)
 #pragma unroll
   for (int r = 0; r < K; ++r) {
-    // the 29-bit mask is applied after the DPP move so that both fuse into one v_and_b32_dpp
-    uint32_t q = bcast_lane0<GEO::G>((uint32_t)LOWC[r] * n0inv) & kLimbMask;
+    uint32_t q = and_bcast_lane0<GEO::G>((uint32_t)LOWC[r] * n0inv, maskv);
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       if (r + j < K) LOWC[r + j] += (uint64_t)n[j] * q;
@@ -121,7 +155,7 @@ __device__ __forceinline__ void mont_block(uint64_t (&LOWC)[GEO::K], uint64_t (&
     // rest carries into column r+1.  In the group's lane 0 the limb is 0 by construction of q,
     // so the top lane of the group below receives 0 and no masking is needed.
     uint64_t c = LOWC[r] >> kLimbBits;
-    recv[r] = dpp_from_next((uint32_t)LOWC[r]) & kLimbMask;
+    recv[r] = and_from_next((uint32_t)LOWC[r], maskv);
     if (r + 1 < K) LOWC[r + 1] += c;
     else UPC[0] += c;
   }
