@@ -117,10 +117,19 @@ int pgpu_paillier_decrypt_crt(const pgpu_privkey* key, const uint64_t* c, uint64
 int pgpu_paillier_decrypt_crt_dev(const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m,
                                   size_t count, void* hip_stream);
 
-/* ---- instrumentation used by bench.py (roofline): timing of the most recent kernel launch
- *      of each kind, measured with hipEvents on the stream the kernel ran on ---- */
+/* ---- instrumentation used by bench.py (roofline) ----
+ * With timing enabled every kernel launch is bracketed by two HIP events recorded on the stream
+ * the kernel is launched on (no synchronisation at launch time).  pgpu_timing_collect waits for
+ * the recorded launches, writes up to max_entries (kind, milliseconds) pairs in launch order,
+ * clears the record and returns the number written. */
+typedef enum pgpu_kernel_kind {
+  PGPU_KERNEL_MODEXP = 1,     /* modexp_kernel (generic / encrypt / decrypt stage 1) */
+  PGPU_KERNEL_MODMUL = 2,     /* modmul_kernel */
+  PGPU_KERNEL_CRT = 3,        /* crt_kernel (decrypt stage 2) */
+  PGPU_KERNEL_FB_ENCRYPT = 4  /* fb_encrypt_kernel (DJN encrypt, fixed-base) */
+} pgpu_kernel_kind;
 int pgpu_set_timing(int enabled);
-double pgpu_last_kernel_ms(void);
+int pgpu_timing_collect(int* kinds, double* ms, int max_entries);
 
 #ifdef __cplusplus
 }

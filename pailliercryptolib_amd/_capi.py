@@ -19,7 +19,7 @@ SYMBOLS = [
     "pgpu_pubkey_create", "pgpu_pubkey_destroy", "pgpu_paillier_encrypt", "pgpu_paillier_encrypt_dev",
     "pgpu_privkey_create", "pgpu_privkey_destroy", "pgpu_paillier_decrypt_crt",
     "pgpu_paillier_decrypt_crt_dev",
-    "pgpu_set_fixed_base_window", "pgpu_set_timing", "pgpu_last_kernel_ms",
+    "pgpu_set_fixed_base_window", "pgpu_set_timing", "pgpu_timing_collect",
 ]
 
 _lib = None
@@ -77,7 +77,7 @@ def lib():
     L.pgpu_paillier_decrypt_crt_dev.restype = c_int
     L.pgpu_set_fixed_base_window.argtypes = [c_int]; L.pgpu_set_fixed_base_window.restype = c_int
     L.pgpu_set_timing.argtypes = [c_int]; L.pgpu_set_timing.restype = c_int
-    L.pgpu_last_kernel_ms.argtypes = []; L.pgpu_last_kernel_ms.restype = c_double
+    L.pgpu_timing_collect.argtypes = [c_void_p, c_void_p, c_int]; L.pgpu_timing_collect.restype = c_int
     _lib = L
     return L
 

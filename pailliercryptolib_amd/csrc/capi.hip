@@ -25,9 +25,13 @@ std::recursive_mutex g_mu;
 bool g_init = false;
 int g_device = -1;
 std::string g_devname;
+// live per-launch timing (bench.py roofline): when enabled every kernel launch is bracketed by a
+// pair of HIP events recorded on the launch stream, WITHOUT synchronising; pgpu_timing_collect
+// synchronises once and returns the durations.
 bool g_timing = false;
-double g_last_ms = 0.0;
-hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+struct TimedLaunch { int kind; hipEvent_t e0, e1; };
+std::vector<TimedLaunch> g_timed;
+std::vector<hipEvent_t> g_event_pool;
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -233,52 +237,65 @@ int fixed_base_window() {
   return g_fb_window;
 }
 
+hipEvent_t pool_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
 struct TimerScope {
   hipStream_t s;
   bool on;
-  explicit TimerScope(hipStream_t st) : s(st), on(g_timing) {
-    if (on) (void)hipEventRecord(g_ev0, s);
+  TimedLaunch t{};
+  TimerScope(hipStream_t st, int kind) : s(st), on(g_timing && g_timed.size() < 65536) {
+    if (!on) return;
+    t.kind = kind;
+    t.e0 = pool_event();
+    t.e1 = pool_event();
+    (void)hipEventRecord(t.e0, s);
   }
   void stop() {
     if (!on) return;
-    (void)hipEventRecord(g_ev1, s);
-    (void)hipEventSynchronize(g_ev1);
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, g_ev0, g_ev1);
-    g_last_ms = ms;
+    (void)hipEventRecord(t.e1, s);
+    g_timed.push_back(t);
   }
 };
 
 template <int G, int K>
 void launch_modexp(const pgpu::ModexpArgs& a, hipStream_t s) {
   typedef pgpu::Geo<G, K> GEO;
-  unsigned blocks = (unsigned)((a.count + GEO::IPW - 1) / GEO::IPW);
-  hipLaunchKernelGGL((pgpu::modexp_kernel<GEO>), dim3(blocks), dim3(pgpu::kWave), 0, s, a);
+  unsigned blocks = (unsigned)((a.count + GEO::IPW * pgpu::kWavesPerWG - 1) / (GEO::IPW * pgpu::kWavesPerWG));
+  hipLaunchKernelGGL((pgpu::modexp_kernel<GEO>), dim3(blocks), dim3(pgpu::kWGThreads), 0, s, a);
 }
 template <int G, int K>
 void launch_modmul(const pgpu::ModmulArgs& a, hipStream_t s) {
   typedef pgpu::Geo<G, K> GEO;
-  unsigned blocks = (unsigned)((a.count + GEO::IPW - 1) / GEO::IPW);
-  hipLaunchKernelGGL((pgpu::modmul_kernel<GEO>), dim3(blocks), dim3(pgpu::kWave), 0, s, a);
+  unsigned blocks = (unsigned)((a.count + GEO::IPW * pgpu::kWavesPerWG - 1) / (GEO::IPW * pgpu::kWavesPerWG));
+  hipLaunchKernelGGL((pgpu::modmul_kernel<GEO>), dim3(blocks), dim3(pgpu::kWGThreads), 0, s, a);
 }
 template <int G, int K>
 void launch_crt(const pgpu::CrtArgs& a, hipStream_t s) {
   typedef pgpu::Geo<G, K> GEO;
-  unsigned blocks = (unsigned)((a.count + GEO::IPW - 1) / GEO::IPW);
-  hipLaunchKernelGGL((pgpu::crt_kernel<GEO>), dim3(blocks), dim3(pgpu::kWave), 0, s, a);
+  unsigned blocks = (unsigned)((a.count + GEO::IPW * pgpu::kWavesPerWG - 1) / (GEO::IPW * pgpu::kWavesPerWG));
+  hipLaunchKernelGGL((pgpu::crt_kernel<GEO>), dim3(blocks), dim3(pgpu::kWGThreads), 0, s, a);
 }
 
 template <int G, int K>
 void launch_fb_build(const pgpu::FixedBaseBuildArgs& a, hipStream_t s) {
   typedef pgpu::Geo<G, K> GEO;
-  unsigned blocks = (unsigned)((a.nwin + GEO::IPW - 1) / GEO::IPW);
-  hipLaunchKernelGGL((pgpu::fb_build_kernel<GEO>), dim3(blocks), dim3(pgpu::kWave), 0, s, a);
+  unsigned blocks = (unsigned)((a.nwin + GEO::IPW * pgpu::kWavesPerWG - 1) / (GEO::IPW * pgpu::kWavesPerWG));
+  hipLaunchKernelGGL((pgpu::fb_build_kernel<GEO>), dim3(blocks), dim3(pgpu::kWGThreads), 0, s, a);
 }
 template <int G, int K>
 void launch_fb_encrypt(const pgpu::FixedBaseArgs& a, hipStream_t s) {
   typedef pgpu::Geo<G, K> GEO;
-  unsigned blocks = (unsigned)((a.count + GEO::IPW - 1) / GEO::IPW);
-  hipLaunchKernelGGL((pgpu::fb_encrypt_kernel<GEO>), dim3(blocks), dim3(pgpu::kWave), 0, s, a);
+  unsigned blocks = (unsigned)((a.count + GEO::IPW * pgpu::kWavesPerWG - 1) / (GEO::IPW * pgpu::kWavesPerWG));
+  hipLaunchKernelGGL((pgpu::fb_encrypt_kernel<GEO>), dim3(blocks), dim3(pgpu::kWGThreads), 0, s, a);
 }
 
 #define GEO_DISPATCH(FN, geo, ...)                                  \
@@ -301,10 +318,11 @@ int check_ready() {
 // common launcher of modexp_kernel: sizes the window table and fills the shared fields
 int run_modexp(pgpu::ModexpArgs& a, const GeoInfo& geo, hipStream_t s) {
   a.window = pick_window(a.exp_bits);
-  size_t padded = (a.count + geo.ipw() - 1) / geo.ipw() * geo.ipw();
+  size_t per_wg = (size_t)geo.ipw() * pgpu::kWavesPerWG;
+  size_t padded = (a.count + per_wg - 1) / per_wg * per_wg;
   RC_TRY(g_table.ensure(padded * ((size_t)1 << a.window) * geo.L() * sizeof(uint32_t)));
   a.table = (uint32_t*)g_table.p;
-  TimerScope t(s);
+  TimerScope t(s, PGPU_KERNEL_MODEXP);
   GEO_DISPATCH(launch_modexp, geo, a, s);
   HIP_TRY(hipGetLastError());
   t.stop();
@@ -384,10 +402,6 @@ int pgpu_init(int device) {
   g_devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(PGPU_ERR_NO_DEVICE, "device is not gfx950: " + g_devname);
-  if (!g_ev0) {
-    HIP_TRY(hipEventCreate(&g_ev0));
-    HIP_TRY(hipEventCreate(&g_ev1));
-  }
   g_init = true;
   return PGPU_OK;
 }
@@ -399,11 +413,10 @@ void pgpu_shutdown(void) {
   g_ctx_cache.clear();
   g_table.release();
   g_vbuf.release();
-  if (g_ev0) {
-    (void)hipEventDestroy(g_ev0);
-    (void)hipEventDestroy(g_ev1);
-    g_ev0 = g_ev1 = nullptr;
-  }
+  for (auto& t : g_timed) { g_event_pool.push_back(t.e0); g_event_pool.push_back(t.e1); }
+  g_timed.clear();
+  for (hipEvent_t e : g_event_pool) (void)hipEventDestroy(e);
+  g_event_pool.clear();
   g_init = false;
 }
 
@@ -419,10 +432,28 @@ int pgpu_set_fixed_base_window(int w) {
 }
 
 int pgpu_set_timing(int enabled) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   g_timing = enabled != 0;
   return PGPU_OK;
 }
-double pgpu_last_kernel_ms(void) { return g_last_ms; }
+
+int pgpu_timing_collect(int* kinds, double* ms, int max_entries) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  int n = 0;
+  for (auto& t : g_timed) {
+    float v = 0;
+    if (hipEventSynchronize(t.e1) == hipSuccess && hipEventElapsedTime(&v, t.e0, t.e1) == hipSuccess &&
+        n < max_entries && kinds && ms) {
+      kinds[n] = t.kind;
+      ms[n] = v;
+      ++n;
+    }
+    g_event_pool.push_back(t.e0);
+    g_event_pool.push_back(t.e1);
+  }
+  g_timed.clear();
+  return n;
+}
 
 // ===================== generic modexp =====================
 int pgpu_modexp_dev(const uint64_t* d_base, size_t base_stride, const uint64_t* d_exp,
@@ -500,7 +531,7 @@ int pgpu_modmul_dev(const uint64_t* d_a, const uint64_t* d_b, size_t b_stride,
   a.out = d_out;
   a.count = count;
   hipStream_t s = (hipStream_t)hip_stream;
-  TimerScope t(s);
+  TimerScope t(s, PGPU_KERNEL_MODMUL);
   GEO_DISPATCH(launch_modmul, ctx->geo, a, s);
   HIP_TRY(hipGetLastError());
   t.stop();
@@ -603,7 +634,7 @@ int pgpu_paillier_encrypt_dev(const pgpu_pubkey* key, const uint64_t* d_m, size_
     f.out = d_c;
     f.out_stride = (size_t)W;
     f.count = count;
-    TimerScope t(s);
+    TimerScope t(s, PGPU_KERNEL_FB_ENCRYPT);
     GEO_DISPATCH(launch_fb_encrypt, geo, f, s);
     HIP_TRY(hipGetLastError());
     t.stop();
@@ -809,8 +840,10 @@ int pgpu_paillier_decrypt_crt_dev(const pgpu_privkey* key, const uint64_t* d_c, 
   c.out = d_m;
   c.out_words = nw;
   c.count = count;
+  TimerScope tc(s, PGPU_KERNEL_CRT);
   GEO_DISPATCH(launch_crt, key->geo_crt, c, s);
   HIP_TRY(hipGetLastError());
+  tc.stop();
   return PGPU_OK;
 }
 

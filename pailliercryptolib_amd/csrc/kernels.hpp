@@ -96,8 +96,17 @@ struct CrtArgs {
   size_t count;
 };
 
-// wave-level LDS hand-off (workgroup == one wavefront)
-__device__ __forceinline__ void wave_lds_sync() { __syncthreads(); }
+// Workgroups are kWavesPerWG independent wavefronts (one per SIMD of a CU, for even SIMD load);
+// each wavefront owns its slice of the LDS arrays and never talks to the others, so the LDS
+// hand-off is wave-scope: LDS executes one wave's instructions in order, only the compiler must
+// not reorder across the hand-off (no s_barrier).
+constexpr int kWavesPerWG = 4;
+constexpr int kWGThreads = kWave * kWavesPerWG;
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // limbs (any lazy form) -> canonical 64-bit words in io[g][0..W64], zero padded
 template <class GEO>
@@ -213,15 +222,18 @@ __device__ __forceinline__ void add_normalise(uint32_t (&a)[GEO::K], const uint3
 }
 
 template <class GEO>
-__global__ __launch_bounds__(kWave, 2) void modexp_kernel(ModexpArgs A) {
+__global__ __launch_bounds__(kWGThreads, 2) void modexp_kernel(ModexpArgs A) {
   constexpr int K = GEO::K, L = GEO::L, G = GEO::G, IPW = GEO::IPW;
-  __shared__ uint32_t bl[IPW][L];
-  __shared__ uint32_t bl2[IPW][L];   // doubled limbs of the operand being squared
-  __shared__ uint64_t io[IPW][GEO::W64 + 1];
+  __shared__ uint32_t bl_[kWavesPerWG][IPW][L];
+  __shared__ uint32_t bl2_[kWavesPerWG][IPW][L];   // doubled limbs of the operand being squared
+  __shared__ uint64_t io_[kWavesPerWG][IPW][GEO::W64 + 1];
 
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  auto& bl = bl_[wv];
+  auto& bl2 = bl2_[wv];
+  auto& io = io_[wv];
   const int g = lane / G, x = lane % G;
-  const size_t first_inst = (size_t)blockIdx.x * IPW;
+  const size_t first_inst = ((size_t)blockIdx.x * kWavesPerWG + wv) * IPW;
   size_t inst = first_inst + g;
   const size_t tinst = inst;                 // table slot (padded instances own a slot too)
   if (inst >= A.count) inst = A.count - 1;   // padded lanes recompute the last element
@@ -421,13 +433,15 @@ struct FixedBaseBuildArgs {
 
 // instance i builds row i of the table: B = hs^(2^(w*i)) by w*i squarings, then T[i][d] = T[i][d-1]*B
 template <class GEO>
-__global__ __launch_bounds__(kWave) void fb_build_kernel(FixedBaseBuildArgs A) {
+__global__ __launch_bounds__(kWGThreads) void fb_build_kernel(FixedBaseBuildArgs A) {
   constexpr int K = GEO::K, L = GEO::L, G = GEO::G, IPW = GEO::IPW;
-  __shared__ uint32_t bl[IPW][L];
-  __shared__ uint64_t io[IPW][GEO::W64 + 1];
-  const int lane = threadIdx.x;
+  __shared__ uint32_t bl_[kWavesPerWG][IPW][L];
+  __shared__ uint64_t io_[kWavesPerWG][IPW][GEO::W64 + 1];
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  auto& bl = bl_[wv];
+  auto& io = io_[wv];
   const int g = lane / G, x = lane % G;
-  const size_t first_inst = (size_t)blockIdx.x * IPW;
+  const size_t first_inst = ((size_t)blockIdx.x * kWavesPerWG + wv) * IPW;
   size_t inst = first_inst + g;
   const bool live = inst < (size_t)A.nwin;
   if (!live) inst = (size_t)A.nwin - 1;
@@ -485,13 +499,15 @@ __global__ __launch_bounds__(kWave) void fb_build_kernel(FixedBaseBuildArgs A) {
 }
 
 template <class GEO>
-__global__ __launch_bounds__(kWave, 2) void fb_encrypt_kernel(FixedBaseArgs A) {
+__global__ __launch_bounds__(kWGThreads, 2) void fb_encrypt_kernel(FixedBaseArgs A) {
   constexpr int K = GEO::K, L = GEO::L, G = GEO::G, IPW = GEO::IPW;
-  __shared__ uint32_t bl[IPW][L];
-  __shared__ uint64_t io[IPW][GEO::W64 + 1];
-  const int lane = threadIdx.x;
+  __shared__ uint32_t bl_[kWavesPerWG][IPW][L];
+  __shared__ uint64_t io_[kWavesPerWG][IPW][GEO::W64 + 1];
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  auto& bl = bl_[wv];
+  auto& io = io_[wv];
   const int g = lane / G, x = lane % G;
-  const size_t first_inst = (size_t)blockIdx.x * IPW;
+  const size_t first_inst = ((size_t)blockIdx.x * kWavesPerWG + wv) * IPW;
   size_t inst = first_inst + g;
   if (inst >= A.count) inst = A.count - 1;
   uint32_t n[K], a[K], acc[K], nxt[K];
@@ -555,13 +571,15 @@ __global__ __launch_bounds__(kWave, 2) void fb_encrypt_kernel(FixedBaseArgs A) {
 
 // out = a*b mod N: montmul(montmul(a, R^2), b) -- two Montgomery multiplications.
 template <class GEO>
-__global__ __launch_bounds__(kWave) void modmul_kernel(ModmulArgs A) {
+__global__ __launch_bounds__(kWGThreads) void modmul_kernel(ModmulArgs A) {
   constexpr int K = GEO::K, L = GEO::L, G = GEO::G, IPW = GEO::IPW;
-  __shared__ uint32_t bl[IPW][L];
-  __shared__ uint64_t io[IPW][GEO::W64 + 1];
-  const int lane = threadIdx.x;
+  __shared__ uint32_t bl_[kWavesPerWG][IPW][L];
+  __shared__ uint64_t io_[kWavesPerWG][IPW][GEO::W64 + 1];
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  auto& bl = bl_[wv];
+  auto& io = io_[wv];
   const int g = lane / G, x = lane % G;
-  const size_t first_inst = (size_t)blockIdx.x * IPW;
+  const size_t first_inst = ((size_t)blockIdx.x * kWavesPerWG + wv) * IPW;
 
   uint32_t n[K], a[K];
 #pragma unroll
@@ -595,15 +613,19 @@ __global__ __launch_bounds__(kWave) void modmul_kernel(ModmulArgs A) {
 //   mp = Zp * p^-1 mod M  (exact division, M coprime to p, M > p)         likewise mq
 //   u  = (mq - mp) * (p^-1 mod q) mod q,  m = mp + u*p  (u*p as an exact product mod M > n)
 template <class GEO>
-__global__ __launch_bounds__(kWave) void crt_kernel(CrtArgs A) {
+__global__ __launch_bounds__(kWGThreads) void crt_kernel(CrtArgs A) {
   constexpr int K = GEO::K, L = GEO::L, G = GEO::G, IPW = GEO::IPW, W64 = GEO::W64;
-  __shared__ uint32_t bl[IPW][L];
-  __shared__ uint64_t io[IPW][W64 + 1];    // working value
-  __shared__ uint64_t ymp[IPW][W64 + 1];   // mp
-  __shared__ uint64_t tmp[IPW][W64 + 1];   // scratch / mq
-  const int lane = threadIdx.x;
+  __shared__ uint32_t bl_[kWavesPerWG][IPW][L];
+  __shared__ uint64_t io_[kWavesPerWG][IPW][W64 + 1];    // working value
+  __shared__ uint64_t ymp_[kWavesPerWG][IPW][W64 + 1];   // mp
+  __shared__ uint64_t tmp_[kWavesPerWG][IPW][W64 + 1];   // scratch / mq
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  auto& bl = bl_[wv];
+  auto& io = io_[wv];
+  auto& ymp = ymp_[wv];
+  auto& tmp = tmp_[wv];
   const int g = lane / G, x = lane % G;
-  const size_t first_inst = (size_t)blockIdx.x * IPW;
+  const size_t first_inst = ((size_t)blockIdx.x * kWavesPerWG + wv) * IPW;
   size_t inst = first_inst + g;
   if (inst >= A.count) inst = A.count - 1;
   const int vw = A.vw;
