@@ -253,7 +253,8 @@ def cpu_baseline(n, p, q, hs, m_host, r_host):
     from pailliercryptolib_amd.limbs import ints_to_limbs
     nw, pw = m_host.shape[1], r_host.shape[1]
     sk = orc.PrivateKey(n, p, q)
-    threads = c_oracle.lib().orc_max_threads()
+    threads = min(c_oracle.lib().orc_max_threads(), c_oracle.usable_cpus())   # honours the cgroup CPU quota
+    c_oracle.set_threads(threads)
     args = [ints_to_limbs([v], pw)[0] for v in (sk.p, sk.q, sk.hp, sk.hq, sk.pinv)]
     n_l, hs_l = ints_to_limbs([n], nw)[0], ints_to_limbs([hs], 2 * nw)[0]
 
@@ -271,7 +272,8 @@ def cpu_baseline(n, p, q, hs, m_host, r_host):
     dt = run(S)
     return {"value": round(3 * S / dt, 1), "unit": "modexps/s", "cores": threads, "kind": "port",
             "sample": f"first {S} elements of the same batch, encrypt + CRT decrypt ({3 * S} modexps) "
-                      f"in {dt:.1f} s; oracle/modexp_oracle.c, gcc -O3 -fopenmp",
+                      f"in {dt:.1f} s; oracle/modexp_oracle.c, gcc -O3 -fopenmp; {threads} OpenMP threads = "
+                      f"min(affinity {len(os.sched_getaffinity(0))}, cgroup cpu quota {c_oracle.usable_cpus()})",
             "lib": os.path.basename(c_oracle.lib()._path)}
 
 

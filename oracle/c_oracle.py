@@ -35,9 +35,26 @@ def lib():
         L.orc_paillier_encrypt.argtypes = [vp, i, vp, vp, i, vp, i, vp, sz]
         L.orc_paillier_decrypt_crt.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, sz]
         L.orc_max_threads.restype = i
+        L.orc_set_threads.argtypes = [i]
         _lib = L
         _lib._path = path
     return _lib
+
+
+def usable_cpus():
+    """CPUs this process may actually use: min(affinity mask, cgroup v2 cpu.max quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
 
 
 def _p(a):

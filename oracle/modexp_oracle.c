@@ -311,6 +311,15 @@ int orc_paillier_decrypt_crt(const u64* p, const u64* q, int pw, const u64* hp, 
   return 0;
 }
 
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+  extern void omp_set_num_threads(int);
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
   extern int omp_get_max_threads(void);
