@@ -17,6 +17,14 @@ _initialized = False
 def initialize(device=None):
     """ipcl::initializeContext counterpart (utils/context.cpp:40-55): bind this process to one GPU."""
     global _initialized
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; if torch is going to
+    # share this process it must bring the runtime up first (the library then binds to the same one).
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     L = _capi.lib()
     _capi.check(L.pgpu_init(-1 if device is None else int(device)))
     _initialized = True
