@@ -140,7 +140,6 @@ __device__ __forceinline__ void mont_block(uint64_t (&LOWC)[GEO::K], uint64_t (&
     }
   }
   // phase B: K quotient digits, each followed by acc += n_chunk * q
-  uint32_t recv[K];
   uint32_t maskv = kLimbMask;
   asm("" : "+v"(maskv));   // keep the mask in a VGPR (v_and_b32_dpp takes no literal)
 #pragma unroll
@@ -151,20 +150,19 @@ __device__ __forceinline__ void mont_block(uint64_t (&LOWC)[GEO::K], uint64_t (&
       if (r + j < K) LOWC[r + j] += (uint64_t)n[j] * q;
       else UPC[r + j - K] += (uint64_t)n[j] * q;
     }
-    // column r is final: its 29-bit limb goes down to lane x-1 (whose window overlaps it), the
-    // rest carries into column r+1.  In the group's lane 0 the limb is 0 by construction of q,
-    // so the top lane of the group below receives 0 and no masking is needed.
+    // column r is final: its 29-bit limb belongs to lane x-1, whose window overlaps it at its
+    // column K+r -- so every lane adds the limb it receives from lane x+1 straight into UPC[r]
+    // (window slide, no deferred copies); the rest carries into column r+1.  In the group's
+    // lane 0 the limb is 0 by construction of q, so the top lane of the group below receives 0
+    // and no masking is needed.
     uint64_t c = LOWC[r] >> kLimbBits;
-    recv[r] = and_from_next((uint32_t)LOWC[r], maskv);
+    UPC[r] += and_from_next((uint32_t)LOWC[r], maskv);
     if (r + 1 < K) LOWC[r + 1] += c;
     else UPC[0] += c;
   }
-  // phase C: slide the window down K columns
+  // the low half is consumed; it becomes the (zero) upper half of the next block
 #pragma unroll
-  for (int j = 0; j < K; ++j) {
-    UPC[j] += recv[j];
-    LOWC[j] = 0;
-  }
+  for (int j = 0; j < K; ++j) LOWC[j] = 0;
 }
 
 // r = a * b * R^-1 mod N (lazy: inputs < 4N -> output < 2N), b read from LDS at bl[0..L).
