@@ -300,7 +300,10 @@ void launch_fb_encrypt(const pgpu::FixedBaseArgs& a, hipStream_t s) {
 
 #define GEO_DISPATCH(FN, geo, ...)                                  \
   do {                                                              \
-    if (geo.G == 2 && geo.K == 9) FN<2, 9>(__VA_ARGS__);            \
+    if (geo.G == 2 && geo.K == 18) FN<2, 18>(__VA_ARGS__);          \
+    else if (geo.G == 4 && geo.K == 18) FN<4, 18>(__VA_ARGS__);     \
+    else if (geo.G == 8 && geo.K == 18) FN<8, 18>(__VA_ARGS__);     \
+    else if (geo.G == 2 && geo.K == 9) FN<2, 9>(__VA_ARGS__);       \
     else if (geo.G == 4 && geo.K == 9) FN<4, 9>(__VA_ARGS__);       \
     else if (geo.G == 4 && geo.K == 14) FN<4, 14>(__VA_ARGS__);     \
     else if (geo.G == 8 && geo.K == 9) FN<8, 9>(__VA_ARGS__);       \
@@ -310,13 +313,27 @@ void launch_fb_encrypt(const pgpu::FixedBaseArgs& a, hipStream_t s) {
     else FN<16, 18>(__VA_ARGS__);                                   \
   } while (0)
 
+// A context built for (G, 9) also serves the "wide" split (G/2, 18): same L, same R, same limb
+// arrays, half the lanes per exponentiation and twice the limbs per lane -- the per-row support
+// instructions are amortised over twice as many MACs.  It only pays when the batch still gives
+// every SIMD at least two wavefronts (v_mad_u64_u32 needs >= 2 waves/SIMD to issue at full rate).
+constexpr size_t kMinWavesForWide = 2 * 256 * 4;
+GeoInfo launch_geo(const GeoInfo& geo, size_t count) {
+  static const bool allow = [] { const char* e = std::getenv("PGPU_WIDE"); return !e || std::atoi(e) != 0; }();
+  if (!allow || geo.K != 9 || geo.G < 4) return geo;
+  GeoInfo wide{geo.G / 2, 18};
+  size_t waves = (count + wide.ipw() - 1) / wide.ipw();
+  return waves >= kMinWavesForWide ? wide : geo;
+}
+
 int check_ready() {
   if (!g_init) return fail(PGPU_ERR_NO_DEVICE, "pgpu_init has not been called (no GPU context)");
   return PGPU_OK;
 }
 
 // common launcher of modexp_kernel: sizes the window table and fills the shared fields
-int run_modexp(pgpu::ModexpArgs& a, const GeoInfo& geo, hipStream_t s) {
+int run_modexp(pgpu::ModexpArgs& a, const GeoInfo& ctx_geo, hipStream_t s) {
+  const GeoInfo geo = launch_geo(ctx_geo, a.count);
   a.window = pick_window(a.exp_bits);
   size_t per_wg = (size_t)geo.ipw() * pgpu::kWavesPerWG;
   size_t padded = (a.count + per_wg - 1) / per_wg * per_wg;
@@ -532,7 +549,8 @@ int pgpu_modmul_dev(const uint64_t* d_a, const uint64_t* d_b, size_t b_stride,
   a.count = count;
   hipStream_t s = (hipStream_t)hip_stream;
   TimerScope t(s, PGPU_KERNEL_MODMUL);
-  GEO_DISPATCH(launch_modmul, ctx->geo, a, s);
+  const GeoInfo lgeo = launch_geo(ctx->geo, count);
+  GEO_DISPATCH(launch_modmul, lgeo, a, s);
   HIP_TRY(hipGetLastError());
   t.stop();
   return PGPU_OK;
@@ -635,7 +653,8 @@ int pgpu_paillier_encrypt_dev(const pgpu_pubkey* key, const uint64_t* d_m, size_
     f.out_stride = (size_t)W;
     f.count = count;
     TimerScope t(s, PGPU_KERNEL_FB_ENCRYPT);
-    GEO_DISPATCH(launch_fb_encrypt, geo, f, s);
+    const GeoInfo lgeo = launch_geo(geo, count);
+    GEO_DISPATCH(launch_fb_encrypt, lgeo, f, s);
     HIP_TRY(hipGetLastError());
     t.stop();
     return PGPU_OK;

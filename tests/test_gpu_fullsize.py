@@ -122,3 +122,27 @@ def test_config5_add_and_mul_131072(engine, iso):
     c2 = T.encrypt(pk, T.to_device(m2), T.to_device(rand_rows(rng, 2048, 16)))
     got = limbs_to_ints(T.to_host(T.decrypt(sk, T.mod_mul(c1, c2, nsq))))
     assert got == [(x + y) % n for x, y in zip(limbs_to_ints(m1), limbs_to_ints(m2))]
+
+
+@pytest.mark.parametrize("mod_bits,count", [(1024, 140000), (2048, 70000), (4096, 33000)])
+def test_wide_geometries_large_batches(engine, mod_bits, count):
+    """Batches large enough that the launcher picks the wide split (G/2 lanes x 18 limbs) of the
+    modulus context: Geo<2,18>, Geo<4,18>, Geo<8,18>.  Short exponents keep it fast; checked against
+    the oracle on samples and through a^(e1+e2) == a^e1 * a^e2 on the whole batch."""
+    import torch
+    from pailliercryptolib_amd import torch_ops as T
+    from pailliercryptolib_amd.limbs import limbs_to_ints
+    rng = np.random.default_rng(mod_bits)
+    pyrng = random.Random(mod_bits)
+    mod = pyrng.getrandbits(mod_bits) | (1 << (mod_bits - 1)) | 1
+    W = mod_bits // 64
+    a = rand_rows(rng, count, W, (1 << 62) - 1)
+    e1 = rand_rows(rng, count, 1, (1 << 20) - 1)
+    e2 = rand_rows(rng, count, 1, (1 << 20) - 1)
+    d_a = T.to_device(a)
+    p1 = T.mod_exp(d_a, T.to_device(e1), mod, exp_bits=20)
+    p2 = T.mod_exp(d_a, T.to_device(e2), mod, exp_bits=20)
+    p12 = T.mod_exp(d_a, T.to_device(e1 + e2), mod, exp_bits=21)
+    assert torch.equal(T.mod_mul(p1, p2, mod), p12)
+    idx = [0, count - 1] + pyrng.sample(range(count), 6)
+    assert limbs_to_ints(T.to_host(p1[idx])) == [pow(x % mod, int(e), mod) for x, e in zip(limbs_to_ints(a[idx]), e1[idx, 0])]

@@ -46,3 +46,5 @@ run(4096, 2048, 8192, True)
 run(1024, 512, 16384, True)
 run(6144, 1536, 8192, False)
 run(4096, 32, 65536, False)
+run(2048, 1024, 65536, True)
+run(4096, 1024, 65536, False)
