@@ -235,7 +235,7 @@ def main():
                 },
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # reported at N=1 only (rank 0)
             result["cpu_baseline"] = cpu_baseline(n, p, q, hs, m_host, r_host)
         print(json.dumps(result), flush=True)
     if world > 1:
