@@ -326,6 +326,8 @@ GeoInfo launch_geo(const GeoInfo& geo, size_t count) {
   return waves >= kMinWavesForWide ? wide : geo;
 }
 
+uint64_t* g_wave_clocks_ptr();
+
 int check_ready() {
   if (!g_init) return fail(PGPU_ERR_NO_DEVICE, "pgpu_init has not been called (no GPU context)");
   return PGPU_OK;
@@ -339,6 +341,7 @@ int run_modexp(pgpu::ModexpArgs& a, const GeoInfo& ctx_geo, hipStream_t s) {
   size_t padded = (a.count + per_wg - 1) / per_wg * per_wg;
   RC_TRY(g_table.ensure(padded * ((size_t)1 << a.window) * geo.L() * sizeof(uint32_t)));
   a.table = (uint32_t*)g_table.p;
+  a.wave_clocks = g_wave_clocks_ptr();
   TimerScope t(s, PGPU_KERNEL_MODEXP);
   GEO_DISPATCH(launch_modexp, geo, a, s);
   HIP_TRY(hipGetLastError());
@@ -447,6 +450,14 @@ int pgpu_set_fixed_base_window(int w) {
   g_fb_window = w;
   return PGPU_OK;
 }
+
+// diagnostics (tools/wave_spread.py): device buffer that receives per-wave start/end clocks of the
+// next modexp_kernel launches; null switches it off.  Not part of the public header.
+uint64_t* g_wave_clocks = nullptr;
+extern "C" void pgpu_debug_set_wave_clocks(uint64_t* d_buf) { g_wave_clocks = d_buf; }
+}  // extern "C" (reopened below)
+namespace { uint64_t* g_wave_clocks_ptr() { return g_wave_clocks; } }
+extern "C" {
 
 int pgpu_set_timing(int enabled) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);

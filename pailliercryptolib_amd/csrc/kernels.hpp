@@ -61,6 +61,8 @@ struct ModexpArgs {
   size_t out_stride;
   uint32_t* table;       // [count rounded up to IPW][2^w][L] workspace
   size_t count;          // number of instances (= 2 * ciphertexts when nctx == 2)
+  uint64_t* wave_clocks; // optional diagnostics (tools/wave_spread.py): [waves][3] = start, end
+                         // (s_memtime ticks), XCC id | HW_ID << 8
 };
 
 struct ModmulArgs {
@@ -238,6 +240,7 @@ __global__ __launch_bounds__(kWGThreads, 2) void modexp_kernel(ModexpArgs A) {
   const size_t tinst = inst;                 // table slot (padded instances own a slot too)
   if (inst >= A.count) inst = A.count - 1;   // padded lanes recompute the last element
   const int nctx = A.nctx;
+  const uint64_t t_start = A.wave_clocks ? __builtin_readcyclecounter() : 0;
   const bool second = (nctx == 2) && (inst & 1);   // explicit selects: no dynamic arg indexing
   ModCtxDev C;
   C.n = second ? A.ctx[1].n : A.ctx[0].n;
@@ -398,6 +401,14 @@ __global__ __launch_bounds__(kWGThreads, 2) void modexp_kernel(ModexpArgs A) {
     int gg = t / mw, ww = t % mw;
     size_t oi = first_inst + gg;
     if (oi < A.count) A.out[oi * A.out_stride + ww] = io[gg][ww];
+  }
+  if (A.wave_clocks && lane == 0) {
+    uint64_t* rec = A.wave_clocks + ((size_t)blockIdx.x * kWavesPerWG + wv) * 3;
+    rec[0] = t_start;
+    rec[1] = __builtin_readcyclecounter();
+    uint64_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID
+    uint64_t hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+    rec[2] = xcc | (hwid << 8);
   }
 }
 
