@@ -146,3 +146,27 @@ def test_wide_geometries_large_batches(engine, mod_bits, count):
     assert torch.equal(T.mod_mul(p1, p2, mod), p12)
     idx = [0, count - 1] + pyrng.sample(range(count), 6)
     assert limbs_to_ints(T.to_host(p1[idx])) == [pow(x % mod, int(e), mod) for x, e in zip(limbs_to_ints(a[idx]), e1[idx, 0])]
+
+
+def test_wide_split_in_fused_encrypt_and_decrypt(engine, iso):
+    """16384 ciphertexts: the fixed-base encrypt launches as Geo<8,18> and the two-context decrypt as
+    Geo<4,18> (wide splits); same round-trip / oracle checks as at 8192."""
+    import torch
+    from pailliercryptolib_amd import torch_ops as T
+    from pailliercryptolib_amd.limbs import limbs_to_ints
+    p, q, hs = iso
+    n = p * q
+    pk, sk = engine.PublicKey(n, 2048, hs=hs), engine.PrivateKey(p, q)
+    rng = np.random.default_rng(16384)
+    N = 16384
+    m = rand_rows(rng, N, 32, (1 << 62) - 1)
+    r = rand_rows(rng, N, 16)
+    d_m = T.to_device(m)
+    d_c = T.encrypt(pk, d_m, T.to_device(r))
+    assert torch.equal(T.decrypt(sk, d_c), d_m)
+    opk = orc.PublicKey(n, 2048)
+    opk.set_djn(hs)
+    idx = [0, N - 1, 12345]
+    assert limbs_to_ints(T.to_host(d_c[idx])) == opk.encrypt(limbs_to_ints(m[idx]), limbs_to_ints(r[idx]))
+    # and the narrow split on a prefix gives the same ciphertexts
+    assert torch.equal(T.encrypt(pk, d_m[:4096].contiguous(), T.to_device(r[:4096])), d_c[:4096])
