@@ -31,6 +31,9 @@ class CipherText : public BaseText {
   CipherText rotate(int shift) const;
 
  private:
+  friend class PublicKey;
+  CipherText(const PublicKey& pk, std::shared_ptr<detail::DeviceBatch> dev);
+  CipherText(std::shared_ptr<PublicKey> pk, std::shared_ptr<detail::DeviceBatch> dev);
   std::shared_ptr<PublicKey> m_pk;
 };
 

@@ -28,6 +28,10 @@ class PlainText : public BaseText {
   CipherText operator+(const CipherText& other) const;  // PT + CT
   CipherText operator*(const CipherText& other) const;  // PT * CT
   PlainText rotate(int shift) const;
+
+ private:
+  friend class PrivateKey;
+  explicit PlainText(std::shared_ptr<detail::DeviceBatch> dev);
 };
 
 }  // namespace ipcl

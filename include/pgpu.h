@@ -117,6 +117,14 @@ int pgpu_paillier_decrypt_crt(const pgpu_privkey* key, const uint64_t* c, uint64
 int pgpu_paillier_decrypt_crt_dev(const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m,
                                   size_t count, void* hip_stream);
 
+/* ---- device buffers for callers that do not link the HIP runtime themselves ----
+ * (the C++ ipcl:: layer keeps ciphertext batches resident in HBM between operations and feeds
+ * them to the *_dev entry points on the default stream).  Copies are synchronous. */
+int pgpu_dev_alloc(size_t bytes, void** out);
+void pgpu_dev_free(void* d_ptr);
+int pgpu_copy_h2d(void* d_dst, const void* h_src, size_t bytes);
+int pgpu_copy_d2h(void* h_dst, const void* d_src, size_t bytes);
+
 /* ---- instrumentation used by bench.py (roofline) ----
  * With timing enabled every kernel launch is bracketed by two HIP events recorded on the stream
  * the kernel is launched on (no synchronisation at launch time).  pgpu_timing_collect waits for

@@ -19,6 +19,7 @@ SYMBOLS = [
     "pgpu_pubkey_create", "pgpu_pubkey_destroy", "pgpu_paillier_encrypt", "pgpu_paillier_encrypt_dev",
     "pgpu_privkey_create", "pgpu_privkey_destroy", "pgpu_paillier_decrypt_crt",
     "pgpu_paillier_decrypt_crt_dev",
+    "pgpu_dev_alloc", "pgpu_dev_free", "pgpu_copy_h2d", "pgpu_copy_d2h",
     "pgpu_set_fixed_base_window", "pgpu_set_timing", "pgpu_timing_collect",
 ]
 
@@ -75,6 +76,10 @@ def lib():
     L.pgpu_paillier_decrypt_crt.restype = c_int
     L.pgpu_paillier_decrypt_crt_dev.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
     L.pgpu_paillier_decrypt_crt_dev.restype = c_int
+    L.pgpu_dev_alloc.argtypes = [c_size_t, POINTER(c_void_p)]; L.pgpu_dev_alloc.restype = c_int
+    L.pgpu_dev_free.argtypes = [c_void_p]; L.pgpu_dev_free.restype = None
+    L.pgpu_copy_h2d.argtypes = [c_void_p, c_void_p, c_size_t]; L.pgpu_copy_h2d.restype = c_int
+    L.pgpu_copy_d2h.argtypes = [c_void_p, c_void_p, c_size_t]; L.pgpu_copy_d2h.restype = c_int
     L.pgpu_set_fixed_base_window.argtypes = [c_int]; L.pgpu_set_fixed_base_window.restype = c_int
     L.pgpu_set_timing.argtypes = [c_int]; L.pgpu_set_timing.restype = c_int
     L.pgpu_timing_collect.argtypes = [c_void_p, c_void_p, c_int]; L.pgpu_timing_collect.restype = c_int

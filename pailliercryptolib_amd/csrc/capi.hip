@@ -327,6 +327,7 @@ GeoInfo launch_geo(const GeoInfo& geo, size_t count) {
 }
 
 uint64_t* g_wave_clocks_ptr();
+void pool_release_all();
 
 int check_ready() {
   if (!g_init) return fail(PGPU_ERR_NO_DEVICE, "pgpu_init has not been called (no GPU context)");
@@ -349,27 +350,58 @@ int run_modexp(pgpu::ModexpArgs& a, const GeoInfo& ctx_geo, hipStream_t s) {
   return PGPU_OK;
 }
 
-// staging helper for the synchronous host-pointer entry points
-struct DevBuf {
-  void* p = nullptr;
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
+// Host <-> device copies go through a persistent pinned staging buffer: hipMemcpy straight from
+// pageable memory takes an erratic 10+ ms for transfers just above 1 MiB (user-pointer pinning),
+// measured with tests/cpp/ipcl_bench.cpp; a pinned bounce buffer is steady at PCIe speed.
+constexpr size_t kStageBytes = (size_t)8 << 20;
+void* g_stage[2] = {nullptr, nullptr};
+int ensure_stage() {
+  for (int i = 0; i < 2; ++i)
+    if (!g_stage[i]) HIP_TRY(hipHostMalloc(&g_stage[i], kStageBytes, hipHostMallocDefault));
+  return PGPU_OK;
+}
+int staged_h2d(void* d_dst, const void* h_src, size_t bytes) {
+  RC_TRY(ensure_stage());
+  size_t off = 0;
+  int buf = 0;
+  while (off < bytes) {
+    size_t n = std::min(kStageBytes, bytes - off);
+    std::memcpy(g_stage[buf], (const char*)h_src + off, n);
+    HIP_TRY(hipMemcpyAsync((char*)d_dst + off, g_stage[buf], n, hipMemcpyHostToDevice, nullptr));
+    off += n;
+    buf ^= 1;
+    if (off < bytes && off >= 2 * kStageBytes) HIP_TRY(hipStreamSynchronize(nullptr));  // buffer reuse
   }
-  int alloc(size_t bytes) {
-    HIP_TRY(hipMalloc(&p, bytes ? bytes : 8));
-    return PGPU_OK;
-  }
-  int from_host(const void* src, size_t bytes) {
-    RC_TRY(alloc(bytes));
-    HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
-    return PGPU_OK;
-  }
-  int to_host(void* dst, size_t bytes) {
-    hipError_t e = hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return PGPU_OK;
+}
+int staged_d2h(void* h_dst, const void* d_src, size_t bytes) {
+  RC_TRY(ensure_stage());
+  size_t off = 0;
+  while (off < bytes) {
+    size_t n = std::min(kStageBytes, bytes - off);
+    hipError_t e = hipMemcpyAsync(g_stage[0], (const char*)d_src + off, n, hipMemcpyDeviceToHost, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess)
       return fail(PGPU_ERR_HIP, std::string("kernel / D2H copy failed: ") + hipGetErrorString(e));
-    return PGPU_OK;
+    std::memcpy((char*)h_dst + off, g_stage[0], n);
+    off += n;
   }
+  return PGPU_OK;
+}
+
+// staging helper for the synchronous host-pointer entry points
+struct DevBuf {   // staging buffers come from the caching allocator (pgpu_dev_alloc)
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) pgpu_dev_free(p);
+  }
+  int alloc(size_t bytes) { return pgpu_dev_alloc(bytes, &p); }
+  int from_host(const void* src, size_t bytes) {
+    RC_TRY(alloc(bytes));
+    return staged_h2d(p, src, bytes);
+  }
+  int to_host(void* dst, size_t bytes) { return staged_d2h(dst, p, bytes); }
 };
 
 }  // namespace
@@ -433,6 +465,11 @@ void pgpu_shutdown(void) {
   g_ctx_cache.clear();
   g_table.release();
   g_vbuf.release();
+  pool_release_all();
+  for (int i = 0; i < 2; ++i) {
+    if (g_stage[i]) (void)hipHostFree(g_stage[i]);
+    g_stage[i] = nullptr;
+  }
   for (auto& t : g_timed) { g_event_pool.push_back(t.e0); g_event_pool.push_back(t.e1); }
   g_timed.clear();
   for (hipEvent_t e : g_event_pool) (void)hipEventDestroy(e);
@@ -481,6 +518,72 @@ int pgpu_timing_collect(int* kinds, double* ms, int max_entries) {
   }
   g_timed.clear();
   return n;
+}
+
+// ===================== device buffers =====================
+// Caching allocator: batches come and go at the same few sizes, and hipMalloc/hipFree of > 1 MiB
+// blocks cost milliseconds (hipFree also synchronises the device).  Freed blocks are kept in
+// per-size free lists (sizes rounded to 64 KiB) and handed out again; all work on them is stream
+// ordered on the default stream, so reuse is safe.  At most kPoolCap bytes are kept idle.
+namespace {
+constexpr size_t kPoolGranule = 64 * 1024, kPoolCap = (size_t)4 << 30;
+std::map<size_t, std::vector<void*>> g_pool_free;
+std::map<void*, size_t> g_pool_size;   // live + cached blocks -> rounded size
+size_t g_pool_idle_bytes = 0;
+void pool_release_all() {
+  for (auto& kv : g_pool_free)
+    for (void* p : kv.second) { (void)hipFree(p); g_pool_size.erase(p); }
+  g_pool_free.clear();
+  g_pool_idle_bytes = 0;
+}
+}  // namespace
+
+int pgpu_dev_alloc(size_t bytes, void** out) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  RC_TRY(check_ready());
+  if (!out) return fail(PGPU_ERR_INVALID_PARAM, "null output pointer");
+  size_t rounded = (std::max<size_t>(bytes, 1) + kPoolGranule - 1) / kPoolGranule * kPoolGranule;
+  auto it = g_pool_free.find(rounded);
+  if (it != g_pool_free.end() && !it->second.empty()) {
+    *out = it->second.back();
+    it->second.pop_back();
+    g_pool_idle_bytes -= rounded;
+    return PGPU_OK;
+  }
+  hipError_t e = hipMalloc(out, rounded);
+  if (e != hipSuccess) {   // out of memory: drop the idle blocks and retry once
+    pool_release_all();
+    HIP_TRY(hipMalloc(out, rounded));
+  }
+  g_pool_size[*out] = rounded;
+  return PGPU_OK;
+}
+void pgpu_dev_free(void* d_ptr) {
+  if (!d_ptr) return;
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  auto it = g_pool_size.find(d_ptr);
+  if (it == g_pool_size.end() || !g_init) {   // not ours / after shutdown
+    if (it != g_pool_size.end()) g_pool_size.erase(it);
+    (void)hipFree(d_ptr);
+    return;
+  }
+  if (g_pool_idle_bytes + it->second > kPoolCap) {
+    g_pool_size.erase(it);
+    (void)hipFree(d_ptr);
+    return;
+  }
+  g_pool_free[it->second].push_back(d_ptr);
+  g_pool_idle_bytes += it->second;
+}
+int pgpu_copy_h2d(void* d_dst, const void* h_src, size_t bytes) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  RC_TRY(check_ready());
+  return staged_h2d(d_dst, h_src, bytes);
+}
+int pgpu_copy_d2h(void* h_dst, const void* d_src, size_t bytes) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  RC_TRY(check_ready());
+  return staged_d2h(h_dst, d_src, bytes);
 }
 
 // ===================== generic modexp =====================

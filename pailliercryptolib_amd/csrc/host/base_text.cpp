@@ -2,12 +2,62 @@
 #include "ipcl/base_text.hpp"
 
 #include <algorithm>
+#include <mutex>
 
+#include "detail.hpp"
 #include "ipcl/ciphertext.hpp"
 #include "ipcl/plaintext.hpp"
 #include "ipcl/utils/util.hpp"
 
 namespace ipcl {
+
+// ---- device-resident values ----
+namespace {
+std::mutex g_materialise_mu;  // lazy host/device copies are created under one lock (const methods)
+}
+
+BaseText::BaseText(std::shared_ptr<detail::DeviceBatch> dev)
+    : m_size(dev->count), m_dev(std::move(dev)), m_host_valid(false) {}
+
+void BaseText::ensureHost() const {
+  if (m_host_valid) return;
+  std::lock_guard<std::mutex> lk(g_materialise_mu);
+  if (m_host_valid) return;
+  m_texts = m_dev->download();
+  m_host_valid = true;
+}
+
+void BaseText::invalidateDevice() {
+  ensureHost();
+  m_dev.reset();
+}
+
+int BaseText::maxBitsHint() const {
+  if (!m_host_valid) return 64 * m_dev->words;
+  return detail::max_bits(m_texts);
+}
+
+std::shared_ptr<detail::DeviceBatch> BaseText::deviceBatch(int words, const BigNumber* reduce_mod) const {
+  {
+    std::lock_guard<std::mutex> lk(g_materialise_mu);
+    if (m_dev && m_dev->words == words) return m_dev;
+  }
+  ensureHost();
+  bool fits = true;
+  for (const auto& x : m_texts)
+    if (x.isNegative() || x.limbs64().size() > (size_t)words) { fits = false; break; }
+  if (fits) {
+    auto b = detail::DeviceBatch::upload(detail::pack(m_texts, words), m_size, words);
+    std::lock_guard<std::mutex> lk(g_materialise_mu);
+    m_dev = b;   // the device copy mirrors m_texts exactly: cache it
+    return b;
+  }
+  ERROR_CHECK(reduce_mod != nullptr, "BaseText: value does not fit the device batch width");
+  std::vector<BigNumber> red(m_texts);
+  for (auto& x : red)
+    if (x.isNegative() || x.limbs64().size() > (size_t)words) x = x % *reduce_mod;
+  return detail::DeviceBatch::upload(detail::pack(red, words), m_size, words);  // not cached
+}
 
 BaseText::BaseText(const uint32_t& n) : m_texts(1, BigNumber((Ipp32u)n)), m_size(1) {}
 
@@ -23,16 +73,20 @@ BaseText::BaseText(const std::vector<BigNumber>& bn_v) : m_texts(bn_v), m_size(b
 
 BigNumber& BaseText::operator[](const std::size_t idx) {
   ERROR_CHECK(idx < m_size, "BaseText:operator[] index is out of range");
+  invalidateDevice();   // the caller may write through the reference
   return m_texts[idx];
 }
 
 void BaseText::insert(const std::size_t pos, BigNumber& bn) {
   ERROR_CHECK(pos <= m_size, "BaseText: insert position is out of range");
+  invalidateDevice();
   m_texts.insert(m_texts.begin() + (std::ptrdiff_t)pos, bn);
   m_size++;
 }
 
 void BaseText::clear() {
+  m_host_valid = true;
+  m_dev.reset();
   m_texts.clear();
   m_size = 0;
 }
@@ -40,17 +94,20 @@ void BaseText::clear() {
 // strict '<' as in the reference (base_text.cpp:58): the last element cannot be removed this way
 void BaseText::remove(const std::size_t pos, const std::size_t length) {
   ERROR_CHECK(pos + length < m_size, "BaseText: remove position is out of range");
+  invalidateDevice();
   m_texts.erase(m_texts.begin() + (std::ptrdiff_t)pos, m_texts.begin() + (std::ptrdiff_t)(pos + length));
   m_size -= length;
 }
 
 BigNumber BaseText::getElement(const std::size_t& idx) const {
   ERROR_CHECK(idx < m_size, "BaseText: getElement index is out of range");
+  ensureHost();
   return m_texts[idx];
 }
 
 std::vector<uint32_t> BaseText::getElementVec(const std::size_t& idx) const {
   ERROR_CHECK(idx < m_size, "BaseText: getElementVec index is out of range");
+  ensureHost();
   std::vector<uint32_t> v;
   m_texts[idx].num2vec(v);
   return v;
@@ -58,6 +115,7 @@ std::vector<uint32_t> BaseText::getElementVec(const std::size_t& idx) const {
 
 std::string BaseText::getElementHex(const std::size_t& idx) const {
   ERROR_CHECK(idx < m_size, "BaseText: getElementHex index is out of range");
+  ensureHost();
   std::string s;
   m_texts[idx].num2hex(s);
   return s;
@@ -65,11 +123,15 @@ std::string BaseText::getElementHex(const std::size_t& idx) const {
 
 std::vector<BigNumber> BaseText::getChunk(const std::size_t& start, const std::size_t& size) const {
   ERROR_CHECK(start + size <= m_size, "BaseText: getChunk parameter is incorrect");
+  ensureHost();
   return std::vector<BigNumber>(m_texts.begin() + (std::ptrdiff_t)start,
                                 m_texts.begin() + (std::ptrdiff_t)(start + size));
 }
 
-std::vector<BigNumber> BaseText::getTexts() const { return m_texts; }
+std::vector<BigNumber> BaseText::getTexts() const {
+  ensureHost();
+  return m_texts;
+}
 std::size_t BaseText::getSize() const { return m_size; }
 
 // ---- PlainText ----
@@ -77,12 +139,14 @@ PlainText::PlainText(const uint32_t& n) : BaseText(n) {}
 PlainText::PlainText(const std::vector<uint32_t>& n_v) : BaseText(n_v) {}
 PlainText::PlainText(const BigNumber& bn) : BaseText(bn) {}
 PlainText::PlainText(const std::vector<BigNumber>& bn_v) : BaseText(bn_v) {}
+PlainText::PlainText(std::shared_ptr<detail::DeviceBatch> dev) : BaseText(std::move(dev)) {}
 
 CipherText PlainText::operator+(const CipherText& other) const { return other + *this; }
 CipherText PlainText::operator*(const CipherText& other) const { return other * *this; }
 
 PlainText::operator std::vector<uint32_t>() const {
   ERROR_CHECK(m_size > 0, "PlainText: type conversion to uint32_t vector error");
+  ensureHost();
   std::vector<uint32_t> v;
   m_texts[0].num2vec(v);
   return v;
@@ -90,11 +154,13 @@ PlainText::operator std::vector<uint32_t>() const {
 
 PlainText::operator BigNumber() const {
   ERROR_CHECK(m_size > 0, "PlainText: type conversion to BigNumber error");
+  ensureHost();
   return m_texts[0];
 }
 
 PlainText::operator std::vector<BigNumber>() const {
   ERROR_CHECK(m_size > 0, "PlainText: type conversion to BigNumber vector error");
+  ensureHost();
   return m_texts;
 }
 
@@ -113,6 +179,9 @@ std::vector<BigNumber> rotated(const std::vector<BigNumber>& v, int shift) {
 }
 }  // namespace detail
 
-PlainText PlainText::rotate(int shift) const { return PlainText(detail::rotated(m_texts, shift)); }
+PlainText PlainText::rotate(int shift) const {
+  ensureHost();
+  return PlainText(detail::rotated(m_texts, shift));
+}
 
 }  // namespace ipcl

@@ -44,5 +44,26 @@ std::vector<BigNumber> unpack(const std::vector<uint64_t>& flat, std::size_t cou
   return v;
 }
 
+std::shared_ptr<DeviceBatch> DeviceBatch::alloc(std::size_t count, int words) {
+  ensure_context();
+  auto b = std::make_shared<DeviceBatch>();
+  b->count = count;
+  b->words = words;
+  IPCL_GPU_CHECK(pgpu_dev_alloc(count * (std::size_t)words * 8, &b->d), "device batch");
+  return b;
+}
+
+std::shared_ptr<DeviceBatch> DeviceBatch::upload(const std::vector<uint64_t>& flat, std::size_t count, int words) {
+  auto b = alloc(count, words);
+  IPCL_GPU_CHECK(pgpu_copy_h2d(b->d, flat.data(), count * (std::size_t)words * 8), "device batch upload");
+  return b;
+}
+
+std::vector<BigNumber> DeviceBatch::download() const {
+  std::vector<uint64_t> flat(count * (std::size_t)words);
+  IPCL_GPU_CHECK(pgpu_copy_d2h(flat.data(), d, flat.size() * 8), "device batch download");
+  return unpack(flat, count, words);
+}
+
 }  // namespace detail
 }  // namespace ipcl

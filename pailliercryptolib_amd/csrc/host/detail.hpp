@@ -3,6 +3,7 @@
 #define PAILLIERCRYPTOLIB_AMD_CSRC_HOST_DETAIL_HPP_
 
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "ipcl/bignum.h"
@@ -21,6 +22,21 @@ inline int words_for_bits(int bits) { return bits <= 0 ? 1 : (bits + 63) / 64; }
 std::vector<uint64_t> pack(const std::vector<BigNumber>& v, int words);
 std::vector<BigNumber> unpack(const std::vector<uint64_t>& flat, std::size_t count, int words);
 int max_bits(const std::vector<BigNumber>& v);
+
+// A batch resident in GPU memory: [count][words] little-endian 64-bit limbs.  Immutable once
+// filled (results are always written to fresh batches), so copies of a text can share it.
+struct DeviceBatch {
+  void* d = nullptr;
+  std::size_t count = 0;
+  int words = 0;
+  ~DeviceBatch() {
+    if (d) pgpu_dev_free(d);
+  }
+  uint64_t* ptr() const { return static_cast<uint64_t*>(d); }
+  static std::shared_ptr<DeviceBatch> alloc(std::size_t count, int words);
+  static std::shared_ptr<DeviceBatch> upload(const std::vector<uint64_t>& flat, std::size_t count, int words);
+  std::vector<BigNumber> download() const;
+};
 
 struct PubKeyDevice {
   pgpu_pubkey* h = nullptr;

@@ -67,10 +67,17 @@ PlainText PrivateKey::decrypt(const CipherText& ct) const {
               "decrypt: The value of N in public key mismatch.");
   std::size_t ct_size = ct.getSize();
   ERROR_CHECK(ct_size > 0, "decrypt: Cannot decrypt empty CipherText");
+  if (m_enable_crt) {
+    // fused GPU pipeline on the (possibly already resident) ciphertext batch; the plaintexts stay
+    // resident until an accessor needs them
+    const int nw = detail::words_for_bits(m_n->BitSize());
+    auto dc = ct.deviceBatch(2 * nw, m_nsquare.get());
+    auto dm = detail::DeviceBatch::alloc(ct_size, nw);
+    IPCL_GPU_CHECK(pgpu_paillier_decrypt_crt_dev(m_dev->h, dc->ptr(), dm->ptr(), ct_size, nullptr), "decrypt");
+    return PlainText(dm);
+  }
   std::vector<BigNumber> pt_bn(ct_size);
-  std::vector<BigNumber> ct_bn = ct.getTexts();
-  if (m_enable_crt) decryptCRT(pt_bn, ct_bn);
-  else decryptRAW(pt_bn, ct_bn);
+  decryptRAW(pt_bn, ct.getTexts());
   return PlainText(pt_bn);
 }
 
@@ -82,15 +89,10 @@ void PrivateKey::decryptRAW(std::vector<BigNumber>& plaintext, const std::vector
   for (std::size_t i = 0; i < sz; ++i) plaintext[i] = (computeLfun(res[i], *m_n) * m_x) % *m_n;
 }
 
+// host-vector variant of the CRT path (kept for the private interface of the reference class)
 void PrivateKey::decryptCRT(std::vector<BigNumber>& plaintext, const std::vector<BigNumber>& ciphertext) const {
-  const std::size_t sz = ciphertext.size();
-  const int nw = detail::words_for_bits(m_n->BitSize());
-  std::vector<BigNumber> c(ciphertext);
-  for (auto& x : c)
-    if (x.isNegative() || x.BitSize() > 64 * 2 * nw) x = x % *m_nsquare;
-  std::vector<uint64_t> fc = detail::pack(c, 2 * nw), fm(sz * (size_t)nw);
-  IPCL_GPU_CHECK(pgpu_paillier_decrypt_crt(m_dev->h, fc.data(), fm.data(), sz), "decrypt");
-  plaintext = detail::unpack(fm, sz, nw);
+  PublicKey pk(*m_n, m_n->BitSize());
+  plaintext = decrypt(CipherText(pk, ciphertext)).getTexts();
 }
 
 }  // namespace ipcl

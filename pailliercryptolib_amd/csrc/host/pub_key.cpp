@@ -103,38 +103,14 @@ std::vector<BigNumber> PublicKey::drawRandom(std::size_t sz) const {
   return r;
 }
 
+// g^m only (make_secure = false, used by CT+PT): cheap, stays on the host (pub_key.cpp:105)
 std::vector<BigNumber> PublicKey::raw_encrypt(const std::vector<BigNumber>& pt, bool make_secure) const {
+  ERROR_CHECK(!make_secure, "raw_encrypt: the obfuscated path runs through encrypt()");
   const BigNumber& n = *m_n;
   const BigNumber& nsq = *m_nsquare;
-  const std::size_t sz = pt.size();
-  if (!make_secure) {  // g^m only (used by CT+PT): cheap, stays on the host
-    std::vector<BigNumber> ct(sz);
-    for (std::size_t i = 0; i < sz; ++i) ct[i] = (n * pt[i] + 1) % nsq;
-    return ct;
-  }
-  std::vector<BigNumber> r = drawRandom(sz);
-  ERROR_CHECK(r.size() == sz, "ippMBModExp: input vector size error");  // reference mod_exp.cpp:452-454
-  auto dev = device();
-  const int nw = detail::words_for_bits(n.BitSize());
-  // plaintexts: any non-negative value; wider than n^2 is reduced first ((n*m+1) % n^2 only
-  // depends on m mod n)
-  std::vector<BigNumber> m(pt);
-  for (auto& x : m)
-    if (x.isNegative() || x.BitSize() > 64 * 2 * nw) x = x % n;
-  for (auto& x : r) ERROR_CHECK(!x.isNegative(), "encrypt: negative random value");
-  const int mw = detail::words_for_bits(detail::max_bits(m));
-  const int rbits = detail::max_bits(r);
-  int rw = detail::words_for_bits(rbits);
-  if (!m_enable_DJN) {
-    for (auto& x : r)
-      if (x.BitSize() > 64 * 2 * nw) x = x % nsq;  // base wider than n^2
-    rw = detail::words_for_bits(detail::max_bits(r));
-  }
-  std::vector<uint64_t> fm = detail::pack(m, mw), fr = detail::pack(r, rw), fc(sz * (size_t)2 * nw);
-  IPCL_GPU_CHECK(pgpu_paillier_encrypt(dev->h, fm.data(), (size_t)mw, mw, fr.data(), (size_t)rw, rw,
-                                       detail::max_bits(r), fc.data(), sz),
-                 "encrypt");
-  return detail::unpack(fc, sz, 2 * nw);
+  std::vector<BigNumber> ct(pt.size());
+  for (std::size_t i = 0; i < pt.size(); ++i) ct[i] = (n * pt[i] + 1) % nsq;
+  return ct;
 }
 
 // kept for API compatibility: multiplies the given values by fresh obfuscators in place
@@ -150,9 +126,31 @@ void PublicKey::applyObfuscator(std::vector<BigNumber>& ciphertext) const {
 
 CipherText PublicKey::encrypt(const PlainText& pt, bool make_secure) const {
   ERROR_CHECK(m_isInitialized, "encrypt: Public key is NOT initialized.");
-  std::size_t pt_size = pt.getSize();
-  ERROR_CHECK(pt_size > 0, "encrypt: Cannot encrypt empty PlainText");
-  return CipherText(*this, raw_encrypt(pt.getTexts(), make_secure));
+  const std::size_t sz = pt.getSize();
+  ERROR_CHECK(sz > 0, "encrypt: Cannot encrypt empty PlainText");
+  if (!make_secure) return CipherText(*this, raw_encrypt(pt.getTexts(), false));
+
+  // One fused GPU launch; plaintexts may already be resident (e.g. the output of decrypt), the
+  // ciphertexts stay resident until somebody asks for their BigNumbers.
+  std::vector<BigNumber> r = drawRandom(sz);
+  ERROR_CHECK(r.size() == sz, "ippMBModExp: input vector size error");  // reference mod_exp.cpp:452-454
+  for (auto& x : r) ERROR_CHECK(!x.isNegative(), "encrypt: negative random value");
+  auto dev = device();
+  const int nw = detail::words_for_bits(m_n->BitSize());
+  // (n*m+1) % n^2 only depends on m mod n: reduce plaintexts that are negative or wider than n^2
+  const int mw = pt.isDeviceResident() ? 0 : std::min(2 * nw, detail::words_for_bits(pt.maxBitsHint()));
+  std::shared_ptr<detail::DeviceBatch> dm = pt.isDeviceResident() ? pt.m_dev : pt.deviceBatch(mw, m_n.get());
+  if (!m_enable_DJN)
+    for (auto& x : r)
+      if (x.BitSize() > 64 * 2 * nw) x = x % *m_nsquare;  // base wider than n^2
+  const int rbits = detail::max_bits(r);
+  const int rw = detail::words_for_bits(rbits);
+  auto dr = detail::DeviceBatch::upload(detail::pack(r, rw), sz, rw);
+  auto dc = detail::DeviceBatch::alloc(sz, 2 * nw);
+  IPCL_GPU_CHECK(pgpu_paillier_encrypt_dev(dev->h, dm->ptr(), (size_t)dm->words, dm->words, dr->ptr(),
+                                           (size_t)rw, rw, rbits, dc->ptr(), sz, nullptr),
+                 "encrypt");
+  return CipherText(*this, dc);
 }
 
 }  // namespace ipcl

@@ -264,6 +264,49 @@ TEST(containers_and_errors) {
   EXPECT_THROW(ipcl::PrivateKey(BigNumber(15u), BigNumber(3u), BigNumber(3u)));
 }
 
+TEST(device_resident_chaining) {
+  // encrypt -> CT+CT -> CT*PT -> CT+PT -> decrypt without materialising host BigNumbers in between
+  ipcl::KeyPair& key = shared_key();
+  auto a = random_u32(64, 21), b = random_u32(64, 22), c = random_u32(64, 23);
+  ipcl::PlainText pa(a), pb(b), pc(c);
+  ipcl::CipherText ca = key.pub_key.encrypt(pa), cb = key.pub_key.encrypt(pb);
+  EXPECT_TRUE(ca.isDeviceResident() && cb.isDeviceResident());
+  ipcl::CipherText r = (ca + cb) * ipcl::PlainText(3u) + pc;          // (a+b)*3 + c
+  EXPECT_TRUE(r.isDeviceResident());
+  EXPECT_TRUE(ca.isDeviceResident());                                  // operands untouched
+  ipcl::PlainText dt = key.priv_key.decrypt(r);
+  EXPECT_TRUE(dt.isDeviceResident());
+  EXPECT_EQ(dt.getSize(), a.size());
+  for (size_t i = 0; i < a.size(); i++) {
+    std::vector<uint32_t> v = dt.getElementVec(i);
+    uint64_t got = v[0] | (v.size() > 1 ? (uint64_t)v[1] << 32 : 0);
+    EXPECT_EQ(got, ((uint64_t)a[i] + b[i]) * 3 + c[i]);
+  }
+  EXPECT_TRUE(!dt.isDeviceResident());                                 // materialised by the accessor
+  // a decrypted (resident) plaintext can be re-encrypted and used as a multiplier directly
+  ipcl::PlainText d2 = key.priv_key.decrypt(ca);
+  ipcl::CipherText again = key.pub_key.encrypt(d2);
+  ipcl::PlainText d3 = key.priv_key.decrypt(again * key.priv_key.decrypt(key.pub_key.encrypt(ipcl::PlainText(2u))));
+  for (size_t i = 0; i < a.size(); i++) {
+    std::vector<uint32_t> v = d3.getElementVec(i);
+    uint64_t got = v[0] | (v.size() > 1 ? (uint64_t)v[1] << 32 : 0);
+    EXPECT_EQ(got, (uint64_t)a[i] * 2);
+  }
+  // copies share the resident batch; mutating a copy must not change the original
+  ipcl::CipherText copy = ca;
+  BigNumber first = ca.getElement(0);
+  copy[0] = BigNumber(7u);
+  EXPECT_EQ(ca.getElement(0), first);
+  EXPECT_EQ(copy.getElement(0), BigNumber(7u));
+  // user-supplied ciphertext values that are wider than n^2 are reduced, as in the reference's
+  // BigNumber arithmetic (a * b % sq)
+  BigNumber nsq = *key.pub_key.getNSQ();
+  ipcl::CipherText wide(key.pub_key, std::vector<BigNumber>{first + nsq * 5, first});
+  ipcl::CipherText s2 = wide + ipcl::CipherText(key.pub_key, std::vector<BigNumber>{first, first});
+  EXPECT_EQ(s2.getElement(0), s2.getElement(1));
+  EXPECT_EQ(s2.getElement(0), nsq.ModMul(first, first));
+}
+
 TEST(keygen_non_djn_and_3072_bit) {
   ipcl::KeyPair k = ipcl::generateKeypair(1024, false);
   EXPECT_TRUE(!k.pub_key.isDJN());

@@ -22,9 +22,10 @@ def build_test_binary():
         for key, macro in names.items():
             f.write(f'#define {macro} "{k[key]}"\n')
     out = os.path.join(CPP, "ipcl_api_tests.bin")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fopenmp", "-I" + os.path.join(ROOT, "include"), "-I" + CPP,
-                    os.path.join(CPP, "ipcl_api_tests.cpp"), "-L" + LIBDIR, "-lipcl_amd", "-lpgpu",
-                    "-Wl,-rpath," + LIBDIR, "-o", out], check=True)
+    for src, exe in (("ipcl_api_tests.cpp", out), ("ipcl_bench.cpp", os.path.join(CPP, "ipcl_bench.bin"))):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fopenmp", "-I" + os.path.join(ROOT, "include"), "-I" + CPP,
+                        os.path.join(CPP, src), "-L" + LIBDIR, "-lipcl_amd", "-lpgpu",
+                        "-Wl,-rpath," + LIBDIR, "-o", exe], check=True)
     return out
 
 
