@@ -176,7 +176,7 @@ def main():
             pmc = json.load(open(pmc_path))
         # encrypt leg: with fixed-base tables the kernel EXECUTES far fewer multiplications than the
         # canonical square-and-multiply count, so its honest ALU fraction uses the executed count
-        fbw = int(os.environ.get("PGPU_FB_WINDOW", "8"))
+        fbw = int(os.environ.get("PGPU_FB_WINDOW", "10"))
         s4096 = 2 * KEY_BITS // 32
         if fixed_base:
             nmul = (KEY_BITS // 2 + fbw - 1) // fbw + 1            # nwin-1 table products + g^m + exit
@@ -204,7 +204,9 @@ def main():
                 "elements_per_s": round(BATCH * world * args.steps / elapsed, 1),
             },
             "roofline": {
-                "bound": "int-alu (v_mad_u64_u32 issue rate; neither hbm nor mfma binds this path)",
+                "bound": "int-alu",
+                "bound_note": "v_mad_u64_u32 issue rate (measured 32.69 T MAC32/s, profiles/r01_ubench_valu_issue_rates.txt); "
+                              "neither hbm nor mfma binds this path: integer carry-chain work, HBM at 1e-4 of peak",
                 "kernel": "modexp_kernel<Geo<8,9>> (CRT-decrypt leg: 16384 half-width modexps per launch; "
                           "the dominant kernel of the step)",
                 "achieved": round(achieved, 3),

@@ -17,6 +17,20 @@ with open(f"profiles/{tag}_rocprofv3_kernel_stats.csv", "w") as f:
     for r in rows:
         w.writerow([r["Name"][:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
 
+# per-kernel durations of the FULL-BATCH dispatches only (the stats file above also averages in the
+# two single-instance modexp launches of the private-key precomputation, hp and hq)
+tr = list(csv.DictReader(open(glob.glob(f"{src}/trace/*/*_kernel_trace.csv")[0])))
+durs = collections.defaultdict(list)
+for r in tr:
+    sname = short(r["Kernel_Name"])
+    if sname and int(r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", 0)) >= 64 * 1000:
+        durs[sname].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+with open(f"profiles/{tag}_rocprofv3_kernel_trace_fullbatch.csv", "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Kernel", "FullBatchCalls", "AverageNs", "MinNs", "MaxNs", "note"])
+    for k, v in durs.items():
+        w.writerow([k, len(v), sum(v) / len(v), min(v), max(v), "dispatches with >= 1000 workgroups, from *_kernel_trace.csv"])
+
 # counters: average per dispatch per kernel (only full-batch dispatches: >= 1000 workgroups)
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 meta = {}
