@@ -111,6 +111,7 @@ struct ModCtx {
 
 // extras: optional constants appended to the context blob
 struct CtxExtras {
+  bool unit_q = false;       // scale the loop modulus to Nhat = N*k == -1 mod 2^29 (if R has room)
   bool want_r2s = false;     // R^2 * 2^(64*mod_words) mod N
   const BigNumber* fc = nullptr;   // plain final multiplier
   const BigNumber* nr_n = nullptr; // n  ->  n*R mod N
@@ -125,20 +126,26 @@ int build_modctx(const BigNumber& N, int mod_words, const GeoInfo& geo, const Ct
     return fail(PGPU_ERR_UNSUPPORTED, "geometry too small for modulus");
   const int L = geo.L(), W64 = geo.w64();
   BigNumber R = pow2(geo.rbits());
-  BigNumber Rm = R % N;
-  BigNumber R2 = (Rm * Rm) % N;
   uint32_t n0 = (uint32_t)(N.limbs64()[0] & pgpu::kLimbMask);
   uint32_t inv = n0;  // Newton iteration for n0^-1 mod 2^32 (n0 odd: correct to 3 bits)
   for (int i = 0; i < 5; ++i) inv *= 2u - n0 * inv;
   uint32_t n0inv = (0u - inv) & pgpu::kLimbMask;
+  // Unit quotient digits: Nhat = N * k with k = -N^-1 mod 2^29 is == -1 mod 2^29, so its
+  // Montgomery constant is 1 and q = low limb.  All loop constants are then taken modulo Nhat
+  // (a multiple of N: lazy values stay correct modulo N).  Needs R >= 256 * Nhat.
+  const bool unit = ex.unit_q && geo.rbits() >= N.BitSize() + pgpu::kLimbBits + 8;
+  const BigNumber M = unit ? N * BigNumber((Ipp32u)n0inv) : N;   // loop modulus
+  BigNumber Rm = R % M;
+  BigNumber R2 = (Rm * Rm) % M;
 
-  std::vector<uint32_t> h((size_t)6 * L, 0);
+  std::vector<uint32_t> h((size_t)7 * L, 0);
   to_limbs29(N, L, h.data());
   to_limbs29(R2, L, h.data() + L);
   to_limbs29(Rm, L, h.data() + 2 * L);
-  if (ex.want_r2s) to_limbs29((R2 * (pow2(64 * mod_words) % N)) % N, L, h.data() + 3 * L);
+  if (ex.want_r2s) to_limbs29((R2 * (pow2(64 * mod_words) % M)) % M, L, h.data() + 3 * L);
   if (ex.fc) to_limbs29(*ex.fc % N, L, h.data() + 4 * L);
-  if (ex.nr_n) to_limbs29((*ex.nr_n * Rm) % N, L, h.data() + 5 * L);
+  if (ex.nr_n) to_limbs29((*ex.nr_n * (R % N)) % N, L, h.data() + 5 * L);   // used under the TRUE modulus
+  if (unit) to_limbs29(M, L, h.data() + 6 * L);
   std::vector<uint64_t> n64((size_t)W64 + 1, 0);
   N.toLimbs64(n64.data(), n64.size());
 
@@ -159,6 +166,7 @@ int build_modctx(const BigNumber& N, int mod_words, const GeoInfo& geo, const Ct
   ctx->dev.r2s = ex.want_r2s ? d32 + 3 * L : nullptr;
   ctx->dev.fc = ex.fc ? d32 + 4 * L : nullptr;
   ctx->dev.nr = ex.nr_n ? d32 + 5 * L : nullptr;
+  ctx->dev.nhat = unit ? d32 + 6 * L : nullptr;
   ctx->dev.n64 = (const uint64_t*)((char*)ctx->blob.p + off64);
   ctx->dev.n0inv = n0inv;
   ctx->dev.mod_words = mod_words;
@@ -168,11 +176,13 @@ int build_modctx(const BigNumber& N, int mod_words, const GeoInfo& geo, const Ct
 
 std::map<std::vector<uint64_t>, std::shared_ptr<ModCtx>> g_ctx_cache;
 
-// cached plain context for the generic seam (pgpu_modexp / pgpu_modmul)
-int get_modctx(const uint64_t* mod, int mod_words, std::shared_ptr<ModCtx>* out) {
+// cached plain context for the generic seam: unit_q = true for pgpu_modexp (loop modulo Nhat),
+// false for pgpu_modmul (two multiplications, true modulus throughout)
+int get_modctx(const uint64_t* mod, int mod_words, bool unit_q, std::shared_ptr<ModCtx>* out) {
   if (!mod || mod_words <= 0) return fail(PGPU_ERR_INVALID_PARAM, "modulus is null/empty");
   if (!(mod[0] & 1)) return fail(PGPU_ERR_EVEN_MODULUS, "modulus must be odd");
   std::vector<uint64_t> key(mod, mod + mod_words);
+  key.push_back(unit_q ? 1 : 0);
   auto it = g_ctx_cache.find(key);
   if (it != g_ctx_cache.end()) {
     *out = it->second;
@@ -183,7 +193,9 @@ int get_modctx(const uint64_t* mod, int mod_words, std::shared_ptr<ModCtx>* out)
     return fail(PGPU_ERR_INVALID_PARAM, "modulus must be > 1");
   const GeoInfo* geo = pick_geo(mod_words, N.BitSize());
   if (!geo) return fail(PGPU_ERR_UNSUPPORTED, "modulus wider than the compiled kernel geometries");
-  RC_TRY(build_modctx(N, mod_words, *geo, CtxExtras(), out));
+  CtxExtras ex;
+  ex.unit_q = unit_q;
+  RC_TRY(build_modctx(N, mod_words, *geo, ex, out));
   if (g_ctx_cache.size() > 64) g_ctx_cache.clear();
   g_ctx_cache[key] = *out;
   return PGPU_OK;
@@ -601,7 +613,7 @@ int pgpu_modexp_dev(const uint64_t* d_base, size_t base_stride, const uint64_t* 
   if (exp_stride != 0 && exp_stride < (size_t)exp_words)
     return fail(PGPU_ERR_INVALID_PARAM, "exponent stride smaller than exp_words");
   std::shared_ptr<ModCtx> ctx;
-  RC_TRY(get_modctx(h_mod, mod_words, &ctx));
+  RC_TRY(get_modctx(h_mod, mod_words, true, &ctx));
   pgpu::ModexpArgs a{};
   a.ctx[0] = a.ctx[1] = ctx->dev;
   a.nctx = 1;
@@ -651,7 +663,7 @@ int pgpu_modmul_dev(const uint64_t* d_a, const uint64_t* d_b, size_t b_stride,
   if (b_stride != 0 && b_stride < (size_t)mod_words)
     return fail(PGPU_ERR_INVALID_PARAM, "b stride smaller than the modulus width");
   std::shared_ptr<ModCtx> ctx;
-  RC_TRY(get_modctx(h_mod, mod_words, &ctx));
+  RC_TRY(get_modctx(h_mod, mod_words, false, &ctx));
   pgpu::ModmulArgs a{};
   a.ctx = ctx->dev;
   a.a = d_a;
@@ -703,6 +715,7 @@ int pgpu_pubkey_create(const uint64_t* n, int n_words, const uint64_t* hs_or_nul
   if (!geo) return fail(PGPU_ERR_UNSUPPORTED, "key wider than the compiled kernel geometries");
   CtxExtras ex;
   ex.nr_n = &k->n;
+  ex.unit_q = true;
   RC_TRY(build_modctx(nsq, 2 * n_words, *geo, ex, &k->nsq));
   if (hs_or_null) {
     k->djn = true;
@@ -876,6 +889,7 @@ int pgpu_privkey_create(const uint64_t* p_in, const uint64_t* q_in, int pq_words
   k->geo_exp = *ge;
   CtxExtras exp_p, exp_q;
   exp_p.want_r2s = exp_q.want_r2s = true;
+  exp_p.unit_q = exp_q.unit_q = true;
   exp_p.fc = &hp;
   exp_q.fc = &hq;
   RC_TRY(build_modctx(psq, nw, *ge, exp_p, &k->p2));

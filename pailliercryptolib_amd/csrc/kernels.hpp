@@ -31,7 +31,13 @@ struct ModCtxDev {
   const uint32_t* fc;   // [L]   constant final multiplier, plain domain (hp, hq)       | may be null
   const uint32_t* nr;   // [L]   n*R mod N for N = n^2 (Paillier g^m = 1 + n*m)          | may be null
   const uint64_t* n64;  // [W64+1] N as little-endian 64-bit words, zero padded
-  uint32_t n0inv;       // -N^-1 mod 2^29
+  // Quotient-digit shortcut.  If nhat != null the exponentiation loop runs modulo Nhat = N*k with
+  // k = -N^-1 mod 2^29, i.e. Nhat == -1 mod 2^29 and the Montgomery constant n0' is 1: the
+  // quotient digit is just the low limb (no multiply).  n / r2 / one / r2s / nr above are then
+  // all taken modulo Nhat (lazy values stay correct modulo N); the multiplication that leaves the
+  // Montgomery domain switches back to the true modulus held here.
+  const uint32_t* nhat; // [L] Nhat limbs, or null (then n is the true modulus everywhere)
+  uint32_t n0inv;       // -N^-1 mod 2^29 (true modulus)
   int mod_words;        // 64-bit words per element of this modulus in the C-ABI layout
 };
 
@@ -250,12 +256,17 @@ __global__ __launch_bounds__(kWGThreads, 2) void modexp_kernel(ModexpArgs A) {
   C.fc = second ? A.ctx[1].fc : A.ctx[0].fc;
   C.nr = second ? A.ctx[1].nr : A.ctx[0].nr;
   C.n64 = second ? A.ctx[1].n64 : A.ctx[0].n64;
+  C.nhat = second ? A.ctx[1].nhat : A.ctx[0].nhat;
   C.n0inv = second ? A.ctx[1].n0inv : A.ctx[0].n0inv;
   C.mod_words = A.ctx[0].mod_words;                // both contexts share the row width
 
+  // loop modulus: Nhat (unit quotient digits) when the context provides it, else N
+  const bool unitq = A.ctx[0].nhat != nullptr;     // wave-uniform (both contexts agree)
   uint32_t n[K], a[K], keep[K];
+  // (g^m = 1 + n*m is formed under the TRUE modulus so that it stays < 2N; see GMUL below)
+  const bool gm_first = A.final_mul == FM_PAILLIER_G;
 #pragma unroll
-  for (int j = 0; j < K; ++j) { n[j] = C.n[x * K + j]; keep[j] = 0; }
+  for (int j = 0; j < K; ++j) { n[j] = (unitq && !gm_first) ? C.nhat[x * K + j] : C.n[x * K + j]; keep[j] = 0; }
   const uint32_t n0inv = C.n0inv;
   const int mw = C.mod_words;
   const bool wide = A.base_words > mw;
@@ -304,9 +315,22 @@ __global__ __launch_bounds__(kWGThreads, 2) void modexp_kernel(ModexpArgs A) {
   for (int j = 0; j < K; ++j) a[j] = limb_from_words(io[g], x * K + j);
 
   for (;;) {
-    if (phase == SQR) montmul<GEO, true>(a, a, bl[g], n, n0inv, bl2[g]);
-    else montmul<GEO, false>(a, a, bl[g], n, n0inv);
-    if (phase == FINAL) break;
+    if (phase == FINAL) {
+      // leave the Montgomery domain modulo the TRUE modulus (result < N + 1)
+      if (unitq) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) n[j] = C.n[x * K + j];
+      }
+      montmul<GEO, false, false>(a, a, bl[g], n, n0inv);
+      break;
+    }
+    if (unitq && phase != GMUL) {
+      if (phase == SQR) montmul<GEO, true, true>(a, a, bl[g], n, n0inv, bl2[g]);
+      else montmul<GEO, false, true>(a, a, bl[g], n, n0inv);
+    } else {
+      if (phase == SQR) montmul<GEO, true, false>(a, a, bl[g], n, n0inv, bl2[g]);
+      else montmul<GEO, false, false>(a, a, bl[g], n, n0inv);
+    }
 
     bool start_main = false;
     if (phase == GMUL || phase == TOMONT_HI) {
@@ -314,6 +338,10 @@ __global__ __launch_bounds__(kWGThreads, 2) void modexp_kernel(ModexpArgs A) {
 #pragma unroll
       for (int j = 0; j < K; ++j) keep[j] = a[j];
       if (phase == GMUL && x == 0) keep[0] += 1;          // g^m = 1 + n*m
+      if (phase == GMUL && unitq) {                        // the loop itself runs modulo Nhat
+#pragma unroll
+        for (int j = 0; j < K; ++j) n[j] = C.nhat[x * K + j];
+      }
       wave_lds_sync();
       stage_words<GEO>(io, A.base, A.base_stride, 0, wide ? mw : A.base_words, first_inst, A.count,
                        nctx, lane);
@@ -456,9 +484,10 @@ __global__ __launch_bounds__(kWGThreads) void fb_build_kernel(FixedBaseBuildArgs
   size_t inst = first_inst + g;
   const bool live = inst < (size_t)A.nwin;
   if (!live) inst = (size_t)A.nwin - 1;
+  const bool unitq = A.ctx.nhat != nullptr;
   uint32_t n[K], a[K];
 #pragma unroll
-  for (int j = 0; j < K; ++j) n[j] = A.ctx.n[x * K + j];
+  for (int j = 0; j < K; ++j) n[j] = unitq ? A.ctx.nhat[x * K + j] : A.ctx.n[x * K + j];
   const uint32_t n0inv = A.ctx.n0inv;
   stage_words<GEO>(io, A.base, 0, 0, A.ctx.mod_words, 0, 1, 1, lane);
 #pragma unroll
@@ -479,7 +508,8 @@ __global__ __launch_bounds__(kWGThreads) void fb_build_kernel(FixedBaseBuildArgs
 #pragma unroll 1
   for (int step = 0; step < total; ++step) {
     uint32_t r[K];
-    montmul<GEO>(r, a, bl[g], n, n0inv);
+    if (unitq) montmul<GEO, false, true>(r, a, bl[g], n, n0inv);
+    else montmul<GEO, false, false>(r, a, bl[g], n, n0inv);
     const bool squaring_phase = step <= wave_sq;   // result of step is hs*R (0) or a square
     if (squaring_phase) {
       if (step <= my_sq) {
@@ -521,9 +551,10 @@ __global__ __launch_bounds__(kWGThreads, 2) void fb_encrypt_kernel(FixedBaseArgs
   const size_t first_inst = ((size_t)blockIdx.x * kWavesPerWG + wv) * IPW;
   size_t inst = first_inst + g;
   if (inst >= A.count) inst = A.count - 1;
+  const bool unitq = A.ctx.nhat != nullptr;
   uint32_t n[K], a[K], acc[K], nxt[K];
 #pragma unroll
-  for (int j = 0; j < K; ++j) n[j] = A.ctx.n[x * K + j];
+  for (int j = 0; j < K; ++j) n[j] = A.ctx.n[x * K + j];   // step 0 (g^m) runs under the TRUE modulus
   const uint32_t n0inv = A.ctx.n0inv;
   const int w = A.w, tsize = 1 << w;
   const uint64_t* ep = A.exp + inst * A.exp_stride;
@@ -555,7 +586,23 @@ __global__ __launch_bounds__(kWGThreads, 2) void fb_encrypt_kernel(FixedBaseArgs
   for (int step = 0; step <= nwin; ++step) {
     if (step + 1 < nwin) load_entry(nxt, step + 1);
     uint32_t r[K];
-    montmul<GEO>(r, a, bl[g], n, n0inv);
+    if (step == 0 || step == nwin) {
+      // g^m (so that it stays < 2N) and the multiplication that leaves the Montgomery domain run
+      // modulo the TRUE modulus; the table products in between modulo Nhat (unit quotient digits)
+      if (unitq && step == nwin) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) n[j] = A.ctx.n[x * K + j];
+      }
+      montmul<GEO, false, false>(r, a, bl[g], n, n0inv);
+      if (unitq && step == 0) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) n[j] = A.ctx.nhat[x * K + j];
+      }
+    } else if (unitq) {
+      montmul<GEO, false, true>(r, a, bl[g], n, n0inv);
+    } else {
+      montmul<GEO, false, false>(r, a, bl[g], n, n0inv);
+    }
     if (step == nwin) {
 #pragma unroll
       for (int j = 0; j < K; ++j) a[j] = r[j];

@@ -111,7 +111,7 @@ __device__ __forceinline__ uint32_t and_bcast_lane0(uint32_t v, uint32_t m) {
 // j < r, against the doubled row limb (brow2 = 2*brow), plus the diagonal j == r once:
 //   sum_{X,S} [ sum_{j<r} 2 a_X[j] a_S[r] + sum_r a_X[r] a_S[r] ] = a^2   (rename X<->S, j<->r)
 // K(K+1)/2 MACs instead of K^2, identical instruction stream in every lane and block.
-template <class GEO, bool SQR>
+template <class GEO, bool SQR, bool UNITQ>
 __device__ __forceinline__ void mont_block(uint64_t (&LOWC)[GEO::K], uint64_t (&UPC)[GEO::K],
                                            const uint32_t (&a)[GEO::K], const uint32_t (&n)[GEO::K],
                                            uint32_t n0inv, const uint32_t* __restrict__ brow,
@@ -144,7 +144,8 @@ __device__ __forceinline__ void mont_block(uint64_t (&LOWC)[GEO::K], uint64_t (&
   asm("" : "+v"(maskv));   // keep the mask in a VGPR (v_and_b32_dpp takes no literal)
 #pragma unroll
   for (int r = 0; r < K; ++r) {
-    uint32_t q = and_bcast_lane0<GEO::G>((uint32_t)LOWC[r] * n0inv, maskv);
+    // UNITQ: the modulus is == -1 mod 2^29 (capi.hip: build_modctx scales it), so n0' = 1
+    uint32_t q = and_bcast_lane0<GEO::G>(UNITQ ? (uint32_t)LOWC[r] : (uint32_t)LOWC[r] * n0inv, maskv);
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       if (r + j < K) LOWC[r + j] += (uint64_t)n[j] * q;
@@ -167,7 +168,7 @@ __device__ __forceinline__ void mont_block(uint64_t (&LOWC)[GEO::K], uint64_t (&
 
 // r = a * b * R^-1 mod N (lazy: inputs < 4N -> output < 2N), b read from LDS at bl[0..L).
 // Output limbs are < 2^29 except that limb 0 of a lane may equal 2^29 (deferred unit carry).
-template <class GEO, bool SQR = false>
+template <class GEO, bool SQR = false, bool UNITQ = false>
 __device__ __forceinline__ void montmul(uint32_t (&r)[GEO::K], const uint32_t (&a)[GEO::K],
                                         const uint32_t* __restrict__ bl,
                                         const uint32_t (&n)[GEO::K], uint32_t n0inv,
@@ -178,8 +179,8 @@ __device__ __forceinline__ void montmul(uint32_t (&r)[GEO::K], const uint32_t (&
   for (int j = 0; j < K; ++j) { c0[j] = 0; c1[j] = 0; }
 #pragma unroll 1
   for (int s = 0; s < GEO::G; s += 2) {
-    mont_block<GEO, SQR>(c0, c1, a, n, n0inv, bl + s * K, bl2 + s * K);
-    mont_block<GEO, SQR>(c1, c0, a, n, n0inv, bl + (s + 1) * K, bl2 + (s + 1) * K);
+    mont_block<GEO, SQR, UNITQ>(c0, c1, a, n, n0inv, bl + s * K, bl2 + s * K);
+    mont_block<GEO, SQR, UNITQ>(c1, c0, a, n, n0inv, bl + (s + 1) * K, bl2 + (s + 1) * K);
   }
   // pass 1: local carry propagation
   uint64_t c = 0;
