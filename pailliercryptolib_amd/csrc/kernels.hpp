@@ -192,17 +192,18 @@ __device__ __forceinline__ void stage_words(uint64_t (*io)[GEO::W64 + 1], const 
 }
 
 // Canonicalise r (value < 3N -> [0, N)) and store it as 64-bit words.
+// nt: limbs of the TRUE modulus held by this lane.
 template <class GEO>
-__device__ __forceinline__ void store_canonical(uint32_t (&r)[GEO::K], const ModCtxDev& ctx,
-                                                uint32_t (*bl)[GEO::L], uint64_t (*io)[GEO::W64 + 1],
-                                                uint64_t* out, size_t out_stride, size_t first_inst,
-                                                size_t count, int lane, int g, int x) {
-  limbs_to_words<GEO>(r, bl, io, lane, g, x);
-  if (x == 0) words_reduce(io[g], ctx.n64, reinterpret_cast<uint64_t*>(bl[g]), GEO::W64, 2);
-  wave_lds_sync();
-  const int mw = ctx.mod_words;
-  for (int t = lane; t < GEO::IPW * mw; t += kWave) {
-    int gg = t / mw, w = t % mw;
+__device__ __forceinline__ void store_canonical(uint32_t (&r)[GEO::K], const uint32_t (&nt)[GEO::K],
+                                                int mod_words, uint32_t (*bl)[GEO::L],
+                                                uint64_t (*io)[GEO::W64 + 1], uint64_t* out,
+                                                size_t out_stride, size_t first_inst, size_t count,
+                                                int lane, int g, int x) {
+  full_normalise<GEO>(r, x);
+  cond_sub_limbs<GEO>(r, nt, x, lane);
+  limbs_to_words<GEO>(r, bl, io, lane, g, x);   // (already canonical: the normalise inside is a no-op pass)
+  for (int t = lane; t < GEO::IPW * mod_words; t += kWave) {
+    int gg = t / mod_words, w = t % mod_words;
     size_t inst = first_inst + gg;
     if (inst < count) out[inst * out_stride + w] = io[gg][w];
   }
@@ -421,15 +422,8 @@ __global__ __launch_bounds__(kWGThreads, 2) void modexp_kernel(ModexpArgs A) {
     }
     // phase == TABLE: multiplier (base*R) is already staged
   }
-  // per-group modulus for the canonical reduction: contexts may differ between groups
-  limbs_to_words<GEO>(a, bl, io, lane, g, x);
-  if (x == 0) words_reduce(io[g], C.n64, reinterpret_cast<uint64_t*>(bl[g]), GEO::W64, 2);
-  wave_lds_sync();
-  for (int t = lane; t < IPW * mw; t += kWave) {
-    int gg = t / mw, ww = t % mw;
-    size_t oi = first_inst + gg;
-    if (oi < A.count) A.out[oi * A.out_stride + ww] = io[gg][ww];
-  }
+  // canonical reduction modulo the TRUE modulus of this group's context (n[] holds it after FINAL)
+  store_canonical<GEO>(a, n, mw, bl, io, A.out, A.out_stride, first_inst, A.count, lane, g, x);
   if (A.wave_clocks && lane == 0) {
     uint64_t* rec = A.wave_clocks + ((size_t)blockIdx.x * kWavesPerWG + wv) * 3;
     rec[0] = t_start;
@@ -624,7 +618,7 @@ __global__ __launch_bounds__(kWGThreads, 2) void fb_encrypt_kernel(FixedBaseArgs
 #pragma unroll
     for (int j = 0; j < K; ++j) a[j] = (step + 1 < nwin) ? nxt[j] : gm[j];
   }
-  store_canonical<GEO>(a, A.ctx, bl, io, A.out, A.out_stride, first_inst, A.count, lane, g, x);
+  store_canonical<GEO>(a, n, A.ctx.mod_words, bl, io, A.out, A.out_stride, first_inst, A.count, lane, g, x);
 }
 
 // out = a*b mod N: montmul(montmul(a, R^2), b) -- two Montgomery multiplications.
@@ -662,7 +656,7 @@ __global__ __launch_bounds__(kWGThreads) void modmul_kernel(ModmulArgs A) {
       wave_lds_sync();
     }
   }
-  store_canonical<GEO>(a, A.ctx, bl, io, A.out, (size_t)A.ctx.mod_words, first_inst, A.count, lane, g, x);
+  store_canonical<GEO>(a, n, A.ctx.mod_words, bl, io, A.out, (size_t)A.ctx.mod_words, first_inst, A.count, lane, g, x);
 }
 
 // CRT recombination, one G-lane group per ciphertext (pri_key.cpp:136-157):

@@ -227,6 +227,49 @@ __device__ __forceinline__ void full_normalise(uint32_t (&r)[GEO::K], int x) {
   }
 }
 
+// Lane-parallel canonical reduction: r (canonical limbs, value V < 3N) -> V mod N.
+// Each round forms D = V - N limb-wise with a borrow that ripples inside the lane and hops to the
+// next lane over DPP (repeated until no borrow is in flight -- data dependent, a handful of
+// instructions, used once per exponentiation / product); the sign of D, known in the group's top
+// lane, selects D or V for the whole group.
+template <class GEO>
+__device__ __forceinline__ void cond_sub_limbs(uint32_t (&r)[GEO::K], const uint32_t (&nt)[GEO::K], int x,
+                                               int lane) {
+  constexpr int K = GEO::K, G = GEO::G;
+  const int top_lane = (lane / G) * G + (G - 1);
+#pragma unroll 1
+  for (int round = 0; round < 2; ++round) {
+    uint32_t d[K];
+    uint32_t b = 0;        // borrow into limb j
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      uint32_t t = r[j] - nt[j] - b;
+      d[j] = t & kLimbMask;
+      b = t >> 31;         // limbs are < 2^29, so a negative difference has bit 31 set
+    }
+    uint32_t top_borrow = b;   // meaningful in the top lane only; accumulates over the ripple passes
+    for (;;) {
+      uint32_t bin = dpp_from_prev(b);
+      if (x == 0) bin = 0;
+      if (__ballot(bin != 0) == 0) break;
+      b = bin;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        uint32_t t = d[j] - b;
+        d[j] = t & kLimbMask;
+        b = t >> 31;
+      }
+      top_borrow |= b;
+    }
+    const uint32_t negative = (uint32_t)__shfl((int)top_borrow, top_lane);   // V < N: keep V
+    if (__ballot(negative == 0) == 0) break;                                // nothing left to subtract
+    if (!negative) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) r[j] = d[j];
+    }
+  }
+}
+
 // limb i (29 bits at bit offset 29*i) of a little-endian u64 array that is zero-padded by one word.
 __device__ __forceinline__ uint32_t limb_from_words(const uint64_t* w, int i) {
   int bit = i * kLimbBits;
