@@ -40,6 +40,10 @@ class BaseText {
   std::vector<BigNumber> getTexts() const;
   std::size_t getSize() const;
 
+  // reference base_text.hpp:108-114: "size", "texts"
+  void save(serializer::OutputArchive& ar) const;
+  void load(serializer::InputArchive& ar);
+
   // true while the values exist only in GPU memory (no host BigNumbers materialised yet)
   bool isDeviceResident() const { return !m_host_valid; }
 

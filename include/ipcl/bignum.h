@@ -20,6 +20,8 @@
 #include <string>
 #include <vector>
 
+#include "ipcl/utils/serialize.hpp"
+
 typedef uint8_t Ipp8u;
 typedef uint32_t Ipp32u;
 typedef int32_t Ipp32s;
@@ -112,6 +114,11 @@ class BigNumber {
   const std::vector<uint64_t>& limbs64() const { return m_mag; }
   bool isNegative() const { return m_neg; }
   bool isZero() const { return m_mag.empty(); }
+
+  // wire format of the reference's cereal save/load (bignum.h:131-153): class version once per
+  // archive, the 32-bit words (num2vec), the sign enum
+  void save(ipcl::serializer::OutputArchive& ar) const;
+  void load(ipcl::serializer::InputArchive& ar);
 
   // divide with remainder: *this = q*d + r, q truncated toward zero, r has the sign of *this
   static void divmod(const BigNumber& a, const BigNumber& d, BigNumber* q, BigNumber* r);

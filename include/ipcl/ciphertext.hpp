@@ -30,6 +30,9 @@ class CipherText : public BaseText {
   std::shared_ptr<PublicKey> getPubKey() const;
   CipherText rotate(int shift) const;
 
+  void save(serializer::OutputArchive& ar) const;   // reference ciphertext.hpp:69-74: base, "pk"
+  void load(serializer::InputArchive& ar);
+
  private:
   friend class PublicKey;
   CipherText(const PublicKey& pk, std::shared_ptr<detail::DeviceBatch> dev);

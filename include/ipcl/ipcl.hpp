@@ -1,11 +1,11 @@
 // pailliercryptolib_amd -- umbrella header (reference ipcl/include/ipcl/ipcl.hpp:19-37).
-// Serialization (cereal wire format, utils/serialize.hpp) is out of scope of this round.
 #ifndef PAILLIERCRYPTOLIB_AMD_IPCL_IPCL_HPP_
 #define PAILLIERCRYPTOLIB_AMD_IPCL_IPCL_HPP_
 
 #include "ipcl/mod_exp.hpp"
 #include "ipcl/pri_key.hpp"
 #include "ipcl/utils/context.hpp"
+#include "ipcl/utils/serialize.hpp"
 
 namespace ipcl {
 

@@ -29,6 +29,9 @@ class PlainText : public BaseText {
   CipherText operator*(const CipherText& other) const;  // PT * CT
   PlainText rotate(int shift) const;
 
+  void save(serializer::OutputArchive& ar) const;   // reference plaintext.hpp:92-98
+  void load(serializer::InputArchive& ar);
+
  private:
   friend class PrivateKey;
   explicit PlainText(std::shared_ptr<detail::DeviceBatch> dev);

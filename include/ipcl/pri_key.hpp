@@ -35,6 +35,10 @@ class PrivateKey {
   BigNumber getLambda() const { return m_lambda; }
   bool isInitialized() { return m_isInitialized; }
 
+  // reference pri_key.hpp:93-133: "bits" (of p), "p", "q"; load re-derives every constant
+  void save(serializer::OutputArchive& ar) const;
+  void load(serializer::InputArchive& ar);
+
  private:
   bool m_isInitialized = false;
   bool m_enable_crt = false;

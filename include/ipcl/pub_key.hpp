@@ -48,6 +48,10 @@ class PublicKey {
   void create(const BigNumber& n, int bits, bool enableDJN_ = false);
   void create(const BigNumber& n, int bits, const BigNumber& hs, int randbits);
 
+  // reference pub_key.hpp:133-164: "bits", "enable_DJN", "randbits", "n", "hs"
+  void save(serializer::OutputArchive& ar) const;
+  void load(serializer::InputArchive& ar);
+
  private:
   bool m_isInitialized = false;
   std::shared_ptr<BigNumber> m_n;

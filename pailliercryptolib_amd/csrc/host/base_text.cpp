@@ -128,6 +128,37 @@ std::vector<BigNumber> BaseText::getChunk(const std::size_t& start, const std::s
                                 m_texts.begin() + (std::ptrdiff_t)(start + size));
 }
 
+// ---- serialization (reference base_text.hpp:108-114, plaintext.hpp:92-98) ----
+void BaseText::save(serializer::OutputArchive& ar) const {
+  ensureHost();
+  ar.class_version("ipcl::BaseText");
+  ar.u64((uint64_t)m_size);
+  ar.u64((uint64_t)m_texts.size());
+  for (const auto& t : m_texts) t.save(ar);
+}
+
+void BaseText::load(serializer::InputArchive& ar) {
+  (void)ar.class_version("ipcl::BaseText");
+  uint64_t size = ar.u64();
+  uint64_t count = ar.u64();
+  ERROR_CHECK(size == count && count < (1u << 28), "BaseText: corrupt archive");
+  m_texts.assign((size_t)count, BigNumber());
+  for (auto& t : m_texts) t.load(ar);
+  m_size = (size_t)size;
+  m_host_valid = true;
+  m_dev.reset();
+}
+
+void PlainText::save(serializer::OutputArchive& ar) const {
+  ar.class_version("ipcl::PlainText");
+  BaseText::save(ar);
+}
+
+void PlainText::load(serializer::InputArchive& ar) {
+  (void)ar.class_version("ipcl::PlainText");
+  BaseText::load(ar);
+}
+
 std::vector<BigNumber> BaseText::getTexts() const {
   ensureHost();
   return m_texts;

@@ -497,3 +497,19 @@ BigNumber BigNumber::fromLimbs64(const uint64_t* limbs, std::size_t nlimbs) {
   r.trim();
   return r;
 }
+
+// ---- serialization (reference bignum.h:131-153) ----
+void BigNumber::save(ipcl::serializer::OutputArchive& ar) const {
+  ar.class_version("BigNumber");
+  std::vector<Ipp32u> vec;
+  num2vec(vec);
+  ar.vec_u32(vec);
+  ar.i32(m_neg ? IppsBigNumNEG : IppsBigNumPOS);
+}
+
+void BigNumber::load(ipcl::serializer::InputArchive& ar) {
+  (void)ar.class_version("BigNumber");
+  std::vector<Ipp32u> vec = ar.vec_u32();
+  int sign = ar.i32();
+  Set(vec.data(), (int)vec.size(), sign == IppsBigNumNEG ? IppsBigNumNEG : IppsBigNumPOS);
+}

@@ -71,6 +71,21 @@ CipherText CipherText::operator*(const PlainText& other) const {
   return CipherText(m_pk, dout);
 }
 
+void CipherText::save(serializer::OutputArchive& ar) const {
+  ERROR_CHECK(m_pk != nullptr, "CipherText: cannot serialize without a public key");
+  ar.class_version("ipcl::CipherText");
+  BaseText::save(ar);
+  m_pk->save(ar);
+}
+
+void CipherText::load(serializer::InputArchive& ar) {
+  (void)ar.class_version("ipcl::CipherText");
+  BaseText::load(ar);
+  auto pk = std::make_shared<PublicKey>();
+  pk->load(ar);
+  m_pk = pk;
+}
+
 CipherText CipherText::getCipherText(const size_t& idx) const {
   ERROR_CHECK(idx < m_size, "CipherText::getCipherText index is out of range");
   ensureHost();

@@ -53,6 +53,26 @@ void PrivateKey::precompute(const BigNumber& p_in, const BigNumber& q_in) {
   m_isInitialized = true;
 }
 
+void PrivateKey::save(serializer::OutputArchive& ar) const {
+  ERROR_CHECK(m_isInitialized, "PrivateKey: cannot serialize an uninitialized key");
+  ar.class_version("ipcl::PrivateKey");
+  ar.i32(m_p->BitSize());
+  m_p->save(ar);
+  m_q->save(ar);
+}
+
+void PrivateKey::load(serializer::InputArchive& ar) {
+  (void)ar.class_version("ipcl::PrivateKey");
+  (void)ar.i32();
+  BigNumber p, q;
+  p.load(ar);
+  q.load(ar);
+  m_n = std::make_shared<BigNumber>(p * q);
+  m_nsquare = std::make_shared<BigNumber>((*m_n) * (*m_n));
+  m_g = std::make_shared<BigNumber>((*m_n) + 1);
+  precompute(p, q);
+}
+
 BigNumber PrivateKey::computeLfun(const BigNumber& a, const BigNumber& b) const { return (a - 1) / b; }
 
 // h = L_a(g^(a-1) mod a^2)^-1 mod a  (reference pri_key.cpp:159-167)

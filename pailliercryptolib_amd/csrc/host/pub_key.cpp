@@ -113,6 +113,28 @@ std::vector<BigNumber> PublicKey::raw_encrypt(const std::vector<BigNumber>& pt, 
   return ct;
 }
 
+void PublicKey::save(serializer::OutputArchive& ar) const {
+  ERROR_CHECK(m_isInitialized, "PublicKey: cannot serialize an uninitialized key");
+  ar.class_version("ipcl::PublicKey");
+  ar.i32(m_bits);
+  ar.boolean(m_enable_DJN);
+  ar.i32(m_randbits);
+  m_n->save(ar);
+  m_hs.save(ar);
+}
+
+void PublicKey::load(serializer::InputArchive& ar) {
+  (void)ar.class_version("ipcl::PublicKey");
+  int bits = ar.i32();
+  bool enable_DJN = ar.boolean();
+  int randbits = ar.i32();
+  BigNumber n, hs;
+  n.load(ar);
+  hs.load(ar);
+  if (enable_DJN) create(n, bits, hs, randbits);
+  else create(n, bits);
+}
+
 // kept for API compatibility: multiplies the given values by fresh obfuscators in place
 void PublicKey::applyObfuscator(std::vector<BigNumber>& ciphertext) const {
   const std::size_t sz = ciphertext.size();

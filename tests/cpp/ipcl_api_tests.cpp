@@ -11,6 +11,7 @@
 #include <functional>
 #include <iostream>
 #include <random>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -305,6 +306,74 @@ TEST(device_resident_chaining) {
   ipcl::CipherText s2 = wide + ipcl::CipherText(key.pub_key, std::vector<BigNumber>{first, first});
   EXPECT_EQ(s2.getElement(0), s2.getElement(1));
   EXPECT_EQ(s2.getElement(0), nsq.ModMul(first, first));
+}
+
+TEST(serialization_roundtrips) {   // after test/test_serialization.cpp:13-106
+  ipcl::KeyPair& key = shared_key();
+  // public key -> fresh object -> still encrypts for the original private key
+  ipcl::PublicKey ret_pk(BigNumber(5u), 2048);
+  {
+    std::ostringstream os;
+    ipcl::serializer::serialize(os, key.pub_key);
+    std::istringstream is(os.str());
+    ipcl::serializer::deserialize(is, ret_pk);
+  }
+  EXPECT_EQ(*ret_pk.getN(), *key.pub_key.getN());
+  EXPECT_TRUE(ret_pk.isDJN());
+  EXPECT_EQ(ret_pk.getHS(), key.pub_key.getHS());
+  ipcl::PlainText pt(123u);
+  EXPECT_EQ(key.priv_key.decrypt(ret_pk.encrypt(pt)).getElement(0), pt.getElement(0));
+  // private key
+  ipcl::PrivateKey ret_sk;
+  {
+    std::ostringstream os;
+    ipcl::serializer::serialize(os, key.priv_key);
+    std::istringstream is(os.str());
+    ipcl::serializer::deserialize(is, ret_sk);
+  }
+  EXPECT_EQ(ret_sk.decrypt(key.pub_key.encrypt(pt)).getElement(0), pt.getElement(0));
+  EXPECT_EQ(ret_sk.getLambda(), key.priv_key.getLambda());
+  // plaintext and (device-resident) ciphertext batches, incl. negative / zero BigNumbers
+  auto vals = random_u32(14, 31);
+  ipcl::PlainText p14(vals), p_after;
+  {
+    std::ostringstream os;
+    ipcl::serializer::serialize(os, p14);
+    std::istringstream is(os.str());
+    ipcl::serializer::deserialize(is, p_after);
+  }
+  for (size_t i = 0; i < vals.size(); i++) EXPECT_EQ(p_after.getElementVec(i)[0], vals[i]);
+  ipcl::CipherText ct = key.pub_key.encrypt(p14), ct_after;
+  EXPECT_TRUE(ct.isDeviceResident());
+  std::string blob;
+  {
+    std::ostringstream os;
+    ipcl::serializer::serialize(os, ct);
+    blob = os.str();
+    std::istringstream is(blob);
+    ipcl::serializer::deserialize(is, ct_after);
+  }
+  EXPECT_EQ(ct_after.getSize(), ct.getSize());
+  EXPECT_EQ(ct_after.getElement(3), ct.getElement(3));
+  ipcl::PlainText dt = key.priv_key.decrypt(ct_after);
+  for (size_t i = 0; i < vals.size(); i++) EXPECT_EQ(dt.getElementVec(i)[0], vals[i]);
+  // framing facts of the PortableBinary subset: endianness byte, class versions once per type
+  EXPECT_EQ((unsigned char)blob[0], 1u);
+  {
+    BigNumber neg("-0x123456789abcdef0123"), back;
+    std::ostringstream os;
+    ipcl::serializer::serialize(os, neg);
+    EXPECT_EQ(os.str().size(), (size_t)(1 + 4 + 8 + 3 * 4 + 4));   // flag, version, count, 3 words, sign
+    std::istringstream is(os.str());
+    ipcl::serializer::deserialize(is, back);
+    EXPECT_EQ(back, neg);
+  }
+  EXPECT_TRUE(ipcl::serializer::serializeToFile("/tmp/ipcl_amd_pk.bin", key.pub_key));
+  ipcl::PublicKey from_file(BigNumber(7u), 2048);
+  EXPECT_TRUE(ipcl::serializer::deserializeFromFile("/tmp/ipcl_amd_pk.bin", from_file));
+  EXPECT_EQ(*from_file.getN(), *key.pub_key.getN());
+  std::istringstream truncated(blob.substr(0, blob.size() / 2));
+  EXPECT_THROW(ipcl::serializer::deserialize(truncated, ct_after));
 }
 
 TEST(keygen_non_djn_and_3072_bit) {
