@@ -272,7 +272,27 @@ def cpu_baseline(n, p, q, hs, m_host, r_host):
     S = int(min(m_host.shape[0], max(probe, probe * 12.0 / dt)))   # aim for ~12 s of CPU work
     S -= S % threads if S > threads else 0
     dt = run(S)
-    return {"value": round(3 * S / dt, 1), "unit": "modexps/s", "cores": threads, "kind": "port",
+    extra = {}
+    if c_oracle.openssl_lib() is not None:
+        # second reference point (BASELINE.md "B2"): the same three modexps per element through OpenSSL
+        # BN_mod_exp_mont on the same threads; modexps only (no L-function / CRT glue), which flatters the CPU
+        nsq_l = ints_to_limbs([n * n], 2 * nw)[0]
+        legs = [(ints_to_limbs([pr - 1], pw)[0], ints_to_limbs([pr * pr], nw)[0]) for pr in (sk.p, sk.q)]
+        c_all = c_oracle.paillier_encrypt(n_l, hs_l, m_host[:S], r_host[:S])      # untimed: decrypt input
+
+        def ossl(S2):
+            t0 = time.perf_counter()
+            c_oracle.openssl_modexp_batch(np.tile(hs_l, (S2, 1)), r_host[:S2], nsq_l)
+            outs = [c_oracle.openssl_modexp_batch(c_all[:S2], np.tile(e, (S2, 1)), mod) for e, mod in legs]
+            return time.perf_counter() - t0, outs
+        S2 = min(S, max(probe, S // 2))
+        d1, outs = ossl(S2)
+        c0 = sum(int(w) << (64 * k) for k, w in enumerate(c_all[0]))
+        assert sum(int(w) << (64 * k) for k, w in enumerate(outs[0][0])) == pow(c0, sk.p - 1, sk.p * sk.p)
+        extra["openssl"] = {"value": round(3 * S2 / d1, 1), "unit": "modexps/s", "cores": threads,
+                            "sample": f"{3 * S2} modexps (hs^r mod n^2, c^(p-1) mod p^2, c^(q-1) mod q^2 for {S2} "
+                                      f"elements) through OpenSSL BN_mod_exp_mont in {d1:.1f} s; modexps only"}
+    return {**extra, "value": round(3 * S / dt, 1), "unit": "modexps/s", "cores": threads, "kind": "port",
             "sample": f"first {S} elements of the same batch, encrypt + CRT decrypt ({3 * S} modexps) "
                       f"in {dt:.1f} s; oracle/modexp_oracle.c, gcc -O3 -fopenmp; {threads} OpenMP threads = "
                       f"min(affinity {len(os.sched_getaffinity(0))}, cgroup cpu quota {c_oracle.usable_cpus()})",

@@ -107,3 +107,38 @@ def paillier_decrypt_crt(p, q, hp, hq, pinv, c):
                                         _p(c), _p(out), c.shape[0])
     assert rc == 0
     return out
+
+
+_ossl = None
+
+
+def openssl_lib():
+    """libopenssl_oracle.so if it was built (libcrypto present at build time), else None."""
+    global _ossl
+    if _ossl is None:
+        path = os.path.join(_HERE, "libopenssl_oracle.so")
+        if not os.path.exists(path):
+            return None
+        try:
+            L = ctypes.CDLL(path)
+        except OSError:
+            return None
+        vp, sz, i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        L.orc_openssl_modexp_batch.argtypes = [vp, sz, vp, sz, i, vp, i, vp, sz]
+        _ossl = L
+    return _ossl
+
+
+def openssl_modexp_batch(base, exp, mod):
+    """Same contract as modexp_batch, computed by OpenSSL BN_mod_exp_mont; None when unavailable."""
+    L = openssl_lib()
+    if L is None:
+        return None
+    base = np.ascontiguousarray(base, dtype=np.uint64)
+    exp = np.ascontiguousarray(exp, dtype=np.uint64)
+    mod = np.ascontiguousarray(mod, dtype=np.uint64)
+    out = np.empty((base.shape[0], mod.shape[0]), dtype=np.uint64)   # base rows may be wider than the modulus
+    rc = L.orc_openssl_modexp_batch(_p(base), base.shape[1], _p(exp), exp.shape[1], exp.shape[1], _p(mod),
+                                    mod.shape[0], _p(out), base.shape[0])
+    assert rc == 0
+    return out

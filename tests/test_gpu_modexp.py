@@ -84,3 +84,25 @@ def test_errors(engine):
         engine.mod_exp([3], [5], 1 << 64)          # even modulus
     with pytest.raises(RuntimeError):
         engine.mod_exp([3, 4, 5], [5, 6], 7)       # size mismatch
+
+
+@pytest.mark.parametrize("mod_bits,exp_bits,count", [(1024, 1024, 256), (2048, 1024, 512), (4096, 2048, 128)])
+def test_modexp_vs_openssl_bulk(engine, mod_bits, exp_bits, count):
+    """The reference's accelerator tests check batched modexp against OpenSSL BN_mod_exp
+    (module/heqat/test/test_bnModExp.cpp:57-60,205-208); same check for the HIP path on bulk
+    batches that CPython pow would be slow for."""
+    import numpy as np
+    from oracle import c_oracle
+    from pailliercryptolib_amd.limbs import ints_to_limbs, limbs_to_ints
+    if c_oracle.openssl_lib() is None:
+        pytest.skip("libcrypto not available at build time")
+    rng = random.Random(mod_bits + count)
+    mod = rand_odd(rng, mod_bits)
+    W, E = mod_bits // 64, exp_bits // 64
+    nrng = np.random.default_rng(mod_bits)
+    base_l = nrng.integers(0, 1 << 63, size=(count, W), dtype=np.uint64) << np.uint64(1)
+    base_l[:, W - 1] >>= np.uint64(2)                       # < 2^(bits-1) <= mod
+    exp_l = nrng.integers(0, 1 << 63, size=(count, E), dtype=np.uint64)
+    want = c_oracle.openssl_modexp_batch(base_l, exp_l, ints_to_limbs([mod], W)[0])
+    got = engine.mod_exp(limbs_to_ints(base_l), limbs_to_ints(exp_l), mod)
+    assert got == limbs_to_ints(want)

@@ -57,3 +57,20 @@ def test_c_paillier_iso_kat():
     opk = orc.PublicKey(n, 2048)
     opk.set_djn(hs)
     assert limbs_to_ints(c2) == opk.encrypt(m, rr)
+
+
+def test_openssl_leg_agrees_with_pow_and_c_port():
+    """OpenSSL BN_mod_exp_mont (the oracle of the reference's own QAT tests,
+    module/heqat/test/test_bnModExp.cpp:57-60) vs CPython pow vs the C port."""
+    if c_oracle.openssl_lib() is None:
+        pytest.skip("libcrypto not available at build time")
+    rng = random.Random(13)
+    for bits, ebits, cnt in ((1024, 512, 4), (2048, 1024, 4), (4096, 1024, 3)):
+        mod = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+        W, E = bits // 64, (ebits + 63) // 64
+        base = [rng.getrandbits(bits) for _ in range(cnt)]
+        exp = [rng.getrandbits(ebits) for _ in range(cnt)]
+        b, e, m = ints_to_limbs(base, W), ints_to_limbs(exp, E), ints_to_limbs([mod], W)[0]
+        got = limbs_to_ints(c_oracle.openssl_modexp_batch(b, e, m))
+        assert got == [pow(x % mod, y, mod) for x, y in zip(base, exp)]
+        assert got == limbs_to_ints(c_oracle.modexp_batch(b, e, m))
