@@ -247,9 +247,15 @@ def main():
 
 
 def cpu_baseline(n, p, q, hs, m_host, r_host):
-    """The oracle's C restatement (kind "port": 64-bit CIOS Montgomery + 5-bit fixed window, OpenMP over
-    the batch like ippMBModExpWrapper) timed on this box's host cores on a bounded sample of the same
-    workload (same key, first S elements of the same batch, encrypt + CRT decrypt)."""
+    """The oracle's CPU restatements (kind "port") timed on this box's host cores on a bounded sample of the
+    same workload (same key, first S elements of the same batch, encrypt + CRT decrypt, results checked).
+    Three legs, each the full reference flow (modexps + the host glue of pub_key.cpp:88-105 /
+    pri_key.cpp:128-157), OpenMP over the batch like ippMBModExpWrapper (mod_exp.cpp:597-636):
+      ifma    oracle/ifma_oracle.c   8 lanes per zmm, radix 2^52, vpmadd52 -- the kind of code the reference's
+                                     mbx_exp_mb8 path runs (a restatement, not IPP-Crypto); needs avx512ifma
+      openssl BN_mod_exp_mont        the oracle of the reference's own QAT tests (BASELINE.md "B2")
+      scalar  oracle/modexp_oracle.c 64-bit CIOS Montgomery + 5-bit fixed window
+    "value" is the fastest leg available on this host."""
     from oracle import c_oracle
     from oracle import paillier_oracle as orc
     from pailliercryptolib_amd.limbs import ints_to_limbs
@@ -260,43 +266,44 @@ def cpu_baseline(n, p, q, hs, m_host, r_host):
     args = [ints_to_limbs([v], pw)[0] for v in (sk.p, sk.q, sk.hp, sk.hq, sk.pinv)]
     n_l, hs_l = ints_to_limbs([n], nw)[0], ints_to_limbs([hs], 2 * nw)[0]
 
-    def run(S):
-        t0 = time.perf_counter()
-        c = c_oracle.paillier_encrypt(n_l, hs_l, m_host[:S], r_host[:S])
-        m = c_oracle.paillier_decrypt_crt(*args, c)
-        dt = time.perf_counter() - t0
-        assert np.array_equal(m, m_host[:S])
-        return dt
-    probe = max(threads, 8)
-    dt = run(probe)
-    S = int(min(m_host.shape[0], max(probe, probe * 12.0 / dt)))   # aim for ~12 s of CPU work
-    S -= S % threads if S > threads else 0
-    dt = run(S)
-    extra = {}
-    if c_oracle.openssl_lib() is not None:
-        # second reference point (BASELINE.md "B2"): the same three modexps per element through OpenSSL
-        # BN_mod_exp_mont on the same threads; modexps only (no L-function / CRT glue), which flatters the CPU
-        nsq_l = ints_to_limbs([n * n], 2 * nw)[0]
-        legs = [(ints_to_limbs([pr - 1], pw)[0], ints_to_limbs([pr * pr], nw)[0]) for pr in (sk.p, sk.q)]
-        c_all = c_oracle.paillier_encrypt(n_l, hs_l, m_host[:S], r_host[:S])      # untimed: decrypt input
+    def flows(backend):
+        if backend is None:
+            return (lambda m, r: c_oracle.paillier_encrypt(n_l, hs_l, m, r),
+                    lambda c: c_oracle.paillier_decrypt_crt(*args, c))
+        return (lambda m, r: c_oracle.paillier_encrypt_with(backend, n_l, hs_l, m, r),
+                lambda c: c_oracle.paillier_decrypt_crt_with(backend, *args, c))
 
-        def ossl(S2):
+    def measure(backend, target_s):
+        enc, dec = flows(backend)
+
+        def run(S):
             t0 = time.perf_counter()
-            c_oracle.openssl_modexp_batch(np.tile(hs_l, (S2, 1)), r_host[:S2], nsq_l)
-            outs = [c_oracle.openssl_modexp_batch(c_all[:S2], np.tile(e, (S2, 1)), mod) for e, mod in legs]
-            return time.perf_counter() - t0, outs
-        S2 = min(S, max(probe, S // 2))
-        d1, outs = ossl(S2)
-        c0 = sum(int(w) << (64 * k) for k, w in enumerate(c_all[0]))
-        assert sum(int(w) << (64 * k) for k, w in enumerate(outs[0][0])) == pow(c0, sk.p - 1, sk.p * sk.p)
-        extra["openssl"] = {"value": round(3 * S2 / d1, 1), "unit": "modexps/s", "cores": threads,
-                            "sample": f"{3 * S2} modexps (hs^r mod n^2, c^(p-1) mod p^2, c^(q-1) mod q^2 for {S2} "
-                                      f"elements) through OpenSSL BN_mod_exp_mont in {d1:.1f} s; modexps only"}
-    return {**extra, "value": round(3 * S / dt, 1), "unit": "modexps/s", "cores": threads, "kind": "port",
-            "sample": f"first {S} elements of the same batch, encrypt + CRT decrypt ({3 * S} modexps) "
-                      f"in {dt:.1f} s; oracle/modexp_oracle.c, gcc -O3 -fopenmp; {threads} OpenMP threads = "
-                      f"min(affinity {len(os.sched_getaffinity(0))}, cgroup cpu quota {c_oracle.usable_cpus()})",
-            "lib": os.path.basename(c_oracle.lib()._path)}
+            m = dec(enc(m_host[:S], r_host[:S]))
+            dt = time.perf_counter() - t0
+            assert np.array_equal(m, m_host[:S])
+            return dt
+        probe = max(8 * threads, 64)
+        dt = run(probe)
+        S = int(min(m_host.shape[0], max(probe, probe * target_s / dt)))
+        S -= S % (8 * threads) if S > 8 * threads else 0
+        dt = run(S)
+        return {"value": round(3 * S / dt, 1), "elements": S, "seconds": round(dt, 2)}
+
+    legs = {}
+    if c_oracle.ifma_lib() is not None:
+        legs["ifma"] = measure(c_oracle.ifma_modexp_batch, 8.0)
+    if c_oracle.openssl_lib() is not None:
+        legs["openssl"] = measure(c_oracle.openssl_modexp_batch, 6.0)
+    legs["scalar"] = measure(None, 8.0)
+    best = max(legs, key=lambda k: legs[k]["value"])
+    what = {"ifma": "oracle/ifma_oracle.c (8-lane AVX512-IFMA radix-2^52 restatement of the reference's mb8 path)",
+            "openssl": "OpenSSL BN_mod_exp_mont", "scalar": "oracle/modexp_oracle.c (64-bit CIOS)"}[best]
+    return {"value": legs[best]["value"], "unit": "modexps/s", "cores": threads, "kind": "port",
+            "sample": f"first {legs[best]['elements']} elements of the same batch, encrypt + CRT decrypt "
+                      f"({3 * legs[best]['elements']} modexps) in {legs[best]['seconds']} s; {what}, gcc -O3 "
+                      f"-fopenmp; {threads} OpenMP threads = min(affinity {len(os.sched_getaffinity(0))}, "
+                      f"cgroup cpu quota {c_oracle.usable_cpus()})",
+            "leg": best, "legs": legs}
 
 
 if __name__ == "__main__":

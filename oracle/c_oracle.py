@@ -34,6 +34,9 @@ def lib():
         L.orc_modmul_batch.argtypes = [vp, vp, sz, vp, i, vp, sz]
         L.orc_paillier_encrypt.argtypes = [vp, i, vp, vp, i, vp, i, vp, sz]
         L.orc_paillier_decrypt_crt.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, sz]
+        L.orc_paillier_encrypt_finish.argtypes = [vp, i, vp, i, vp, vp, sz]
+        L.orc_paillier_decrypt_prepare.argtypes = [vp, vp, i, vp, vp, vp, sz]
+        L.orc_paillier_decrypt_finish.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, sz]
         L.orc_max_threads.restype = i
         L.orc_set_threads.argtypes = [i]
         _lib = L
@@ -142,3 +145,90 @@ def openssl_modexp_batch(base, exp, mod):
                                     mod.shape[0], _p(out), base.shape[0])
     assert rc == 0
     return out
+
+
+_ifma = None
+
+
+def ifma_lib():
+    """libifma_oracle.so (oracle/ifma_oracle.c) when it was built AND this CPU reports avx512ifma."""
+    global _ifma
+    if _ifma is None:
+        path = os.path.join(_HERE, "libifma_oracle.so")
+        if not (os.path.exists(path) and _cpu_has("avx512ifma") and _cpu_has("avx512f")):
+            return None
+        try:
+            L = ctypes.CDLL(path)
+        except OSError:
+            return None
+        vp, sz, i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        L.orc_ifma_modexp_batch.argtypes = [vp, sz, vp, sz, i, vp, i, vp, sz]
+        _ifma = L
+    return _ifma
+
+
+def ifma_modexp_batch(base, exp, mod):
+    """Same contract as modexp_batch (base < mod required), 8 lanes per zmm; None when unavailable."""
+    L = ifma_lib()
+    if L is None:
+        return None
+    base = np.ascontiguousarray(base, dtype=np.uint64)
+    exp = np.ascontiguousarray(exp, dtype=np.uint64)
+    mod = np.ascontiguousarray(mod, dtype=np.uint64)
+    assert base.shape[1] == mod.shape[0]
+    out = np.empty_like(base)
+    rc = L.orc_ifma_modexp_batch(_p(base), base.shape[1], _p(exp), exp.shape[1], exp.shape[1], _p(mod),
+                                 mod.shape[0], _p(out), base.shape[0])
+    assert rc == 0, rc
+    return out
+
+
+# ---- the same encrypt / CRT-decrypt flows with the modexps done by another backend -------------------
+# backend(base [cnt, W], exp [cnt, E], mod [W]) -> [cnt, W]: ifma_modexp_batch or openssl_modexp_batch;
+# the reference's host glue around them (pub_key.cpp:88-89,105; pri_key.cpp:128-157) stays in
+# oracle/modexp_oracle.c (orc_paillier_encrypt_finish / _decrypt_prepare / _decrypt_finish).
+
+def paillier_encrypt_with(backend, n, hs, m, r):
+    n = np.ascontiguousarray(n, dtype=np.uint64)
+    m = np.ascontiguousarray(m, dtype=np.uint64)
+    r = np.ascontiguousarray(r, dtype=np.uint64)
+    nw, cnt = n.shape[0], m.shape[0]
+    nsq = np.zeros(2 * nw, dtype=np.uint64)
+    v = _to_int(n) ** 2
+    for k in range(2 * nw):
+        nsq[k] = (v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    if hs is not None:                                   # DJN: hs^r   pub_key.cpp:63
+        obf = backend(np.tile(np.ascontiguousarray(hs, dtype=np.uint64), (cnt, 1)), r, nsq)
+    else:                                                # r^n        pub_key.cpp:79
+        base = np.zeros((cnt, 2 * nw), dtype=np.uint64)
+        base[:, :r.shape[1]] = r
+        obf = backend(base, np.tile(n, (cnt, 1)), nsq)
+    out = np.empty((cnt, 2 * nw), dtype=np.uint64)
+    rc = lib().orc_paillier_encrypt_finish(_p(n), nw, _p(m), m.shape[1], _p(obf), _p(out), cnt)
+    assert rc == 0
+    return out
+
+
+def paillier_decrypt_crt_with(backend, p, q, hp, hq, pinv, c):
+    arrs = [np.ascontiguousarray(v, dtype=np.uint64) for v in (p, q, hp, hq, pinv)]
+    c = np.ascontiguousarray(c, dtype=np.uint64)
+    pw, cnt = arrs[0].shape[0], c.shape[0]
+    bp = np.empty((cnt, 2 * pw), dtype=np.uint64)
+    bq = np.empty_like(bp)
+    rc = lib().orc_paillier_decrypt_prepare(_p(arrs[0]), _p(arrs[1]), pw, _p(c), _p(bp), _p(bq), cnt)
+    assert rc == 0
+    res = []
+    for prime, b in ((arrs[0], bp), (arrs[1], bq)):
+        pv = _to_int(prime)
+        e = np.array([((pv - 1) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(pw)], dtype=np.uint64)
+        sq = np.array([((pv * pv) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(2 * pw)], dtype=np.uint64)
+        res.append(np.ascontiguousarray(backend(b, np.tile(e, (cnt, 1)), sq)))   # pri_key.cpp:133-134
+    out = np.empty((cnt, 2 * pw), dtype=np.uint64)
+    rc = lib().orc_paillier_decrypt_finish(_p(arrs[0]), _p(arrs[1]), pw, _p(arrs[2]), _p(arrs[3]), _p(arrs[4]),
+                                           _p(res[0]), _p(res[1]), _p(out), cnt)
+    assert rc == 0
+    return out
+
+
+def _to_int(limbs):
+    return sum(int(w) << (64 * k) for k, w in enumerate(limbs))

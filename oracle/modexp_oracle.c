@@ -200,6 +200,21 @@ int orc_modmul_batch(const u64* a, const u64* b, size_t b_stride, const u64* mod
   return 0;
 }
 
+/* c = obf * ((n*m + 1) % n^2) % n^2     pub_key.cpp:88-89,105 */
+static void enc_finish_one(const u64* n, int nw, const u64* nsq, const u64* m, int m_words, const u64* obf,
+                           u64* c) {
+  const int W = 2 * nw;
+  u64 g[2 * MAXW + 1], gm[MAXW], t[2 * MAXW];
+  memset(g, 0, sizeof(g));
+  bn_mul(g, n, nw, m, m_words);
+  int gw = nw + m_words;
+  for (int j = 0; j < gw + 1; ++j)
+    if (++g[j]) break;
+  bn_mod(gm, g, gw + 1, nsq, W);
+  bn_mul(t, gm, W, obf, W);
+  bn_mod(c, t, 2 * W, nsq, W);
+}
+
 /* c[i] = obf[i] * (1 + n*m[i]) mod n^2, obf = hs^r (djn) or r^n.   nw = limbs of n. */
 int orc_paillier_encrypt(const u64* n, int nw, const u64* hs_or_null, const u64* m, int m_words,
                          const u64* r, int r_words, u64* c, size_t count) {
@@ -211,7 +226,7 @@ int orc_paillier_encrypt(const u64* n, int nw, const u64* hs_or_null, const u64*
   mont_init(M, nsq, W);
 #pragma omp parallel for schedule(dynamic, 1)
   for (long i = 0; i < (long)count; ++i) {
-    u64 obf[MAXW], g[2 * MAXW + 1], gm[MAXW], t[2 * MAXW], base[MAXW];
+    u64 obf[MAXW], base[MAXW];
     if (hs_or_null) {
       mont_modexp(M, obf, hs_or_null, r + (size_t)i * r_words, r_words);   /* pub_key.cpp:63 */
     } else {
@@ -219,15 +234,7 @@ int orc_paillier_encrypt(const u64* n, int nw, const u64* hs_or_null, const u64*
       memcpy(base, r + (size_t)i * r_words, sizeof(u64) * (size_t)(r_words < W ? r_words : W));
       mont_modexp(M, obf, base, n, nw);                                   /* pub_key.cpp:79 */
     }
-    /* (n*m + 1) % n^2   pub_key.cpp:105 */
-    memset(g, 0, sizeof(g));
-    bn_mul(g, n, nw, m + (size_t)i * m_words, m_words);
-    int gw = nw + m_words;
-    for (int j = 0; j < gw + 1; ++j)
-      if (++g[j]) break;
-    bn_mod(gm, g, gw + 1, nsq, W);
-    bn_mul(t, gm, W, obf, W);                                             /* pub_key.cpp:88-89 */
-    bn_mod(c + (size_t)i * W, t, 2 * W, nsq, W);
+    enc_finish_one(n, nw, nsq, m + (size_t)i * m_words, m_words, obf, c + (size_t)i * W);
   }
   free(M);
   return 0;
@@ -254,6 +261,40 @@ static void bn_divexact(u64* q, const u64* a, int wa, const u64* d, int wd) {
   }
 }
 
+/* from rp = c^(p-1) mod p^2, rq = c^(q-1) mod q^2 (clobbered) to the plaintext: L-function, *hp / *hq,
+ * CRT recombination   pri_key.cpp:142-157 */
+static void dec_finish_one(const u64* p, const u64* q, int pw, const u64* hp, const u64* hq, const u64* pinv,
+                           u64* rp, u64* rq, u64* mi) {
+  const int hw = 2 * pw;
+  u64 lp[MAXW], lq[MAXW], t[2 * MAXW], dp[MAXW], dq[MAXW], onev[MAXW];
+  memset(onev, 0, sizeof(u64) * (size_t)hw);
+  onev[0] = 1;
+  bn_sub(rp, rp, onev, hw);                            /* L(x) = (x-1)/p  pri_key.cpp:154-157 */
+  bn_sub(rq, rq, onev, hw);
+  bn_divexact(lp, rp, hw, p, pw);
+  bn_divexact(lq, rq, hw, q, pw);
+  bn_mul(t, lp, pw, hp, pw);
+  bn_mod(dp, t, 2 * pw, p, pw);                        /* pri_key.cpp:142 */
+  bn_mul(t, lq, pw, hq, pw);
+  bn_mod(dq, t, 2 * pw, q, pw);                        /* pri_key.cpp:143 */
+  /* u = (dq - dp) * pinv mod q, non-negative residue   pri_key.cpp:150 */
+  u64 d[MAXW], u[MAXW];
+  u64 dpq[MAXW];
+  bn_mod(dpq, dp, pw, q, pw);
+  if (bn_cmp(dq, dpq, pw) >= 0) {
+    bn_sub(d, dq, dpq, pw);
+  } else {
+    bn_add(d, dq, q, pw);
+    bn_sub(d, d, dpq, pw);
+  }
+  bn_mul(t, d, pw, pinv, pw);
+  bn_mod(u, t, 2 * pw, q, pw);
+  bn_mul(t, u, pw, p, pw);                             /* pri_key.cpp:151 */
+  memset(mi, 0, sizeof(u64) * (size_t)hw);
+  memcpy(mi, dp, sizeof(u64) * (size_t)pw);
+  bn_add(mi, mi, t, hw);
+}
+
 /* CRT decrypt.  p < q REQUIRED (caller orders them, pri_key.cpp:19-22); pw limbs each;
  * hp, hq, pinv (= p^-1 mod q) host-precomputed by the caller (pri_key.cpp:27-29), pw limbs.
  * c: 4*pw limbs per element, m: 2*pw limbs per element. */
@@ -275,39 +316,55 @@ int orc_paillier_decrypt_crt(const u64* p, const u64* q, int pw, const u64* hp, 
 #pragma omp parallel for schedule(dynamic, 1)
   for (long i = 0; i < (long)count; ++i) {
     const u64* ci = c + (size_t)i * cw;
-    u64 bp[MAXW], bq[MAXW], rp[MAXW], rq[MAXW], lp[MAXW], lq[MAXW], t[2 * MAXW], dp[MAXW], dq[MAXW];
+    u64 bp[MAXW], bq[MAXW], rp[MAXW], rq[MAXW];
     bn_mod(bp, ci, cw, psq, hw);                         /* pri_key.cpp:128 */
     bn_mod(bq, ci, cw, qsq, hw);                         /* pri_key.cpp:129 */
     mont_modexp(Mp, rp, bp, pm1, pw);                    /* pri_key.cpp:133 */
     mont_modexp(Mq, rq, bq, qm1, pw);                    /* pri_key.cpp:134 */
-    bn_sub(rp, rp, onev, hw);                            /* L(x) = (x-1)/p  pri_key.cpp:154-157 */
-    bn_sub(rq, rq, onev, hw);
-    bn_divexact(lp, rp, hw, p, pw);
-    bn_divexact(lq, rq, hw, q, pw);
-    bn_mul(t, lp, pw, hp, pw);
-    bn_mod(dp, t, 2 * pw, p, pw);                        /* pri_key.cpp:142 */
-    bn_mul(t, lq, pw, hq, pw);
-    bn_mod(dq, t, 2 * pw, q, pw);                        /* pri_key.cpp:143 */
-    /* u = (dq - dp) * pinv mod q, non-negative residue   pri_key.cpp:150 */
-    u64 d[MAXW], u[MAXW];
-    u64 dpq[MAXW];
-    bn_mod(dpq, dp, pw, q, pw);
-    if (bn_cmp(dq, dpq, pw) >= 0) {
-      bn_sub(d, dq, dpq, pw);
-    } else {
-      bn_add(d, dq, q, pw);
-      bn_sub(d, d, dpq, pw);
-    }
-    bn_mul(t, d, pw, pinv, pw);
-    bn_mod(u, t, 2 * pw, q, pw);
-    bn_mul(t, u, pw, p, pw);                             /* pri_key.cpp:151 */
-    u64* mi = m + (size_t)i * hw;
-    memset(mi, 0, sizeof(u64) * (size_t)hw);
-    memcpy(mi, dp, sizeof(u64) * (size_t)pw);
-    bn_add(mi, mi, t, hw);
+    dec_finish_one(p, q, pw, hp, hq, pinv, rp, rq, m + (size_t)i * hw);
   }
   free(Mp);
   free(Mq);
+  return 0;
+}
+
+/* ---------- split entry points: the same flows with the modexps done by another backend ----------
+ * (oracle/ifma_oracle.c or OpenSSL compute obf / rp / rq; these do the reference's host glue around them) */
+int orc_paillier_encrypt_finish(const u64* n, int nw, const u64* m, int m_words, const u64* obf, u64* c,
+                                size_t count) {
+  const int W = 2 * nw;
+  if (W > MAXW) return -1;
+  u64 nsq[MAXW];
+  bn_mul(nsq, n, nw, n, nw);
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < (long)count; ++i)
+    enc_finish_one(n, nw, nsq, m + (size_t)i * m_words, m_words, obf + (size_t)i * W, c + (size_t)i * W);
+  return 0;
+}
+
+/* bp = c mod p^2, bq = c mod q^2 (2*pw limbs each)   pri_key.cpp:128-129 */
+int orc_paillier_decrypt_prepare(const u64* p, const u64* q, int pw, const u64* c, u64* bp, u64* bq,
+                                 size_t count) {
+  const int hw = 2 * pw, cw = 4 * pw;
+  if (cw > MAXW) return -1;
+  u64 psq[MAXW], qsq[MAXW];
+  bn_mul(psq, p, pw, p, pw);
+  bn_mul(qsq, q, pw, q, pw);
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < (long)count; ++i) {
+    bn_mod(bp + (size_t)i * hw, c + (size_t)i * cw, cw, psq, hw);
+    bn_mod(bq + (size_t)i * hw, c + (size_t)i * cw, cw, qsq, hw);
+  }
+  return 0;
+}
+
+int orc_paillier_decrypt_finish(const u64* p, const u64* q, int pw, const u64* hp, const u64* hq,
+                                const u64* pinv, u64* rp, u64* rq, u64* m, size_t count) {
+  const int hw = 2 * pw;
+  if (4 * pw > MAXW) return -1;
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < (long)count; ++i)
+    dec_finish_one(p, q, pw, hp, hq, pinv, rp + (size_t)i * hw, rq + (size_t)i * hw, m + (size_t)i * hw);
   return 0;
 }
 

@@ -62,7 +62,8 @@ def build_ipcl(force=False):
 def build_oracle(force=False):
     odir = os.path.join(ROOT, "oracle")
     out = os.path.join(odir, "libmodexp_oracle.so")
-    if force or _newer(out, [os.path.join(odir, "modexp_oracle.c"), os.path.join(odir, "Makefile")]):
+    srcs = [os.path.join(odir, f) for f in ("modexp_oracle.c", "openssl_oracle.c", "ifma_oracle.c", "Makefile")]
+    if force or _newer(out, srcs):
         _run(["make", "-C", odir, "-B"])
     return out
 

@@ -74,3 +74,65 @@ def test_openssl_leg_agrees_with_pow_and_c_port():
         got = limbs_to_ints(c_oracle.openssl_modexp_batch(b, e, m))
         assert got == [pow(x % mod, y, mod) for x, y in zip(base, exp)]
         assert got == limbs_to_ints(c_oracle.modexp_batch(b, e, m))
+
+
+def test_ifma_leg_agrees_with_pow():
+    """AVX512-IFMA 8-lane restatement (oracle/ifma_oracle.c, CPU baseline B3) vs CPython pow: every
+    modulus width of the BASELINE configs, ragged batch sizes (the 8-lane tail), exponent 0/1, base 0."""
+    if c_oracle.ifma_lib() is None:
+        pytest.skip("no avx512ifma on this host (or compiler without -mavx512ifma)")
+    rng = random.Random(17)
+    for bits, ebits, cnt in ((1024, 512, 9), (2048, 1024, 17), (3072, 1536, 8), (4096, 1024, 11), (4096, 2048, 3),
+                             (6144, 1536, 5), (4096, 32, 7), (1000, 333, 10), (4000, 77, 1)):
+        mod = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+        W, E = (bits + 63) // 64, (ebits + 63) // 64
+        base = [rng.randrange(mod) for _ in range(cnt)]
+        exp = [rng.getrandbits(ebits) for _ in range(cnt)]
+        exp[0] = 0
+        base[-1] = 0 if cnt > 2 else base[-1]
+        if cnt > 3:
+            exp[1], base[2] = 1, mod - 1
+        got = limbs_to_ints(c_oracle.ifma_modexp_batch(ints_to_limbs(base, W), ints_to_limbs(exp, E),
+                                                       ints_to_limbs([mod], W)[0]))
+        assert got == [pow(b, e, mod) for b, e in zip(base, exp)], (bits, ebits)
+
+
+def test_ifma_leg_on_iso_kat():
+    """r^n mod n^2 of the reference's ISO/IEC 18033-6 vector (test/test_cryptography.cpp:99-241)."""
+    if c_oracle.ifma_lib() is None:
+        pytest.skip("no avx512ifma on this host")
+    k = json.load(open(os.path.join(GOLD, "iso_kat.json")))
+    p, q = int(k["p"], 16), int(k["q"], 16)
+    n = p * q
+    r = [int(k["r0"], 16), int(k["r1"], 16)]
+    got = limbs_to_ints(c_oracle.ifma_modexp_batch(ints_to_limbs(r, 64), ints_to_limbs([n, n], 32),
+                                                   ints_to_limbs([n * n], 64)[0]))
+    assert got == [pow(x, n, n * n) for x in r]
+
+
+@pytest.mark.parametrize("which", ["ifma", "openssl"])
+def test_split_flows_match_scalar_port_and_kat(which):
+    """encrypt / CRT decrypt with the modexps done by the IFMA or OpenSSL leg and the host glue by
+    oracle/modexp_oracle.c: bit-identical to the scalar port and to the reference's ISO KAT."""
+    backend = {"ifma": (c_oracle.ifma_lib, c_oracle.ifma_modexp_batch),
+               "openssl": (c_oracle.openssl_lib, c_oracle.openssl_modexp_batch)}[which]
+    if backend[0]() is None:
+        pytest.skip(which + " leg not available on this host")
+    k = json.load(open(os.path.join(GOLD, "iso_kat.json")))
+    p, q = sorted((int(k["p"], 16), int(k["q"], 16)))
+    n = p * q
+    sk = orc.PrivateKey(n, p, q)
+    rng = random.Random(23)
+    m = [int(k["m0"], 16), int(k["m1"], 16)] + [rng.randrange(n) for _ in range(9)]
+    r = [int(k["r0"], 16), int(k["r1"], 16)] + [rng.randrange(1, n) for _ in range(9)]
+    n_l, m_l, r_l = ints_to_limbs([n], 32)[0], ints_to_limbs(m, 32), ints_to_limbs(r, 32)
+    c = c_oracle.paillier_encrypt_with(backend[1], n_l, None, m_l, r_l)
+    assert np.array_equal(c, c_oracle.paillier_encrypt(n_l, None, m_l, r_l))
+    assert limbs_to_ints(c[:2]) == [int(k["c1"], 16), int(k["c2"], 16)]
+    hs = int(k["bench_hs"], 16)
+    hs_l, rs_l = ints_to_limbs([hs], 64)[0], ints_to_limbs([rng.getrandbits(1024) for _ in m], 16)
+    cd = c_oracle.paillier_encrypt_with(backend[1], n_l, hs_l, m_l, rs_l)
+    assert np.array_equal(cd, c_oracle.paillier_encrypt(n_l, hs_l, m_l, rs_l))
+    args = [ints_to_limbs([v], 16)[0] for v in (sk.p, sk.q, sk.hp, sk.hq, sk.pinv)]
+    for ct in (c, cd):
+        assert limbs_to_ints(c_oracle.paillier_decrypt_crt_with(backend[1], *args, ct)) == m
