@@ -207,8 +207,8 @@ def main():
                 "bound": "int-alu",
                 "bound_note": "v_mad_u64_u32 issue rate (measured 32.69 T MAC32/s, profiles/r01_ubench_valu_issue_rates.txt); "
                               "neither hbm nor mfma binds this path: integer carry-chain work, HBM at 1e-4 of peak",
-                "kernel": "modexp_kernel<Geo<8,9>> (CRT-decrypt leg: 16384 half-width modexps per launch; "
-                          "the dominant kernel of the step)",
+                "kernel": f"modexp_kernel<{geo_name(nw, KEY_BITS, 2 * BATCH)}> (CRT-decrypt leg: {2 * BATCH} half-width "
+                          "modexps per launch; the dominant kernel of the step)",
                 "achieved": round(achieved, 3),
                 "peak": PEAK_TMAC32,
                 "unit": "TMAC32/s",
@@ -221,8 +221,9 @@ def main():
                 "hbm_peak_GBs": HBM_PEAK_GBS,
                 "hbm_frac": round(alg_bytes_dec / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                 "other_kernels": {
-                    "crt_kernel<Geo<8,9>>": {"ms": round(crt_ms, 4)},
-                    ("fb_encrypt_kernel<Geo<16,9>>" if fixed_base else "modexp_kernel<Geo<16,9>> (encrypt)"): {
+                    f"crt_kernel<{geo_name(nw, KEY_BITS, 0)}>": {"ms": round(crt_ms, 4)},
+                    (f"fb_encrypt_kernel<{geo_name(2 * nw, 2 * KEY_BITS, BATCH)}>" if fixed_base
+                     else f"modexp_kernel<{geo_name(2 * nw, 2 * KEY_BITS, BATCH)}> (encrypt)"): {
                         "ms": round(enc_ms, 4),
                         "canonical_mac32_per_launch": mac_enc,
                         "executed_mac32_per_launch": mac_enc_exec,
@@ -244,6 +245,16 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     pa.terminate()
+
+
+def geo_name(in_words, mod_bits, count):
+    """Kernel instantiation the library launches for this shape (pgpu_kernel_geometry); count = 0 for
+    crt_kernel, which always runs the base geometry."""
+    import ctypes
+    from pailliercryptolib_amd import _capi
+    g, k = ctypes.c_int(), ctypes.c_int()
+    _capi.check(_capi.lib().pgpu_kernel_geometry(in_words, mod_bits, max(count, 1), ctypes.byref(g), ctypes.byref(k)))
+    return f"Geo<{g.value},{k.value}>"
 
 
 def cpu_baseline(n, p, q, hs, m_host, r_host):

@@ -21,6 +21,7 @@ SYMBOLS = [
     "pgpu_paillier_decrypt_crt_dev",
     "pgpu_dev_alloc", "pgpu_dev_free", "pgpu_copy_h2d", "pgpu_copy_d2h",
     "pgpu_set_fixed_base_window", "pgpu_set_timing", "pgpu_timing_collect",
+    "pgpu_kernel_geometry",
 ]
 
 _lib = None
@@ -83,6 +84,8 @@ def lib():
     L.pgpu_set_fixed_base_window.argtypes = [c_int]; L.pgpu_set_fixed_base_window.restype = c_int
     L.pgpu_set_timing.argtypes = [c_int]; L.pgpu_set_timing.restype = c_int
     L.pgpu_timing_collect.argtypes = [c_void_p, c_void_p, c_int]; L.pgpu_timing_collect.restype = c_int
+    L.pgpu_kernel_geometry.argtypes = [c_int, c_int, c_size_t, POINTER(c_int), POINTER(c_int)]
+    L.pgpu_kernel_geometry.restype = c_int
     _lib = L
     return L
 

@@ -327,15 +327,20 @@ void launch_fb_encrypt(const pgpu::FixedBaseArgs& a, hipStream_t s) {
 
 // A context built for (G, 9) also serves the "wide" split (G/2, 18): same L, same R, same limb
 // arrays, half the lanes per exponentiation and twice the limbs per lane -- the per-row support
-// instructions are amortised over twice as many MACs.  It only pays when the batch still gives
-// every SIMD at least two wavefronts (v_mad_u64_u32 needs >= 2 waves/SIMD to issue at full rate).
-constexpr size_t kMinWavesForWide = 2 * 256 * 4;
+// instructions are amortised over twice as many MACs (78-80 % of the VALU slots are MACs instead of
+// 61-67 %).  It pays as soon as the wide split still puts one wavefront on every SIMD: measured on the
+// bench's CRT-decrypt launch, (4,18) at 1 wave/SIMD 7.50 ms vs (8,9) at 2 waves/SIMD 8.07 ms.
+constexpr size_t kMinWavesForWide = 256 * 4;
 GeoInfo launch_geo(const GeoInfo& geo, size_t count) {
   static const bool allow = [] { const char* e = std::getenv("PGPU_WIDE"); return !e || std::atoi(e) != 0; }();
   if (!allow || geo.K != 9 || geo.G < 4) return geo;
   GeoInfo wide{geo.G / 2, 18};
   size_t waves = (count + wide.ipw() - 1) / wide.ipw();
-  return waves >= kMinWavesForWide ? wide : geo;
+  static const size_t min_waves = [] {
+    const char* e = std::getenv("PGPU_WIDE_MIN_WAVES");     // tuning knob (tools/quick_bench.py)
+    return e && std::atol(e) > 0 ? (size_t)std::atol(e) : kMinWavesForWide;
+  }();
+  return waves >= min_waves ? wide : geo;
 }
 
 uint64_t* g_wave_clocks_ptr();
@@ -492,6 +497,17 @@ void pgpu_shutdown(void) {
 int pgpu_is_initialized(void) { return g_init ? 1 : 0; }
 const char* pgpu_last_error(void) { return g_err.c_str(); }
 const char* pgpu_device_name(void) { return g_devname.c_str(); }
+
+int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, int* limbs) {
+  if (in_words <= 0 || mod_bits <= 1 || !lanes || !limbs)
+    return fail(PGPU_ERR_INVALID_PARAM, "pgpu_kernel_geometry: bad argument");
+  const GeoInfo* geo = pick_geo(in_words, mod_bits);
+  if (!geo) return fail(PGPU_ERR_UNSUPPORTED, "modulus wider than the compiled kernel geometries");
+  const GeoInfo g = launch_geo(*geo, count);
+  *lanes = g.G;
+  *limbs = g.K;
+  return PGPU_OK;
+}
 
 int pgpu_set_fixed_base_window(int w) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);

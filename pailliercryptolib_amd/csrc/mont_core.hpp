@@ -67,37 +67,29 @@ __device__ __forceinline__ uint32_t bcast_lane0(uint32_t v) {
   }
 }
 
-// ---- fused DPP + mask (one VALU slot instead of v_mov_b32_dpp + v_and_b32) ----
-// hipcc does not fold a v_and into the DPP move, so these are written as v_and_b32_dpp by hand.
-// The leading s_nop 1 covers the "VALU write -> DPP read of the same VGPR" hazard (2 wait states),
-// which the compiler cannot see inside an asm statement.
+// ---- fused DPP + mask (one VALU slot: v_and_b32_dpp) ----
+// m must live in a VGPR (callers launder it through an empty asm): with a register mask hipcc's DPP
+// combiner folds the v_and into the DPP move, schedules it freely and inserts the "VALU write -> DPP
+// read" wait states only where they are needed.  Only the two-instruction G = 8 broadcast is written
+// by hand (bank-masked halves of one destination are beyond the combiner); its leading s_nop 1 covers
+// that hazard, which the compiler cannot see inside an asm statement.
 // (value of lane x+1) & m; 0 at the row end
 __device__ __forceinline__ uint32_t and_from_next(uint32_t v, uint32_t m) {
-  uint32_t r;
-  asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-      : "=v"(r) : "v"(v), "v"(m));
-  return r;
+  return dpp_from_next(v) & m;
 }
 // (value held by lane 0 of the G-lane group) & m, in every lane of the group
 template <int G>
 __device__ __forceinline__ uint32_t and_bcast_lane0(uint32_t v, uint32_t m) {
-  uint32_t r;
-  if constexpr (G == 16) {
-    asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "=v"(r) : "v"(v), "v"(m));
-  } else if constexpr (G == 8) {
+  if constexpr (G == 8) {
+    uint32_t r;
     // lanes 0-7 take lane 0, lanes 8-15 take lane 8: two bank-masked broadcasts into one VGPR
     asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
         "v_and_b32_dpp %0, %1, %2 row_newbcast:8 row_mask:0xf bank_mask:0xc bound_ctrl:1"
         : "=&v"(r) : "v"(v), "v"(m));
-  } else if constexpr (G == 4) {
-    asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "=v"(r) : "v"(v), "v"(m));
+    return r;
   } else {
-    asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "=v"(r) : "v"(v), "v"(m));
+    return bcast_lane0<G>(v) & m;
   }
-  return r;
 }
 
 // One K-row block of the word-serial Montgomery product.

@@ -55,11 +55,12 @@ for s, cs in agg.items():
 json.dump(out, open(f"profiles/{tag}_pmc_counters.json", "w"), indent=1)
 summary = {"source": f"profiles/{tag}_pmc_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                      "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, the x2 on FETCH per MI355X_MICROARCH.md (HBM)"}
-dec = out.get("modexp_kernel<pgpu::Geo<8, 9> >")
+dec = next((v for k, v in out.items() if k.startswith("modexp_kernel<")), None)   # the bench launches one shape
 if dec and "hbm_bytes_fetch_x2_corrected" in dec:
+    summary["modexp_decrypt_kernel"] = next(k for k in out if k.startswith("modexp_kernel<"))
     summary["modexp_decrypt_hbm_bytes_per_launch"] = dec["hbm_bytes_fetch_x2_corrected"]
     summary["modexp_decrypt_hbm_bytes_per_launch_raw"] = dec["hbm_bytes_raw"]
-fb = out.get("fb_encrypt_kernel<pgpu::Geo<16, 9> >")
+fb = next((v for k, v in out.items() if k.startswith("fb_encrypt_kernel<")), None)
 if fb and "hbm_bytes_fetch_x2_corrected" in fb:
     summary["fb_encrypt_hbm_bytes_per_launch"] = fb["hbm_bytes_fetch_x2_corrected"]
     summary["fb_encrypt_hbm_bytes_per_launch_raw"] = fb["hbm_bytes_raw"]
