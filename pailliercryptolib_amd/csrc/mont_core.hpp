@@ -134,25 +134,61 @@ __device__ __forceinline__ void mont_block(uint64_t (&LOWC)[GEO::K], uint64_t (&
   // phase B: K quotient digits, each followed by acc += n_chunk * q
   uint32_t maskv = kLimbMask;
   asm("" : "+v"(maskv));   // keep the mask in a VGPR (v_and_b32_dpp takes no literal)
+  // The dependent chain of a row is q -> MAC (columns r, r+1) -> carry -> q of the next row.  A lone
+  // wavefront on a SIMD (small batches) stalls when those sit back to back, so the row is issued as
+  // q | 4 MACs | limb hand-over + carry shift | 2 MACs | carry add | remaining MACs, pinned with VALU
+  // scheduling barriers (memory and scalar instructions may still cross).
+  constexpr int kNoValuCross = 0x3fc;
+  constexpr int J1 = K < 4 ? K : 4, J2 = K < 6 ? K : 6, J3 = K - 2 > J2 ? K - 2 : J2;
+  auto mac = [&](int r, int j, uint32_t q) {
+    if (r + j < K) LOWC[r + j] += (uint64_t)n[j] * q;
+    else UPC[r + j - K] += (uint64_t)n[j] * q;
+  };
+  uint32_t recv = 0, qprev = 0;
 #pragma unroll
   for (int r = 0; r < K; ++r) {
     // UNITQ: the modulus is == -1 mod 2^29 (capi.hip: build_modctx scales it), so n0' = 1
+    __builtin_amdgcn_sched_barrier(kNoValuCross);
     uint32_t q = and_bcast_lane0<GEO::G>(UNITQ ? (uint32_t)LOWC[r] : (uint32_t)LOWC[r] * n0inv, maskv);
+    // fillers between the broadcast and its first use: the last two MACs of the previous row, and
+    // the hand-over of column r-1, final since the previous row: its 29-bit limb belongs to lane x-1,
+    // whose window overlaps it at its column K+r-1 -- so every lane adds the limb it received from
+    // lane x+1 straight into UPC[r-1] (window slide, no deferred copies).  In the group's lane 0 the
+    // limb is 0 by construction of q, so the top lane of the group below receives 0: no masking.
+    __builtin_amdgcn_sched_barrier(kNoValuCross);
+    if (r > 0) {
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-      if (r + j < K) LOWC[r + j] += (uint64_t)n[j] * q;
-      else UPC[r + j - K] += (uint64_t)n[j] * q;
+      for (int j = J3; j < K; ++j) mac(r - 1, j, qprev);
+      UPC[r - 1] += recv;
     }
-    // column r is final: its 29-bit limb belongs to lane x-1, whose window overlaps it at its
-    // column K+r -- so every lane adds the limb it receives from lane x+1 straight into UPC[r]
-    // (window slide, no deferred copies); the rest carries into column r+1.  In the group's
-    // lane 0 the limb is 0 by construction of q, so the top lane of the group below receives 0
-    // and no masking is needed.
-    uint64_t c = LOWC[r] >> kLimbBits;
-    UPC[r] += and_from_next((uint32_t)LOWC[r], maskv);
+    __builtin_amdgcn_sched_barrier(kNoValuCross);
+#pragma unroll
+    for (int j = 0; j < J1; ++j) mac(r, j, q);
+    __builtin_amdgcn_sched_barrier(kNoValuCross);
+    recv = and_from_next((uint32_t)LOWC[r], maskv);
+    uint64_t c = LOWC[r] >> kLimbBits;             // the rest of column r carries into column r+1
+    // anchor the shift here, away from the add below: the accumulator of the next MAC is laundered
+    // together with c, so the shift has to precede that MAC (an empty asm is not a VALU op and could
+    // itself be moved across the VALU scheduling barriers)
+    if constexpr (J1 < K) {
+      uint64_t& accj = (r + J1 < K) ? LOWC[r + J1] : UPC[r + J1 - K];
+      asm("" : "+v"(c), "+v"(accj));
+    }
+    __builtin_amdgcn_sched_barrier(kNoValuCross);
+    if constexpr (J1 < K) mac(r, J1, q);
+#pragma unroll
+    for (int j = J1 + 1; j < J2; ++j) mac(r, j, q);
+    __builtin_amdgcn_sched_barrier(kNoValuCross);
     if (r + 1 < K) LOWC[r + 1] += c;
     else UPC[0] += c;
+    __builtin_amdgcn_sched_barrier(kNoValuCross);
+#pragma unroll
+    for (int j = J2; j < J3; ++j) mac(r, j, q);
+    qprev = q;
   }
+#pragma unroll
+  for (int j = J3; j < K; ++j) mac(K - 1, j, qprev);
+  UPC[K - 1] += recv;
   // the low half is consumed; it becomes the (zero) upper half of the next block
 #pragma unroll
   for (int j = 0; j < K; ++j) LOWC[j] = 0;
