@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 BATCH = 8192
 KEY_BITS = 2048
 # measured v_mad_u64_u32 issue rate on MI355X: profiles/r01_ubench_valu_issue_rates.txt (8 waves/SIMD row)
-PEAK_TMAC32 = 32.69
+PEAK_TMAC32 = 39.32   # 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz: v_mad_u64_u32 is full rate (38.35 measured)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -223,7 +223,8 @@ def main():
             },
             "roofline": {
                 "bound": "int-alu",
-                "bound_note": "v_mad_u64_u32 issue rate (measured 32.69 T MAC32/s, profiles/r01_ubench_valu_issue_rates.txt); "
+                "bound_note": "VALU issue rate: v_mad_u64_u32 issues at full rate, one wave64 instruction per 4 cycles per SIMD "
+                              "= 39.32 T MAC32/s at 2.4 GHz (38.35 measured, profiles/r01_ubench_mad_peak.txt); "
                               "neither hbm nor mfma binds this path: integer carry-chain work, HBM at 1e-4 of peak",
                 "kernel": f"modexp_kernel<{geo_name(nw, KEY_BITS, 2 * BATCH)}> (CRT-decrypt leg: {2 * BATCH} half-width "
                           "modexps per launch; the dominant kernel of the step)",
