@@ -123,27 +123,9 @@ def main():
     # stream (no sync inside the timed region); collected after the final synchronisation
     _capi.check(L.pgpu_set_timing(1))
     t0 = time.perf_counter()
-    if os.environ.get("PGPU_BENCH_OVERLAP") == "1":
-        # EXPERIMENT (not the reported configuration): encrypt of step i+1 on a second stream while step i decrypts
-        se, sd = torch.cuda.Stream(), torch.cuda.Stream()
-        cbuf = [d_c, torch.empty_like(d_c)]
-        e_done = [torch.cuda.Event(), torch.cuda.Event()]
-        d_done = [torch.cuda.Event(), torch.cuda.Event()]
-        for i in range(args.steps):
-            b = i & 1
-            if i >= 2:
-                se.wait_event(d_done[b])
-            _capi.check(L.pgpu_paillier_encrypt_dev(pk._h, d_m.data_ptr(), nw, nw, d_r.data_ptr(), pw, pw, 64 * pw,
-                                                    cbuf[b].data_ptr(), BATCH, ctypes.c_void_p(se.cuda_stream)))
-            e_done[b].record(se)
-            sd.wait_event(e_done[b])
-            _capi.check(L.pgpu_paillier_decrypt_crt_dev(sk._h, cbuf[b].data_ptr(), d_out.data_ptr(), BATCH,
-                                                        ctypes.c_void_p(sd.cuda_stream)))
-            d_done[b].record(sd)
-    else:
-        for i in range(args.steps):
-            enc()
-            dec()
+    for i in range(args.steps):
+        enc()
+        dec()
     sync_all()
     elapsed = time.perf_counter() - t0
     kinds = (ctypes.c_int * (4 * args.steps + 8))()

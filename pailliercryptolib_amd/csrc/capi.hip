@@ -227,6 +227,12 @@ Workspace g_table, g_vbuf;
 
 // fixed-window width: the w in 1..5 that minimises (2^w - 2) table multiplications +
 // ceil(e/w) window multiplications (w = 5 for e >= ~240 bits).
+// PGPU_SLIDING=0 keeps the fixed-window digit scan for key exponents too (A/B measurements)
+bool sliding_enabled() {
+  static const bool on = [] { const char* e = std::getenv("PGPU_SLIDING"); return !e || std::atoi(e) != 0; }();
+  return on;
+}
+
 int pick_window(int exp_bits) {
   int best = 1;
   long best_cost = 1L << 60;
@@ -235,6 +241,53 @@ int pick_window(int exp_bits) {
     if (cost < best_cost) { best_cost = cost; best = w; }
   }
   return best;
+}
+
+// Sliding-window schedule of an exponent the host knows (key constants: p-1, q-1): odd powers
+// base^(2i+1), i < 2^(w-1); step = (nsq << 6) | (idx + 1) -- nsq squarings then * base^(2 idx + 1)
+// (idx + 1 == 0: squarings only); step 0 has nsq == 0 and loads its entry (kernels.hpp ModexpArgs).
+struct ExpSchedule {
+  DevBlob dev;
+  int len = 0;
+  int w = 0;
+};
+std::vector<uint16_t> sliding_schedule(const BigNumber& e, int w) {
+  std::vector<uint16_t> st;
+  int i = e.BitSize() - 1, pending = 0;
+  auto emit = [&](int nsq, int idx_plus1) {
+    while (nsq > 1023) { st.push_back((uint16_t)(1023 << 6)); nsq -= 1023; }
+    st.push_back((uint16_t)((nsq << 6) | idx_plus1));
+  };
+  while (i >= 0) {
+    if (!e.TestBit(i)) { ++pending; --i; continue; }
+    int j = std::max(i - w + 1, 0);
+    while (!e.TestBit(j)) ++j;              // window [i..j], odd value
+    int v = 0;
+    for (int b = i; b >= j; --b) v = (v << 1) | (e.TestBit(b) ? 1 : 0);
+    emit(st.empty() ? 0 : pending + (i - j + 1), (v - 1) / 2 + 1);
+    pending = 0;
+    i = j - 1;
+  }
+  if (pending) emit(pending, 0);
+  return st;
+}
+// window of the cheapest sliding schedule for a random exponent of this length (w <= 6: 32 odd powers,
+// the same table footprint as the fixed 5-bit window)
+int pick_sliding_window(int exp_bits) {
+  int best = 1;
+  long best_cost = 1L << 60;
+  for (int w = 1; w <= 6; ++w) {
+    long cost = (1L << (w - 1)) + exp_bits / (w + 1);
+    if (cost < best_cost) { best_cost = cost; best = w; }
+  }
+  return best;
+}
+int make_schedule(const BigNumber& e, int w, ExpSchedule* out) {
+  std::vector<uint16_t> st = sliding_schedule(e, w);
+  out->len = (int)st.size();
+  out->w = w;
+  if (st.empty()) st.push_back(0);
+  return out->dev.upload(st.data(), st.size() * sizeof(uint16_t));
 }
 
 // window width of the fixed-base table for the DJN obfuscator; PGPU_FB_WINDOW=0 selects the
@@ -278,10 +331,15 @@ struct TimerScope {
   }
 };
 
+// wavefronts of a modexp launch: with two contexts every wave takes one parity of the instances
+// (kernels.hpp: ModexpArgs::nctx), i.e. 2 * ceil(elements / IPW)
+size_t modexp_waves(size_t count, int parity_waves, int ipw) {
+  return parity_waves ? 2 * ((count / 2 + ipw - 1) / ipw) : (count + ipw - 1) / ipw;
+}
 template <int G, int K>
 void launch_modexp(const pgpu::ModexpArgs& a, hipStream_t s) {
   typedef pgpu::Geo<G, K> GEO;
-  unsigned blocks = (unsigned)((a.count + GEO::IPW * pgpu::kWavesPerWG - 1) / (GEO::IPW * pgpu::kWavesPerWG));
+  unsigned blocks = (unsigned)((modexp_waves(a.count, a.parity_waves, GEO::IPW) + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
   hipLaunchKernelGGL((pgpu::modexp_kernel<GEO>), dim3(blocks), dim3(pgpu::kWGThreads), 0, s, a);
 }
 template <int G, int K>
@@ -352,12 +410,31 @@ int check_ready() {
 }
 
 // common launcher of modexp_kernel: sizes the window table and fills the shared fields
-int run_modexp(pgpu::ModexpArgs& a, const GeoInfo& ctx_geo, hipStream_t s) {
+// sched: per-context sliding-window schedules of a host-known shared exponent (device arrays), or null
+struct SchedRef {
+  const uint16_t* p[2] = {nullptr, nullptr};
+  int len[2] = {0, 0};
+  int w = 0;
+};
+int run_modexp(pgpu::ModexpArgs& a, const GeoInfo& ctx_geo, hipStream_t s, const SchedRef* sched = nullptr) {
   const GeoInfo geo = launch_geo(ctx_geo, a.count);
-  a.window = pick_window(a.exp_bits);
-  size_t per_wg = (size_t)geo.ipw() * pgpu::kWavesPerWG;
-  size_t padded = (a.count + per_wg - 1) / per_wg * per_wg;
-  RC_TRY(g_table.ensure(padded * ((size_t)1 << a.window) * geo.L() * sizeof(uint32_t)));
+  size_t entries;
+  a.parity_waves = 0;
+  if (sched && sched->p[0]) {
+    a.parity_waves = a.nctx == 2;
+    a.window = sched->w;
+    for (int i = 0; i < 2; ++i) {
+      a.sched[i] = sched->p[a.nctx == 2 ? i : 0];
+      a.sched_len[i] = sched->len[a.nctx == 2 ? i : 0];
+    }
+    entries = (size_t)1 << (a.window - 1);
+  } else {
+    a.window = pick_window(a.exp_bits);
+    entries = (size_t)1 << a.window;
+  }
+  size_t waves = modexp_waves(a.count, a.parity_waves, geo.ipw());
+  size_t padded = (waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG * pgpu::kWavesPerWG * geo.ipw();
+  RC_TRY(g_table.ensure(padded * (entries + 1) * geo.L() * sizeof(uint32_t)));   // + the parking slot
   a.table = (uint32_t*)g_table.p;
   a.wave_clocks = g_wave_clocks_ptr();
   TimerScope t(s, PGPU_KERNEL_MODEXP);
@@ -431,6 +508,7 @@ struct pgpu_pubkey {
   std::shared_ptr<ModCtx> nsq;  // modulus n^2, with nr = n*R mod n^2
   DevBlob d_hs;                 // DJN: hs, 2*n_words words
   DevBlob d_n;                  // plain: the exponent n, n_words words
+  ExpSchedule sched_n;          // plain: sliding-window schedule of n (r^n mod n^2)
   // fixed-base table for hs^r (built lazily, grown when a longer exponent shows up)
   mutable Workspace fb_table;
   mutable int fb_nwin = 0;
@@ -447,6 +525,7 @@ struct pgpu_privkey {
   std::shared_ptr<ModCtx> cM, cQ;   // auxiliary modulus M, modulus q (CRT geometry)
   DevBlob d_exps;               // [2][pq_words]: p-1, q-1
   int exp_bits = 0;
+  ExpSchedule sched[2];         // sliding-window schedules of p-1 and q-1
   DevBlob d_crt32;              // cp | cq | pinvR | pRM  (29-bit limbs, CRT geometry)
   DevBlob d_crt64;              // hp | hq | p^2 | q^2 | q   (n_words words each)
 };
@@ -615,9 +694,10 @@ int pgpu_copy_d2h(void* h_dst, const void* d_src, size_t bytes) {
 }
 
 // ===================== generic modexp =====================
-int pgpu_modexp_dev(const uint64_t* d_base, size_t base_stride, const uint64_t* d_exp,
-                    size_t exp_stride, int exp_words, int exp_bits, const uint64_t* h_mod,
-                    int mod_words, uint64_t* d_out, size_t count, void* hip_stream) {
+static int modexp_dev_impl(const uint64_t* d_base, size_t base_stride, const uint64_t* d_exp,
+                           size_t exp_stride, int exp_words, int exp_bits, const uint64_t* h_mod,
+                           int mod_words, uint64_t* d_out, size_t count, void* hip_stream,
+                           const SchedRef* sched) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   RC_TRY(check_ready());
   if (count == 0) return PGPU_OK;
@@ -645,7 +725,14 @@ int pgpu_modexp_dev(const uint64_t* d_base, size_t base_stride, const uint64_t* 
   a.out = d_out;
   a.out_stride = (size_t)mod_words;
   a.count = count;
-  return run_modexp(a, ctx->geo, (hipStream_t)hip_stream);
+  return run_modexp(a, ctx->geo, (hipStream_t)hip_stream, sched);
+}
+
+int pgpu_modexp_dev(const uint64_t* d_base, size_t base_stride, const uint64_t* d_exp,
+                    size_t exp_stride, int exp_words, int exp_bits, const uint64_t* h_mod,
+                    int mod_words, uint64_t* d_out, size_t count, void* hip_stream) {
+  return modexp_dev_impl(d_base, base_stride, d_exp, exp_stride, exp_words, exp_bits, h_mod, mod_words,
+                         d_out, count, hip_stream, nullptr);
 }
 
 int pgpu_modexp(const uint64_t* base, size_t base_stride, const uint64_t* exp, size_t exp_stride,
@@ -663,8 +750,21 @@ int pgpu_modexp(const uint64_t* base, size_t base_stride, const uint64_t* exp, s
   RC_TRY(db.from_host(base, nb));
   RC_TRY(de.from_host(exp, ne));
   RC_TRY(dout.alloc(no));
-  RC_TRY(pgpu_modexp_dev((const uint64_t*)db.p, base_stride, (const uint64_t*)de.p, exp_stride,
-                         exp_words, exp_bits, mod, mod_words, (uint64_t*)dout.p, count, nullptr));
+  // one exponent for the whole batch, and the host has it: sliding-window schedule instead of a digit scan
+  DevBuf dsched;
+  SchedRef sr;
+  if (exp_stride == 0 && count >= 16 && exp_bits > 8 && sliding_enabled()) {
+    BigNumber e = BigNumber::fromLimbs64(exp, (size_t)exp_words);
+    if (!e.isZero()) {
+      sr.w = pick_sliding_window(e.BitSize());
+      std::vector<uint16_t> st = sliding_schedule(e, sr.w);
+      RC_TRY(dsched.from_host(st.data(), st.size() * sizeof(uint16_t)));
+      sr.p[0] = (const uint16_t*)dsched.p;
+      sr.len[0] = (int)st.size();
+    }
+  }
+  RC_TRY(modexp_dev_impl((const uint64_t*)db.p, base_stride, (const uint64_t*)de.p, exp_stride, exp_words,
+                         exp_bits, mod, mod_words, (uint64_t*)dout.p, count, nullptr, sr.p[0] ? &sr : nullptr));
   return dout.to_host(out, no);
 }
 
@@ -738,6 +838,7 @@ int pgpu_pubkey_create(const uint64_t* n, int n_words, const uint64_t* hs_or_nul
     RC_TRY(k->d_hs.upload(hs_or_null, (size_t)2 * n_words * 8));
   }
   RC_TRY(k->d_n.upload(n, (size_t)n_words * 8));
+  if (sliding_enabled()) RC_TRY(make_schedule(k->n, pick_sliding_window(k->n.BitSize()), &k->sched_n));
   *out = k.release();
   return PGPU_OK;
 }
@@ -831,7 +932,13 @@ int pgpu_paillier_encrypt_dev(const pgpu_pubkey* key, const uint64_t* d_m, size_
   a.out = d_c;
   a.out_stride = (size_t)W;
   a.count = count;
-  return run_modexp(a, key->nsq->geo, (hipStream_t)hip_stream);
+  SchedRef sr;
+  if (!key->djn && key->sched_n.dev.p) {     // r^n: the exponent is the key constant n
+    sr.p[0] = (const uint16_t*)key->sched_n.dev.p;
+    sr.len[0] = key->sched_n.len;
+    sr.w = key->sched_n.w;
+  }
+  return run_modexp(a, key->nsq->geo, (hipStream_t)hip_stream, sr.p[0] ? &sr : nullptr);
 }
 
 int pgpu_paillier_encrypt(const pgpu_pubkey* key, const uint64_t* m, size_t m_stride, int m_words,
@@ -915,6 +1022,11 @@ int pgpu_privkey_create(const uint64_t* p_in, const uint64_t* q_in, int pq_words
   qm1.toLimbs64(exps.data() + pq_words, pq_words);
   RC_TRY(k->d_exps.upload(exps.data(), exps.size() * 8));
   k->exp_bits = std::max(pm1.BitSize(), qm1.BitSize());
+  if (sliding_enabled()) {
+    const int sw = pick_sliding_window(k->exp_bits);
+    RC_TRY(make_schedule(pm1, sw, &k->sched[0]));
+    RC_TRY(make_schedule(qm1, sw, &k->sched[1]));
+  }
 
   // recombination: auxiliary modulus M = 2^(29*(L-1)) - 1 must exceed n (exact u*p product)
   const GeoInfo* gc = nullptr;
@@ -981,7 +1093,13 @@ int pgpu_paillier_decrypt_crt_dev(const pgpu_privkey* key, const uint64_t* d_c, 
   a.out = (uint64_t*)g_vbuf.p;
   a.out_stride = (size_t)nw;
   a.count = 2 * count;
-  RC_TRY(run_modexp(a, key->geo_exp, s));
+  SchedRef sr;
+  for (int i = 0; i < 2; ++i) {
+    sr.p[i] = (const uint16_t*)key->sched[i].dev.p;
+    sr.len[i] = key->sched[i].len;
+  }
+  sr.w = key->sched[0].w;
+  RC_TRY(run_modexp(a, key->geo_exp, s, &sr));
   // stage 2: L function, CRT
   const int Lc = key->geo_crt.L(), pad = key->geo_crt.w64() + 1;
   pgpu::CrtArgs c{};

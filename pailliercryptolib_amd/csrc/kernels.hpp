@@ -49,7 +49,9 @@ enum FinalMul : int {
 
 struct ModexpArgs {
   ModCtxDev ctx[2];
-  int nctx;              // 1, or 2: instance i uses ctx[i % 2] and base element i / 2
+  int nctx;              // 1, or 2: instance i uses ctx[i % 2] and base element i / 2.  With 2 contexts a
+                         // wavefront takes instances of ONE parity (wave W: parity W & 1, elements
+                         // (W >> 1)*IPW ...), so context and exponent are wave-uniform
   const uint64_t* base;  // [.][base_stride] (0: one shared base)
   size_t base_stride;
   int base_words;        // valid words per base; may be 2*mod_words (reduced on load) if ctx.r2s
@@ -58,7 +60,14 @@ struct ModexpArgs {
   int exp_per_ctx;
   int exp_words;
   int exp_bits;          // max exponent bit length over the batch (mod_exp.cpp:484)
-  int window;            // fixed window width w, 1..5
+  int window;            // fixed window width w, 1..5 (table of 2^w entries); with a schedule: 2^w ODD powers
+  // Shared exponents known to the host (key constants p-1, q-1, n) come with a sliding-window
+  // schedule per context instead of being scanned digit by digit: step k = (nsq << 6) | (idx + 1):
+  // nsq squarings, then a multiplication by base^(2*idx+1) (idx + 1 == 0: squarings only; step 0 has
+  // nsq == 0 and loads the entry).  null: fixed-window scan of exp.
+  const uint16_t* sched[2];
+  int sched_len[2];
+  int parity_waves;      // nctx == 2 only: 1 = a wavefront takes one parity (required by a schedule)
   int final_mul;         // FinalMul
   const uint64_t* fm_words;  // FM_PAILLIER_G: plaintexts [count][fm_stride]
   size_t fm_stride;
@@ -178,15 +187,17 @@ __device__ __forceinline__ void words_submod(uint64_t* v, const uint64_t* a, con
 
 // Load one element per group (64-bit words, C-ABI layout) into LDS, zero padded to W64+1.
 // Instance i reads source row (i / div); words [first, first+words) of that row.
+// Group g of the wave works on instance first_inst + g * step (step 2: one parity of a two-context
+// launch); out-of-range groups recompute the last instance of the same parity.
 template <class GEO>
 __device__ __forceinline__ void stage_words(uint64_t (*io)[GEO::W64 + 1], const uint64_t* src,
                                             size_t stride, int first, int words, size_t first_inst,
-                                            size_t count, int div, int lane) {
+                                            size_t count, int div, int lane, int step = 1) {
   constexpr int WW = GEO::W64 + 1;
   for (int t = lane; t < GEO::IPW * WW; t += kWave) {
     int g = t / WW, w = t % WW;
-    size_t inst = first_inst + g;
-    if (inst >= count) inst = count - 1;
+    size_t inst = first_inst + (size_t)g * step;
+    if (inst >= count) inst = count - step + first_inst % step;
     io[g][w] = (w < words) ? src[(inst / div) * stride + first + w] : 0;
   }
 }
@@ -198,13 +209,13 @@ __device__ __forceinline__ void store_canonical(uint32_t (&r)[GEO::K], const uin
                                                 int mod_words, uint32_t (*bl)[GEO::L],
                                                 uint64_t (*io)[GEO::W64 + 1], uint64_t* out,
                                                 size_t out_stride, size_t first_inst, size_t count,
-                                                int lane, int g, int x) {
+                                                int lane, int g, int x, int step = 1) {
   full_normalise<GEO>(r, x);
   cond_sub_limbs<GEO>(r, nt, x, lane);
   limbs_to_words<GEO>(r, bl, io, lane, g, x);   // (already canonical: the normalise inside is a no-op pass)
   for (int t = lane; t < GEO::IPW * mod_words; t += kWave) {
     int gg = t / mod_words, w = t % mod_words;
-    size_t inst = first_inst + gg;
+    size_t inst = first_inst + (size_t)gg * step;
     if (inst < count) out[inst * out_stride + w] = io[gg][w];
   }
 }
@@ -242,39 +253,43 @@ __global__ __launch_bounds__(kWGThreads, 2) void modexp_kernel(ModexpArgs A) {
   auto& bl2 = bl2_[wv];
   auto& io = io_[wv];
   const int g = lane / G, x = lane % G;
-  const size_t first_inst = ((size_t)blockIdx.x * kWavesPerWG + wv) * IPW;
-  size_t inst = first_inst + g;
-  const size_t tinst = inst;                 // table slot (padded instances own a slot too)
-  if (inst >= A.count) inst = A.count - 1;   // padded lanes recompute the last element
   const int nctx = A.nctx;
+  const size_t wave_id = (size_t)blockIdx.x * kWavesPerWG + wv;
+  const size_t tinst = wave_id * IPW + g;    // table slot (padded instances own a slot too)
+  // instance of group g: first_inst + g * istep (two contexts: this wave takes one parity)
+  const int istep = A.parity_waves ? 2 : 1;
+  const size_t first_inst = A.parity_waves ? (wave_id >> 1) * IPW * 2 + (wave_id & 1) : wave_id * IPW;
+  size_t inst = first_inst + (size_t)g * istep;
+  if (inst >= A.count) inst = A.count - istep + first_inst % istep;   // padded lanes recompute the last element
   const uint64_t t_start = A.wave_clocks ? __builtin_readcyclecounter() : 0;
   const bool second = (nctx == 2) && (inst & 1);   // explicit selects: no dynamic arg indexing
-  ModCtxDev C;
-  C.n = second ? A.ctx[1].n : A.ctx[0].n;
-  C.r2 = second ? A.ctx[1].r2 : A.ctx[0].r2;
-  C.one = second ? A.ctx[1].one : A.ctx[0].one;
-  C.r2s = second ? A.ctx[1].r2s : A.ctx[0].r2s;
-  C.fc = second ? A.ctx[1].fc : A.ctx[0].fc;
-  C.nr = second ? A.ctx[1].nr : A.ctx[0].nr;
-  C.n64 = second ? A.ctx[1].n64 : A.ctx[0].n64;
-  C.nhat = second ? A.ctx[1].nhat : A.ctx[0].nhat;
-  C.n0inv = second ? A.ctx[1].n0inv : A.ctx[0].n0inv;
-  C.mod_words = A.ctx[0].mod_words;                // both contexts share the row width
+  // Context fields are selected where they are used (all outside the multiplication loop) rather than
+  // held in a per-lane copy: eight 64-bit pointers would otherwise stay live across every montmul.
+#define PGPU_CTX(field) (second ? A.ctx[1].field : A.ctx[0].field)
 
   // loop modulus: Nhat (unit quotient digits) when the context provides it, else N
   const bool unitq = A.ctx[0].nhat != nullptr;     // wave-uniform (both contexts agree)
-  uint32_t n[K], a[K], keep[K];
+  uint32_t n[K], a[K];
   // (g^m = 1 + n*m is formed under the TRUE modulus so that it stays < 2N; see GMUL below)
   const bool gm_first = A.final_mul == FM_PAILLIER_G;
 #pragma unroll
-  for (int j = 0; j < K; ++j) { n[j] = (unitq && !gm_first) ? C.nhat[x * K + j] : C.n[x * K + j]; keep[j] = 0; }
-  const uint32_t n0inv = C.n0inv;
-  const int mw = C.mod_words;
+  for (int j = 0; j < K; ++j) n[j] = (unitq && !gm_first) ? PGPU_CTX(nhat)[x * K + j] : PGPU_CTX(n)[x * K + j];
+  const uint32_t n0inv = PGPU_CTX(n0inv);
+  const int mw = A.ctx[0].mod_words;                // both contexts share the row width
   const bool wide = A.base_words > mw;
 
   const int w = A.window;
-  const int tsize = 1 << w;
-  uint32_t* tbl = A.table + tinst * (size_t)tsize * L + x * K;   // this lane's slice of entry 0
+  // A schedule implies parity waves, so the context index is wave-uniform: say so (readfirstlane), or
+  // the step counters and with them the whole phase machine would be compiled as divergent control flow.
+  const bool sched_mode = A.sched[0] != nullptr;
+  const bool second_u = __builtin_amdgcn_readfirstlane((int)second) != 0;
+  const uint16_t* sch = second_u ? A.sched[1] : A.sched[0];
+  const int nsteps = second_u ? A.sched_len[1] : A.sched_len[0];
+  const int tsize = sched_mode ? 1 << (w - 1) : 1 << w;     // odd powers only under a schedule
+  // this lane's slice of entry 0; one spare entry behind the table parks the value that waits for a later
+  // multiplication (hi part of a wide base, g^m) -- in HBM rather than in K registers for the whole loop
+  uint32_t* tbl = A.table + tinst * (size_t)(tsize + 1) * L + x * K;
+  uint32_t* keep = tbl + (size_t)tsize * L;
   const uint64_t* ep = A.exp + (A.exp_per_ctx ? (inst % nctx) : inst) * A.exp_stride;
   const int nwin = (A.exp_bits + w - 1) / w;
 
@@ -288,28 +303,29 @@ __global__ __launch_bounds__(kWGThreads, 2) void modexp_kernel(ModexpArgs A) {
 
   // The whole exponentiation is one loop around a single montmul call site; the wave-uniform
   // phase variable selects how the multiplier operand is staged and what happens to the result.
-  enum { GMUL, TOMONT_HI, TOMONT, TABLE, SQR, MUL, FINAL };
+  enum { GMUL, TOMONT_HI, TOMONT, X2, TABLE, SQR, MUL, FINAL };
   int phase;
   int e = 2;         // next table entry to build
-  int win = 0;       // current window index
+  int win = 0;       // current window index (schedule: next step)
   int sq = 0;        // squarings left in the current window
+  int mul_idx = 0;   // schedule: table entry of the pending multiplication, -1 = none
 
   // ---- first multiplication: operand a from global words, multiplier from the context ----
   if (A.final_mul == FM_PAILLIER_G) {
     phase = GMUL;    // keep = m * (n*R) * R^-1 = n*m mod n^2 (plain domain, lazy)
-    stage_words<GEO>(io, A.fm_words, A.fm_stride, 0, A.fm_nwords, first_inst, A.count, 1, lane);
+    stage_words<GEO>(io, A.fm_words, A.fm_stride, 0, A.fm_nwords, first_inst, A.count, 1, lane, istep);
 #pragma unroll
-    for (int j = 0; j < K; ++j) bl[g][x * K + j] = C.nr[x * K + j];
+    for (int j = 0; j < K; ++j) bl[g][x * K + j] = PGPU_CTX(nr)[x * K + j];
   } else if (wide) {
     phase = TOMONT_HI;  // keep = hi(base) * 2^(64 mw) * R mod N
-    stage_words<GEO>(io, A.base, A.base_stride, mw, A.base_words - mw, first_inst, A.count, nctx, lane);
+    stage_words<GEO>(io, A.base, A.base_stride, mw, A.base_words - mw, first_inst, A.count, nctx, lane, istep);
 #pragma unroll
-    for (int j = 0; j < K; ++j) bl[g][x * K + j] = C.r2s[x * K + j];
+    for (int j = 0; j < K; ++j) bl[g][x * K + j] = PGPU_CTX(r2s)[x * K + j];
   } else {
     phase = TOMONT;
-    stage_words<GEO>(io, A.base, A.base_stride, 0, A.base_words, first_inst, A.count, nctx, lane);
+    stage_words<GEO>(io, A.base, A.base_stride, 0, A.base_words, first_inst, A.count, nctx, lane, istep);
 #pragma unroll
-    for (int j = 0; j < K; ++j) bl[g][x * K + j] = C.r2[x * K + j];
+    for (int j = 0; j < K; ++j) bl[g][x * K + j] = PGPU_CTX(r2)[x * K + j];
   }
   wave_lds_sync();
 #pragma unroll
@@ -320,16 +336,16 @@ __global__ __launch_bounds__(kWGThreads, 2) void modexp_kernel(ModexpArgs A) {
       // leave the Montgomery domain modulo the TRUE modulus (result < N + 1)
       if (unitq) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) n[j] = C.n[x * K + j];
+        for (int j = 0; j < K; ++j) n[j] = PGPU_CTX(n)[x * K + j];
       }
       montmul<GEO, false, false>(a, a, bl[g], n, n0inv);
       break;
     }
     if (unitq && phase != GMUL) {
-      if (phase == SQR) montmul<GEO, true, true>(a, a, bl[g], n, n0inv, bl2[g]);
+      if (phase == SQR || phase == X2) montmul<GEO, true, true>(a, a, bl[g], n, n0inv, bl2[g]);
       else montmul<GEO, false, true>(a, a, bl[g], n, n0inv);
     } else {
-      if (phase == SQR) montmul<GEO, true, false>(a, a, bl[g], n, n0inv, bl2[g]);
+      if (phase == SQR || phase == X2) montmul<GEO, true, false>(a, a, bl[g], n, n0inv, bl2[g]);
       else montmul<GEO, false, false>(a, a, bl[g], n, n0inv);
     }
 
@@ -337,50 +353,86 @@ __global__ __launch_bounds__(kWGThreads, 2) void modexp_kernel(ModexpArgs A) {
     if (phase == GMUL || phase == TOMONT_HI) {
       // park the result, then run the (low-part) to-Montgomery multiplication of the base
 #pragma unroll
-      for (int j = 0; j < K; ++j) keep[j] = a[j];
-      if (phase == GMUL && x == 0) keep[0] += 1;          // g^m = 1 + n*m
+      for (int j = 0; j < K; ++j) keep[j] = a[j] + ((phase == GMUL && x == 0 && j == 0) ? 1u : 0u);   // g^m = 1 + n*m
       if (phase == GMUL && unitq) {                        // the loop itself runs modulo Nhat
 #pragma unroll
-        for (int j = 0; j < K; ++j) n[j] = C.nhat[x * K + j];
+        for (int j = 0; j < K; ++j) n[j] = PGPU_CTX(nhat)[x * K + j];
       }
       wave_lds_sync();
       stage_words<GEO>(io, A.base, A.base_stride, 0, wide ? mw : A.base_words, first_inst, A.count,
-                       nctx, lane);
+                       nctx, lane, istep);
 #pragma unroll
-      for (int j = 0; j < K; ++j) bl[g][x * K + j] = C.r2[x * K + j];
+      for (int j = 0; j < K; ++j) bl[g][x * K + j] = PGPU_CTX(r2)[x * K + j];
       wave_lds_sync();
 #pragma unroll
       for (int j = 0; j < K; ++j) a[j] = limb_from_words(io[g], x * K + j);
       phase = TOMONT;
       continue;
     }
+    // schedule mode: load step `win` (nsq squarings, then maybe a multiplication); FINAL after the last
+    auto next_step = [&]() {
+      if (win >= nsteps) { phase = FINAL; return; }
+      const int st = __builtin_amdgcn_readfirstlane((int)sch[win++]);
+      sq = st >> 6;
+      mul_idx = (st & 63) - 1;
+      phase = SQR;
+    };
     if (phase == TOMONT) {
-      if (wide) add_normalise<GEO>(a, keep);               // (lo + hi*2^S) * R, lazy < 4N
-      // a = base*R.  table[1] = a, table[0] = R mod N; multiplier for the table build = a.
+      if (wide) {                                           // (lo + hi*2^S) * R, lazy < 4N
+        uint32_t hi[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) hi[j] = keep[j];
+        add_normalise<GEO>(a, hi);
+      }
+      // a = base*R.  Fixed window: table[1] = a, table[0] = R mod N, multiplier of the table build = a.
+      // Schedule: table[0] = a (odd powers base^(2i+1)), multiplier of the table build = a^2.
+      wave_lds_sync();
+      if (sched_mode) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) tbl[j] = a[j];
+        if (tsize > 1) phase = X2; else start_main = true;
+      } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          tbl[L + j] = a[j];
+          tbl[j] = PGPU_CTX(one)[x * K + j];
+          bl[g][x * K + j] = a[j];
+        }
+        wave_lds_sync();
+        if (tsize > 2) phase = TABLE; else start_main = true;
+      }
+    } else if (phase == X2) {
+      // a = base^2 * R: it becomes the staged multiplier; the running value restarts from base
       wave_lds_sync();
 #pragma unroll
-      for (int j = 0; j < K; ++j) {
-        tbl[L + j] = a[j];
-        tbl[j] = C.one[x * K + j];
-        bl[g][x * K + j] = a[j];
-      }
+      for (int j = 0; j < K; ++j) { bl[g][x * K + j] = a[j]; a[j] = tbl[j]; }
       wave_lds_sync();
-      if (tsize > 2) phase = TABLE; else start_main = true;
+      e = 1;
+      phase = TABLE;
     } else if (phase == TABLE) {
 #pragma unroll
       for (int j = 0; j < K; ++j) tbl[(size_t)e * L + j] = a[j];
       if (++e == tsize) start_main = true;
     } else if (phase == SQR) {
-      if (--sq == 0) phase = MUL;
+      if (--sq == 0) {
+        if (!sched_mode || mul_idx >= 0) phase = MUL; else next_step();
+      }
     } else {  // MUL
-      if (--win < 0) phase = FINAL; else { phase = SQR; sq = w; }
+      if (sched_mode) next_step();
+      else if (--win < 0) phase = FINAL; else { phase = SQR; sq = w; }
     }
 
     if (start_main) {
-      if (nwin == 0) {
+      if (sched_mode ? nsteps == 0 : nwin == 0) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) a[j] = C.one[x * K + j];
+        for (int j = 0; j < K; ++j) a[j] = PGPU_CTX(one)[x * K + j];
         phase = FINAL;
+      } else if (sched_mode) {
+        const int d = (__builtin_amdgcn_readfirstlane((int)sch[0]) & 63) - 1;   // step 0: a = table[d] (this lane's own earlier stores)
+#pragma unroll
+        for (int j = 0; j < K; ++j) a[j] = tbl[(size_t)d * L + j];
+        win = 1;
+        next_step();
       } else {
         int d = digit(nwin - 1);   // top window: a = table[d] (this lane's own earlier stores)
 #pragma unroll
@@ -391,13 +443,13 @@ __global__ __launch_bounds__(kWGThreads, 2) void modexp_kernel(ModexpArgs A) {
     }
 
     // ---- stage the multiplier operand of the next multiplication ----
-    if (phase == SQR) {
+    if (phase == SQR || phase == X2) {
       wave_lds_sync();
 #pragma unroll
       for (int j = 0; j < K; ++j) { bl[g][x * K + j] = a[j]; bl2[g][x * K + j] = a[j] << 1; }
       wave_lds_sync();
     } else if (phase == MUL) {
-      int d = digit(win);
+      int d = sched_mode ? mul_idx : digit(win);
       uint32_t t[K];
 #pragma unroll
       for (int j = 0; j < K; ++j) t[j] = tbl[(size_t)d * L + j];
@@ -413,7 +465,7 @@ __global__ __launch_bounds__(kWGThreads, 2) void modexp_kernel(ModexpArgs A) {
         for (int j = 0; j < K; ++j) bl[g][x * K + j] = (x == 0 && j == 0) ? 1u : 0u;
       } else if (A.final_mul == FM_CTX_CONST) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) bl[g][x * K + j] = C.fc[x * K + j];
+        for (int j = 0; j < K; ++j) bl[g][x * K + j] = PGPU_CTX(fc)[x * K + j];
       } else {
 #pragma unroll
         for (int j = 0; j < K; ++j) bl[g][x * K + j] = keep[j];
@@ -423,7 +475,7 @@ __global__ __launch_bounds__(kWGThreads, 2) void modexp_kernel(ModexpArgs A) {
     // phase == TABLE: multiplier (base*R) is already staged
   }
   // canonical reduction modulo the TRUE modulus of this group's context (n[] holds it after FINAL)
-  store_canonical<GEO>(a, n, mw, bl, io, A.out, A.out_stride, first_inst, A.count, lane, g, x);
+  store_canonical<GEO>(a, n, mw, bl, io, A.out, A.out_stride, first_inst, A.count, lane, g, x, istep);
   if (A.wave_clocks && lane == 0) {
     uint64_t* rec = A.wave_clocks + ((size_t)blockIdx.x * kWavesPerWG + wv) * 3;
     rec[0] = t_start;
@@ -433,6 +485,8 @@ __global__ __launch_bounds__(kWGThreads, 2) void modexp_kernel(ModexpArgs A) {
     rec[2] = xcc | (hwid << 8);
   }
 }
+
+#undef PGPU_CTX
 
 // ---------------------------------------------------------------------------------------------
 // Fixed-base exponentiation for the DJN obfuscator hs^r (pub_key.cpp:51-64): the base hs is a key

@@ -106,3 +106,19 @@ def test_modexp_vs_openssl_bulk(engine, mod_bits, exp_bits, count):
     want = c_oracle.openssl_modexp_batch(base_l, exp_l, ints_to_limbs([mod], W)[0])
     got = engine.mod_exp(limbs_to_ints(base_l), limbs_to_ints(exp_l), mod)
     assert got == limbs_to_ints(want)
+
+
+def test_modexp_shared_exponent_schedules(engine):
+    """One exponent for the whole batch (>= 16 elements) runs a host-built sliding-window schedule instead of
+    the per-element digit scan: exercise its corner cases -- single bit, all ones, long zero runs (squarings
+    only, also more than 1023 in a row), trailing zeros, tiny exponents -- at two modulus widths."""
+    rng = random.Random(4242)
+    for mod_bits in (1024, 4096):
+        mod = rand_odd(rng, mod_bits)
+        base = [rng.randrange(mod) for _ in range(24)]
+        exps = [1, 2, 3, 5, 64, (1 << 300), (1 << 300) - 1, (1 << 1100) + 1, ((1 << 1100) + 1) << 37,
+                0x5555555555555555555555555555, int("1" + "0" * 70 + "1" * 9 + "0" * 33 + "101", 2),
+                rng.getrandbits(1024) | (1 << 1023), rng.getrandbits(2048) << 5]
+        for e in exps:
+            got = engine.mod_exp(base, [e], mod)
+            assert got == [pow(b, e, mod) for b in base], (mod_bits, hex(e)[:40])
