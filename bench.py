@@ -176,7 +176,7 @@ def main():
             pmc = json.load(open(pmc_path))
         # encrypt leg: with fixed-base tables the kernel EXECUTES far fewer multiplications than the
         # canonical square-and-multiply count, so its honest ALU fraction uses the executed count
-        fbw = int(os.environ.get("PGPU_FB_WINDOW", "10"))
+        fbw = int(os.environ.get("PGPU_FB_WINDOW", "12"))
         s4096 = 2 * KEY_BITS // 32
         if fixed_base:
             nmul = (KEY_BITS // 2 + fbw - 1) // fbw + 1            # nwin-1 table products + g^m + exit

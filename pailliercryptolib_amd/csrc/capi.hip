@@ -296,8 +296,8 @@ int g_fb_window = -1;
 int fixed_base_window() {
   if (g_fb_window < 0) {
     const char* e = std::getenv("PGPU_FB_WINDOW");
-    int v = e ? std::atoi(e) : 10;
-    g_fb_window = (v < 0 || v > 12) ? 10 : v;
+    int v = e ? std::atoi(e) : 12;
+    g_fb_window = (v < 0 || v > 12) ? 12 : v;
   }
   return g_fb_window;
 }

@@ -39,7 +39,7 @@ struct Geo {
   static constexpr int IPW = kWave / G_;           // exponentiations per wavefront
   static constexpr int W64 = (RBITS + 63) / 64;    // 64-bit words that cover R
   static_assert(G_ == 2 || G_ == 4 || G_ == 8 || G_ == 16, "group must sit inside a DPP row");
-  static_assert(2 * K_ < 64, "column accumulators would overflow 64 bits");
+  static_assert(2 * K_ + 3 < 64, "column accumulators would overflow 64 bits (2K products + relaxed limbs)");
 };
 
 // ---- DPP cross-lane moves (VALU, no LDS traffic) ----
@@ -195,7 +195,7 @@ __device__ __forceinline__ void mont_block(uint64_t (&LOWC)[GEO::K], uint64_t (&
 }
 
 // r = a * b * R^-1 mod N (lazy: inputs < 4N -> output < 2N), b read from LDS at bl[0..L).
-// Output limbs are < 2^29 except that limb 0 of a lane may equal 2^29 (deferred unit carry).
+// Output limbs are < 2^29 except limbs 0 and 1 of a lane, which hold an unrippled carry (see pass 2).
 template <class GEO, bool SQR = false, bool UNITQ = false>
 __device__ __forceinline__ void montmul(uint32_t (&r)[GEO::K], const uint32_t (&a)[GEO::K],
                                         const uint32_t* __restrict__ bl,
@@ -218,20 +218,15 @@ __device__ __forceinline__ void montmul(uint32_t (&r)[GEO::K], const uint32_t (&
     r[j] = (uint32_t)t & kLimbMask;
     c = t >> kLimbBits;
   }
-  // pass 2: carry-out (< 2^36) of lane x-1 enters lane x and ripples locally.  The value is
-  // < R, so the top lane of a group never carries out and nothing leaks into the next group.
-  uint64_t cin = (uint64_t)dpp_from_prev((uint32_t)c) | ((uint64_t)dpp_from_prev((uint32_t)(c >> 32)) << 32);
-  uint64_t t0 = (uint64_t)r[0] + cin;
-  r[0] = (uint32_t)t0 & kLimbMask;
-  uint32_t cc = (uint32_t)(t0 >> kLimbBits);
-#pragma unroll
-  for (int j = 1; j < K; ++j) {
-    uint32_t u = r[j] + cc;
-    r[j] = u & kLimbMask;
-    cc = u >> kLimbBits;
-  }
-  // pass 3: the remaining carry is 0 or 1; park it in the next lane's limb 0 (may become 2^29).
-  r[0] += dpp_from_prev(cc);
+  // pass 2: the carry-out of lane x-1 (< 2^36) enters lane x WITHOUT rippling: its low 29 bits join
+  // limb 0 and the rest joins limb 1, so limb 0 < 2^30 and limb 1 < 2^29 + 2^7 on exit -- a relaxed form
+  // every consumer accepts: the next multiplication (one column then holds at most one 2^60 product,
+  // 2^60 + 35 * 2^58 < 2^64), the doubled rows (2^31 fits), add_normalise and full_normalise.
+  // The value is < R, so the top lane of a group never carries out and nothing leaks into the next group.
+  uint32_t maskv = kLimbMask;
+  asm("" : "+v"(maskv));
+  r[0] += dpp_from_prev((uint32_t)c) & maskv;
+  r[1] += dpp_from_prev((uint32_t)(c >> kLimbBits));
 }
 
 // Fully canonical limbs (< 2^29 everywhere).  Data-dependent trip count (<= G+1); used only

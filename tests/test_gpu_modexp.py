@@ -122,3 +122,20 @@ def test_modexp_shared_exponent_schedules(engine):
         for e in exps:
             got = engine.mod_exp(base, [e], mod)
             assert got == [pow(b, e, mod) for b in base], (mod_bits, hex(e)[:40])
+
+
+@pytest.mark.parametrize("mod_bits", [1024, 2048, 3072, 4096, 6144])
+def test_modexp_saturated_limbs(engine, mod_bits):
+    """Column-accumulator headroom: moduli 2^bits - c (every limb all ones), operands mod-1, mod-2, all-ones
+    bit patterns and an all-ones exponent keep every 29-bit limb, every quotient digit and every carry at its
+    maximum through whole exponentiations (the relaxed-limb epilogue is sized for exactly this case)."""
+    rng = random.Random(mod_bits)
+    for c in (1, 3, 189):
+        mod = (1 << mod_bits) - c
+        base = [mod - 1, mod - 2, (1 << (mod_bits - 1)) - 1, mod >> 1, int("1" * (mod_bits - 3), 2)] * 4
+        base += [rng.randrange(mod) for _ in range(4)]
+        for e in ((1 << 200) - 1, (1 << 64) | 1):
+            got = engine.mod_exp(base, [e] * len(base), mod)
+            assert got == [pow(b, e, mod) for b in base], (mod_bits, c)
+        got = engine.mod_mul(base, base[::-1], mod)
+        assert got == [(x * y) % mod for x, y in zip(base, base[::-1])]

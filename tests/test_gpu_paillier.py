@@ -54,7 +54,7 @@ def test_bench_key_djn(engine, kat):
     assert sk.decrypt(ct) == m
 
 
-@pytest.mark.parametrize("fbw", [0, 4, 8, 11])
+@pytest.mark.parametrize("fbw", [0, 4, 8, 12])
 def test_djn_encrypt_generic_vs_fixed_base(engine, kat, fbw):
     """The DJN obfuscator hs^r through the generic kernel (w=0) and through fixed-base tables of
     several window widths must give the same bits, incl. r = 0, r = 1, short and full-width r."""
@@ -75,7 +75,7 @@ def test_djn_encrypt_generic_vs_fixed_base(engine, kat, fbw):
         assert pk.encrypt(m, r) == want                      # ... and regrown for the 2047-bit R_BN
         assert pk.encrypt(m[:2], r[:2]) == want[:2]          # r in {0, 1}
     finally:
-        _capi.check(_capi.lib().pgpu_set_fixed_base_window(10))
+        _capi.check(_capi.lib().pgpu_set_fixed_base_window(12))   # the library default
 
 
 def test_seeded_fixtures(engine):
