@@ -59,10 +59,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run --nproc-per-node N")
+    # validation-only knobs (exercise the N>1 code path on a 1-GPU box): BENCH_SINGLE_DEVICE=1 puts every
+    # rank on device 0, BENCH_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU)
+    if os.environ.get("BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import pailliercryptolib_amd as pa
     from pailliercryptolib_amd import _capi

@@ -387,7 +387,7 @@ void launch_fb_encrypt(const pgpu::FixedBaseArgs& a, hipStream_t s) {
 // arrays, half the lanes per exponentiation and twice the limbs per lane -- the per-row support
 // instructions are amortised over twice as many MACs (78-80 % of the VALU slots are MACs instead of
 // 61-67 %).  It pays as soon as the wide split still puts one wavefront on every SIMD: measured on the
-// bench's CRT-decrypt launch, (4,18) at 1 wave/SIMD 7.50 ms vs (8,9) at 2 waves/SIMD 8.07 ms.
+// bench's CRT-decrypt launch (fixed-window build), (4,18) at 1 wave/SIMD 7.2 ms vs (8,9) at 2 waves/SIMD 8.1 ms.
 constexpr size_t kMinWavesForWide = 256 * 4;
 GeoInfo launch_geo(const GeoInfo& geo, size_t count) {
   static const bool allow = [] { const char* e = std::getenv("PGPU_WIDE"); return !e || std::atoi(e) != 0; }();

@@ -6,14 +6,14 @@
 //                       F_i = (1 + n*m_i) mod n^2 is computed in-kernel and becomes the
 //                       multiplication that leaves the Montgomery domain (zero extra cost)
 //        decrypt form-> first half of PrivateKey::decryptCRT (pri_key.cpp:119-134): two
-//                       interleaved contexts (p^2, q^2), the 2k-bit ciphertext is reduced on load
+//                       contexts (p^2, q^2; a wavefront serves one), the 2k-bit ciphertext is reduced on load
 //                       (c mod p^2 / q^2, pri_key.cpp:128-129), F = hp / hq
 //   crt_kernel    : second half of decryptCRT (pri_key.cpp:136-157): L-function by exact
 //                   division, *hp mod p, CRT recombination
 //   modmul_kernel : out[i] = a[i]*b[i] mod N     (CipherText::raw_add, ciphertext.cpp:135-141)
 //
-// One wavefront (= one 64-thread workgroup) handles 64/G exponentiations; nothing is shared
-// between wavefronts, so the only synchronisation is the single-wave LDS hand-off.
+// One wavefront handles 64/G exponentiations (a workgroup is 4 independent wavefronts, one per SIMD);
+// nothing is shared between wavefronts, so the only synchronisation is the single-wave LDS hand-off.
 #ifndef PAILLIERCRYPTOLIB_AMD_CSRC_KERNELS_HPP_
 #define PAILLIERCRYPTOLIB_AMD_CSRC_KERNELS_HPP_
 

@@ -2,13 +2,14 @@
 //
 // Replaces the arithmetic the reference obtains from IPP-Crypto's mbx_exp_mb8 / ippsMontExp
 // (call sites: ipcl/mod_exp.cpp:508-516, 549-579).  Design derived from measured gfx950 issue
-// rates (profiles/r01_ubench_valu_issue_rates.txt): v_mad_u64_u32 is a FULL-rate instruction
-// (~4.8 cyc per wave64 per SIMD, 32.7 T MAC32/s chip-wide) while every carry-chain instruction
-// (v_addc_co_u32) costs as much as a MAC and ds_bpermute_b32 costs 24 cyc.  Hence:
+// rates (profiles/r01_ubench_*.txt): v_mad_u64_u32 is a FULL-rate instruction
+// (one wave64 per 4 cycles per SIMD, 39.3 T MAC32/s chip-wide), every other VALU instruction --
+// a carry add, a shift, a DPP move -- costs the same issue slot, dependent issue is free, and
+// ds_bpermute_b32 costs 24 cycles.  So the goal is the fewest instructions per product.  Hence:
 //
 //   * reduced radix: a value is L = G*K limbs of LB = 29 bits, each held in a 32-bit VGPR;
 //     column sums live in 64-bit VGPR pairs, so  acc += a*b  is ONE v_mad_u64_u32 with no carry
-//     handling at all (2K products of < 2^58 per column lifetime < 2^64 for K <= 31);
+//     handling at all ((2K + 3) * 2^58 per column lifetime < 2^64 for K <= 30, see montmul);
 //   * G lanes (G in {2,4,8,16}, inside one 16-lane DPP row) co-operate on one exponentiation,
 //     64/G exponentiations per wavefront; lane x owns limbs [x*K, x*K+K);
 //   * word-serial Montgomery (operand scanning) in blocks of K rows: K*K MACs of a*b, then K*K
