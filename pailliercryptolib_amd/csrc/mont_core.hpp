@@ -9,7 +9,7 @@
 //
 //   * reduced radix: a value is L = G*K limbs of LB = 29 bits, each held in a 32-bit VGPR;
 //     column sums live in 64-bit VGPR pairs, so  acc += a*b  is ONE v_mad_u64_u32 with no carry
-//     handling at all ((2K + 3) * 2^58 per column lifetime < 2^64 for K <= 30, see montmul);
+//     handling at all ((2K + 4) * 2^58 per column lifetime < 2^64 for K <= 29, see montmul);
 //   * G lanes (G in {2,4,8,16}, inside one 16-lane DPP row) co-operate on one exponentiation,
 //     64/G exponentiations per wavefront; lane x owns limbs [x*K, x*K+K);
 //   * word-serial Montgomery (operand scanning) in blocks of K rows: K*K MACs of a*b, then K*K
@@ -40,7 +40,7 @@ struct Geo {
   static constexpr int IPW = kWave / G_;           // exponentiations per wavefront
   static constexpr int W64 = (RBITS + 63) / 64;    // 64-bit words that cover R
   static_assert(G_ == 2 || G_ == 4 || G_ == 8 || G_ == 16, "group must sit inside a DPP row");
-  static_assert(2 * K_ + 3 < 64, "column accumulators would overflow 64 bits (2K products + relaxed limbs)");
+  static_assert(2 * K_ + 4 < 64, "column accumulators would overflow 64 bits (2K products + relaxed limbs)");
 };
 
 // ---- DPP cross-lane moves (VALU, no LDS traffic) ----
@@ -221,8 +221,9 @@ __device__ __forceinline__ void montmul(uint32_t (&r)[GEO::K], const uint32_t (&
   }
   // pass 2: the carry-out of lane x-1 (< 2^36) enters lane x WITHOUT rippling: its low 29 bits join
   // limb 0 and the rest joins limb 1, so limb 0 < 2^30 and limb 1 < 2^29 + 2^7 on exit -- a relaxed form
-  // every consumer accepts: the next multiplication (one column then holds at most one 2^60 product,
-  // 2^60 + 35 * 2^58 < 2^64), the doubled rows (2^31 fits), add_normalise and full_normalise.
+  // every consumer accepts: the next multiplication (a column's K + K products then sum to less than
+  // (2K + 4) * 2^58 -- one pair of oversized factors per column, doubled in a squaring -- i.e. < 2^64 for
+  // K <= 29), the doubled rows (2^31 fits), add_normalise and full_normalise.
   // The value is < R, so the top lane of a group never carries out and nothing leaks into the next group.
   uint32_t maskv = kLimbMask;
   asm("" : "+v"(maskv));
