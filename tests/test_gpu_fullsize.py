@@ -170,3 +170,26 @@ def test_wide_split_in_fused_encrypt_and_decrypt(engine, iso):
     assert limbs_to_ints(T.to_host(d_c[idx])) == opk.encrypt(limbs_to_ints(m[idx]), limbs_to_ints(r[idx]))
     # and the narrow split on a prefix gives the same ciphertexts
     assert torch.equal(T.encrypt(pk, d_m[:4096].contiguous(), T.to_device(r[:4096])), d_c[:4096])
+
+
+@pytest.mark.parametrize("count", [8191, 8201, 16391])
+def test_ragged_batches_on_the_wide_split(engine, iso, count):
+    """Batch sizes that are not multiples of the instances per wavefront, large enough for the wide lane
+    split (>= 1024 wavefronts) and, for decrypt, for parity waves (every wavefront serves one of p^2 / q^2):
+    the padded tail groups must neither corrupt nor skip elements."""
+    import torch
+    from pailliercryptolib_amd import torch_ops as T
+    from pailliercryptolib_amd.limbs import limbs_to_ints
+    p, q, hs = iso
+    n = p * q
+    pk, sk = engine.PublicKey(n, 2048, hs=hs), engine.PrivateKey(p, q)
+    rng = np.random.default_rng(count)
+    m = rand_rows(rng, count, 32, (1 << 62) - 1)
+    r = rand_rows(rng, count, 16)
+    d_m = T.to_device(m)
+    d_c = T.encrypt(pk, d_m, T.to_device(r))
+    assert torch.equal(T.decrypt(sk, d_c), d_m)
+    opk = orc.PublicKey(n, 2048)
+    opk.set_djn(hs)
+    idx = [0, count - 1, count - 2, count - 9, count - 17]
+    assert limbs_to_ints(T.to_host(d_c[idx])) == opk.encrypt(limbs_to_ints(m[idx]), limbs_to_ints(r[idx]))
