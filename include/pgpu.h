@@ -141,8 +141,8 @@ int pgpu_set_timing(int enabled);
 int pgpu_timing_collect(int* kinds, double* ms, int max_entries);
 /* Kernel geometry a batch of `count` exponentiations / products under an odd modulus of mod_bits bits
  * (operand rows of in_words 64-bit words) is launched with: *lanes lanes per element, *limbs 29-bit limbs
- * per lane.  Pure host-side query (needs no device); lets a profile be labelled with the kernel
- * instantiation that actually ran.  PGPU_ERR_UNSUPPORTED when no compiled geometry is wide enough. */
+ * per lane (modexp_kernel; small batches take a 16-lane latency split, large ones the wide split).  Pure
+ * host-side query (needs no device); lets a profile be labelled with the kernel instantiation that ran.  PGPU_ERR_UNSUPPORTED when no compiled geometry is wide enough. */
 int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, int* limbs);
 
 #ifdef __cplusplus

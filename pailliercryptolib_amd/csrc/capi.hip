@@ -178,11 +178,15 @@ std::map<std::vector<uint64_t>, std::shared_ptr<ModCtx>> g_ctx_cache;
 
 // cached plain context for the generic seam: unit_q = true for pgpu_modexp (loop modulo Nhat),
 // false for pgpu_modmul (two multiplications, true modulus throughout)
-int get_modctx(const uint64_t* mod, int mod_words, bool unit_q, std::shared_ptr<ModCtx>* out) {
+GeoInfo latency_geo(const GeoInfo& geo);
+// latency: build the context for the 16-lane latency geometry of the modulus' class (same context when L
+// is unchanged or the class has none)
+int get_modctx(const uint64_t* mod, int mod_words, bool unit_q, std::shared_ptr<ModCtx>* out,
+               bool latency = false) {
   if (!mod || mod_words <= 0) return fail(PGPU_ERR_INVALID_PARAM, "modulus is null/empty");
   if (!(mod[0] & 1)) return fail(PGPU_ERR_EVEN_MODULUS, "modulus must be odd");
   std::vector<uint64_t> key(mod, mod + mod_words);
-  key.push_back(unit_q ? 1 : 0);
+  key.push_back((unit_q ? 1 : 0) | (latency ? 2 : 0));
   auto it = g_ctx_cache.find(key);
   if (it != g_ctx_cache.end()) {
     *out = it->second;
@@ -195,7 +199,7 @@ int get_modctx(const uint64_t* mod, int mod_words, bool unit_q, std::shared_ptr<
   if (!geo) return fail(PGPU_ERR_UNSUPPORTED, "modulus wider than the compiled kernel geometries");
   CtxExtras ex;
   ex.unit_q = unit_q;
-  RC_TRY(build_modctx(N, mod_words, *geo, ex, out));
+  RC_TRY(build_modctx(N, mod_words, latency ? latency_geo(*geo) : *geo, ex, out));
   if (g_ctx_cache.size() > 64) g_ctx_cache.clear();
   g_ctx_cache[key] = *out;
   return PGPU_OK;
@@ -383,6 +387,31 @@ void launch_fb_encrypt(const pgpu::FixedBaseArgs& a, hipStream_t s) {
     else FN<16, 18>(__VA_ARGS__);                                   \
   } while (0)
 
+// modexp_kernel additionally exists in two "latency" geometries, 16 lanes per element with 5 / 7 limbs each
+#define GEO_DISPATCH_MODEXP(FN, geo, ...)                           \
+  do {                                                              \
+    if (geo.G == 16 && geo.K == 5) FN<16, 5>(__VA_ARGS__);          \
+    else if (geo.G == 16 && geo.K == 7) FN<16, 7>(__VA_ARGS__);     \
+    else GEO_DISPATCH(FN, geo, __VA_ARGS__);                        \
+  } while (0)
+
+// Small batches do not fill the chip: a launch of fewer wavefronts than SIMDs runs as long as ONE wavefront's
+// serial chain of ~1200 multiplications.  Spreading an element over 16 lanes instead of 8 shortens every
+// multiplication (2048-bit class: (16,5), 1190 instructions instead of 1590 for (8,9); 3072-bit class: (16,7)
+// for (8,14), same L and therefore the same context).  Used while the 16-lane split still fits one wavefront
+// per SIMD; (16,5) has L = 80, so it needs its own Montgomery context.
+constexpr size_t kSimds = 256 * 4;
+GeoInfo latency_geo(const GeoInfo& geo) {
+  static const bool allow = [] { const char* e = std::getenv("PGPU_LATENCY_GEO"); return !e || std::atoi(e) != 0; }();
+  if (!allow) return geo;
+  if (geo.G == 8 && geo.K == 9) return GeoInfo{16, 5};
+  if (geo.G == 8 && geo.K == 14) return GeoInfo{16, 7};
+  return geo;
+}
+bool use_latency_geo(const GeoInfo& lat, const GeoInfo& geo, size_t instances) {
+  return lat.G != geo.G && (instances + lat.ipw() - 1) / lat.ipw() <= kSimds;
+}
+
 // A context built for (G, 9) also serves the "wide" split (G/2, 18): same L, same R, same limb
 // arrays, half the lanes per exponentiation and twice the limbs per lane -- the per-row support
 // instructions are amortised over twice as many MACs (78-80 % of the VALU slots are MACs instead of
@@ -438,7 +467,7 @@ int run_modexp(pgpu::ModexpArgs& a, const GeoInfo& ctx_geo, hipStream_t s, const
   a.table = (uint32_t*)g_table.p;
   a.wave_clocks = g_wave_clocks_ptr();
   TimerScope t(s, PGPU_KERNEL_MODEXP);
-  GEO_DISPATCH(launch_modexp, geo, a, s);
+  GEO_DISPATCH_MODEXP(launch_modexp, geo, a, s);
   HIP_TRY(hipGetLastError());
   t.stop();
   return PGPU_OK;
@@ -522,6 +551,8 @@ struct pgpu_privkey {
   GeoInfo geo_exp{};            // geometry of the two half-width exponentiations
   GeoInfo geo_crt{};            // geometry of the recombination kernel
   std::shared_ptr<ModCtx> p2, q2;   // moduli p^2, q^2 (fc = hp / hq, r2s set)
+  GeoInfo geo_lat{};            // latency geometry of the exponentiations (== geo_exp if there is none)
+  std::shared_ptr<ModCtx> p2l, q2l; // the same moduli for geo_lat (aliases of p2, q2 when L is equal)
   std::shared_ptr<ModCtx> cM, cQ;   // auxiliary modulus M, modulus q (CRT geometry)
   DevBlob d_exps;               // [2][pq_words]: p-1, q-1
   int exp_bits = 0;
@@ -582,7 +613,8 @@ int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, i
     return fail(PGPU_ERR_INVALID_PARAM, "pgpu_kernel_geometry: bad argument");
   const GeoInfo* geo = pick_geo(in_words, mod_bits);
   if (!geo) return fail(PGPU_ERR_UNSUPPORTED, "modulus wider than the compiled kernel geometries");
-  const GeoInfo g = launch_geo(*geo, count);
+  const GeoInfo lat = latency_geo(*geo);
+  const GeoInfo g = use_latency_geo(lat, *geo, count) ? lat : launch_geo(*geo, count);
   *lanes = g.G;
   *limbs = g.K;
   return PGPU_OK;
@@ -710,6 +742,12 @@ static int modexp_dev_impl(const uint64_t* d_base, size_t base_stride, const uin
     return fail(PGPU_ERR_INVALID_PARAM, "exponent stride smaller than exp_words");
   std::shared_ptr<ModCtx> ctx;
   RC_TRY(get_modctx(h_mod, mod_words, true, &ctx));
+  GeoInfo run_geo = ctx->geo;
+  const GeoInfo lat = latency_geo(ctx->geo);
+  if (use_latency_geo(lat, ctx->geo, count)) {       // small batch: 16 lanes per element
+    if (lat.L() != ctx->geo.L()) RC_TRY(get_modctx(h_mod, mod_words, true, &ctx, true));
+    run_geo = lat;
+  }
   pgpu::ModexpArgs a{};
   a.ctx[0] = a.ctx[1] = ctx->dev;
   a.nctx = 1;
@@ -725,7 +763,7 @@ static int modexp_dev_impl(const uint64_t* d_base, size_t base_stride, const uin
   a.out = d_out;
   a.out_stride = (size_t)mod_words;
   a.count = count;
-  return run_modexp(a, ctx->geo, (hipStream_t)hip_stream, sched);
+  return run_modexp(a, run_geo, (hipStream_t)hip_stream, sched);
 }
 
 int pgpu_modexp_dev(const uint64_t* d_base, size_t base_stride, const uint64_t* d_exp,
@@ -1017,6 +1055,14 @@ int pgpu_privkey_create(const uint64_t* p_in, const uint64_t* q_in, int pq_words
   exp_q.fc = &hq;
   RC_TRY(build_modctx(psq, nw, *ge, exp_p, &k->p2));
   RC_TRY(build_modctx(qsq, nw, *ge, exp_q, &k->q2));
+  k->geo_lat = latency_geo(*ge);
+  if (k->geo_lat.L() == ge->L()) {
+    k->p2l = k->p2;
+    k->q2l = k->q2;
+  } else {
+    RC_TRY(build_modctx(psq, nw, k->geo_lat, exp_p, &k->p2l));
+    RC_TRY(build_modctx(qsq, nw, k->geo_lat, exp_q, &k->q2l));
+  }
   std::vector<uint64_t> exps((size_t)2 * pq_words, 0);
   pm1.toLimbs64(exps.data(), pq_words);
   qm1.toLimbs64(exps.data() + pq_words, pq_words);
@@ -1078,8 +1124,9 @@ int pgpu_paillier_decrypt_crt_dev(const pgpu_privkey* key, const uint64_t* d_c, 
   RC_TRY(g_vbuf.ensure(2 * count * (size_t)nw * 8));
   // stage 1: V[2i] = c^(p-1)*hp mod p^2, V[2i+1] = c^(q-1)*hq mod q^2   (2*count instances)
   pgpu::ModexpArgs a{};
-  a.ctx[0] = key->p2->dev;
-  a.ctx[1] = key->q2->dev;
+  const bool lat = use_latency_geo(key->geo_lat, key->geo_exp, 2 * count);
+  a.ctx[0] = lat ? key->p2l->dev : key->p2->dev;
+  a.ctx[1] = lat ? key->q2l->dev : key->q2->dev;
   a.nctx = 2;
   a.base = d_c;
   a.base_stride = (size_t)2 * nw;
@@ -1099,7 +1146,7 @@ int pgpu_paillier_decrypt_crt_dev(const pgpu_privkey* key, const uint64_t* d_c, 
     sr.len[i] = key->sched[i].len;
   }
   sr.w = key->sched[0].w;
-  RC_TRY(run_modexp(a, key->geo_exp, s, &sr));
+  RC_TRY(run_modexp(a, lat ? key->geo_lat : key->geo_exp, s, &sr));
   // stage 2: L function, CRT
   const int Lc = key->geo_crt.L(), pad = key->geo_crt.w64() + 1;
   pgpu::CrtArgs c{};

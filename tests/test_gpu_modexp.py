@@ -139,3 +139,16 @@ def test_modexp_saturated_limbs(engine, mod_bits):
             assert got == [pow(b, e, mod) for b in base], (mod_bits, c)
         got = engine.mod_mul(base, base[::-1], mod)
         assert got == [(x * y) % mod for x, y in zip(base, base[::-1])]
+
+
+@pytest.mark.parametrize("mod_bits,count", [(2048, 5), (2048, 130), (2040, 33), (3072, 7), (3072, 70)])
+def test_modexp_small_batches_latency_split(engine, mod_bits, count):
+    """Batches that leave SIMDs idle run 16 lanes per element (Geo<16,5> / Geo<16,7>, capi.hip: latency_geo),
+    with their own Montgomery context where the limb count differs; same bits as every other split."""
+    rng = random.Random(mod_bits + count)
+    mod = rand_odd(rng, mod_bits)
+    base = [rng.randrange(mod) for _ in range(count)]
+    exp = [rng.getrandbits(300) for _ in range(count)]
+    assert engine.mod_exp(base, exp, mod) == [pow(b, e, mod) for b, e in zip(base, exp)]
+    e = rng.getrandbits(1024)
+    assert engine.mod_exp(base, [e], mod) == [pow(b, e, mod) for b in base]
