@@ -29,11 +29,46 @@ typedef uint64_t u64;
 static inline v8 lo52(v8 acc, v8 a, v8 b) { return _mm512_madd52lo_epu64(acc, a, b); }
 static inline v8 hi52(v8 acc, v8 a, v8 b) { return _mm512_madd52hi_epu64(acc, a, b); }
 
-/* r = a * b / R  (almost) mod n; a, b, n: L vectors of digits < 2^52; t: scratch of L vectors */
+/* r = a * b / R  (almost) mod n; a, b, n: L vectors of digits < 2^52; t: scratch of L + 2 vectors.
+ * Two multiplier digits per sweep over the columns (halves the loads / stores per multiply-add: the sweep
+ * is memory-operand bound otherwise); the second quotient digit comes from the column the first row has
+ * just completed.  Column j of row i lands in slot j-1, of row i+1 in slot j-2 (division by 2^52 each). */
 static void amm(v8* r, const v8* a, const v8* b, const v8* n, v8 k0, int L, v8* t) {
   const v8 zero = _mm512_setzero_si512();
-  for (int j = 0; j < L; ++j) t[j] = zero;
-  for (int i = 0; i < L; ++i) {
+  for (int j = 0; j < L + 2; ++j) t[j] = zero;
+  int i = 0;
+  for (; i + 1 < L; i += 2) {
+    const v8 b0 = b[i], b1 = b[i + 1];
+    /* row i, column 0 */
+    v8 c = lo52(t[0], a[0], b0);
+    const v8 q0 = lo52(zero, c, k0);
+    c = lo52(c, n[0], q0);
+    v8 up0 = _mm512_srli_epi64(c, 52);                    /* into column 1 of row i */
+    up0 = hi52(hi52(up0, a[0], b0), n[0], q0);
+    /* row i, column 1 = first column of row i+1 */
+    v8 d = lo52(lo52(t[1], a[1], b0), n[1], q0);
+    d = _mm512_add_epi64(d, up0);
+    up0 = hi52(hi52(zero, a[1], b0), n[1], q0);           /* into column 2 of row i */
+    d = lo52(d, a[0], b1);
+    const v8 q1 = lo52(zero, d, k0);
+    d = lo52(d, n[0], q1);
+    v8 up1 = _mm512_srli_epi64(d, 52);                    /* into column 1 of row i+1 */
+    up1 = hi52(hi52(up1, a[0], b1), n[0], q1);
+    for (int j = 2; j < L; ++j) {
+      /* row i, column j  ->  its value is column j-1 of row i+1 */
+      v8 s = lo52(lo52(t[j], a[j], b0), n[j], q0);
+      s = _mm512_add_epi64(s, up0);
+      up0 = hi52(hi52(zero, a[j], b0), n[j], q0);
+      s = lo52(lo52(s, a[j - 1], b1), n[j - 1], q1);
+      t[j - 2] = _mm512_add_epi64(s, up1);
+      up1 = hi52(hi52(zero, a[j - 1], b1), n[j - 1], q1);
+    }
+    /* row i column L (= up0) is column L-1 of row i+1 */
+    v8 s = lo52(lo52(up0, a[L - 1], b1), n[L - 1], q1);
+    t[L - 2] = _mm512_add_epi64(s, up1);
+    t[L - 1] = hi52(hi52(zero, a[L - 1], b1), n[L - 1], q1);
+  }
+  for (; i < L; ++i) {                                    /* odd L: the last row alone */
     const v8 bi = b[i];
     v8 c0 = lo52(t[0], a[0], bi);
     const v8 q = lo52(zero, c0, k0);          /* (column 0 mod 2^52) * (-1/n mod 2^52) mod 2^52 */
@@ -56,11 +91,27 @@ static void amm(v8* r, const v8* a, const v8* b, const v8* n, v8 k0, int L, v8* 
   }
 }
 
-/* dedicated squaring: cross products once, doubled; then a separate reduction sweep (3 L^2 vs 4 L^2) */
-static void ams(v8* r, const v8* a, const v8* n, v8 k0, int L, v8* t /* 2L+1 */) {
+/* dedicated squaring (3 L^2 multiply-adds instead of 4 L^2): cross products once and doubled, the diagonal,
+ * then a reduction sweep that retires two columns per pass (the same blocking as amm). */
+static void ams(v8* r, const v8* a, const v8* n, v8 k0, int L, v8* t /* 2L+2 */) {
   const v8 zero = _mm512_setzero_si512();
-  for (int j = 0; j <= 2 * L; ++j) t[j] = zero;
-  for (int i = 0; i < L; ++i) {               /* off-diagonal part, i < j */
+  for (int j = 0; j < 2 * L; ++j) t[j] = zero;
+  /* cross products a_i a_j, i < j, once; two rows (i, i+1) per sweep over the columns:
+   * column i+j collects lo(a_i a_j), hi(a_i a_{j-1}), lo(a_{i+1} a_{j-1}), hi(a_{i+1} a_{j-2}) */
+  int i = 0;
+  for (; i + 5 < L; i += 2) {
+    const v8 x = a[i], y = a[i + 1];
+    t[2 * i + 1] = lo52(t[2 * i + 1], a[i + 1], x);
+    t[2 * i + 2] = hi52(lo52(t[2 * i + 2], a[i + 2], x), a[i + 1], x);
+    t[2 * i + 3] = lo52(hi52(lo52(t[2 * i + 3], a[i + 3], x), a[i + 2], x), a[i + 2], y);
+    for (int j = i + 4; j < L; ++j) {
+      v8 s = hi52(lo52(t[i + j], a[j], x), a[j - 1], x);
+      t[i + j] = hi52(lo52(s, a[j - 1], y), a[j - 2], y);
+    }
+    t[i + L] = hi52(lo52(hi52(t[i + L], a[L - 1], x), a[L - 1], y), a[L - 2], y);
+    t[i + L + 1] = hi52(t[i + L + 1], a[L - 1], y);
+  }
+  for (; i < L; ++i) {                              /* remaining rows one at a time */
     const v8 ai = a[i];
     for (int j = i + 1; j < L; ++j) {
       t[i + j] = lo52(t[i + j], a[j], ai);
@@ -68,11 +119,38 @@ static void ams(v8* r, const v8* a, const v8* n, v8 k0, int L, v8* t /* 2L+1 */)
     }
   }
   for (int j = 0; j < 2 * L; ++j) t[j] = _mm512_slli_epi64(t[j], 1);
-  for (int i = 0; i < L; ++i) {               /* diagonal */
-    t[2 * i] = lo52(t[2 * i], a[i], a[i]);
-    t[2 * i + 1] = hi52(t[2 * i + 1], a[i], a[i]);
+  for (int d = 0; d < L; ++d) {                     /* diagonal */
+    t[2 * d] = lo52(t[2 * d], a[d], a[d]);
+    t[2 * d + 1] = hi52(t[2 * d + 1], a[d], a[d]);
   }
-  for (int i = 0; i < L; ++i) {               /* reduction: clears column i */
+  t[2 * L] = zero;
+  t[2 * L + 1] = zero;
+  i = 0;
+  for (; i + 1 < L; i += 2) {                       /* reduction: clears columns i and i+1 */
+    const v8 q0 = lo52(zero, t[i], k0);
+    v8 c = lo52(t[i], n[0], q0);
+    v8 d = _mm512_add_epi64(t[i + 1], _mm512_srli_epi64(c, 52));
+    d = lo52(hi52(d, n[0], q0), n[1], q0);
+    const v8 q1 = lo52(zero, d, k0);
+    d = lo52(d, n[0], q1);
+    /* column i+2 receives: carry of d, hi(n1 q0), lo(n2 q0), hi(n0 q1), lo(n1 q1) */
+    v8 e = _mm512_add_epi64(t[i + 2], _mm512_srli_epi64(d, 52));
+    e = hi52(hi52(e, n[1], q0), n[0], q1);
+    if (L > 2) e = lo52(e, n[2], q0);
+    e = lo52(e, n[1], q1);
+    t[i + 2] = e;
+    for (int j = 3; j < L; ++j) {                   /* column i+j: lo(n_j q0) hi(n_{j-1} q0) lo(n_{j-1} q1) hi(n_{j-2} q1) */
+      v8 s = lo52(hi52(t[i + j], n[j - 1], q0), n[j], q0);
+      t[i + j] = lo52(hi52(s, n[j - 2], q1), n[j - 1], q1);
+    }
+    if (L > 2) {
+      /* column i+L: hi(n_{L-1} q0), lo(n_{L-1} q1), hi(n_{L-2} q1);  column i+L+1: hi(n_{L-1} q1) */
+      v8 s = hi52(t[i + L], n[L - 1], q0);
+      t[i + L] = lo52(hi52(s, n[L - 2], q1), n[L - 1], q1);
+      t[i + L + 1] = hi52(t[i + L + 1], n[L - 1], q1);
+    }
+  }
+  for (; i < L; ++i) {                              /* odd L: the last column alone */
     const v8 q = lo52(zero, t[i], k0);
     v8 c0 = lo52(t[i], n[0], q);
     t[i + 1] = _mm512_add_epi64(t[i + 1], _mm512_srli_epi64(c0, 52));
@@ -183,7 +261,7 @@ int orc_ifma_modexp_batch(const u64* base, size_t base_stride, const u64* exp, s
 #pragma omp parallel
   {
     const size_t vec = (size_t)L;
-    v8* mem = (v8*)aligned_alloc(64, sizeof(v8) * vec * (5 + (1u << WIN)) + sizeof(v8) * (2 * vec + 2));
+    v8* mem = (v8*)aligned_alloc(64, sizeof(v8) * vec * (5 + (1u << WIN)) + sizeof(v8) * (2 * vec + 4));
     if (!mem) {
 #pragma omp atomic write
       bad = 1;
