@@ -70,27 +70,76 @@ static int bn_bits(const u64* a, int w) {
     if (a[i]) return i * 64 + 64 - __builtin_clzll(a[i]);
   return 0;
 }
-/* r = a mod m by binary shift-subtract; a has wa limbs, m has w limbs (slow, used for
- * per-key constants and per-element reductions of the restatement; clarity over speed) */
-static void bn_mod(u64* r, const u64* a, int wa, const u64* m, int w) {
-  u64 acc[MAXW + 1];
-  memset(acc, 0, sizeof(u64) * (size_t)(w + 1));
-  int nb = bn_bits(a, wa);
-  for (int i = nb - 1; i >= 0; --i) {
-    /* acc = acc*2 + bit */
-    u64 c = (a[i >> 6] >> (i & 63)) & 1;
-    for (int j = 0; j <= w; ++j) {
-      u64 nc = acc[j] >> 63;
-      acc[j] = (acc[j] << 1) | c;
-      c = nc;
-    }
-    if (acc[w] || bn_cmp(acc, m, w) >= 0) {
-      u64 br = bn_sub(acc, acc, m, w);
-      acc[w] -= br;
-    }
+/* q = a / d (wa limbs, may be NULL), r = a % d (wd limbs, may be NULL): schoolbook long division on 64-bit
+ * digits (Knuth 4.3.1 D).  This is the host "glue" arithmetic of the reference (BigNumber / and %,
+ * bignum.cpp:204-308 -> ippsDiv_BN / ippsMod_BN), so it must not be slower than a word-level division. */
+static void bn_divrem(u64* q, u64* r, const u64* a, int wa, const u64* d, int wd) {
+  typedef unsigned __int128 u128;
+  int n = wd;
+  while (n > 0 && d[n - 1] == 0) --n;               /* significant limbs of the divisor (n > 0 required) */
+  int m = wa;
+  while (m > 0 && a[m - 1] == 0) --m;
+  if (q) memset(q, 0, sizeof(u64) * (size_t)wa);
+  if (m < n) {
+    if (r) { memset(r, 0, sizeof(u64) * (size_t)wd); memcpy(r, a, sizeof(u64) * (size_t)m); }
+    return;
   }
-  memcpy(r, acc, sizeof(u64) * (size_t)w);
+  if (n == 1) {
+    u128 rem = 0;
+    for (int i = m - 1; i >= 0; --i) {
+      u128 cur = (rem << 64) | a[i];
+      u64 qd = (u64)(cur / d[0]);
+      rem = cur - (u128)qd * d[0];
+      if (q) q[i] = qd;
+    }
+    if (r) { memset(r, 0, sizeof(u64) * (size_t)wd); r[0] = (u64)rem; }
+    return;
+  }
+  u64 dn[MAXW + 1], an[2 * MAXW + 3];
+  const int sh = __builtin_clzll(d[n - 1]);
+  for (int i = n - 1; i > 0; --i) dn[i] = sh ? (d[i] << sh) | (d[i - 1] >> (64 - sh)) : d[i];
+  dn[0] = d[0] << sh;
+  an[m] = sh ? a[m - 1] >> (64 - sh) : 0;
+  for (int i = m - 1; i > 0; --i) an[i] = sh ? (a[i] << sh) | (a[i - 1] >> (64 - sh)) : a[i];
+  an[0] = a[0] << sh;
+  for (int j = m - n; j >= 0; --j) {
+    u128 num = ((u128)an[j + n] << 64) | an[j + n - 1];
+    u128 qhat = num / dn[n - 1], rhat = num - qhat * dn[n - 1];
+    while (qhat >> 64 || (u128)(u64)qhat * dn[n - 2] > ((rhat << 64) | an[j + n - 2])) {
+      --qhat;
+      rhat += dn[n - 1];
+      if (rhat >> 64) break;
+    }
+    u128 borrow = 0, carry = 0;                     /* an[j..j+n] -= qhat * dn */
+    for (int i = 0; i < n; ++i) {
+      u128 pr = (u128)(u64)qhat * dn[i] + carry;
+      carry = pr >> 64;
+      u128 sub = (u128)an[i + j] - (u64)pr - borrow;
+      an[i + j] = (u64)sub;
+      borrow = (sub >> 64) & 1;
+    }
+    u128 sub = (u128)an[j + n] - carry - borrow;
+    an[j + n] = (u64)sub;
+    if ((sub >> 64) & 1) {                          /* one too many: add the divisor back */
+      --qhat;
+      u128 c = 0;
+      for (int i = 0; i < n; ++i) {
+        u128 t = (u128)an[i + j] + dn[i] + c;
+        an[i + j] = (u64)t;
+        c = t >> 64;
+      }
+      an[j + n] += (u64)c;
+    }
+    if (q) q[j] = (u64)qhat;
+  }
+  if (r) {
+    memset(r, 0, sizeof(u64) * (size_t)wd);
+    for (int i = 0; i < n; ++i) r[i] = sh ? (an[i] >> sh) | (an[i + 1] << (64 - sh)) : an[i];
+  }
 }
+
+/* r = a mod m; a has wa limbs, m has w limbs */
+static void bn_mod(u64* r, const u64* a, int wa, const u64* m, int w) { bn_divrem(NULL, r, a, wa, m, w); }
 
 /* ---------- Montgomery context ---------- */
 typedef struct {
@@ -240,26 +289,8 @@ int orc_paillier_encrypt(const u64* n, int nw, const u64* hs_or_null, const u64*
   return 0;
 }
 
-/* exact division helper: q = a / d for a an exact multiple, via binary long division */
-static void bn_divexact(u64* q, const u64* a, int wa, const u64* d, int wd) {
-  u64 rem[MAXW + 1];
-  memset(rem, 0, sizeof(u64) * (size_t)(wd + 1));
-  memset(q, 0, sizeof(u64) * (size_t)wa);
-  int nb = bn_bits(a, wa);
-  for (int i = nb - 1; i >= 0; --i) {
-    u64 c = (a[i >> 6] >> (i & 63)) & 1;
-    for (int j = 0; j <= wd; ++j) {
-      u64 nc = rem[j] >> 63;
-      rem[j] = (rem[j] << 1) | c;
-      c = nc;
-    }
-    if (rem[wd] || bn_cmp(rem, d, wd) >= 0) {
-      u64 br = bn_sub(rem, rem, d, wd);
-      rem[wd] -= br;
-      q[i >> 6] |= 1ull << (i & 63);
-    }
-  }
-}
+/* exact division helper: q = a / d for a an exact multiple (the L function, pri_key.cpp:154-157) */
+static void bn_divexact(u64* q, const u64* a, int wa, const u64* d, int wd) { bn_divrem(q, NULL, a, wa, d, wd); }
 
 /* from rp = c^(p-1) mod p^2, rq = c^(q-1) mod q^2 (clobbered) to the plaintext: L-function, *hp / *hq,
  * CRT recombination   pri_key.cpp:142-157 */
