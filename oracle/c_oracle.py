@@ -1,6 +1,7 @@
 """ctypes loader of the C oracle (oracle/modexp_oracle.c).  TEST INFRASTRUCTURE ONLY."""
 import ctypes
 import os
+import subprocess
 
 import numpy as np
 
@@ -19,9 +20,16 @@ def _cpu_has(flag):
     return False
 
 
+def _ensure_built():
+    """Fresh checkout: the .so files are build products (git-ignored); build them on first use."""
+    if not os.path.exists(os.path.join(_HERE, "libmodexp_oracle.so")):
+        subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)
+
+
 def lib():
     global _lib
     if _lib is None:
+        _ensure_built()
         name = "libmodexp_oracle_v3.so" if (_cpu_has("bmi2") and _cpu_has("avx2")) else "libmodexp_oracle.so"
         path = os.path.join(_HERE, name)
         if not os.path.exists(path):
@@ -119,6 +127,7 @@ def openssl_lib():
     """libopenssl_oracle.so if it was built (libcrypto present at build time), else None."""
     global _ossl
     if _ossl is None:
+        _ensure_built()
         path = os.path.join(_HERE, "libopenssl_oracle.so")
         if not os.path.exists(path):
             return None
@@ -154,6 +163,7 @@ def ifma_lib():
     """libifma_oracle.so (oracle/ifma_oracle.c) when it was built AND this CPU reports avx512ifma."""
     global _ifma
     if _ifma is None:
+        _ensure_built()
         path = os.path.join(_HERE, "libifma_oracle.so")
         if not (os.path.exists(path) and _cpu_has("avx512ifma") and _cpu_has("avx512f")):
             return None
