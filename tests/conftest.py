@@ -15,6 +15,9 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def engine():
     import pailliercryptolib_amd as pa
+    from pailliercryptolib_amd import build
+    build.build_pgpu()          # no-ops when the in-tree libraries are up to date (a fresh checkout has none)
+    build.build_ipcl()
     pa.initialize()
     yield pa
     pa.terminate()
