@@ -13,6 +13,8 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <condition_variable>
+#include <thread>
 #include <vector>
 
 #include "ipcl/bignum.h"
@@ -476,40 +478,114 @@ int run_modexp(pgpu::ModexpArgs& a, const GeoInfo& ctx_geo, hipStream_t s, const
 // Host <-> device copies go through a persistent pinned staging buffer: hipMemcpy straight from
 // pageable memory takes an erratic 10+ ms for transfers just above 1 MiB (user-pointer pinning),
 // measured with tests/cpp/ipcl_bench.cpp; a pinned bounce buffer is steady at PCIe speed.
-constexpr size_t kStageBytes = (size_t)8 << 20;
+constexpr size_t kStageBytes = (size_t)16 << 20;
 void* g_stage[2] = {nullptr, nullptr};
+hipStream_t g_copy_stream = nullptr;       // DMA of the staged copies, concurrent with the host-side memcpy
+hipEvent_t g_stage_ev[2] = {nullptr, nullptr};
+hipEvent_t g_order_ev = nullptr;           // default-stream work a staged copy has to wait for
 int ensure_stage() {
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
     if (!g_stage[i]) HIP_TRY(hipHostMalloc(&g_stage[i], kStageBytes, hipHostMallocDefault));
+    if (!g_stage_ev[i]) HIP_TRY(hipEventCreateWithFlags(&g_stage_ev[i], hipEventDisableTiming));
+  }
+  if (!g_copy_stream) HIP_TRY(hipStreamCreateWithFlags(&g_copy_stream, hipStreamNonBlocking));
+  if (!g_order_ev) HIP_TRY(hipEventCreateWithFlags(&g_order_ev, hipEventDisableTiming));
   return PGPU_OK;
 }
+
+// A single thread moves ~8 GB/s between pageable memory and the pinned bounce buffer -- less than the DMA
+// engine behind it -- so large copies are split over a few persistent helper threads (never joined: they
+// sleep on a condition variable and die with the process).
+class CopyPool {
+ public:
+  static constexpr int kHelpers = 3;
+  static CopyPool& get() {
+    static CopyPool* p = new CopyPool();
+    return *p;
+  }
+  void copy(void* dst, const void* src, size_t n) {
+    if (n < ((size_t)2 << 20)) { std::memcpy(dst, src, n); return; }
+    const size_t per = (n / (kHelpers + 1) + 63) & ~(size_t)63;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      dst_ = (char*)dst; src_ = (const char*)src; n_ = n; per_ = per;
+      pending_ = kHelpers;
+      ++gen_;
+    }
+    cv_.notify_all();
+    std::memcpy(dst, src, std::min(per, n));                     // slice 0 on the calling thread
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+  }
+
+ private:
+  CopyPool() {
+    for (int i = 0; i < kHelpers; ++i) std::thread([this, i] { run(i + 1); }).detach();
+  }
+  void run(int slice) {
+    unsigned seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(m_);
+      cv_.wait(lk, [&] { return gen_ != seen; });
+      seen = gen_;
+      char* d = dst_; const char* s = src_; const size_t n = n_, per = per_;
+      lk.unlock();
+      const size_t lo = std::min(n, per * (size_t)slice), hi = std::min(n, per * (size_t)(slice + 1));
+      if (hi > lo) std::memcpy(d + lo, s + lo, hi - lo);
+      lk.lock();
+      if (--pending_ == 0) done_.notify_one();
+    }
+  }
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  char* dst_ = nullptr;
+  const char* src_ = nullptr;
+  size_t n_ = 0, per_ = 0;
+  unsigned gen_ = 0;
+  int pending_ = 0;
+};
+
+// host -> device: chunk i+1 is packed into the other pinned buffer while chunk i is on the wire
 int staged_h2d(void* d_dst, const void* h_src, size_t bytes) {
   RC_TRY(ensure_stage());
+  // d_dst may be a pooled buffer that a kernel still queued on the default stream reads (device buffers
+  // go back to the pool at once): the copy stream must not overtake that work
+  HIP_TRY(hipEventRecord(g_order_ev, nullptr));
+  HIP_TRY(hipStreamWaitEvent(g_copy_stream, g_order_ev, 0));
   size_t off = 0;
-  int buf = 0;
-  while (off < bytes) {
-    size_t n = std::min(kStageBytes, bytes - off);
-    std::memcpy(g_stage[buf], (const char*)h_src + off, n);
-    HIP_TRY(hipMemcpyAsync((char*)d_dst + off, g_stage[buf], n, hipMemcpyHostToDevice, nullptr));
+  for (int i = 0; off < bytes; ++i) {
+    const int b = i & 1;
+    const size_t n = std::min(kStageBytes, bytes - off);
+    if (i >= 2) HIP_TRY(hipEventSynchronize(g_stage_ev[b]));      // the DMA that last read this buffer is done
+    CopyPool::get().copy(g_stage[b], (const char*)h_src + off, n);
+    HIP_TRY(hipMemcpyAsync((char*)d_dst + off, g_stage[b], n, hipMemcpyHostToDevice, g_copy_stream));
+    HIP_TRY(hipEventRecord(g_stage_ev[b], g_copy_stream));
     off += n;
-    buf ^= 1;
-    if (off < bytes && off >= 2 * kStageBytes) HIP_TRY(hipStreamSynchronize(nullptr));  // buffer reuse
   }
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(g_copy_stream));
   return PGPU_OK;
 }
+// device -> host (after the work queued on the default stream): chunk i+1 is on the wire while chunk i is
+// unpacked from its pinned buffer
 int staged_d2h(void* h_dst, const void* d_src, size_t bytes) {
   RC_TRY(ensure_stage());
-  size_t off = 0;
-  while (off < bytes) {
-    size_t n = std::min(kStageBytes, bytes - off);
-    hipError_t e = hipMemcpyAsync(g_stage[0], (const char*)d_src + off, n, hipMemcpyDeviceToHost, nullptr);
-    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-    if (e != hipSuccess)
-      return fail(PGPU_ERR_HIP, std::string("kernel / D2H copy failed: ") + hipGetErrorString(e));
-    std::memcpy((char*)h_dst + off, g_stage[0], n);
-    off += n;
+  hipError_t e = hipStreamSynchronize(nullptr);
+  if (e != hipSuccess) return fail(PGPU_ERR_HIP, std::string("kernel failed: ") + hipGetErrorString(e));
+  auto issue = [&](int i) -> hipError_t {
+    const size_t off = (size_t)i * kStageBytes, n = std::min(kStageBytes, bytes - off);
+    hipError_t r = hipMemcpyAsync(g_stage[i & 1], (const char*)d_src + off, n, hipMemcpyDeviceToHost, g_copy_stream);
+    return r == hipSuccess ? hipEventRecord(g_stage_ev[i & 1], g_copy_stream) : r;
+  };
+  const int chunks = (int)((bytes + kStageBytes - 1) / kStageBytes);
+  if (chunks > 0) e = issue(0);
+  for (int i = 0; i < chunks && e == hipSuccess; ++i) {
+    if (i + 1 < chunks) e = issue(i + 1);                         // its buffer was unpacked in iteration i-1
+    if (e == hipSuccess) e = hipEventSynchronize(g_stage_ev[i & 1]);
+    if (e != hipSuccess) break;
+    const size_t off = (size_t)i * kStageBytes, n = std::min(kStageBytes, bytes - off);
+    CopyPool::get().copy((char*)h_dst + off, g_stage[i & 1], n);
   }
+  if (e != hipSuccess) return fail(PGPU_ERR_HIP, std::string("D2H copy failed: ") + hipGetErrorString(e));
   return PGPU_OK;
 }
 
@@ -596,7 +672,13 @@ void pgpu_shutdown(void) {
   for (int i = 0; i < 2; ++i) {
     if (g_stage[i]) (void)hipHostFree(g_stage[i]);
     g_stage[i] = nullptr;
+    if (g_stage_ev[i]) (void)hipEventDestroy(g_stage_ev[i]);
+    g_stage_ev[i] = nullptr;
   }
+  if (g_copy_stream) (void)hipStreamDestroy(g_copy_stream);
+  g_copy_stream = nullptr;
+  if (g_order_ev) (void)hipEventDestroy(g_order_ev);
+  g_order_ev = nullptr;
   for (auto& t : g_timed) { g_event_pool.push_back(t.e0); g_event_pool.push_back(t.e1); }
   g_timed.clear();
   for (hipEvent_t e : g_event_pool) (void)hipEventDestroy(e);

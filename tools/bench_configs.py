@@ -70,6 +70,33 @@ out["config5_mul_ctpt_u32_n131072"] = {"ms": t, "modexps_per_s": 131072 / t * 1e
 de64 = T.to_device(rows(rng, 131072, 1))
 t = timed(lambda: T.mod_exp(da, de64, NSQ, exp_bits=64))
 out["config5_mul_ctpt_u64_n131072"] = {"ms": t, "modexps_per_s": 131072 / t * 1e3, "frac_of_39.32T": mac32(4096, 64) * 131072 / (t * 1e-3) / 39.32e12}
+# ---- end-to-end from HOST buffers through the synchronous C-ABI entry points (H2D + kernels + D2H; flat
+# uint64 arrays, i.e. without the BigNumber marshalling of the C++ layer) ----
+def wall(fn, reps=3):
+    fn()
+    best = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); best = min(best, time.perf_counter() - t0)
+    return best * 1e3
+
+import ctypes
+from pailliercryptolib_amd import _capi
+Lc = _capi.lib()
+vp = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+hm, hr = rows(rng, 8192, 32, (1 << 62) - 1), rows(rng, 8192, 16)
+hc, hout = np.zeros((8192, 64), dtype=np.uint64), np.zeros((8192, 32), dtype=np.uint64)   # caller-owned, reused
+enc_h = lambda: _capi.check(Lc.pgpu_paillier_encrypt(pk._h, vp(hm), 32, 32, vp(hr), 16, 16, 1024, vp(hc), 8192))
+dec_h = lambda: _capi.check(Lc.pgpu_paillier_decrypt_crt(sk._h, vp(hc), vp(hout), 8192))
+t_e, t_d = wall(enc_h), wall(dec_h)
+assert np.array_equal(hout, hm)
+out["host_buffers_config2_3_k2048_n8192"] = {"encrypt_ms": t_e, "decrypt_ms": t_d,
+                                             "modexps_per_s": 3 * 8192 / (t_e + t_d) * 1e3}
+ha, hb = T.to_host(da), T.to_host(db)
+hs_out = np.zeros_like(ha)
+nsq_l = np.array([(NSQ >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(64)], dtype=np.uint64)
+t = wall(lambda: _capi.check(Lc.pgpu_modmul(vp(ha), vp(hb), 64, vp(nsq_l), 64, vp(hs_out), 131072)))
+out["host_buffers_config5_add_n131072"] = {"ms": t, "modmuls_per_s": 131072 / t * 1e3,
+                                           "host_GBs": 131072 * 1536 / (t * 1e-3) / 1e9}
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/config_sweep.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
