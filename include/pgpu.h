@@ -102,7 +102,8 @@ int pgpu_paillier_encrypt_dev(const pgpu_pubkey* key, const uint64_t* d_m, size_
  * hs^(d*2^(w*i)) (built on the GPU at the first encrypt, no squarings afterwards).  w = 0 selects
  * the generic square-and-multiply kernel instead; default 12 (env PGPU_FB_WINDOW): 86 table products
  * for a 1024-bit r, 203 MB of table per 2048-bit key (w = 10: 103 products, 61 MB; measured on the
- * bench batch: 1.19 ms vs 1.41 ms).  Results are identical either way. */
+ * bench batch: 1.19 ms vs 1.41 ms).  Unless a window was set explicitly, a key starts with w = 8 (13 MB,
+ * built in ~2 ms) and switches to the default after its first 4096 elements.  Results are identical. */
 int pgpu_set_fixed_base_window(int w);
 
 /* ---- Paillier private key: fused CRT decrypt ----

@@ -299,14 +299,19 @@ int make_schedule(const BigNumber& e, int w, ExpSchedule* out) {
 // window width of the fixed-base table for the DJN obfuscator; PGPU_FB_WINDOW=0 selects the
 // generic (per-instance table, square-and-multiply) kernel instead.
 int g_fb_window = -1;
+bool g_fb_window_explicit = false;   // set through the environment or pgpu_set_fixed_base_window
 int fixed_base_window() {
   if (g_fb_window < 0) {
     const char* e = std::getenv("PGPU_FB_WINDOW");
     int v = e ? std::atoi(e) : 12;
     g_fb_window = (v < 0 || v > 12) ? 12 : v;
+    g_fb_window_explicit = e != nullptr;
   }
   return g_fb_window;
 }
+// A key that has encrypted little so far starts with an 8-bit window (table 16x smaller, built in ~2 ms
+// instead of ~37 ms) and moves to the configured one once this many elements have gone through it.
+constexpr size_t kFbGrowAfter = 4096;
 
 hipEvent_t pool_event() {
   if (!g_event_pool.empty()) {
@@ -618,6 +623,7 @@ struct pgpu_pubkey {
   mutable Workspace fb_table;
   mutable int fb_nwin = 0;
   mutable int fb_w = 0;
+  mutable size_t fb_elems = 0;  // elements encrypted with this key so far (window policy)
   ~pgpu_pubkey() { fb_table.release(); }
 };
 
@@ -706,6 +712,7 @@ int pgpu_set_fixed_base_window(int w) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   if (w < 0 || w > 12) return fail(PGPU_ERR_INVALID_PARAM, "fixed-base window must be 0..12");
   g_fb_window = w;
+  g_fb_window_explicit = true;
   return PGPU_OK;
 }
 
@@ -983,7 +990,9 @@ int pgpu_paillier_encrypt_dev(const pgpu_pubkey* key, const uint64_t* d_m, size_
     return fail(PGPU_ERR_INVALID_PARAM, "random width/stride invalid");
   if (key->djn && (r_bits < 0 || r_bits > 64 * r_words))
     return fail(PGPU_ERR_INVALID_PARAM, "r_bits/r_words inconsistent");
-  const int fbw = fixed_base_window();
+  int fbw = fixed_base_window();
+  if (key->djn && fbw > 8 && !g_fb_window_explicit && key->fb_elems + count < kFbGrowAfter) fbw = 8;
+  if (key->djn) key->fb_elems += count;
   if (key->djn && fbw > 0) {
     // hs is a key constant: fixed-base windowing, no squarings (kernels.hpp: fb_encrypt_kernel)
     hipStream_t s = (hipStream_t)hip_stream;
