@@ -53,3 +53,24 @@ def test_product_never_imports_oracle():
                 if f.endswith((".py", ".hpp", ".h", ".hip", ".cpp")):
                     src = open(os.path.join(d, f), errors="replace").read()
                     assert "oracle" not in src.lower() or f == "build.py", (d, f)
+
+
+def test_kernel_geometry_query_is_host_only():
+    """pgpu_kernel_geometry needs no device: the launch rules (latency / base / wide lane split) as documented
+    in include/pgpu.h and DESIGN.md section 3."""
+    from pailliercryptolib_amd import _capi
+    L = _capi.lib()
+    g, k = ctypes.c_int(), ctypes.c_int()
+
+    def geo(words, bits, count):
+        assert L.pgpu_kernel_geometry(words, bits, count, ctypes.byref(g), ctypes.byref(k)) == 0
+        return g.value, k.value
+    assert geo(32, 2048, 16) == (16, 5)            # small batch of the 2048-bit class: 16 lanes per element
+    assert geo(32, 2048, 4096) == (16, 5)          # ... while it fits one wavefront per SIMD
+    assert geo(32, 2048, 6000) == (8, 9)           # base geometry
+    assert geo(32, 2048, 16384) == (4, 18)         # wide split from 1024 wavefronts up (the bench's decrypt launch)
+    assert geo(64, 4096, 8192) == (8, 18)
+    assert geo(64, 4096, 100) == (16, 9)
+    assert geo(48, 3072, 64) == (16, 7)
+    assert geo(16, 1024, 16384) == (4, 9)          # its wide split (2,18) would leave half the SIMDs empty
+    assert L.pgpu_kernel_geometry(200, 12800, 8, ctypes.byref(g), ctypes.byref(k)) != 0   # wider than any geometry
