@@ -15,6 +15,8 @@ struct RedcArgs {
   const int* corr1;      // [tiles*16]
   const int* corr2;      // [tiles*16]
   int D, tiles, steps, elems, top;
+  int reps;              // repeat the reduction in-kernel (timing: tiles come from cache after the first pass)
+  long long* clocks;     // optional [waves][5]: cycles of GEMM 1, carry 1, GEMM 2, final stage, total (last repetition)
 };
 
 constexpr int kMaxSteps = 9;     // K dimension up to 576 bytes
@@ -33,6 +35,9 @@ extern "C" __global__ __launch_bounds__(64) void redc_kernel(RedcArgs A) {
   const int D = A.D, cols = A.tiles * 16;
   const uint8_t* t = A.T + (size_t)elem * 2 * D;
   v4i B[kMaxSteps];
+  long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+  for (int rep = 0; rep < A.reps; ++rep) {
+  c0 = __builtin_readcyclecounter();
   // ---- GEMM 1: column sums of T_lo * N' ----
   for (int s = 0; s < A.steps; ++s) B[s] = offset128(*(const v4i*)(t + 64 * s + 16 * rho));
   for (int tl = 0; tl < A.tiles; ++tl) {
@@ -46,6 +51,7 @@ extern "C" __global__ __launch_bounds__(64) void redc_kernel(RedcArgs A) {
     *(v4i*)(lds + n * cols + tl * 16 + 4 * rho) = c;     // rows 4*rho .. 4*rho+3 of this tile, element n
   }
   __syncthreads();
+  c1 = __builtin_readcyclecounter();
   // ---- Q = column sums mod R as bytes (serial carry per element: lanes 0..15; an experiment, not tuned) ----
   uint8_t* qb = (uint8_t*)(lds + 16 * cols);      // [16][steps*64]
   const int kbytes = A.steps * 64;
@@ -58,6 +64,7 @@ extern "C" __global__ __launch_bounds__(64) void redc_kernel(RedcArgs A) {
     }
   }
   __syncthreads();
+  c2 = __builtin_readcyclecounter();
   // ---- GEMM 2: column sums c0 .. of Q * N ----
   for (int s = 0; s < A.steps; ++s) B[s] = offset128(*(const v4i*)(qb + n * kbytes + 64 * s + 16 * rho));
   for (int tl = 0; tl < A.tiles; ++tl) {
@@ -70,6 +77,7 @@ extern "C" __global__ __launch_bounds__(64) void redc_kernel(RedcArgs A) {
     *(v4i*)(lds + n * cols + tl * 16 + 4 * rho) = c;
   }
   __syncthreads();
+  c3 = __builtin_readcyclecounter();
   // ---- U = T_hi + high columns + carry of the low half (serial per element) ----
   if (rho == 0 && wave * 16 + n < A.elems) {
     const int top = A.top;
@@ -82,6 +90,13 @@ extern "C" __global__ __launch_bounds__(64) void redc_kernel(RedcArgs A) {
       u[c] = (uint8_t)(v & 0xFF);
       carry = v >> 8;
     }
+  }
+  __syncthreads();
+  c4 = __builtin_readcyclecounter();
+  }
+  if (A.clocks && lane == 0) {
+    long long* r = A.clocks + (size_t)wave * 5;
+    r[0] = c1 - c0; r[1] = c2 - c1; r[2] = c3 - c2; r[3] = c4 - c3; r[4] = c4 - c0;
   }
 }
 

@@ -17,7 +17,7 @@ class Args(ctypes.Structure):
     _fields_ = [("T", ctypes.c_void_p), ("U", ctypes.c_void_p), ("dump", ctypes.c_void_p), ("A1", ctypes.c_void_p),
                 ("A2", ctypes.c_void_p), ("corr1", ctypes.c_void_p), ("corr2", ctypes.c_void_p),
                 ("D", ctypes.c_int), ("tiles", ctypes.c_int), ("steps", ctypes.c_int), ("elems", ctypes.c_int),
-                ("top", ctypes.c_int)]
+                ("top", ctypes.c_int), ("reps", ctypes.c_int), ("clocks", ctypes.c_void_p)]
 
 
 def lane_tiles(A, tiles, steps):
@@ -56,8 +56,9 @@ def run(bits, D, elems, seed=1, reps=5):
     dU = torch.zeros(elems * (D + 8), dtype=torch.uint8, device="cuda")
     waves = (elems + 15) // 16
     ddump = torch.zeros(waves * 2 * tiles * 64 * 4, dtype=torch.int32, device="cuda")
+    dclk = torch.zeros(waves * 5, dtype=torch.int64, device="cuda")
     a = Args(dT.data_ptr(), dU.data_ptr(), ddump.data_ptr(), dA1.data_ptr(), dA2.data_ptr(), dc1.data_ptr(),
-             dc2.data_ptr(), D, tiles, steps, elems, mdl.TOP)
+             dc2.data_ptr(), D, tiles, steps, elems, mdl.TOP, 1, dclk.data_ptr())
     lds = 16 * tiles * 16 * 4 + 16 * steps * 64
     rc = lib.redc_launch(ctypes.byref(a), waves, lds)
     assert rc == 0, rc
@@ -75,6 +76,12 @@ def run(bits, D, elems, seed=1, reps=5):
                     got[16 * tl + 4 * (lane // 16): 16 * tl + 4 * (lane // 16) + 4] = d[0, 0, tl, lane]
         print("GEMM1 element 1: want", want[:8], "got", got[:8], "equal:", np.array_equal(want, got[:D]))
     a.dump = None
+    a.reps = 4
+    lib.redc_launch(ctypes.byref(a), waves, lds)
+    clk = dclk.cpu().numpy().reshape(waves, 5).astype(np.float64).mean(axis=0)
+    print("  cycles per 16-element reduction with warm caches (mean over waves): GEMM1 %.0f, carry1 %.0f, GEMM2 %.0f, "
+          "final %.0f, total %.0f" % tuple(clk))
+    a.reps = 1
     best = 1e9
     for _ in range(reps):
         t0 = time.perf_counter(); lib.redc_launch(ctypes.byref(a), waves, lds); best = min(best, time.perf_counter() - t0)
