@@ -2,6 +2,7 @@
 #ifndef PAILLIERCRYPTOLIB_AMD_IPCL_BASE_TEXT_HPP_
 #define PAILLIERCRYPTOLIB_AMD_IPCL_BASE_TEXT_HPP_
 
+#include <atomic>
 #include <cstdint>
 #include <memory>
 #include <string>
@@ -11,7 +12,25 @@
 
 namespace ipcl {
 
-namespace detail { struct DeviceBatch; }
+namespace detail {
+struct DeviceBatch;
+// std::atomic<bool> with value-copy semantics: "the host copy exists" is published by one thread (lazy
+// download) while others may be reading or copying the text
+struct AtomicFlag {
+  std::atomic<bool> v;
+  AtomicFlag(bool b = false) : v(b) {}
+  AtomicFlag(const AtomicFlag& o) : v(o.v.load(std::memory_order_acquire)) {}
+  AtomicFlag& operator=(const AtomicFlag& o) {
+    v.store(o.v.load(std::memory_order_acquire), std::memory_order_release);
+    return *this;
+  }
+  AtomicFlag& operator=(bool b) {
+    v.store(b, std::memory_order_release);
+    return *this;
+  }
+  operator bool() const { return v.load(std::memory_order_acquire); }
+};
+}  // namespace detail
 
 // Container of BigNumbers (reference base_text.hpp:14-115) with one addition: the values may live
 // in GPU memory as a flat limb batch (the result of encrypt / decrypt / CT+CT / CT*PT) and are
@@ -26,8 +45,8 @@ class BaseText {
   explicit BaseText(const std::vector<uint32_t>& n_v);
   explicit BaseText(const BigNumber& bn);
   explicit BaseText(const std::vector<BigNumber>& bn_v);
-  BaseText(const BaseText& bt) = default;
-  BaseText& operator=(const BaseText& other) = default;
+  BaseText(const BaseText& bt);               // (copies take the materialisation lock: see base_text.cpp)
+  BaseText& operator=(const BaseText& other);
 
   BigNumber& operator[](const std::size_t idx);
   void insert(const std::size_t pos, BigNumber& bn);
@@ -51,7 +70,7 @@ class BaseText {
   mutable std::vector<BigNumber> m_texts;   // host values; valid iff m_host_valid
   std::size_t m_size = 0;
   mutable std::shared_ptr<detail::DeviceBatch> m_dev;  // immutable device copy (may be the only copy)
-  mutable bool m_host_valid = true;
+  mutable detail::AtomicFlag m_host_valid{true};
 
   // construct around a device batch (no host copy yet)
   explicit BaseText(std::shared_ptr<detail::DeviceBatch> dev);

@@ -64,12 +64,15 @@ class PublicKey {
   bool m_enable_DJN = false;
   std::vector<BigNumber> m_r;
   bool m_testv = false;
-  // device-side key (n^2 Montgomery context, hs); rebuilt lazily when n / hs change
-  mutable std::shared_ptr<detail::PubKeyDevice> m_dev;
+  // device-side key (n^2 Montgomery context, hs; one copy per pool GPU): rebuilt by every mutator, read-only
+  // in between, shared by copies of the key
+  std::shared_ptr<detail::PubKeyDevice> m_dev;
+  friend class CipherText;
 
   std::vector<BigNumber> raw_encrypt(const std::vector<BigNumber>& pt, bool make_secure = true) const;
   std::vector<BigNumber> drawRandom(std::size_t sz) const;
   std::shared_ptr<detail::PubKeyDevice> device() const;
+  void rebuildDevice();
 };
 
 }  // namespace ipcl

@@ -17,10 +17,33 @@
  * OWNERSHIP / THREADING.  The caller owns every buffer it passes.  Functions without the
  * `_dev` suffix take HOST pointers and are synchronous (like release_bnModExp_buffer,
  * bnops.h:134-148): on return the outputs are complete.  `_dev` functions take DEVICE
- * pointers plus a hipStream_t (as void*) and only enqueue work on that stream.  All entry
- * points may be called from several host threads (the reference's APPLEVEL_OMP test calls
- * encrypt/decrypt from 4 threads, test/test_cryptography.cpp:45-57); calls on one process
- * are serialised internally.  One process drives one GPU (pgpu_init selects it).
+ * pointers plus a hipStream_t (as void*) and only enqueue work on that stream; calls on different
+ * streams never share scratch memory (window tables and the CRT hand-over buffer are per stream), so
+ * they may be issued concurrently.  All entry points may be called from several host threads (the
+ * reference's APPLEVEL_OMP test calls encrypt/decrypt from 4 threads,
+ * test/test_cryptography.cpp:45-57): host-pointer calls run as tasks on the worker lanes of the
+ * device pool (two per GPU), so one caller's copies overlap another caller's kernels.
+ *
+ * DEVICE POOL.  pgpu_init binds the process to one GPU; pgpu_init_all builds a pool over several
+ * (the counterpart of acquire_qat_devices taking every QAT instance, heqat/context.h:18-26, and
+ * of the reference's own two-way batch split over a second std::thread, mod_exp.cpp:700-731).
+ * With a pool, every host-pointer entry point cuts its batch [0, count) into contiguous shards,
+ * one per GPU (output order is preserved by construction), and key objects hold one copy of their
+ * constants per GPU: the image is uploaded to GPU 0 and reaches the others through one RCCL
+ * broadcast over xGMI (per-device copies when RCCL is unavailable).  There is no other collective
+ * on the data path.  The `_dev` functions and pgpu_dev_alloc/free/copy address ONE pool entry: the
+ * calling thread's current one (pgpu_set_device, default 0).  pgpu_batch handles are the sharded,
+ * device-resident form of a batch.
+ *
+ * SIDE CHANNELS.  Operation sequences do not depend on secret data unless the caller opts in:
+ * exponents that are private-key constants (p-1, q-1) run a fixed-window schedule (always w
+ * squarings and one multiplication, also for zero digits), the same instruction stream for every
+ * key; pgpu_set_secret_exponent_policy(PGPU_EXP_SLIDING) trades that for ~5 % fewer
+ * multiplications with a key-dependent schedule.  Table ADDRESSES are not hidden: the window table
+ * of a wavefront is indexed by exponent digits (per-key constant pattern for p-1/q-1, per-element
+ * for the randomness r of the DJN fixed-base product and for CT*PT exponents), i.e. the engine
+ * is not hardened against a co-resident observer of the memory system.  Device copies of
+ * private-key constants are zeroed before they are freed.
  *
  * ERRORS.  Every function returns PGPU_OK (0) or a negative pgpu_status; nothing calls
  * exit().  pgpu_last_error() returns a thread-local description.  The C++ layer turns a
@@ -51,11 +74,24 @@ typedef enum pgpu_status {
 /* ---- context: behind ipcl::initializeContext / terminateContext (utils/context.cpp:40-71);
  *      replaces acquire_qat_devices / release_qat_devices (heqat/context.h:18-26) ---- */
 int pgpu_init(int device /* HIP ordinal; -1 = keep the current device */);
+/* Pool over the first n visible GPUs (0 = all).  With the environment variable
+ * PGPU_POOL_OVERSUBSCRIBE=1, n may exceed the number of visible GPUs: pool entries then wrap around
+ * the physical devices (validation of the multi-device paths on a single-GPU box). */
+int pgpu_init_all(int n_devices_or_0);
 void pgpu_shutdown(void);
-int pgpu_device_count(void);
+int pgpu_device_count(void);       /* visible HIP devices */
 int pgpu_is_initialized(void);
 const char* pgpu_last_error(void);
-const char* pgpu_device_name(void);
+const char* pgpu_device_name(void); /* of the calling thread's current pool entry */
+int pgpu_pool_size(void);           /* entries of the pool (0 before init) */
+int pgpu_set_device(int pool_index);/* pool entry addressed by this thread's `_dev` / dev_alloc / copy calls */
+int pgpu_get_device(void);
+/* "rccl" | "memcpy" | "single": how key images reached the pool devices (xGMI broadcast, per-device
+ * copies, or a pool of one) */
+const char* pgpu_pool_transport(void);
+/* batches smaller than min_shard * k elements are spread over at most k GPUs (default 256; env
+ * PGPU_MIN_SHARD) */
+int pgpu_set_min_shard(size_t min_elements_per_device);
 
 /* ---- generic batched modular exponentiation: out[i] = base[i]^exp[i] mod mod ----
  * Replaces mbx_exp_mb8 (mod_exp.cpp:508-516) / ippsMontExp (mod_exp.cpp:549-579) under
@@ -126,6 +162,45 @@ int pgpu_dev_alloc(size_t bytes, void** out);
 void pgpu_dev_free(void* d_ptr);
 int pgpu_copy_h2d(void* d_dst, const void* h_src, size_t bytes);
 int pgpu_copy_d2h(void* h_dst, const void* d_src, size_t bytes);
+
+/* ---- exponent schedules of private-key constants (see SIDE CHANNELS above) ---- */
+typedef enum pgpu_exp_policy {
+  PGPU_EXP_FIXED_WINDOW = 0, /* default: key-independent operation sequence                     */
+  PGPU_EXP_SLIDING = 1       /* host-built sliding-window schedule of p-1 / q-1 (fewer products) */
+} pgpu_exp_policy;
+int pgpu_set_secret_exponent_policy(int policy);
+int pgpu_get_secret_exponent_policy(void);
+
+/* ---- sharded device-resident batches (SURVEY 8(f) N1 across the pool) ----
+ * A pgpu_batch is [count][words] little-endian limbs living in GPU memory, cut into contiguous shards
+ * over the pool (count == 1: one copy on every GPU, the reference's "vector (+) scalar" operand,
+ * ciphertext.cpp:51-58).  Operations enqueue one launch per shard on the GPUs' batch streams and
+ * return at once; pgpu_batch_download waits.  Batches are immutable once produced.
+ * Ciphertext batches produced on the device stay in the MONTGOMERY DOMAIN of n^2 (value*R mod n^2):
+ * CT+CT is then ONE Montgomery product (ciphertext.cpp:135-141 does a multiply and a divide),
+ * encrypt emits that form for free and CRT decrypt absorbs it into its load constants; the plain
+ * value only materialises in pgpu_batch_download.  Callers never see the difference. */
+typedef struct pgpu_batch pgpu_batch;
+int pgpu_batch_create(size_t count, int words, pgpu_batch** out);            /* uninitialised */
+int pgpu_batch_upload(const uint64_t* host, size_t count, int words, size_t stride, pgpu_batch** out);
+int pgpu_batch_download(const pgpu_batch* b, uint64_t* host /* [count][words] */);
+void pgpu_batch_destroy(pgpu_batch* b);
+size_t pgpu_batch_count(const pgpu_batch* b);
+int pgpu_batch_words(const pgpu_batch* b);
+int pgpu_batch_is_montgomery(const pgpu_batch* b);
+/* c = Enc(m; r): m, r batches of `count` elements (PublicKey::encrypt, pub_key.cpp:112-129) */
+int pgpu_batch_encrypt(const pgpu_pubkey* key, const pgpu_batch* m, const pgpu_batch* r, int r_bits,
+                       pgpu_batch** c);
+/* m = Dec(c) (PrivateKey::decrypt CRT path, pri_key.cpp:65-90,114-157) */
+int pgpu_batch_decrypt_crt(const pgpu_privkey* key, const pgpu_batch* c, pgpu_batch** m);
+/* out = a*b mod n^2 under `key` (CipherText + CipherText, ciphertext.cpp:35-72); b may hold one element */
+int pgpu_batch_ct_add(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_batch* b, pgpu_batch** out);
+/* out = a * (1 + n*m) mod n^2 (CipherText + PlainText, ciphertext.cpp:75-80: g^m without obfuscator, then the
+ * product -- here fused in one launch, no host loop); m may hold one element */
+int pgpu_batch_ct_add_plain(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_batch* m, pgpu_batch** out);
+/* out = a^e mod n^2 (CipherText * PlainText, ciphertext.cpp:83-106); e may hold one element */
+int pgpu_batch_ct_mul(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_batch* e, int e_bits,
+                      pgpu_batch** out);
 
 /* ---- instrumentation used by bench.py (roofline) ----
  * With timing enabled every kernel launch is bracketed by two HIP events recorded on the stream

@@ -22,6 +22,11 @@ SYMBOLS = [
     "pgpu_dev_alloc", "pgpu_dev_free", "pgpu_copy_h2d", "pgpu_copy_d2h",
     "pgpu_set_fixed_base_window", "pgpu_set_timing", "pgpu_timing_collect",
     "pgpu_kernel_geometry",
+    "pgpu_init_all", "pgpu_pool_size", "pgpu_set_device", "pgpu_get_device", "pgpu_pool_transport",
+    "pgpu_set_min_shard", "pgpu_set_secret_exponent_policy", "pgpu_get_secret_exponent_policy",
+    "pgpu_batch_create", "pgpu_batch_upload", "pgpu_batch_download", "pgpu_batch_destroy", "pgpu_batch_count",
+    "pgpu_batch_words", "pgpu_batch_is_montgomery", "pgpu_batch_encrypt", "pgpu_batch_decrypt_crt",
+    "pgpu_batch_ct_add", "pgpu_batch_ct_add_plain", "pgpu_batch_ct_mul",
 ]
 
 _lib = None
@@ -86,6 +91,32 @@ def lib():
     L.pgpu_timing_collect.argtypes = [c_void_p, c_void_p, c_int]; L.pgpu_timing_collect.restype = c_int
     L.pgpu_kernel_geometry.argtypes = [c_int, c_int, c_size_t, POINTER(c_int), POINTER(c_int)]
     L.pgpu_kernel_geometry.restype = c_int
+    L.pgpu_init_all.argtypes = [c_int]; L.pgpu_init_all.restype = c_int
+    L.pgpu_pool_size.argtypes = []; L.pgpu_pool_size.restype = c_int
+    L.pgpu_set_device.argtypes = [c_int]; L.pgpu_set_device.restype = c_int
+    L.pgpu_get_device.argtypes = []; L.pgpu_get_device.restype = c_int
+    L.pgpu_pool_transport.argtypes = []; L.pgpu_pool_transport.restype = c_char_p
+    L.pgpu_set_min_shard.argtypes = [c_size_t]; L.pgpu_set_min_shard.restype = c_int
+    L.pgpu_set_secret_exponent_policy.argtypes = [c_int]; L.pgpu_set_secret_exponent_policy.restype = c_int
+    L.pgpu_get_secret_exponent_policy.argtypes = []; L.pgpu_get_secret_exponent_policy.restype = c_int
+    L.pgpu_batch_create.argtypes = [c_size_t, c_int, POINTER(c_void_p)]; L.pgpu_batch_create.restype = c_int
+    L.pgpu_batch_upload.argtypes = [c_void_p, c_size_t, c_int, c_size_t, POINTER(c_void_p)]
+    L.pgpu_batch_upload.restype = c_int
+    L.pgpu_batch_download.argtypes = [c_void_p, c_void_p]; L.pgpu_batch_download.restype = c_int
+    L.pgpu_batch_destroy.argtypes = [c_void_p]; L.pgpu_batch_destroy.restype = None
+    L.pgpu_batch_count.argtypes = [c_void_p]; L.pgpu_batch_count.restype = c_size_t
+    L.pgpu_batch_words.argtypes = [c_void_p]; L.pgpu_batch_words.restype = c_int
+    L.pgpu_batch_is_montgomery.argtypes = [c_void_p]; L.pgpu_batch_is_montgomery.restype = c_int
+    L.pgpu_batch_encrypt.argtypes = [c_void_p, c_void_p, c_void_p, c_int, POINTER(c_void_p)]
+    L.pgpu_batch_encrypt.restype = c_int
+    L.pgpu_batch_decrypt_crt.argtypes = [c_void_p, c_void_p, POINTER(c_void_p)]
+    L.pgpu_batch_decrypt_crt.restype = c_int
+    L.pgpu_batch_ct_add.argtypes = [c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]
+    L.pgpu_batch_ct_add.restype = c_int
+    L.pgpu_batch_ct_add_plain.argtypes = [c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]
+    L.pgpu_batch_ct_add_plain.restype = c_int
+    L.pgpu_batch_ct_mul.argtypes = [c_void_p, c_void_p, c_void_p, c_int, POINTER(c_void_p)]
+    L.pgpu_batch_ct_mul.restype = c_int
     _lib = L
     return L
 

@@ -1,6 +1,7 @@
 """In-tree build of the native pieces (no JIT cache: the .so files travel with the repo snapshot).
 
-  libpgpu.so       hipcc --offload-arch=gfx950   csrc/capi.hip + csrc/host/bignum.cpp   (the product)
+  libpgpu.so       hipcc --offload-arch=gfx950   csrc/k_*.hip (kernels) + g++ csrc/capi.cpp, runtime.cpp,
+                                                 host/bignum.cpp                        (the product)
   libipcl_amd.so   g++                           csrc/host/*.cpp (ipcl:: C++ API over the C-ABI)
   oracle/*.so      gcc                           oracle/modexp_oracle.c (test infrastructure)
 """
@@ -32,14 +33,44 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: cannot build the HIP extension (there is no CPU fallback)")
 
 
+def _objects():
+    """(object file, compile command, dependencies) of every translation unit of libpgpu.so.  The device code
+    is split so that it compiles in parallel (k_modexp.hip once per PGPU_PART, k_misc.hip) and a change of the
+    host runtime never recompiles a kernel."""
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    hip = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + inc
+    host = ["g++", "-O2", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + inc
+    kdeps = [os.path.join(CSRC, f) for f in ("kernels.hpp", "mont_core.hpp", "kargs.hpp", "launch.hpp")]
+    hdeps = [os.path.join(CSRC, f) for f in ("kargs.hpp", "launch.hpp", "runtime.hpp")]
+    hdeps += [os.path.join(ROOT, "include", "pgpu.h"), os.path.join(ROOT, "include", "ipcl", "bignum.h"),
+              os.path.join(ROOT, "include", "ipcl", "utils", "serialize.hpp")]
+    obj = os.path.join(HERE, "build")
+    out = []
+    for part in range(4):
+        src = os.path.join(CSRC, "k_modexp.hip")
+        o = os.path.join(obj, f"k_modexp_{part}.o")
+        out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src] + kdeps))
+    src = os.path.join(CSRC, "k_misc.hip")
+    out.append((os.path.join(obj, "k_misc.o"), hip + ["-c", src, "-o", os.path.join(obj, "k_misc.o")], [src] + kdeps))
+    for name in ("capi.cpp", "runtime.cpp", os.path.join("host", "bignum.cpp")):
+        src = os.path.join(CSRC, name)
+        o = os.path.join(obj, os.path.basename(name).replace(".cpp", ".o"))
+        out.append((o, host + ["-c", src, "-o", o], [src] + hdeps))
+    return out
+
+
 def build_pgpu(force=False):
+    from concurrent.futures import ThreadPoolExecutor
     out = os.path.join(HERE, "libpgpu.so")
-    srcs = [os.path.join(CSRC, f) for f in ("capi.hip", "kernels.hpp", "mont_core.hpp", "host/bignum.cpp")]
-    srcs += [os.path.join(ROOT, "include", "pgpu.h"), os.path.join(ROOT, "include", "ipcl", "bignum.h")]
-    if force or _newer(out, srcs):
-        _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-              os.path.join(CSRC, "capi.hip"), os.path.join(CSRC, "host", "bignum.cpp"), "-o", out])
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    objs = _objects()
+    todo = [(o, cmd) for o, cmd, deps in objs if force or _newer(o, deps)]
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
+            list(ex.map(lambda oc: _run(oc[1]), todo))
+    if todo or not os.path.exists(out):
+        _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _, _ in objs]
+             + ["-ldl", "-lpthread", "-o", out])
     return out
 
 

@@ -1,0 +1,1505 @@
+// pailliercryptolib_amd -- implementation of the C-ABI declared in include/pgpu.h.
+// Host side: Montgomery-constant precomputation (host BigNumber), geometry selection, kernel launches,
+// sharding over the device pool (runtime.hpp).  No CPU fallback: everything computes on the GPU.
+#include "pgpu.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "ipcl/bignum.h"
+#include "kargs.hpp"
+#include "launch.hpp"
+#include "runtime.hpp"
+
+namespace rt = pgpu::rt;
+using rt::fail;
+
+namespace {
+
+// ---------- geometry table ----------
+struct GeoInfo {
+  int G, K;
+  int L() const { return G * K; }
+  int rbits() const { return pgpu::kLimbBits * G * K; }
+  int w64() const { return (rbits() + 63) / 64; }
+  int ipw() const { return pgpu::kWave / G; }
+};
+const GeoInfo kGeos[] = {{2, 9}, {4, 9}, {4, 10}, {4, 14}, {8, 9}, {8, 14}, {16, 9}, {16, 14}, {16, 18}};
+
+// (4,10): the 1024-bit class with room for unit quotient digits (R >= 256 * Nhat needs 37 bits above the
+// modulus; (4,9) offers 20).  PGPU_GEO_410=0 keeps those moduli on (4,9) with the per-row n0' multiply.
+bool geo410_enabled() {
+  static const bool on = [] { const char* e = std::getenv("PGPU_GEO_410"); return !e || std::atoi(e) != 0; }();
+  return on;
+}
+
+bool unit_fits(const GeoInfo& geo, int mod_bits) { return geo.rbits() >= mod_bits + pgpu::kLimbBits + 8; }
+
+// smallest geometry with R = 2^(29*G*K) >= 2^(64*in_words) (any input row fits) and R >= 256*N.
+// unit_q: the caller wants unit quotient digits; a (4,9)-class modulus without the headroom moves to (4,10)
+const GeoInfo* pick_geo(int in_words, int mod_bits, bool unit_q = false) {
+  const GeoInfo* fit = nullptr;
+  const GeoInfo* g410 = nullptr;
+  for (const GeoInfo& g : kGeos) {
+    if (g.G == 4 && g.K == 10) { g410 = &g; continue; }
+    if (!fit && g.rbits() >= 64 * in_words && g.rbits() >= mod_bits + 8) fit = &g;
+  }
+  if (fit && unit_q && !unit_fits(*fit, mod_bits) && fit->G == 4 && fit->K == 9 && geo410_enabled() && g410 &&
+      g410->rbits() >= 64 * in_words && unit_fits(*g410, mod_bits))
+    return g410;
+  return fit;
+}
+
+void to_limbs29(const BigNumber& v, int L, uint32_t* out) {
+  const std::vector<uint64_t>& w = v.limbs64();
+  for (int i = 0; i < L; ++i) {
+    int bit = i * pgpu::kLimbBits;
+    size_t word = (size_t)bit >> 6;
+    int sh = bit & 63;
+    uint64_t x = word < w.size() ? w[word] >> sh : 0;
+    if (sh > 64 - pgpu::kLimbBits && word + 1 < w.size()) x |= w[word + 1] << (64 - sh);
+    out[i] = (uint32_t)x & pgpu::kLimbMask;
+  }
+}
+
+BigNumber pow2(int bits) {
+  std::vector<uint64_t> w((size_t)bits / 64 + 1, 0);
+  w[(size_t)bits / 64] = 1ull << (bits % 64);
+  return BigNumber::fromLimbs64(w.data(), w.size());
+}
+
+// ---------- modulus context ----------
+// Host description of a pgpu::ModCtxDev: the constants live in ONE position-independent image that is
+// replicated to every pool device (runtime.hpp: Replicated); view() turns offsets into the pointers of a device.
+enum CtxSlot { S_N, S_R2, S_ONE, S_R2S, S_FC, S_NR, S_NHAT, S_ONE_N, S_NR2, S_R2M, S_R2SM, S_COUNT };
+enum ViewFlags : int {
+  VF_NONE = 0,
+  VF_BASE_MONT = 1,   // the (wide) base arrives in the Montgomery domain of another modulus: r2/r2s := r2m/r2sm
+  VF_GM_MONT = 2,     // Paillier g^m in Montgomery form: nr := n*R^2, gadd := R mod N  (Montgomery-form result)
+  VF_IN_MONT = 4,     // base already in THIS context's Montgomery form: r2 := R (the first product is an identity)
+  VF_OUT_MONT = 8     // leave the result in Montgomery form: fc := R mod N (use with FM_CTX_CONST)
+};
+
+struct ModCtx {
+  GeoInfo geo{};
+  int mod_words = 0;
+  BigNumber N;
+  rt::Replicated blob;
+  bool has[S_COUNT] = {};
+  size_t off64 = 0;
+  uint32_t n0inv = 0;
+  bool unit = false;
+  pgpu::ModCtxDev view(int dev, int flags = VF_NONE) const {
+    const uint32_t* d32 = (const uint32_t*)blob.d[(size_t)dev];
+    const int L = geo.L();
+    auto at = [&](int slot) -> const uint32_t* { return has[slot] ? d32 + (size_t)slot * L : nullptr; };
+    pgpu::ModCtxDev v{};
+    v.n = at(S_N);
+    v.r2 = at((flags & VF_BASE_MONT) ? S_R2M : (flags & VF_IN_MONT) ? S_ONE : S_R2);
+    v.one = at(S_ONE);
+    v.r2s = at((flags & VF_BASE_MONT) ? S_R2SM : S_R2S);
+    v.fc = at((flags & VF_OUT_MONT) ? S_ONE_N : S_FC);
+    v.nr = at((flags & VF_GM_MONT) ? S_NR2 : S_NR);
+    v.nhat = at(S_NHAT);
+    v.gadd = (flags & VF_GM_MONT) ? at(S_ONE_N) : nullptr;
+    v.n64 = (const uint64_t*)((const char*)blob.d[(size_t)dev] + off64);
+    v.n0inv = n0inv;
+    v.mod_words = mod_words;
+    return v;
+  }
+};
+
+// extras: optional constants of the context image
+struct CtxExtras {
+  bool unit_q = false;        // scale the loop modulus to Nhat = N*k == -1 mod 2^29 (if R has room)
+  int force_unit = -1;        // -1: decide from the headroom; 0 / 1: both contexts of a pair must agree
+  bool want_r2s = false;      // R^2 * 2^(64*mod_words) mod N
+  const BigNumber* fc = nullptr;    // plain final multiplier
+  const BigNumber* nr_n = nullptr;  // n  ->  n*R mod N and n*R^2 mod N
+  int mont_src_rbits = 0;     // > 0: bases arrive as x * 2^mont_src_rbits mod (another modulus): r2m / r2sm
+  bool secret = false;        // zero the device copies before they are freed
+};
+
+int build_modctx(const BigNumber& N, int mod_words, const GeoInfo& geo, const CtxExtras& ex,
+                 std::shared_ptr<ModCtx>* out) {
+  if (N.isZero() || N.isNegative() || N == BigNumber::One())
+    return fail(PGPU_ERR_INVALID_PARAM, "modulus must be > 1");
+  if (!N.IsOdd()) return fail(PGPU_ERR_EVEN_MODULUS, "modulus must be odd");
+  if (geo.rbits() < N.BitSize() + 8)
+    return fail(PGPU_ERR_UNSUPPORTED, "geometry too small for modulus");
+  const int L = geo.L(), W64 = geo.w64();
+  BigNumber R = pow2(geo.rbits());
+  uint32_t n0 = (uint32_t)(N.limbs64()[0] & pgpu::kLimbMask);
+  uint32_t inv = n0;  // Newton iteration for n0^-1 mod 2^32 (n0 odd: correct to 3 bits)
+  for (int i = 0; i < 5; ++i) inv *= 2u - n0 * inv;
+  uint32_t n0inv = (0u - inv) & pgpu::kLimbMask;
+  // Unit quotient digits: Nhat = N * k with k = -N^-1 mod 2^29 is == -1 mod 2^29, so its
+  // Montgomery constant is 1 and q = low limb.  All loop constants are then taken modulo Nhat
+  // (a multiple of N: lazy values stay correct modulo N).  Needs R >= 256 * Nhat.
+  bool unit = ex.unit_q && unit_fits(geo, N.BitSize());
+  if (ex.force_unit >= 0) unit = ex.force_unit != 0 && unit_fits(geo, N.BitSize());
+  const BigNumber M = unit ? N * BigNumber((Ipp32u)n0inv) : N;   // loop modulus
+  BigNumber Rm = R % M;
+  BigNumber R2 = (Rm * Rm) % M;
+
+  auto ctx = std::make_shared<ModCtx>();
+  std::vector<uint32_t> h((size_t)S_COUNT * L, 0);
+  auto put = [&](int slot, const BigNumber& v) {
+    to_limbs29(v, L, h.data() + (size_t)slot * L);
+    ctx->has[slot] = true;
+  };
+  put(S_N, N);
+  put(S_R2, R2);
+  put(S_ONE, Rm);
+  put(S_ONE_N, R % N);
+  const BigNumber shift = pow2(64 * mod_words) % M;
+  if (ex.want_r2s) put(S_R2S, (R2 * shift) % M);
+  if (ex.fc) put(S_FC, *ex.fc % N);
+  if (ex.nr_n) {
+    const BigNumber Rn = R % N;
+    put(S_NR, (*ex.nr_n * Rn) % N);              // used under the TRUE modulus
+    put(S_NR2, (((*ex.nr_n * Rn) % N) * Rn) % N);
+  }
+  if (unit) put(S_NHAT, M);
+  if (ex.mont_src_rbits > 0) {
+    // x arrives as x*Rs mod (a multiple of N); to-Montgomery constants that cancel Rs: R^2 * Rs^-1
+    const BigNumber Rs_inv = M.InverseMul(pow2(ex.mont_src_rbits) % M);
+    const BigNumber r2m = (R2 * Rs_inv) % M;
+    put(S_R2M, r2m);
+    put(S_R2SM, (r2m * shift) % M);
+  }
+  std::vector<uint64_t> n64((size_t)W64 + 1, 0);
+  N.toLimbs64(n64.data(), n64.size());
+
+  ctx->geo = geo;
+  ctx->mod_words = mod_words;
+  ctx->N = N;
+  ctx->n0inv = n0inv;
+  ctx->unit = unit;
+  const size_t bytes32 = h.size() * sizeof(uint32_t);
+  ctx->off64 = (bytes32 + 15) & ~(size_t)15;
+  std::vector<uint8_t> host(ctx->off64 + n64.size() * 8, 0);
+  std::memcpy(host.data(), h.data(), bytes32);
+  std::memcpy(host.data() + ctx->off64, n64.data(), n64.size() * 8);
+  RC_TRY(ctx->blob.upload(host.data(), host.size(), ex.secret));
+  if (ex.secret) {
+    std::fill(host.begin(), host.end(), 0);
+    std::fill(h.begin(), h.end(), 0u);
+  }
+  *out = ctx;
+  return PGPU_OK;
+}
+
+std::mutex g_ctx_mu;
+std::map<std::vector<uint64_t>, std::shared_ptr<ModCtx>> g_ctx_cache;
+
+GeoInfo latency_geo(const GeoInfo& geo);
+// cached plain context for the generic seam: unit_q = true for pgpu_modexp (loop modulo Nhat),
+// false for pgpu_modmul (true modulus throughout).  latency: build it for the 16-lane latency geometry of the
+// modulus' class (same context when L is unchanged or the class has none)
+int get_modctx(const uint64_t* mod, int mod_words, bool unit_q, std::shared_ptr<ModCtx>* out,
+               bool latency = false) {
+  if (!mod || mod_words <= 0) return fail(PGPU_ERR_INVALID_PARAM, "modulus is null/empty");
+  if (!(mod[0] & 1)) return fail(PGPU_ERR_EVEN_MODULUS, "modulus must be odd");
+  std::vector<uint64_t> key(mod, mod + mod_words);
+  key.push_back((unit_q ? 1 : 0) | (latency ? 2 : 0));
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  auto it = g_ctx_cache.find(key);
+  if (it != g_ctx_cache.end()) {
+    *out = it->second;
+    return PGPU_OK;
+  }
+  BigNumber N = BigNumber::fromLimbs64(mod, (size_t)mod_words);
+  if (N.isZero() || N == BigNumber::One())
+    return fail(PGPU_ERR_INVALID_PARAM, "modulus must be > 1");
+  const GeoInfo* geo = pick_geo(mod_words, N.BitSize(), unit_q);
+  if (!geo) return fail(PGPU_ERR_UNSUPPORTED, "modulus wider than the compiled kernel geometries");
+  CtxExtras ex;
+  ex.unit_q = unit_q;
+  RC_TRY(build_modctx(N, mod_words, latency ? latency_geo(*geo) : *geo, ex, out));
+  if (g_ctx_cache.size() > 64) g_ctx_cache.clear();   // (contexts in use stay alive through their shared_ptr)
+  g_ctx_cache[key] = *out;
+  return PGPU_OK;
+}
+
+// ---------- exponent scanning ----------
+// PGPU_SLIDING=0 keeps the fixed-window digit scan for host-known PUBLIC exponents too (A/B measurements)
+bool sliding_enabled() {
+  static const bool on = [] { const char* e = std::getenv("PGPU_SLIDING"); return !e || std::atoi(e) != 0; }();
+  return on;
+}
+// private-key exponents (p-1, q-1): include/pgpu.h, SIDE CHANNELS
+std::atomic<int> g_secret_policy{-1};
+int secret_policy() {
+  int p = g_secret_policy.load();
+  if (p < 0) {
+    const char* e = std::getenv("PGPU_SECRET_EXP");
+    p = (e && (std::strcmp(e, "sliding") == 0 || std::strcmp(e, "1") == 0)) ? PGPU_EXP_SLIDING : PGPU_EXP_FIXED_WINDOW;
+    g_secret_policy.store(p);
+  }
+  return p;
+}
+
+// fixed-window width: the w in 1..5 that minimises (2^w - 2) table multiplications +
+// ceil(e/w) window multiplications (w = 5 for e >= ~240 bits).
+int pick_window(int exp_bits) {
+  int best = 1;
+  long best_cost = 1L << 60;
+  for (int w = 1; w <= 5; ++w) {
+    long cost = ((1L << w) - 2) + (exp_bits + w - 1) / w;
+    if (cost < best_cost) { best_cost = cost; best = w; }
+  }
+  return best;
+}
+
+// Sliding-window schedule of an exponent the host knows: odd powers base^(2i+1), i < 2^(w-1);
+// step = (nsq << 6) | (idx + 1) -- nsq squarings then * base^(2 idx + 1) (idx + 1 == 0: squarings only);
+// step 0 has nsq == 0 and loads its entry (kargs.hpp ModexpArgs).
+struct ExpSchedule {
+  rt::Replicated dev;
+  int len = 0;
+  int w = 0;
+};
+std::vector<uint16_t> sliding_schedule(const BigNumber& e, int w) {
+  std::vector<uint16_t> st;
+  int i = e.BitSize() - 1, pending = 0;
+  auto emit = [&](int nsq, int idx_plus1) {
+    while (nsq > 1023) { st.push_back((uint16_t)(1023 << 6)); nsq -= 1023; }
+    st.push_back((uint16_t)((nsq << 6) | idx_plus1));
+  };
+  while (i >= 0) {
+    if (!e.TestBit(i)) { ++pending; --i; continue; }
+    int j = std::max(i - w + 1, 0);
+    while (!e.TestBit(j)) ++j;              // window [i..j], odd value
+    int v = 0;
+    for (int b = i; b >= j; --b) v = (v << 1) | (e.TestBit(b) ? 1 : 0);
+    emit(st.empty() ? 0 : pending + (i - j + 1), (v - 1) / 2 + 1);
+    pending = 0;
+    i = j - 1;
+  }
+  if (pending) emit(pending, 0);
+  return st;
+}
+// window of the cheapest sliding schedule for a random exponent of this length (w <= 6: 32 odd powers,
+// the same table footprint as the fixed 5-bit window)
+int pick_sliding_window(int exp_bits) {
+  int best = 1;
+  long best_cost = 1L << 60;
+  for (int w = 1; w <= 6; ++w) {
+    long cost = (1L << (w - 1)) + exp_bits / (w + 1);
+    if (cost < best_cost) { best_cost = cost; best = w; }
+  }
+  return best;
+}
+int make_schedule(const BigNumber& e, int w, ExpSchedule* out, bool secret) {
+  std::vector<uint16_t> st = sliding_schedule(e, w);
+  out->len = (int)st.size();
+  out->w = w;
+  if (st.empty()) st.push_back(0);
+  return out->dev.upload(st.data(), st.size() * sizeof(uint16_t), secret);
+}
+
+// window width of the fixed-base table for the DJN obfuscator; PGPU_FB_WINDOW=0 selects the
+// generic (per-instance table, square-and-multiply) kernel instead.
+std::atomic<int> g_fb_window{-1};
+std::atomic<bool> g_fb_window_explicit{false};   // set through the environment or pgpu_set_fixed_base_window
+int fixed_base_window() {
+  if (g_fb_window.load() < 0) {
+    const char* e = std::getenv("PGPU_FB_WINDOW");
+    int v = e ? std::atoi(e) : 12;
+    g_fb_window.store((v < 0 || v > 12) ? 12 : v);
+    if (e) g_fb_window_explicit.store(true);
+  }
+  return g_fb_window.load();
+}
+// A key that has encrypted little so far starts with an 8-bit window (table 16x smaller, built in ~2 ms
+// instead of ~37 ms) and moves to the configured one once this many elements have gone through it.
+constexpr size_t kFbGrowAfter = 4096;
+
+// ---------- live launch timing ----------
+std::atomic<bool> g_timing{false};
+struct TimerScope {
+  rt::Device& d;
+  hipStream_t s;
+  bool on;
+  rt::TimedLaunch t{};
+  TimerScope(rt::Device& dev, hipStream_t st, int kind) : d(dev), s(st), on(g_timing.load()) {
+    if (!on) return;
+    t.kind = kind;
+    t.e0 = d.pool_event();
+    t.e1 = d.pool_event();
+    (void)hipEventRecord(t.e0, s);
+  }
+  void stop() {
+    if (!on) return;
+    (void)hipEventRecord(t.e1, s);
+    std::lock_guard<std::mutex> lk(d.mu);
+    if (d.timed.size() < 65536) d.timed.push_back(t);
+  }
+};
+
+// ---------- launch geometry ----------
+// wavefronts of a modexp launch: with parity waves every wave takes one parity of the instances
+// (kargs.hpp: ModexpArgs::nctx), i.e. 2 * ceil(elements / IPW)
+size_t modexp_waves(size_t count, int parity_waves, int ipw) {
+  return parity_waves ? 2 * ((count / 2 + ipw - 1) / ipw) : (count + ipw - 1) / ipw;
+}
+unsigned blocks_for(size_t count, const GeoInfo& g) {
+  return (unsigned)((count + (size_t)g.ipw() * pgpu::kWavesPerWG - 1) / ((size_t)g.ipw() * pgpu::kWavesPerWG));
+}
+
+// Small batches do not fill the chip: a launch of fewer wavefronts than SIMDs runs as long as ONE wavefront's
+// serial chain of ~1200 multiplications.  Spreading an element over 16 lanes instead of 8 shortens every
+// multiplication (2048-bit class: (16,5), 1190 instructions instead of 1590 for (8,9); 3072-bit class: (16,7)
+// for (8,14), same L and therefore the same context).  Used while the 16-lane split still fits one wavefront
+// per SIMD; (16,5) has L = 80, so it needs its own Montgomery context.
+constexpr size_t kSimds = 256 * 4;
+GeoInfo latency_geo(const GeoInfo& geo) {
+  static const bool allow = [] { const char* e = std::getenv("PGPU_LATENCY_GEO"); return !e || std::atoi(e) != 0; }();
+  if (!allow) return geo;
+  if (geo.G == 8 && geo.K == 9) return GeoInfo{16, 5};
+  if (geo.G == 8 && geo.K == 14) return GeoInfo{16, 7};
+  return geo;
+}
+bool use_latency_geo(const GeoInfo& lat, const GeoInfo& geo, size_t instances) {
+  return lat.G != geo.G && (instances + lat.ipw() - 1) / lat.ipw() <= kSimds;
+}
+
+// A context built for (G, 9) also serves the "wide" split (G/2, 18): same L, same R, same limb
+// arrays, half the lanes per exponentiation and twice the limbs per lane -- the per-row support
+// instructions are amortised over twice as many MACs.  It pays as soon as the wide split still puts one
+// wavefront on every SIMD: measured on the bench's CRT-decrypt launch, (4,18) at 1 wave/SIMD 7.2 ms vs
+// (8,9) at 2 waves/SIMD 8.1 ms.
+constexpr size_t kMinWavesForWide = 256 * 4;
+GeoInfo launch_geo(const GeoInfo& geo, size_t count) {
+  static const bool allow = [] { const char* e = std::getenv("PGPU_WIDE"); return !e || std::atoi(e) != 0; }();
+  if (!allow || geo.K != 9 || geo.G < 4) return geo;
+  GeoInfo wide{geo.G / 2, 18};
+  size_t waves = (count + wide.ipw() - 1) / wide.ipw();
+  static const size_t min_waves = [] {
+    const char* e = std::getenv("PGPU_WIDE_MIN_WAVES");     // tuning knob (tools/quick_bench.py)
+    return e && std::atol(e) > 0 ? (size_t)std::atol(e) : kMinWavesForWide;
+  }();
+  return waves >= min_waves ? wide : geo;
+}
+
+uint64_t* g_wave_clocks = nullptr;   // diagnostics (tools/wave_spread.py)
+
+// common launcher of modexp_kernel on device `d`, stream `s`: sizes the window table of the stream's
+// workspace and fills the shared fields.  sched: per-context sliding-window schedules (device arrays) or null.
+struct SchedRef {
+  const uint16_t* p[2] = {nullptr, nullptr};
+  int len[2] = {0, 0};
+  int w = 0;
+};
+int run_modexp(rt::Device& d, pgpu::ModexpArgs& a, const GeoInfo& ctx_geo, hipStream_t s,
+               const SchedRef* sched = nullptr, rt::StreamWork* held = nullptr) {
+  const GeoInfo geo = launch_geo(ctx_geo, a.count);
+  size_t entries;
+  a.parity_waves = 0;
+  if (sched && sched->p[0]) {
+    a.parity_waves = a.nctx == 2;
+    a.window = sched->w;
+    for (int i = 0; i < 2; ++i) {
+      a.sched[i] = sched->p[a.nctx == 2 ? i : 0];
+      a.sched_len[i] = sched->len[a.nctx == 2 ? i : 0];
+    }
+    entries = (size_t)1 << (a.window - 1);
+  } else {
+    a.window = pick_window(a.exp_bits);
+    entries = (size_t)1 << a.window;
+  }
+  const size_t waves = modexp_waves(a.count, a.parity_waves, geo.ipw());
+  const size_t padded = (waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG * pgpu::kWavesPerWG * geo.ipw();
+  rt::StreamWork& w = held ? *held : d.work_for(s);
+  std::unique_lock<std::mutex> lk(w.mu, std::defer_lock);
+  if (!held) lk.lock();
+  RC_TRY(w.table.ensure(padded * (entries + 1) * geo.L() * sizeof(uint32_t)));   // + the parking slot
+  a.table = (uint32_t*)w.table.p;
+  a.wave_clocks = g_wave_clocks;
+  TimerScope t(d, s, PGPU_KERNEL_MODEXP);
+  const unsigned blocks = (unsigned)((waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
+  if (!pgpu::launch_modexp(geo.G, geo.K, a, blocks, s))
+    return fail(PGPU_ERR_UNSUPPORTED, "modexp kernel geometry not compiled");
+  HIP_TRY(hipGetLastError());
+  t.stop();
+  return PGPU_OK;
+}
+
+}  // namespace
+
+// ---------- Paillier key objects ----------
+struct FbTable {   // immutable once built: hs^(d * 2^(w*i)) * R, [nwin][2^w][L]
+  void* p = nullptr;
+  int w = 0, nwin = 0;
+  hipEvent_t ready = nullptr;   // recorded behind the build; launches on other streams wait for it
+};
+struct pgpu_pubkey {
+  int n_words = 0;
+  BigNumber n;
+  bool djn = false;
+  std::shared_ptr<ModCtx> nsq;  // modulus n^2, with nr = n*R mod n^2
+  rt::Replicated d_hs;          // DJN: hs, 2*n_words words
+  rt::Replicated d_n;           // plain: the exponent n, n_words words
+  ExpSchedule sched_n;          // plain: sliding-window schedule of n (r^n mod n^2; n is public)
+  // fixed-base tables for hs^r, per pool device; built lazily, kept until the key dies
+  mutable std::mutex mu;
+  mutable std::vector<std::deque<FbTable>> fb;   // [device]; entries never move once handed out
+  mutable size_t fb_elems = 0;  // elements encrypted with this key so far (window policy)
+  ~pgpu_pubkey() {
+    for (size_t d = 0; d < fb.size(); ++d) {
+      if (fb[d].empty() || (int)d >= rt::pool_size()) continue;
+      rt::DeviceGuard g(rt::device((int)d).ordinal);
+      for (FbTable& t : fb[d]) {
+        if (t.ready) (void)hipEventDestroy(t.ready);
+        if (t.p) (void)hipFree(t.p);
+      }
+    }
+  }
+};
+
+struct pgpu_privkey {
+  int n_words = 0;              // words of n (= words of p^2, q^2 rows)
+  int pq_words = 0;
+  GeoInfo geo_exp{};            // geometry of the two half-width exponentiations
+  GeoInfo geo_crt{};            // geometry of the recombination kernel
+  std::shared_ptr<ModCtx> p2, q2;   // moduli p^2, q^2 (fc = hp / hq, r2s set)
+  GeoInfo geo_lat{};            // latency geometry of the exponentiations (== geo_exp if there is none)
+  std::shared_ptr<ModCtx> p2l, q2l; // the same moduli for geo_lat (aliases of p2, q2 when L is equal)
+  std::shared_ptr<ModCtx> cM, cQ;   // auxiliary modulus M, modulus q (CRT geometry)
+  rt::Replicated d_exps;        // [2][pq_words]: p-1, q-1
+  int exp_bits = 0;
+  ExpSchedule sched[2];         // sliding-window schedules of p-1 and q-1 (used under PGPU_EXP_SLIDING only)
+  rt::Replicated d_crt32;       // cp | cq | pinvR | pRM  (29-bit limbs, CRT geometry)
+  rt::Replicated d_crt64;       // hp | hq | p^2 | q^2 | q   (n_words words each)
+  int nsq_rbits = 0;            // R of the n^2 context: Montgomery-form ciphertexts carry this factor
+};
+
+// sharded device-resident batch
+struct pgpu_batch {
+  size_t count = 0;
+  int words = 0;
+  int ndev = 1;                        // devices the shards are spread over; count == 1: a copy everywhere
+  bool replicated = false;
+  std::vector<rt::DevMem> shard;
+  std::shared_ptr<ModCtx> mont;        // non-null: values are x*R mod N (canonical) for this context
+  uint64_t* ptr(int d) const { return (uint64_t*)shard[(size_t)d].p; }
+  void bounds(int d, size_t* lo, size_t* hi) const {
+    if (replicated) { *lo = 0; *hi = count; }
+    else rt::shard_bounds(count, ndev, d, lo, hi);
+  }
+};
+
+namespace {
+
+int new_batch(size_t count, int words, std::unique_ptr<pgpu_batch>* out) {
+  if (count == 0 || words <= 0) return fail(PGPU_ERR_INVALID_PARAM, "batch needs count > 0 and words > 0");
+  std::unique_ptr<pgpu_batch> b(new pgpu_batch);
+  b->count = count;
+  b->words = words;
+  b->replicated = count == 1 && rt::pool_size() > 1;
+  b->ndev = b->replicated ? rt::pool_size() : rt::shard_devices(count);
+  b->shard.resize((size_t)b->ndev);
+  for (int d = 0; d < b->ndev; ++d) {
+    size_t lo, hi;
+    b->bounds(d, &lo, &hi);
+    rt::Device& dev = rt::device(d);
+    RC_TRY(b->shard[(size_t)d].alloc(dev, dev.bstream, (hi - lo) * (size_t)words * 8));
+  }
+  *out = std::move(b);
+  return PGPU_OK;
+}
+
+// operands of one operation must be cut the same way (they are, unless min_shard changed in between)
+int same_layout(const pgpu_batch* a, const pgpu_batch* b) {
+  if (b->count == 1 && a->count != 1) return PGPU_OK;   // broadcast operand: a copy everywhere (or on device 0)
+  if (a->ndev != b->ndev || a->replicated != b->replicated)
+    return fail(PGPU_ERR_INVALID_PARAM, "batches were sharded differently (pgpu_set_min_shard changed in between)");
+  return PGPU_OK;
+}
+
+// ---- launch helpers on one device ----
+int modmul_on(rt::Device& d, const ModCtx& ctx, int mode, const uint64_t* a, const uint64_t* b, size_t b_stride,
+              int b_words, uint64_t* out, size_t count, hipStream_t s, int view_flags = VF_NONE) {
+  pgpu::ModmulArgs m{};
+  m.ctx = ctx.view(d.index, view_flags);
+  m.a = a;
+  m.a_stride = (size_t)ctx.mod_words;
+  m.b = b;
+  m.b_stride = b_stride;
+  m.in_words = ctx.mod_words;
+  m.out = out;
+  m.count = count;
+  m.mode = mode;
+  m.b_words = b_words;
+  TimerScope t(d, s, PGPU_KERNEL_MODMUL);
+  const GeoInfo lgeo = launch_geo(ctx.geo, count);
+  if (!pgpu::launch_modmul(lgeo.G, lgeo.K, m, blocks_for(count, lgeo), s))
+    return fail(PGPU_ERR_UNSUPPORTED, "modmul kernel geometry not compiled");
+  HIP_TRY(hipGetLastError());
+  t.stop();
+  return PGPU_OK;
+}
+
+// generic modexp on one device (bases / result plain or in the context's Montgomery form)
+int modexp_on(rt::Device& d, const uint64_t* d_base, size_t base_stride, const uint64_t* d_exp, size_t exp_stride,
+              int exp_words, int exp_bits, const uint64_t* h_mod, int mod_words, uint64_t* d_out, size_t count,
+              hipStream_t s, const SchedRef* sched, bool in_mont, bool out_mont, std::shared_ptr<ModCtx> ctx_in) {
+  std::shared_ptr<ModCtx> ctx = ctx_in;
+  if (!ctx) RC_TRY(get_modctx(h_mod, mod_words, true, &ctx));
+  GeoInfo run_geo = ctx->geo;
+  const GeoInfo lat = latency_geo(ctx->geo);
+  if (!in_mont && !out_mont && use_latency_geo(lat, ctx->geo, count)) {   // small batch: 16 lanes per element
+    if (lat.L() != ctx->geo.L()) {
+      std::vector<uint64_t> mw((size_t)mod_words);
+      ctx->N.toLimbs64(mw.data(), mw.size());
+      RC_TRY(get_modctx(mw.data(), mod_words, true, &ctx, true));
+    }
+    run_geo = lat;
+  }
+  pgpu::ModexpArgs a{};
+  a.ctx[0] = a.ctx[1] = ctx->view(d.index, (in_mont ? VF_IN_MONT : 0) | (out_mont ? VF_OUT_MONT : 0));
+  a.nctx = 1;
+  a.base = d_base;
+  a.base_stride = base_stride;
+  a.base_words = mod_words;
+  a.exp = d_exp;
+  a.exp_stride = exp_stride;
+  a.exp_per_ctx = 0;
+  a.exp_words = exp_words;
+  a.exp_bits = exp_bits;
+  a.final_mul = out_mont ? pgpu::FM_CTX_CONST : pgpu::FM_UNIT;
+  a.out = d_out;
+  a.out_stride = (size_t)mod_words;
+  a.count = count;
+  return run_modexp(d, a, run_geo, s, sched);
+}
+
+// fixed-base table of (key, device) for window w covering nwin windows: built on first use
+int fb_table_for(const pgpu_pubkey* key, rt::Device& d, int w, int nwin, hipStream_t s, const FbTable** out) {
+  std::lock_guard<std::mutex> lk(key->mu);
+  if (key->fb.size() < (size_t)rt::pool_size()) key->fb.resize((size_t)rt::pool_size());
+  auto& list = key->fb[(size_t)d.index];
+  for (const FbTable& t : list)
+    if (t.w == w && t.nwin >= nwin) {
+      HIP_TRY(hipStreamWaitEvent(s, t.ready, 0));
+      *out = &t;
+      return PGPU_OK;
+    }
+  const GeoInfo& geo = key->nsq->geo;
+  FbTable t;
+  t.w = w;
+  t.nwin = nwin;
+  HIP_TRY(hipMalloc(&t.p, (size_t)nwin * ((size_t)1 << w) * geo.L() * sizeof(uint32_t)));
+  HIP_TRY(hipEventCreateWithFlags(&t.ready, hipEventDisableTiming));
+  pgpu::FixedBaseBuildArgs b{};
+  b.ctx = key->nsq->view(d.index);
+  b.base = (const uint64_t*)key->d_hs.d[(size_t)d.index];
+  b.table = (uint32_t*)t.p;
+  b.nwin = nwin;
+  b.w = w;
+  if (!pgpu::launch_fb_build(geo.G, geo.K, b, blocks_for((size_t)nwin, geo), s))
+    return fail(PGPU_ERR_UNSUPPORTED, "fixed-base build kernel geometry not compiled");
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(t.ready, s));
+  list.push_back(t);
+  *out = &list.back();
+  return PGPU_OK;
+}
+
+// fused encrypt on one device; out_mont: ciphertexts leave in the Montgomery domain of n^2
+int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_t m_stride, int m_words,
+               const uint64_t* d_r, size_t r_stride, int r_words, int r_bits, uint64_t* d_c, size_t count,
+               hipStream_t s, bool out_mont, size_t total_count) {
+  const int W = 2 * key->n_words;
+  if (m_words <= 0 || m_words > W || m_stride < (size_t)m_words)
+    return fail(PGPU_ERR_INVALID_PARAM, "plaintext width/stride invalid");
+  if (r_words <= 0 || r_stride < (size_t)r_words)
+    return fail(PGPU_ERR_INVALID_PARAM, "random width/stride invalid");
+  if (key->djn && (r_bits < 0 || r_bits > 64 * r_words))
+    return fail(PGPU_ERR_INVALID_PARAM, "r_bits/r_words inconsistent");
+  const int vflags = out_mont ? VF_GM_MONT : VF_NONE;
+  int fbw = fixed_base_window();
+  if (key->djn && fbw > 0) {
+    {
+      std::lock_guard<std::mutex> lk(key->mu);
+      if (fbw > 8 && !g_fb_window_explicit.load() && key->fb_elems + total_count < kFbGrowAfter) fbw = 8;
+    }
+    // hs is a key constant: fixed-base windowing, no squarings (kernels.hpp: fb_encrypt_kernel)
+    const GeoInfo& geo = key->nsq->geo;
+    const int nwin = std::max(1, (r_bits + fbw - 1) / fbw);
+    const FbTable* tab = nullptr;
+    RC_TRY(fb_table_for(key, d, fbw, nwin, s, &tab));
+    pgpu::FixedBaseArgs f{};
+    f.ctx = key->nsq->view(d.index, vflags);
+    f.table = (const uint32_t*)tab->p;
+    f.nwin = nwin;
+    f.w = fbw;
+    f.exp = d_r;
+    f.exp_stride = r_stride;
+    f.exp_words = r_words;
+    f.fm_words = d_m;
+    f.fm_stride = m_stride;
+    f.fm_nwords = m_words;
+    f.out = d_c;
+    f.out_stride = (size_t)W;
+    f.count = count;
+    TimerScope t(d, s, PGPU_KERNEL_FB_ENCRYPT);
+    const GeoInfo lgeo = launch_geo(geo, count);
+    if (!pgpu::launch_fb_encrypt(lgeo.G, lgeo.K, f, blocks_for(count, lgeo), s))
+      return fail(PGPU_ERR_UNSUPPORTED, "fixed-base kernel geometry not compiled");
+    HIP_TRY(hipGetLastError());
+    t.stop();
+    return PGPU_OK;
+  }
+  pgpu::ModexpArgs a{};
+  a.ctx[0] = a.ctx[1] = key->nsq->view(d.index, vflags);
+  a.nctx = 1;
+  if (key->djn) {  // hs^r: shared base, per-element exponent (pub_key.cpp:51-64)
+    a.base = (const uint64_t*)key->d_hs.d[(size_t)d.index];
+    a.base_stride = 0;
+    a.base_words = W;
+    a.exp = d_r;
+    a.exp_stride = r_stride;
+    a.exp_words = r_words;
+    a.exp_bits = r_bits;
+  } else {         // r^n: per-element base, shared exponent n (pub_key.cpp:66-80)
+    if (r_words > W) return fail(PGPU_ERR_INVALID_PARAM, "random wider than n^2");
+    a.base = d_r;
+    a.base_stride = r_stride;
+    a.base_words = r_words;
+    a.exp = (const uint64_t*)key->d_n.d[(size_t)d.index];
+    a.exp_stride = 0;
+    a.exp_words = key->n_words;
+    a.exp_bits = key->n.BitSize();
+  }
+  a.exp_per_ctx = 0;
+  a.final_mul = pgpu::FM_PAILLIER_G;
+  a.fm_words = d_m;
+  a.fm_stride = m_stride;
+  a.fm_nwords = m_words;
+  a.out = d_c;
+  a.out_stride = (size_t)W;
+  a.count = count;
+  SchedRef sr;
+  if (!key->djn && key->sched_n.dev.bytes) {     // r^n: the exponent is the PUBLIC key constant n
+    sr.p[0] = (const uint16_t*)key->sched_n.dev.d[(size_t)d.index];
+    sr.len[0] = key->sched_n.len;
+    sr.w = key->sched_n.w;
+  }
+  return run_modexp(d, a, key->nsq->geo, s, sr.p[0] ? &sr : nullptr);
+}
+
+// fused CRT decrypt on one device; in_mont: ciphertexts arrive in the Montgomery domain of n^2
+int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m, size_t count,
+               hipStream_t s, bool in_mont) {
+  const int nw = key->n_words;
+  rt::StreamWork& w = d.work_for(s);
+  std::lock_guard<std::mutex> lk(w.mu);   // the hand-over buffer is ours until both stages are queued
+  RC_TRY(w.vbuf.ensure(2 * count * (size_t)nw * 8));
+  // stage 1: V[2i] = c^(p-1)*hp mod p^2, V[2i+1] = c^(q-1)*hq mod q^2   (2*count instances)
+  pgpu::ModexpArgs a{};
+  const bool lat = use_latency_geo(key->geo_lat, key->geo_exp, 2 * count);
+  const int vf = in_mont ? VF_BASE_MONT : VF_NONE;
+  a.ctx[0] = (lat ? key->p2l : key->p2)->view(d.index, vf);
+  a.ctx[1] = (lat ? key->q2l : key->q2)->view(d.index, vf);
+  a.nctx = 2;
+  a.base = d_c;
+  a.base_stride = (size_t)2 * nw;
+  a.base_words = 2 * nw;
+  a.exp = (const uint64_t*)key->d_exps.d[(size_t)d.index];
+  a.exp_stride = (size_t)key->pq_words;
+  a.exp_per_ctx = 1;
+  a.exp_words = key->pq_words;
+  a.exp_bits = key->exp_bits;
+  a.final_mul = pgpu::FM_CTX_CONST;
+  a.out = (uint64_t*)w.vbuf.p;
+  a.out_stride = (size_t)nw;
+  a.count = 2 * count;
+  SchedRef sr;
+  const bool sliding = secret_policy() == PGPU_EXP_SLIDING && key->sched[0].dev.bytes;
+  if (sliding) {
+    for (int i = 0; i < 2; ++i) {
+      sr.p[i] = (const uint16_t*)key->sched[i].dev.d[(size_t)d.index];
+      sr.len[i] = key->sched[i].len;
+    }
+    sr.w = key->sched[0].w;
+  }
+  RC_TRY(run_modexp(d, a, lat ? key->geo_lat : key->geo_exp, s, sliding ? &sr : nullptr, &w));
+  // stage 2: L function, CRT
+  const int Lc = key->geo_crt.L(), pad = key->geo_crt.w64() + 1;
+  pgpu::CrtArgs c{};
+  c.ctxM = key->cM->view(d.index);
+  c.ctxQ = key->cQ->view(d.index);
+  const uint32_t* c32 = (const uint32_t*)key->d_crt32.d[(size_t)d.index];
+  c.cp = c32;
+  c.cq = c32 + Lc;
+  c.pinvR = c32 + 2 * Lc;
+  c.pRM = c32 + 3 * Lc;
+  const uint64_t* c64 = (const uint64_t*)key->d_crt64.d[(size_t)d.index];
+  c.hp64 = c64;
+  c.hq64 = c64 + pad;
+  c.p2_64 = c64 + 2 * pad;
+  c.q2_64 = c64 + 3 * pad;
+  c.q64 = c64 + 4 * pad;
+  c.v = (const uint64_t*)w.vbuf.p;
+  c.vw = nw;
+  c.out = d_m;
+  c.out_words = nw;
+  c.count = count;
+  TimerScope tc(d, s, PGPU_KERNEL_CRT);
+  if (!pgpu::launch_crt(key->geo_crt.G, key->geo_crt.K, c, blocks_for(count, key->geo_crt), s))
+    return fail(PGPU_ERR_UNSUPPORTED, "crt kernel geometry not compiled");
+  HIP_TRY(hipGetLastError());
+  tc.stop();
+  return PGPU_OK;
+}
+
+// ---- sharding of the host-pointer entry points ----
+// fn(lane, lo, hi) handles elements [lo, hi) on lane.dev; sub_min: smallest sub-batch worth its own task
+template <class F>
+int run_sharded(size_t count, size_t sub_min, F fn) {
+  const int D = rt::shard_devices(count);
+  rt::TaskGroup tg;
+  for (int d = 0; d < D; ++d) {
+    size_t lo, hi;
+    rt::shard_bounds(count, D, d, &lo, &hi);
+    if (hi == lo) continue;
+    const size_t n = hi - lo;
+    const int subs = (int)std::max<size_t>(1, std::min<size_t>(4, n / std::max<size_t>(sub_min, 1)));
+    for (int k = 0; k < subs; ++k) {
+      size_t slo, shi;
+      rt::shard_bounds(n, subs, k, &slo, &shi);
+      slo += lo;
+      shi += lo;
+      tg.run(rt::device(d), [fn, slo, shi](rt::Lane& lane) { return fn(lane, slo, shi); });
+    }
+  }
+  return tg.wait();
+}
+// sub-batches: long exponentiations keep their launches whole (a half-sized launch runs a slower geometry and
+// the copies are < 5 % of the time); products and short exponents are copy-bound and pipeline in pieces
+constexpr size_t kSubMinHeavy = (size_t)1 << 17, kSubMinLight = (size_t)1 << 14;
+
+}  // namespace
+
+extern "C" {
+
+int pgpu_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int pgpu_init(int device) {
+  int n = pgpu_device_count();
+  if (n <= 0) return fail(PGPU_ERR_NO_DEVICE, "no HIP device visible");
+  if (device >= n) return fail(PGPU_ERR_INVALID_PARAM, "device ordinal out of range");
+  if (device < 0) {
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
+  }
+  return rt::pool_init(std::vector<int>{device});
+}
+
+int pgpu_init_all(int n_devices) {
+  int n = pgpu_device_count();
+  if (n <= 0) return fail(PGPU_ERR_NO_DEVICE, "no HIP device visible");
+  if (n_devices < 0) return fail(PGPU_ERR_INVALID_PARAM, "negative device count");
+  const char* over = std::getenv("PGPU_POOL_OVERSUBSCRIBE");
+  const bool wrap = over && std::atoi(over) != 0;
+  if (n_devices == 0) n_devices = n;
+  if (n_devices > n && !wrap)
+    return fail(PGPU_ERR_INVALID_PARAM, "more pool entries requested than GPUs visible (PGPU_POOL_OVERSUBSCRIBE=1 wraps)");
+  std::vector<int> ord;
+  for (int i = 0; i < n_devices; ++i) ord.push_back(i % n);
+  return rt::pool_init(ord);
+}
+
+void pgpu_shutdown(void) {
+  if (!rt::initialized()) return;
+  {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    g_ctx_cache.clear();
+  }
+  rt::pool_shutdown();
+}
+
+int pgpu_is_initialized(void) { return rt::initialized() ? 1 : 0; }
+const char* pgpu_last_error(void) { return rt::g_err.c_str(); }
+const char* pgpu_device_name(void) { return rt::initialized() ? rt::current().name.c_str() : ""; }
+int pgpu_pool_size(void) { return rt::initialized() ? rt::pool_size() : 0; }
+int pgpu_set_device(int pool_index) { return rt::set_current(pool_index); }
+int pgpu_get_device(void) { return rt::initialized() ? rt::current_index() : 0; }
+const char* pgpu_pool_transport(void) { return rt::replicate_transport(); }
+int pgpu_set_min_shard(size_t n) {
+  rt::set_min_shard(n);
+  return PGPU_OK;
+}
+
+int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, int* limbs) {
+  if (in_words <= 0 || mod_bits <= 1 || !lanes || !limbs)
+    return fail(PGPU_ERR_INVALID_PARAM, "pgpu_kernel_geometry: bad argument");
+  const GeoInfo* geo = pick_geo(in_words, mod_bits, true);
+  if (!geo) return fail(PGPU_ERR_UNSUPPORTED, "modulus wider than the compiled kernel geometries");
+  const GeoInfo lat = latency_geo(*geo);
+  const GeoInfo g = use_latency_geo(lat, *geo, count) ? lat : launch_geo(*geo, count);
+  *lanes = g.G;
+  *limbs = g.K;
+  return PGPU_OK;
+}
+
+int pgpu_set_fixed_base_window(int w) {
+  if (w < 0 || w > 12) return fail(PGPU_ERR_INVALID_PARAM, "fixed-base window must be 0..12");
+  g_fb_window.store(w);
+  g_fb_window_explicit.store(true);
+  return PGPU_OK;
+}
+
+int pgpu_set_secret_exponent_policy(int policy) {
+  if (policy != PGPU_EXP_FIXED_WINDOW && policy != PGPU_EXP_SLIDING)
+    return fail(PGPU_ERR_INVALID_PARAM, "unknown exponent policy");
+  g_secret_policy.store(policy);
+  return PGPU_OK;
+}
+int pgpu_get_secret_exponent_policy(void) { return secret_policy(); }
+
+// diagnostics (tools/wave_spread.py): device buffer that receives per-wave start/end clocks of the
+// next modexp_kernel launches; null switches it off.  Not part of the public header.
+void pgpu_debug_set_wave_clocks(uint64_t* d_buf) { g_wave_clocks = d_buf; }
+
+int pgpu_set_timing(int enabled) {
+  g_timing.store(enabled != 0);
+  return PGPU_OK;
+}
+
+int pgpu_timing_collect(int* kinds, double* ms, int max_entries) {
+  if (!rt::initialized()) return 0;
+  rt::Device& d = rt::current();
+  rt::DeviceGuard g(d.ordinal);
+  std::vector<rt::TimedLaunch> rec;
+  {
+    std::lock_guard<std::mutex> lk(d.mu);
+    rec.swap(d.timed);
+  }
+  int n = 0;
+  for (auto& t : rec) {
+    float v = 0;
+    if (hipEventSynchronize(t.e1) == hipSuccess && hipEventElapsedTime(&v, t.e0, t.e1) == hipSuccess &&
+        n < max_entries && kinds && ms) {
+      kinds[n] = t.kind;
+      ms[n] = v;
+      ++n;
+    }
+  }
+  std::lock_guard<std::mutex> lk(d.mu);
+  for (auto& t : rec) {
+    d.event_pool.push_back(t.e0);
+    d.event_pool.push_back(t.e1);
+  }
+  return n;
+}
+
+// ===================== device buffers (current pool entry) =====================
+// Blocks handed out here are used on the default stream and on caller streams: their free list is the one of
+// the null stream, and a freed block may be handed out again at once -- the caller orders its work on it.
+int pgpu_dev_alloc(size_t bytes, void** out) {
+  RC_TRY(rt::check_ready());
+  return rt::current().alloc(bytes, nullptr, out);
+}
+void pgpu_dev_free(void* d_ptr) {
+  if (!d_ptr) return;
+  if (!rt::initialized()) {
+    (void)hipFree(d_ptr);
+    return;
+  }
+  rt::current().free(d_ptr, nullptr);
+}
+int pgpu_copy_h2d(void* d_dst, const void* h_src, size_t bytes) {
+  RC_TRY(rt::check_ready());
+  rt::TaskGroup tg;
+  // ordered behind the default stream (the buffer may still be read by queued work), complete on return
+  tg.run(rt::current(), [=](rt::Lane& lane) -> int {
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    RC_TRY(lane.h2d(d_dst, h_src, bytes, lane.stream));
+    HIP_TRY(hipStreamSynchronize(lane.stream));
+    return PGPU_OK;
+  });
+  return tg.wait();
+}
+int pgpu_copy_d2h(void* h_dst, const void* d_src, size_t bytes) {
+  RC_TRY(rt::check_ready());
+  rt::TaskGroup tg;
+  tg.run(rt::current(), [=](rt::Lane& lane) -> int {
+    hipError_t e = hipStreamSynchronize(nullptr);   // producers on the default stream
+    if (e != hipSuccess) return fail(PGPU_ERR_HIP, std::string("kernel failed: ") + hipGetErrorString(e));
+    return lane.d2h(h_dst, d_src, bytes, lane.stream);
+  });
+  return tg.wait();
+}
+
+// ===================== generic modexp =====================
+int pgpu_modexp_dev(const uint64_t* d_base, size_t base_stride, const uint64_t* d_exp,
+                    size_t exp_stride, int exp_words, int exp_bits, const uint64_t* h_mod,
+                    int mod_words, uint64_t* d_out, size_t count, void* hip_stream) {
+  RC_TRY(rt::check_ready());
+  if (count == 0) return PGPU_OK;
+  if (!d_base || !d_exp || !d_out) return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer");
+  if (exp_words <= 0 || exp_bits < 0 || exp_bits > 64 * exp_words)
+    return fail(PGPU_ERR_INVALID_PARAM, "exp_bits/exp_words inconsistent");
+  if (base_stride != 0 && base_stride < (size_t)mod_words)
+    return fail(PGPU_ERR_INVALID_PARAM, "base stride smaller than the modulus width");
+  if (exp_stride != 0 && exp_stride < (size_t)exp_words)
+    return fail(PGPU_ERR_INVALID_PARAM, "exponent stride smaller than exp_words");
+  rt::Device& d = rt::current();
+  rt::DeviceGuard g(d.ordinal);
+  return modexp_on(d, d_base, base_stride, d_exp, exp_stride, exp_words, exp_bits, h_mod, mod_words, d_out, count,
+                   (hipStream_t)hip_stream, nullptr, false, false, nullptr);
+}
+
+int pgpu_modexp(const uint64_t* base, size_t base_stride, const uint64_t* exp, size_t exp_stride,
+                int exp_words, int exp_bits, const uint64_t* mod, int mod_words, uint64_t* out,
+                size_t count) {
+  RC_TRY(rt::check_ready());
+  if (count == 0) return PGPU_OK;
+  if (!base || !exp || !out || mod_words <= 0 || exp_words <= 0)
+    return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer or zero width");
+  if (exp_bits < 0 || exp_bits > 64 * exp_words)
+    return fail(PGPU_ERR_INVALID_PARAM, "exp_bits/exp_words inconsistent");
+  if (base_stride != 0 && base_stride < (size_t)mod_words)
+    return fail(PGPU_ERR_INVALID_PARAM, "base stride smaller than the modulus width");
+  if (exp_stride != 0 && exp_stride < (size_t)exp_words)
+    return fail(PGPU_ERR_INVALID_PARAM, "exponent stride smaller than exp_words");
+  std::shared_ptr<ModCtx> ctx;
+  RC_TRY(get_modctx(mod, mod_words, true, &ctx));   // validates the modulus before any task starts
+  // one exponent for the whole batch, and the host has it: sliding-window schedule instead of a digit scan
+  // (the caller handed the exponent over in the clear: not a secret of this library)
+  std::vector<uint16_t> sched;
+  int sched_w = 0;
+  if (exp_stride == 0 && count >= 16 && exp_bits > 8 && sliding_enabled()) {
+    BigNumber e = BigNumber::fromLimbs64(exp, (size_t)exp_words);
+    if (!e.isZero()) {
+      sched_w = pick_sliding_window(e.BitSize());
+      sched = sliding_schedule(e, sched_w);
+    }
+  }
+  const size_t sub_min = exp_bits >= 256 ? kSubMinHeavy : kSubMinLight;
+  return run_sharded(count, sub_min, [=, &sched](rt::Lane& lane, size_t lo, size_t hi) -> int {
+    rt::Device& d = *lane.dev;
+    hipStream_t s = lane.stream;
+    const size_t n = hi - lo;
+    rt::DevMem db, de, dout, dsched;
+    const size_t nb = (base_stride ? n * base_stride : (size_t)mod_words) * 8;
+    const size_t ne = (exp_stride ? n * exp_stride : (size_t)exp_words) * 8;
+    RC_TRY(db.alloc(d, s, nb));
+    RC_TRY(de.alloc(d, s, ne));
+    RC_TRY(dout.alloc(d, s, n * (size_t)mod_words * 8));
+    RC_TRY(lane.h2d(db.p, base + lo * base_stride, nb, s));
+    RC_TRY(lane.h2d(de.p, exp + lo * exp_stride, ne, s));
+    SchedRef sr;
+    if (!sched.empty()) {
+      RC_TRY(dsched.alloc(d, s, sched.size() * sizeof(uint16_t)));
+      RC_TRY(lane.h2d(dsched.p, sched.data(), sched.size() * sizeof(uint16_t), s));
+      sr.p[0] = (const uint16_t*)dsched.p;
+      sr.len[0] = (int)sched.size();
+      sr.w = sched_w;
+    }
+    RC_TRY(modexp_on(d, (const uint64_t*)db.p, base_stride, (const uint64_t*)de.p, exp_stride, exp_words, exp_bits,
+                     mod, mod_words, (uint64_t*)dout.p, n, s, sr.p[0] ? &sr : nullptr, false, false, ctx));
+    return lane.d2h(out + lo * (size_t)mod_words, dout.p, n * (size_t)mod_words * 8, s);
+  });
+}
+
+// ===================== modmul =====================
+int pgpu_modmul_dev(const uint64_t* d_a, const uint64_t* d_b, size_t b_stride,
+                    const uint64_t* h_mod, int mod_words, uint64_t* d_out, size_t count,
+                    void* hip_stream) {
+  RC_TRY(rt::check_ready());
+  if (count == 0) return PGPU_OK;
+  if (!d_a || !d_b || !d_out) return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer");
+  if (b_stride != 0 && b_stride < (size_t)mod_words)
+    return fail(PGPU_ERR_INVALID_PARAM, "b stride smaller than the modulus width");
+  std::shared_ptr<ModCtx> ctx;
+  RC_TRY(get_modctx(h_mod, mod_words, false, &ctx));
+  rt::Device& d = rt::current();
+  rt::DeviceGuard g(d.ordinal);
+  return modmul_on(d, *ctx, pgpu::MM_PLAIN, d_a, d_b, b_stride, 0, d_out, count, (hipStream_t)hip_stream);
+}
+
+int pgpu_modmul(const uint64_t* a, const uint64_t* b, size_t b_stride, const uint64_t* mod,
+                int mod_words, uint64_t* out, size_t count) {
+  RC_TRY(rt::check_ready());
+  if (count == 0) return PGPU_OK;
+  if (!a || !b || !out || mod_words <= 0)
+    return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer or zero width");
+  if (b_stride != 0 && b_stride < (size_t)mod_words)
+    return fail(PGPU_ERR_INVALID_PARAM, "b stride smaller than the modulus width");
+  std::shared_ptr<ModCtx> ctx;
+  RC_TRY(get_modctx(mod, mod_words, false, &ctx));
+  return run_sharded(count, kSubMinLight, [=](rt::Lane& lane, size_t lo, size_t hi) -> int {
+    rt::Device& d = *lane.dev;
+    hipStream_t s = lane.stream;
+    const size_t n = hi - lo, row = (size_t)mod_words * 8;
+    rt::DevMem da, db, dout;
+    RC_TRY(da.alloc(d, s, n * row));
+    RC_TRY(db.alloc(d, s, b_stride ? n * b_stride * 8 : row));
+    RC_TRY(dout.alloc(d, s, n * row));
+    RC_TRY(lane.h2d(da.p, a + lo * (size_t)mod_words, n * row, s));
+    RC_TRY(lane.h2d(db.p, b + lo * b_stride, b_stride ? n * b_stride * 8 : row, s));
+    RC_TRY(modmul_on(d, *ctx, pgpu::MM_PLAIN, (const uint64_t*)da.p, (const uint64_t*)db.p, b_stride, 0,
+                     (uint64_t*)dout.p, n, s));
+    return lane.d2h(out + lo * (size_t)mod_words, dout.p, n * row, s);
+  });
+}
+
+// ===================== Paillier public key / encrypt =====================
+int pgpu_pubkey_create(const uint64_t* n, int n_words, const uint64_t* hs_or_null,
+                       pgpu_pubkey** out) {
+  RC_TRY(rt::check_ready());
+  if (!n || n_words <= 0 || !out) return fail(PGPU_ERR_INVALID_PARAM, "null key material");
+  std::unique_ptr<pgpu_pubkey> k(new pgpu_pubkey);
+  k->n_words = n_words;
+  k->n = BigNumber::fromLimbs64(n, (size_t)n_words);
+  if (!k->n.IsOdd()) return fail(PGPU_ERR_EVEN_MODULUS, "n must be odd");
+  BigNumber nsq = k->n * k->n;
+  const GeoInfo* geo = pick_geo(2 * n_words, nsq.BitSize(), true);
+  if (!geo) return fail(PGPU_ERR_UNSUPPORTED, "key wider than the compiled kernel geometries");
+  CtxExtras ex;
+  ex.nr_n = &k->n;
+  ex.unit_q = true;
+  RC_TRY(build_modctx(nsq, 2 * n_words, *geo, ex, &k->nsq));
+  if (hs_or_null) {
+    k->djn = true;
+    RC_TRY(k->d_hs.upload(hs_or_null, (size_t)2 * n_words * 8, false));
+  }
+  RC_TRY(k->d_n.upload(n, (size_t)n_words * 8, false));
+  if (sliding_enabled()) RC_TRY(make_schedule(k->n, pick_sliding_window(k->n.BitSize()), &k->sched_n, false));
+  k->fb.resize((size_t)rt::pool_size());
+  *out = k.release();
+  return PGPU_OK;
+}
+
+void pgpu_pubkey_destroy(pgpu_pubkey* key) { delete key; }
+
+int pgpu_paillier_encrypt_dev(const pgpu_pubkey* key, const uint64_t* d_m, size_t m_stride,
+                              int m_words, const uint64_t* d_r, size_t r_stride, int r_words,
+                              int r_bits, uint64_t* d_c, size_t count, void* hip_stream) {
+  RC_TRY(rt::check_ready());
+  if (!key) return fail(PGPU_ERR_INVALID_PARAM, "null key");
+  if (count == 0) return PGPU_OK;
+  if (!d_m || !d_r || !d_c) return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer");
+  rt::Device& d = rt::current();
+  rt::DeviceGuard g(d.ordinal);
+  RC_TRY(encrypt_on(d, key, d_m, m_stride, m_words, d_r, r_stride, r_words, r_bits, d_c, count,
+                    (hipStream_t)hip_stream, false, count));
+  if (key->djn) {
+    std::lock_guard<std::mutex> lk(key->mu);
+    key->fb_elems += count;
+  }
+  return PGPU_OK;
+}
+
+int pgpu_paillier_encrypt(const pgpu_pubkey* key, const uint64_t* m, size_t m_stride, int m_words,
+                          const uint64_t* r, size_t r_stride, int r_words, int r_bits,
+                          uint64_t* c, size_t count) {
+  RC_TRY(rt::check_ready());
+  if (!key) return fail(PGPU_ERR_INVALID_PARAM, "null key");
+  if (count == 0) return PGPU_OK;
+  if (!m || !r || !c) return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer");
+  const int W = 2 * key->n_words;
+  if (m_words <= 0 || m_words > W || m_stride < (size_t)m_words)
+    return fail(PGPU_ERR_INVALID_PARAM, "plaintext width/stride invalid");
+  if (r_words <= 0 || r_stride < (size_t)r_words)
+    return fail(PGPU_ERR_INVALID_PARAM, "random width/stride invalid");
+  const size_t sub_min = (key->djn && fixed_base_window() > 0) ? kSubMinLight : kSubMinHeavy;
+  int rc = run_sharded(count, sub_min, [=](rt::Lane& lane, size_t lo, size_t hi) -> int {
+    rt::Device& d = *lane.dev;
+    hipStream_t s = lane.stream;
+    const size_t n = hi - lo;
+    rt::DevMem dm, dr, dc;
+    RC_TRY(dm.alloc(d, s, n * m_stride * 8));
+    RC_TRY(dr.alloc(d, s, n * r_stride * 8));
+    RC_TRY(dc.alloc(d, s, n * (size_t)W * 8));
+    RC_TRY(lane.h2d(dm.p, m + lo * m_stride, n * m_stride * 8, s));
+    RC_TRY(lane.h2d(dr.p, r + lo * r_stride, n * r_stride * 8, s));
+    RC_TRY(encrypt_on(d, key, (const uint64_t*)dm.p, m_stride, m_words, (const uint64_t*)dr.p, r_stride, r_words,
+                      r_bits, (uint64_t*)dc.p, n, s, false, count));
+    return lane.d2h(c + lo * (size_t)W, dc.p, n * (size_t)W * 8, s);
+  });
+  if (rc == PGPU_OK && key->djn) {
+    std::lock_guard<std::mutex> lk(key->mu);
+    key->fb_elems += count;
+  }
+  return rc;
+}
+
+// ===================== Paillier private key / CRT decrypt =====================
+int pgpu_privkey_create(const uint64_t* p_in, const uint64_t* q_in, int pq_words,
+                        pgpu_privkey** out) {
+  RC_TRY(rt::check_ready());
+  if (!p_in || !q_in || pq_words <= 0 || !out) return fail(PGPU_ERR_INVALID_PARAM, "null key material");
+  BigNumber p = BigNumber::fromLimbs64(p_in, (size_t)pq_words);
+  BigNumber q = BigNumber::fromLimbs64(q_in, (size_t)pq_words);
+  if (q < p) std::swap(p, q);  // pri_key.cpp:19-22
+  if (p == q) return fail(PGPU_ERR_NOT_INVERTIBLE, "PrivateKey: p and q are same");
+  if (!p.IsOdd() || !q.IsOdd() || p <= BigNumber::Two())
+    return fail(PGPU_ERR_EVEN_MODULUS, "p and q must be odd primes");
+  std::unique_ptr<pgpu_privkey> k(new pgpu_privkey);
+  const BigNumber n = p * q;
+  const int nw = (n.BitSize() + 63) / 64;  // words of n; p^2, q^2 rows use the same width
+  k->n_words = nw;
+  k->pq_words = pq_words;
+  const BigNumber psq = p * p, qsq = q * q;
+  const BigNumber pm1 = p - 1, qm1 = q - 1;
+  if (psq.BitSize() > 64 * nw || qsq.BitSize() > 64 * nw)
+    return fail(PGPU_ERR_INVALID_PARAM, "p and q differ too much in size");
+  // hp = L_p(g^(p-1) mod p^2)^-1 mod p   (computeHfun, pri_key.cpp:159-167).  The reference's g is always
+  // n + 1 (pub_key.cpp:17, pri_key.cpp:47) and n^2 == 0 mod p^2, so the binomial series stops after two terms:
+  //   g^(p-1) = 1 + (p-1)*n  (mod p^2)   =>   L_p(.) = ((p-1)*n mod p^2) / p = (p-1)*q mod p
+  // -- the same value without an exponentiation.
+  BigNumber hp, hq;
+  try {
+    hp = p.InverseMul((pm1 * q) % p);
+    hq = q.InverseMul((qm1 * p) % q);
+  } catch (const std::exception& e) {
+    return fail(PGPU_ERR_NOT_INVERTIBLE, std::string("PrivateKey precompute: ") + e.what());
+  }
+  // half-width exponentiation contexts: inputs are 2*nw-word ciphertexts reduced on load
+  const int sq_bits = std::max(psq.BitSize(), qsq.BitSize());
+  const GeoInfo* ge = pick_geo(nw, sq_bits, true);
+  if (!ge) return fail(PGPU_ERR_UNSUPPORTED, "key wider than the compiled kernel geometries");
+  k->geo_exp = *ge;
+  // Montgomery-form ciphertexts carry the R of the n^2 context (pgpu_pubkey_create picks it the same way)
+  const BigNumber nsq = n * n;
+  const GeoInfo* gn = pick_geo(2 * nw, nsq.BitSize(), true);
+  if (!gn) return fail(PGPU_ERR_UNSUPPORTED, "key wider than the compiled kernel geometries");
+  k->nsq_rbits = gn->rbits();
+  CtxExtras exp_p, exp_q;
+  exp_p.want_r2s = exp_q.want_r2s = true;
+  exp_p.unit_q = exp_q.unit_q = true;
+  exp_p.secret = exp_q.secret = true;
+  exp_p.mont_src_rbits = exp_q.mont_src_rbits = k->nsq_rbits;
+  exp_p.fc = &hp;
+  exp_q.fc = &hq;
+  // both sides of a launch share one instruction stream: unit quotient digits only if BOTH moduli leave room
+  // (p^2 can be a bit shorter than q^2 and straddle the threshold on its own)
+  exp_p.force_unit = exp_q.force_unit = unit_fits(*ge, sq_bits) ? 1 : 0;
+  RC_TRY(build_modctx(psq, nw, *ge, exp_p, &k->p2));
+  RC_TRY(build_modctx(qsq, nw, *ge, exp_q, &k->q2));
+  k->geo_lat = latency_geo(*ge);
+  if (k->geo_lat.L() == ge->L()) {
+    k->p2l = k->p2;
+    k->q2l = k->q2;
+  } else {
+    exp_p.force_unit = exp_q.force_unit = unit_fits(k->geo_lat, sq_bits) ? 1 : 0;
+    RC_TRY(build_modctx(psq, nw, k->geo_lat, exp_p, &k->p2l));
+    RC_TRY(build_modctx(qsq, nw, k->geo_lat, exp_q, &k->q2l));
+  }
+  std::vector<uint64_t> exps((size_t)2 * pq_words, 0);
+  pm1.toLimbs64(exps.data(), pq_words);
+  qm1.toLimbs64(exps.data() + pq_words, pq_words);
+  RC_TRY(k->d_exps.upload(exps.data(), exps.size() * 8, true));
+  std::fill(exps.begin(), exps.end(), 0);
+  k->exp_bits = std::max(pm1.BitSize(), qm1.BitSize());
+  {
+    const int sw = pick_sliding_window(k->exp_bits);
+    RC_TRY(make_schedule(pm1, sw, &k->sched[0], true));
+    RC_TRY(make_schedule(qm1, sw, &k->sched[1], true));
+  }
+
+  // recombination: auxiliary modulus M = 2^(29*(L-1)) - 1 must exceed n (exact u*p product)
+  const GeoInfo* gc = nullptr;
+  for (const GeoInfo& gg : kGeos)
+    if (!(gg.G == 4 && gg.K == 10) && pgpu::kLimbBits * (gg.L() - 1) >= n.BitSize() + 2 && gg.rbits() >= 64 * nw) {
+      gc = &gg;
+      break;
+    }
+  if (!gc) return fail(PGPU_ERR_UNSUPPORTED, "key wider than the compiled kernel geometries");
+  k->geo_crt = *gc;
+  const int Lc = gc->L();
+  const BigNumber M = pow2(pgpu::kLimbBits * (Lc - 1)) - 1;
+  if (M.gcd(p) != BigNumber::One() || M.gcd(q) != BigNumber::One())
+    return fail(PGPU_ERR_NOT_INVERTIBLE, "auxiliary modulus shares a factor with the key");
+  const int mwM = (M.BitSize() + 63) / 64;
+  CtxExtras sec;
+  sec.secret = true;
+  RC_TRY(build_modctx(M, mwM, *gc, CtxExtras(), &k->cM));
+  RC_TRY(build_modctx(q, nw, *gc, sec, &k->cQ));
+  const BigNumber Rc = pow2(gc->rbits());
+  const BigNumber pinv_q = q.InverseMul(p);  // p^-1 mod q (pri_key.cpp:27)
+  std::vector<uint32_t> c32((size_t)4 * Lc);
+  to_limbs29((M.InverseMul(p) * Rc) % M, Lc, c32.data());
+  to_limbs29((M.InverseMul(q) * Rc) % M, Lc, c32.data() + Lc);
+  to_limbs29((pinv_q * Rc) % q, Lc, c32.data() + 2 * Lc);
+  to_limbs29((p * Rc) % M, Lc, c32.data() + 3 * Lc);
+  RC_TRY(k->d_crt32.upload(c32.data(), c32.size() * 4, true));
+  std::fill(c32.begin(), c32.end(), 0u);
+  const int pad = gc->w64() + 1;  // rows padded so word helpers can run over W64 words
+  std::vector<uint64_t> c64((size_t)5 * pad, 0);
+  hp.toLimbs64(c64.data(), pad);
+  hq.toLimbs64(c64.data() + pad, pad);
+  psq.toLimbs64(c64.data() + 2 * pad, pad);
+  qsq.toLimbs64(c64.data() + 3 * pad, pad);
+  q.toLimbs64(c64.data() + 4 * pad, pad);
+  RC_TRY(k->d_crt64.upload(c64.data(), c64.size() * 8, true));
+  std::fill(c64.begin(), c64.end(), 0);
+  *out = k.release();
+  return PGPU_OK;
+}
+
+void pgpu_privkey_destroy(pgpu_privkey* key) { delete key; }
+
+int pgpu_paillier_decrypt_crt_dev(const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m,
+                                  size_t count, void* hip_stream) {
+  RC_TRY(rt::check_ready());
+  if (!key) return fail(PGPU_ERR_INVALID_PARAM, "null key");
+  if (count == 0) return PGPU_OK;
+  if (!d_c || !d_m) return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer");
+  rt::Device& d = rt::current();
+  rt::DeviceGuard g(d.ordinal);
+  return decrypt_on(d, key, d_c, d_m, count, (hipStream_t)hip_stream, false);
+}
+
+int pgpu_paillier_decrypt_crt(const pgpu_privkey* key, const uint64_t* c, uint64_t* m,
+                              size_t count) {
+  RC_TRY(rt::check_ready());
+  if (!key) return fail(PGPU_ERR_INVALID_PARAM, "null key");
+  if (count == 0) return PGPU_OK;
+  if (!c || !m) return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer");
+  const int nw = key->n_words;
+  return run_sharded(count, kSubMinHeavy, [=](rt::Lane& lane, size_t lo, size_t hi) -> int {
+    rt::Device& d = *lane.dev;
+    hipStream_t s = lane.stream;
+    const size_t n = hi - lo;
+    rt::DevMem dc, dm;
+    RC_TRY(dc.alloc(d, s, n * (size_t)2 * nw * 8));
+    RC_TRY(dm.alloc(d, s, n * (size_t)nw * 8));
+    RC_TRY(lane.h2d(dc.p, c + lo * (size_t)2 * nw, n * (size_t)2 * nw * 8, s));
+    RC_TRY(decrypt_on(d, key, (const uint64_t*)dc.p, (uint64_t*)dm.p, n, s, false));
+    return lane.d2h(m + lo * (size_t)nw, dm.p, n * (size_t)nw * 8, s);
+  });
+}
+
+// ===================== sharded device-resident batches =====================
+int pgpu_batch_create(size_t count, int words, pgpu_batch** out) {
+  RC_TRY(rt::check_ready());
+  if (!out) return fail(PGPU_ERR_INVALID_PARAM, "null output pointer");
+  std::unique_ptr<pgpu_batch> b;
+  RC_TRY(new_batch(count, words, &b));
+  *out = b.release();
+  return PGPU_OK;
+}
+
+void pgpu_batch_destroy(pgpu_batch* b) { delete b; }
+size_t pgpu_batch_count(const pgpu_batch* b) { return b ? b->count : 0; }
+int pgpu_batch_words(const pgpu_batch* b) { return b ? b->words : 0; }
+int pgpu_batch_is_montgomery(const pgpu_batch* b) { return b && b->mont ? 1 : 0; }
+
+int pgpu_batch_upload(const uint64_t* host, size_t count, int words, size_t stride, pgpu_batch** out) {
+  RC_TRY(rt::check_ready());
+  if (!host || !out) return fail(PGPU_ERR_INVALID_PARAM, "null pointer");
+  if (stride < (size_t)words) return fail(PGPU_ERR_INVALID_PARAM, "stride smaller than the row width");
+  if (stride != (size_t)words) return fail(PGPU_ERR_UNSUPPORTED, "batch upload needs densely packed rows");
+  std::unique_ptr<pgpu_batch> b;
+  RC_TRY(new_batch(count, words, &b));
+  rt::TaskGroup tg;
+  pgpu_batch* bp = b.get();
+  for (int d = 0; d < bp->ndev; ++d) {
+    tg.run(rt::device(d), [=](rt::Lane& lane) -> int {
+      size_t lo, hi;
+      bp->bounds(d, &lo, &hi);
+      hipStream_t s = lane.dev->bstream;
+      RC_TRY(lane.h2d(bp->ptr(d), host + lo * (size_t)words, (hi - lo) * (size_t)words * 8, s));
+      HIP_TRY(hipStreamSynchronize(s));   // the caller may reuse `host` as soon as we return
+      return PGPU_OK;
+    });
+  }
+  RC_TRY(tg.wait());
+  *out = b.release();
+  return PGPU_OK;
+}
+
+int pgpu_batch_download(const pgpu_batch* b, uint64_t* host) {
+  RC_TRY(rt::check_ready());
+  if (!b || !host) return fail(PGPU_ERR_INVALID_PARAM, "null pointer");
+  rt::TaskGroup tg;
+  const int nd = b->replicated ? 1 : b->ndev;
+  for (int d = 0; d < nd; ++d) {
+    tg.run(rt::device(d), [=](rt::Lane& lane) -> int {
+      size_t lo, hi;
+      b->bounds(d, &lo, &hi);
+      rt::Device& dev = *lane.dev;
+      hipStream_t s = dev.bstream;
+      const size_t bytes = (hi - lo) * (size_t)b->words * 8;
+      if (!b->mont) return lane.d2h(host + lo * (size_t)b->words, b->ptr(d), bytes, s);
+      rt::DevMem plain;   // leave the Montgomery domain on the way out
+      RC_TRY(plain.alloc(dev, s, bytes));
+      RC_TRY(modmul_on(dev, *b->mont, pgpu::MM_BY_ONE, b->ptr(d), nullptr, 0, 0, (uint64_t*)plain.p, hi - lo, s));
+      return lane.d2h(host + lo * (size_t)b->words, plain.p, bytes, s);
+    });
+  }
+  return tg.wait();
+}
+
+int pgpu_batch_encrypt(const pgpu_pubkey* key, const pgpu_batch* m, const pgpu_batch* r, int r_bits,
+                       pgpu_batch** c) {
+  RC_TRY(rt::check_ready());
+  if (!key || !m || !r || !c) return fail(PGPU_ERR_INVALID_PARAM, "null argument");
+  if (m->count != r->count) return fail(PGPU_ERR_INVALID_PARAM, "modExp: input vector size error");
+  if (m->mont || r->mont) return fail(PGPU_ERR_INVALID_PARAM, "encrypt: operands must be plain batches");
+  RC_TRY(same_layout(m, r));
+  std::unique_ptr<pgpu_batch> out;
+  RC_TRY(new_batch(m->count, 2 * key->n_words, &out));
+  out->mont = key->nsq;
+  for (int d = 0; d < out->ndev; ++d) {
+    size_t lo, hi;
+    out->bounds(d, &lo, &hi);
+    rt::Device& dev = rt::device(d);
+    rt::DeviceGuard g(dev.ordinal);
+    RC_TRY(encrypt_on(dev, key, m->ptr(d), (size_t)m->words, m->words, r->ptr(d), (size_t)r->words, r->words, r_bits,
+                      out->ptr(d), hi - lo, dev.bstream, true, m->count));
+  }
+  if (key->djn) {
+    std::lock_guard<std::mutex> lk(key->mu);
+    key->fb_elems += m->count;
+  }
+  *c = out.release();
+  return PGPU_OK;
+}
+
+int pgpu_batch_decrypt_crt(const pgpu_privkey* key, const pgpu_batch* c, pgpu_batch** m) {
+  RC_TRY(rt::check_ready());
+  if (!key || !c || !m) return fail(PGPU_ERR_INVALID_PARAM, "null argument");
+  if (c->words != 2 * key->n_words) return fail(PGPU_ERR_INVALID_PARAM, "decrypt: ciphertext width mismatch");
+  if (c->mont && c->mont->geo.rbits() != key->nsq_rbits)
+    return fail(PGPU_ERR_INVALID_PARAM, "decrypt: ciphertext batch belongs to a different key size");
+  std::unique_ptr<pgpu_batch> out;
+  RC_TRY(new_batch(c->count, key->n_words, &out));
+  for (int d = 0; d < out->ndev; ++d) {
+    size_t lo, hi;
+    out->bounds(d, &lo, &hi);
+    rt::Device& dev = rt::device(d);
+    rt::DeviceGuard g(dev.ordinal);
+    RC_TRY(decrypt_on(dev, key, c->ptr(d), out->ptr(d), hi - lo, dev.bstream, c->mont != nullptr));
+  }
+  *m = out.release();
+  return PGPU_OK;
+}
+
+// brings a plain ciphertext batch into the key's Montgomery domain (fresh batch), shard by shard
+static int to_montgomery(const pgpu_pubkey* key, const pgpu_batch* a, std::unique_ptr<pgpu_batch>* out) {
+  std::unique_ptr<pgpu_batch> t;
+  RC_TRY(new_batch(a->count, a->words, &t));
+  t->mont = key->nsq;
+  for (int d = 0; d < t->ndev; ++d) {
+    size_t lo, hi;
+    t->bounds(d, &lo, &hi);
+    rt::Device& dev = rt::device(d);
+    rt::DeviceGuard g(dev.ordinal);
+    RC_TRY(modmul_on(dev, *key->nsq, pgpu::MM_BY_R2, a->ptr(d), nullptr, 0, 0, t->ptr(d), hi - lo, dev.bstream));
+  }
+  *out = std::move(t);
+  return PGPU_OK;
+}
+
+int pgpu_batch_ct_add(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_batch* b, pgpu_batch** out) {
+  RC_TRY(rt::check_ready());
+  if (!key || !a || !b || !out) return fail(PGPU_ERR_INVALID_PARAM, "null argument");
+  const int W = 2 * key->n_words;
+  if (a->words != W || b->words != W) return fail(PGPU_ERR_INVALID_PARAM, "CT + CT error: width mismatch");
+  if (b->count != a->count && b->count != 1) return fail(PGPU_ERR_INVALID_PARAM, "CT + CT error: Size mismatch!");
+  if ((a->mont && a->mont != key->nsq) || (b->mont && b->mont != key->nsq))
+    return fail(PGPU_ERR_INVALID_PARAM, "CT + CT error: batch belongs to a different key object");
+  // both operands in the Montgomery domain -> ONE product per element, result stays there
+  RC_TRY(same_layout(a, b));
+  std::unique_ptr<pgpu_batch> ta, tb;
+  if (!a->mont) {
+    RC_TRY(to_montgomery(key, a, &ta));
+    a = ta.get();
+  }
+  if (!b->mont) {
+    RC_TRY(to_montgomery(key, b, &tb));
+    b = tb.get();
+  }
+  std::unique_ptr<pgpu_batch> o;
+  RC_TRY(new_batch(a->count, W, &o));
+  o->mont = key->nsq;
+  const bool bcast = b->count == 1 && a->count != 1;
+  for (int d = 0; d < o->ndev; ++d) {
+    size_t lo, hi;
+    o->bounds(d, &lo, &hi);
+    rt::Device& dev = rt::device(d);
+    rt::DeviceGuard g(dev.ordinal);
+    RC_TRY(modmul_on(dev, *key->nsq, pgpu::MM_SINGLE, a->ptr(d), b->ptr(b->replicated ? d : (bcast ? 0 : d)),
+                     bcast ? 0 : (size_t)W, 0, o->ptr(d), hi - lo, dev.bstream));
+  }
+  *out = o.release();
+  return PGPU_OK;
+}
+
+int pgpu_batch_ct_add_plain(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_batch* m, pgpu_batch** out) {
+  RC_TRY(rt::check_ready());
+  if (!key || !a || !m || !out) return fail(PGPU_ERR_INVALID_PARAM, "null argument");
+  const int W = 2 * key->n_words;
+  if (a->words != W || m->words > W) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: width mismatch");
+  if (m->count != a->count && m->count != 1) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: Size mismatch!");
+  if (a->mont && a->mont != key->nsq) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: batch belongs to a different key object");
+  if (m->mont) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: plaintext batch in Montgomery form");
+  RC_TRY(same_layout(a, m));
+  std::unique_ptr<pgpu_batch> o;
+  RC_TRY(new_batch(a->count, W, &o));
+  o->mont = a->mont;   // the product keeps the form of the ciphertext
+  const bool bcast = m->count == 1 && a->count != 1;
+  for (int d = 0; d < o->ndev; ++d) {
+    size_t lo, hi;
+    o->bounds(d, &lo, &hi);
+    rt::Device& dev = rt::device(d);
+    rt::DeviceGuard g(dev.ordinal);
+    RC_TRY(modmul_on(dev, *key->nsq, pgpu::MM_GM, a->ptr(d), m->ptr(m->replicated ? d : (bcast ? 0 : d)),
+                     bcast ? 0 : (size_t)m->words, m->words, o->ptr(d), hi - lo, dev.bstream, VF_GM_MONT));
+  }
+  *out = o.release();
+  return PGPU_OK;
+}
+
+int pgpu_batch_ct_mul(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_batch* e, int e_bits,
+                      pgpu_batch** out) {
+  RC_TRY(rt::check_ready());
+  if (!key || !a || !e || !out) return fail(PGPU_ERR_INVALID_PARAM, "null argument");
+  const int W = 2 * key->n_words;
+  if (a->words != W) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: width mismatch");
+  if (e->count != a->count && e->count != 1) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: Size mismatch!");
+  if (e->mont) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: exponent batch in Montgomery form");
+  if (a->mont && a->mont != key->nsq) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: batch belongs to a different key object");
+  if (e_bits < 0 || e_bits > 64 * e->words) return fail(PGPU_ERR_INVALID_PARAM, "exp_bits/exp_words inconsistent");
+  RC_TRY(same_layout(a, e));
+  std::unique_ptr<pgpu_batch> o;
+  RC_TRY(new_batch(a->count, W, &o));
+  o->mont = key->nsq;
+  const bool bcast = e->count == 1 && a->count != 1;
+  std::vector<uint64_t> mod((size_t)W);
+  key->nsq->N.toLimbs64(mod.data(), mod.size());
+  for (int d = 0; d < o->ndev; ++d) {
+    size_t lo, hi;
+    o->bounds(d, &lo, &hi);
+    rt::Device& dev = rt::device(d);
+    rt::DeviceGuard g(dev.ordinal);
+    RC_TRY(modexp_on(dev, a->ptr(d), (size_t)W, e->ptr(e->replicated ? d : (bcast ? 0 : d)),
+                     bcast ? 0 : (size_t)e->words, e->words, e_bits, mod.data(), W, o->ptr(d), hi - lo, dev.bstream,
+                     nullptr, a->mont != nullptr, true, key->nsq));
+  }
+  *out = o.release();
+  return PGPU_OK;
+}
+
+}  // extern "C"

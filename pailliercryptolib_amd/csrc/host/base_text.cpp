@@ -19,6 +19,25 @@ std::mutex g_materialise_mu;  // lazy host/device copies are created under one l
 BaseText::BaseText(std::shared_ptr<detail::DeviceBatch> dev)
     : m_size(dev->count), m_dev(std::move(dev)), m_host_valid(false) {}
 
+// a text may be copied while another thread materialises its host values (const accessors download lazily)
+BaseText::BaseText(const BaseText& o) {
+  std::lock_guard<std::mutex> lk(g_materialise_mu);
+  m_texts = o.m_texts;
+  m_size = o.m_size;
+  m_dev = o.m_dev;
+  m_host_valid = (bool)o.m_host_valid;
+}
+
+BaseText& BaseText::operator=(const BaseText& o) {
+  if (this == &o) return *this;
+  std::lock_guard<std::mutex> lk(g_materialise_mu);
+  m_texts = o.m_texts;
+  m_size = o.m_size;
+  m_dev = o.m_dev;
+  m_host_valid = (bool)o.m_host_valid;
+  return *this;
+}
+
 void BaseText::ensureHost() const {
   if (m_host_valid) return;
   std::lock_guard<std::mutex> lk(g_materialise_mu);

@@ -3,6 +3,8 @@
 // OpenMP, ciphertext.cpp:35-72,135-141); CT*PT is one batched GPU modexp (ciphertext.cpp:83-106).
 #include "ipcl/ciphertext.hpp"
 
+#include <algorithm>
+
 #include "detail.hpp"
 #include "ipcl/mod_exp.hpp"
 
@@ -31,22 +33,32 @@ CipherText CipherText::operator+(const CipherText& other) const {
   ERROR_CHECK(*(m_pk->getN()) == *(other.m_pk->getN()),
               "CT + CT error: 2 different public keys detected!");
   ERROR_CHECK(m_size > 0, "CT + CT error: empty CipherText");
-  // one batched modmul mod n^2 on resident batches; the sum stays resident
+  // one batched Montgomery product mod n^2 on resident batches (sharded over the pool); the sum stays resident
   const BigNumber& nsq = *(m_pk->getNSQ());
   const int W = detail::words_for_bits(nsq.BitSize());
   auto da = deviceBatch(W, &nsq), db = other.deviceBatch(W, &nsq);
-  auto dout = detail::DeviceBatch::alloc(m_size, W);
-  std::vector<uint64_t> mod((size_t)W);
-  nsq.toLimbs64(mod.data(), (size_t)W);
-  const size_t bstride = (b_size == m_size) ? (size_t)W : 0;   // size-1 right operand: broadcast
-  IPCL_GPU_CHECK(pgpu_modmul_dev(da->ptr(), db->ptr(), bstride, mod.data(), W, dout->ptr(), m_size, nullptr),
-                 "CT + CT");
-  return CipherText(m_pk, dout);
+  pgpu_batch* o = nullptr;
+  IPCL_GPU_CHECK(pgpu_batch_ct_add(m_pk->device()->h, da->h, db->h, &o), "CT + CT");
+  return CipherText(m_pk, detail::DeviceBatch::adopt(o));
 }
 
+// CT + PT: multiply by g^m = 1 + n*m without obfuscator (ciphertext.cpp:75-80 builds it with a host loop in
+// raw_encrypt and then runs CT + CT; here one fused launch forms g^m and the product)
 CipherText CipherText::operator+(const PlainText& other) const {
-  CipherText b = m_pk->encrypt(other, false);  // g^m without obfuscator (ciphertext.cpp:75-80)
-  return *this + b;
+  std::size_t b_size = other.getSize();
+  ERROR_CHECK(b_size > 0, "encrypt: Cannot encrypt empty PlainText");   // what encrypt(other, false) reports
+  ERROR_CHECK(this->m_size == b_size || b_size == 1, "CT + CT error: Size mismatch!");
+  ERROR_CHECK(m_size > 0, "CT + CT error: empty CipherText");
+  const BigNumber& nsq = *(m_pk->getNSQ());
+  const int W = detail::words_for_bits(nsq.BitSize());
+  // g^m only depends on m mod n: reduce plaintexts that are negative or wider than n^2
+  const int mw = other.isDeviceResident() ? other.m_dev->words
+                                          : std::min(W, detail::words_for_bits(other.maxBitsHint()));
+  auto da = deviceBatch(W, &nsq);
+  auto dm = other.isDeviceResident() ? other.m_dev : other.deviceBatch(mw, m_pk->getN().get());
+  pgpu_batch* o = nullptr;
+  IPCL_GPU_CHECK(pgpu_batch_ct_add_plain(m_pk->device()->h, da->h, dm->h, &o), "CT + PT");
+  return CipherText(m_pk, detail::DeviceBatch::adopt(o));
 }
 
 CipherText CipherText::operator*(const PlainText& other) const {
@@ -61,14 +73,9 @@ CipherText CipherText::operator*(const PlainText& other) const {
   const int ebits = other.maxBitsHint();
   const int ew = other.isDeviceResident() ? other.m_dev->words : detail::words_for_bits(ebits);
   auto dbase = deviceBatch(W, &nsq), dexp = other.deviceBatch(ew);
-  auto dout = detail::DeviceBatch::alloc(m_size, W);
-  std::vector<uint64_t> mod((size_t)W);
-  nsq.toLimbs64(mod.data(), (size_t)W);
-  const size_t estride = (b_size == m_size) ? (size_t)ew : 0;   // scalar plaintext: shared exponent
-  IPCL_GPU_CHECK(pgpu_modexp_dev(dbase->ptr(), (size_t)W, dexp->ptr(), estride, ew, ebits, mod.data(), W,
-                                 dout->ptr(), m_size, nullptr),
-                 "CT * PT");
-  return CipherText(m_pk, dout);
+  pgpu_batch* o = nullptr;
+  IPCL_GPU_CHECK(pgpu_batch_ct_mul(m_pk->device()->h, dbase->h, dexp->h, ebits, &o), "CT * PT");
+  return CipherText(m_pk, detail::DeviceBatch::adopt(o));
 }
 
 void CipherText::save(serializer::OutputArchive& ar) const {

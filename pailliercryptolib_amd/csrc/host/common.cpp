@@ -44,24 +44,24 @@ std::vector<BigNumber> unpack(const std::vector<uint64_t>& flat, std::size_t cou
   return v;
 }
 
-std::shared_ptr<DeviceBatch> DeviceBatch::alloc(std::size_t count, int words) {
-  ensure_context();
+std::shared_ptr<DeviceBatch> DeviceBatch::adopt(pgpu_batch* h) {
   auto b = std::make_shared<DeviceBatch>();
-  b->count = count;
-  b->words = words;
-  IPCL_GPU_CHECK(pgpu_dev_alloc(count * (std::size_t)words * 8, &b->d), "device batch");
+  b->h = h;
+  b->count = pgpu_batch_count(h);
+  b->words = pgpu_batch_words(h);
   return b;
 }
 
 std::shared_ptr<DeviceBatch> DeviceBatch::upload(const std::vector<uint64_t>& flat, std::size_t count, int words) {
-  auto b = alloc(count, words);
-  IPCL_GPU_CHECK(pgpu_copy_h2d(b->d, flat.data(), count * (std::size_t)words * 8), "device batch upload");
-  return b;
+  ensure_context();
+  pgpu_batch* h = nullptr;
+  IPCL_GPU_CHECK(pgpu_batch_upload(flat.data(), count, words, (size_t)words, &h), "device upload");
+  return adopt(h);
 }
 
 std::vector<BigNumber> DeviceBatch::download() const {
-  std::vector<uint64_t> flat(count * (std::size_t)words);
-  IPCL_GPU_CHECK(pgpu_copy_d2h(flat.data(), d, flat.size() * 8), "device batch download");
+  std::vector<uint64_t> flat(count * (size_t)words);
+  IPCL_GPU_CHECK(pgpu_batch_download(h, flat.data()), "device download");
   return unpack(flat, count, words);
 }
 

@@ -22,18 +22,23 @@ void check_gpu(int status, const char* what, const char* file, int line) {
                                                        pgpu_last_error() + ")"));
 }
 
-static int pick_device() {
-  for (const char* var : {"IPCL_GPU_DEVICE", "LOCAL_RANK"}) {
-    const char* v = std::getenv(var);
-    if (v && *v) return std::atoi(v);
-  }
-  return 0;
-}
-
+// Which GPUs the process drives (the reference's QAT runtime acquires every instance, heqat/context.h:18-26):
+//   IPCL_GPU_DEVICE=<ordinal>   or a torchrun-style LOCAL_RANK  -> that one GPU (one process per GPU)
+//   IPCL_GPU_DEVICES=<n>|all    -> an in-process pool over the first n / all visible GPUs (default: all)
 void ensure_context() {
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
-  if (!pgpu_is_initialized()) IPCL_GPU_CHECK(pgpu_init(pick_device()), "initializeContext");
+  if (pgpu_is_initialized()) return;
+  for (const char* var : {"IPCL_GPU_DEVICE", "LOCAL_RANK"}) {
+    const char* v = std::getenv(var);
+    if (v && *v) {
+      IPCL_GPU_CHECK(pgpu_init(std::atoi(v)), "initializeContext");
+      return;
+    }
+  }
+  const char* v = std::getenv("IPCL_GPU_DEVICES");
+  const int n = (v && *v && std::string(v) != "all") ? std::atoi(v) : 0;
+  IPCL_GPU_CHECK(pgpu_init_all(n), "initializeContext");
 }
 
 }  // namespace detail

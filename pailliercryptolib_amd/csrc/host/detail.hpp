@@ -23,17 +23,18 @@ std::vector<uint64_t> pack(const std::vector<BigNumber>& v, int words);
 std::vector<BigNumber> unpack(const std::vector<uint64_t>& flat, std::size_t count, int words);
 int max_bits(const std::vector<BigNumber>& v);
 
-// A batch resident in GPU memory: [count][words] little-endian 64-bit limbs.  Immutable once
-// filled (results are always written to fresh batches), so copies of a text can share it.
+// A batch resident in GPU memory: [count][words] little-endian 64-bit limbs, cut into contiguous shards over
+// the device pool (pgpu_batch).  Immutable once produced (results are always written to fresh batches), so
+// copies of a text can share it.  Ciphertext batches produced on the device are in the Montgomery domain of
+// n^2; download() returns plain values either way.
 struct DeviceBatch {
-  void* d = nullptr;
+  pgpu_batch* h = nullptr;
   std::size_t count = 0;
   int words = 0;
   ~DeviceBatch() {
-    if (d) pgpu_dev_free(d);
+    if (h) pgpu_batch_destroy(h);
   }
-  uint64_t* ptr() const { return static_cast<uint64_t*>(d); }
-  static std::shared_ptr<DeviceBatch> alloc(std::size_t count, int words);
+  static std::shared_ptr<DeviceBatch> adopt(pgpu_batch* h);
   static std::shared_ptr<DeviceBatch> upload(const std::vector<uint64_t>& flat, std::size_t count, int words);
   std::vector<BigNumber> download() const;
 };

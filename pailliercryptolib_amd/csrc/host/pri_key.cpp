@@ -40,7 +40,9 @@ void PrivateKey::precompute(const BigNumber& p_in, const BigNumber& q_in) {
   m_hp = computeHfun(p, m_psquare);
   m_hq = computeHfun(q, m_qsquare);
   m_lambda = lcm(m_pminusone, m_qminusone);
-  m_x = m_n->InverseMul((modExp(*m_g, m_lambda, *m_nsquare) - 1) / *m_n);
+  // x = L(g^lambda mod n^2)^-1 mod n (pri_key.cpp:33-34); g = n + 1, so g^lambda = 1 + lambda*n (mod n^2) and
+  // L(.) = lambda mod n: the same value without an exponentiation
+  m_x = m_n->InverseMul(m_lambda % *m_n);
   // device-side key: Montgomery contexts mod p^2, q^2, recombination constants
   detail::ensure_context();
   auto d = std::make_shared<detail::PrivKeyDevice>();
@@ -75,9 +77,11 @@ void PrivateKey::load(serializer::InputArchive& ar) {
 
 BigNumber PrivateKey::computeLfun(const BigNumber& a, const BigNumber& b) const { return (a - 1) / b; }
 
-// h = L_a(g^(a-1) mod a^2)^-1 mod a  (reference pri_key.cpp:159-167)
+// h = L_a(g^(a-1) mod a^2)^-1 mod a  (reference pri_key.cpp:159-167).  The reference's g is n + 1
+// (pri_key.cpp:47) and n^2 == 0 (mod a^2) for a in {p, q}, so the binomial expansion of (1 + n)^(a-1) stops after
+// two terms: g^(a-1) mod a^2 = 1 + (a-1)*n mod a^2 -- identical value, no exponentiation.
 BigNumber PrivateKey::computeHfun(const BigNumber& a, const BigNumber& b) const {
-  BigNumber pm = modExp(*m_g % b, a - 1, b);
+  BigNumber pm = (BigNumber::One() + (a - 1) * *m_n) % b;
   return a.InverseMul(computeLfun(pm, a));
 }
 
@@ -92,8 +96,9 @@ PlainText PrivateKey::decrypt(const CipherText& ct) const {
     // resident until an accessor needs them
     const int nw = detail::words_for_bits(m_n->BitSize());
     auto dc = ct.deviceBatch(2 * nw, m_nsquare.get());
-    auto dm = detail::DeviceBatch::alloc(ct_size, nw);
-    IPCL_GPU_CHECK(pgpu_paillier_decrypt_crt_dev(m_dev->h, dc->ptr(), dm->ptr(), ct_size, nullptr), "decrypt");
+    pgpu_batch* m = nullptr;
+    IPCL_GPU_CHECK(pgpu_batch_decrypt_crt(m_dev->h, dc->h, &m), "decrypt");
+    auto dm = detail::DeviceBatch::adopt(m);
     return PlainText(dm);
   }
   std::vector<BigNumber> pt_bn(ct_size);

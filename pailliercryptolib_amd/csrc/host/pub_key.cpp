@@ -26,6 +26,7 @@ void PublicKey::create(const BigNumber& n, int bits, bool enableDJN_) {
   m_r.clear();
   m_dev.reset();
   if (enableDJN_) enableDJN();
+  else rebuildDevice();
   m_isInitialized = true;
 }
 
@@ -34,7 +35,7 @@ void PublicKey::create(const BigNumber& n, int bits, const BigNumber& hs, int ra
   m_enable_DJN = true;
   m_hs = hs;
   m_randbits = randbits;
-  m_dev.reset();
+  rebuildDevice();
 }
 
 // hs = (-x^2 mod n)^n mod n^2 for a random x coprime to n (reference pub_key.cpp:29-49)
@@ -49,7 +50,7 @@ void PublicKey::enableDJN() {
   m_hs = modExp(h, n, *m_nsquare);
   m_randbits = m_bits >> 1;
   m_enable_DJN = true;
-  m_dev.reset();
+  rebuildDevice();
 }
 
 void PublicKey::setDJN(const BigNumber& hs, int randbit) {
@@ -57,7 +58,7 @@ void PublicKey::setDJN(const BigNumber& hs, int randbit) {
   m_hs = hs;
   m_randbits = randbit;
   m_enable_DJN = true;
-  m_dev.reset();
+  rebuildDevice();
 }
 
 void PublicKey::setRandom(const std::vector<BigNumber>& r) {
@@ -67,12 +68,13 @@ void PublicKey::setRandom(const std::vector<BigNumber>& r) {
 
 void PublicKey::setHS(const BigNumber& hs) {
   m_hs = hs;
-  m_dev.reset();
+  rebuildDevice();
 }
 
-std::shared_ptr<detail::PubKeyDevice> PublicKey::device() const {
-  if (m_dev && m_dev->n == *m_n && m_dev->djn == m_enable_DJN && (!m_enable_DJN || m_dev->hs == m_hs))
-    return m_dev;
+// The device-side key (n^2 Montgomery context, hs, one copy per pool GPU) is built EAGERLY by every mutator, so a
+// key that is shared between threads afterwards (the reference's APPLEVEL_OMP pattern: generateKeypair, then four
+// threads encrypt) is only ever read: no lazy initialisation from const methods.
+void PublicKey::rebuildDevice() {
   detail::ensure_context();
   auto d = std::make_shared<detail::PubKeyDevice>();
   d->n = *m_n;
@@ -86,7 +88,11 @@ std::shared_ptr<detail::PubKeyDevice> PublicKey::device() const {
   IPCL_GPU_CHECK(pgpu_pubkey_create(n_l.data(), nw, m_enable_DJN ? hs_l.data() : nullptr, &d->h),
                  "PublicKey");
   m_dev = d;
-  return d;
+}
+
+std::shared_ptr<detail::PubKeyDevice> PublicKey::device() const {
+  ERROR_CHECK(m_dev != nullptr, "PublicKey: key is NOT initialized.");
+  return m_dev;
 }
 
 // the per-element randomness: injected (setRandom) or drawn on the host like the reference
@@ -168,10 +174,9 @@ CipherText PublicKey::encrypt(const PlainText& pt, bool make_secure) const {
   const int rbits = detail::max_bits(r);
   const int rw = detail::words_for_bits(rbits);
   auto dr = detail::DeviceBatch::upload(detail::pack(r, rw), sz, rw);
-  auto dc = detail::DeviceBatch::alloc(sz, 2 * nw);
-  IPCL_GPU_CHECK(pgpu_paillier_encrypt_dev(dev->h, dm->ptr(), (size_t)dm->words, dm->words, dr->ptr(),
-                                           (size_t)rw, rw, rbits, dc->ptr(), sz, nullptr),
-                 "encrypt");
+  pgpu_batch* c = nullptr;
+  IPCL_GPU_CHECK(pgpu_batch_encrypt(dev->h, dm->h, dr->h, rbits, &c), "encrypt");
+  auto dc = detail::DeviceBatch::adopt(c);
   return CipherText(*this, dc);
 }
 

@@ -1,0 +1,151 @@
+// pailliercryptolib_amd -- kernel argument blocks shared by the device code (kernels.hpp) and the host
+// runtime (capi.cpp, runtime.cpp).  Plain data only: this header is included by files that are
+// compiled without any device code.
+#ifndef PAILLIERCRYPTOLIB_AMD_CSRC_KARGS_HPP_
+#define PAILLIERCRYPTOLIB_AMD_CSRC_KARGS_HPP_
+
+#include <stddef.h>
+#include <stdint.h>
+
+namespace pgpu {
+
+constexpr int kWave = 64;
+constexpr int kLimbBits = 29;
+constexpr uint32_t kLimbMask = (1u << kLimbBits) - 1;
+// Workgroups are kWavesPerWG independent wavefronts (one per SIMD of a CU, for even SIMD load)
+constexpr int kWavesPerWG = 4;
+constexpr int kWGThreads = kWave * kWavesPerWG;
+
+// Montgomery context of one odd modulus N, resident in device memory (built by the host,
+// capi.hip: build_modctx).  R = 2^(29*L) for the geometry the context was built for.
+struct ModCtxDev {
+  const uint32_t* n;    // [L]   N, 29-bit limbs
+  const uint32_t* r2;   // [L]   R^2 mod N
+  const uint32_t* one;  // [L]   R mod N
+  const uint32_t* r2s;  // [L]   R^2 * 2^(64*mod_words) mod N   (wide-base reduction)   | may be null
+  const uint32_t* fc;   // [L]   constant final multiplier, plain domain (hp, hq)       | may be null
+  const uint32_t* nr;   // [L]   n*R mod N for N = n^2 (Paillier g^m = 1 + n*m)          | may be null
+  const uint64_t* n64;  // [W64+1] N as little-endian 64-bit words, zero padded
+  // Quotient-digit shortcut.  If nhat != null the exponentiation loop runs modulo Nhat = N*k with
+  // k = -N^-1 mod 2^29, i.e. Nhat == -1 mod 2^29 and the Montgomery constant n0' is 1: the
+  // quotient digit is just the low limb (no multiply).  n / r2 / one / r2s / nr above are then
+  // all taken modulo Nhat (lazy values stay correct modulo N); the multiplication that leaves the
+  // Montgomery domain switches back to the true modulus held here.
+  const uint32_t* nhat; // [L] Nhat limbs, or null (then n is the true modulus everywhere)
+  // Montgomery-form output of the Paillier encrypt forms: with gadd != null the kernel adds these L limbs
+  // (R mod N, true modulus) instead of 1 to m*nr, and the host points nr at n*R^2 mod N, so that
+  // g^m arrives as (1 + n*m)*R and the result c*R stays in the Montgomery domain of N.
+  const uint32_t* gadd;
+  uint32_t n0inv;       // -N^-1 mod 2^29 (true modulus)
+  int mod_words;        // 64-bit words per element of this modulus in the C-ABI layout
+};
+
+enum FinalMul : int {
+  FM_UNIT = 0,       // multiply by 1: plain modexp
+  FM_CTX_CONST = 1,  // multiply by ctx.fc
+  FM_PAILLIER_G = 2  // multiply by (1 + n*m) mod n^2, m read from fm_words
+};
+
+struct ModexpArgs {
+  ModCtxDev ctx[2];
+  int nctx;              // 1, or 2: instance i uses ctx[i % 2] and base element i / 2.  With 2 contexts a
+                         // wavefront takes instances of ONE parity (wave W: parity W & 1, elements
+                         // (W >> 1)*IPW ...), so context and exponent are wave-uniform
+  const uint64_t* base;  // [.][base_stride] (0: one shared base)
+  size_t base_stride;
+  int base_words;        // valid words per base; may be 2*mod_words (reduced on load) if ctx.r2s
+  const uint64_t* exp;   // [.][exp_stride]; exp_per_ctx: row (i % nctx), else row i (0: shared)
+  size_t exp_stride;
+  int exp_per_ctx;
+  int exp_words;
+  int exp_bits;          // max exponent bit length over the batch (mod_exp.cpp:484)
+  int window;            // fixed window width w, 1..5 (table of 2^w entries); with a schedule: 2^w ODD powers
+  // Shared exponents known to the host (key constants p-1, q-1, n) come with a sliding-window
+  // schedule per context instead of being scanned digit by digit: step k = (nsq << 6) | (idx + 1):
+  // nsq squarings, then a multiplication by base^(2*idx+1) (idx + 1 == 0: squarings only; step 0 has
+  // nsq == 0 and loads the entry).  null: fixed-window scan of exp.
+  const uint16_t* sched[2];
+  int sched_len[2];
+  int parity_waves;      // nctx == 2 only: 1 = a wavefront takes one parity (required by a schedule)
+  int final_mul;         // FinalMul
+  const uint64_t* fm_words;  // FM_PAILLIER_G: plaintexts [count][fm_stride]
+  size_t fm_stride;
+  int fm_nwords;
+  uint64_t* out;         // [count][out_stride]
+  size_t out_stride;
+  uint32_t* table;       // [count rounded up to IPW][2^w][L] workspace
+  size_t count;          // number of instances (= 2 * ciphertexts when nctx == 2)
+  uint64_t* wave_clocks; // optional diagnostics (tools/wave_spread.py): [waves][3] = start, end
+                         // (s_memtime ticks), XCC id | HW_ID << 8
+};
+
+struct ModmulArgs {
+  ModCtxDev ctx;
+  const uint64_t* a;     // [count][a_stride]
+  size_t a_stride;
+  const uint64_t* b;     // [count][b_stride]  (b_stride == 0: scalar broadcast)
+  size_t b_stride;
+  int in_words;          // valid words per operand
+  uint64_t* out;         // [count][ctx.mod_words]
+  size_t count;
+  int mode;              // ModmulMode
+  int b_words;           // MM_GM: valid words per plaintext
+};
+
+enum ModmulMode : int {
+  MM_PLAIN = 0,   // out = a*b mod N, plain operands and result (two Montgomery products)
+  MM_SINGLE = 1,  // out = montmul(a, b): Montgomery-form operands and result (one product)
+  MM_BY_R2 = 2,   // out = montmul(a, R^2): plain -> Montgomery form
+  MM_BY_ONE = 3,  // out = montmul(a, 1): Montgomery form -> plain
+  MM_GM = 4       // out = a * (1 + n*b) mod n^2 (CT + PT): b = plaintexts of b_words words; keeps a's form
+};
+
+// Second half of CRT decryption.  All constants are host-precomputed for the geometry of this
+// launch (R = 2^(29*L)); M is the auxiliary modulus 2^(29*(L-1)) - 1 (odd, coprime to p and q)
+// under which "multiply by p^-1" is an exact division and "multiply by p" an exact product.
+struct CrtArgs {
+  ModCtxDev ctxM;        // modulus M
+  ModCtxDev ctxQ;        // modulus q
+  const uint32_t* cp;    // [L] p^-1 * R mod M
+  const uint32_t* cq;    // [L] q^-1 * R mod M
+  const uint32_t* pinvR; // [L] (p^-1 mod q) * R mod q
+  const uint32_t* pRM;   // [L] p * R mod M
+  const uint64_t* hp64;  // [vw] hp
+  const uint64_t* hq64;  // [vw] hq
+  const uint64_t* p2_64; // [vw] p^2
+  const uint64_t* q2_64; // [vw] q^2
+  const uint64_t* q64;   // [vw] q (zero padded)
+  const uint64_t* v;     // [2*count][vw]: row 2i = xp*hp mod p^2, row 2i+1 = xq*hq mod q^2
+  int vw;                // words per row of v (= words of p^2)
+  uint64_t* out;         // [count][out_words]  plaintexts (< n)
+  int out_words;
+  size_t count;
+};
+
+struct FixedBaseArgs {
+  ModCtxDev ctx;         // modulus n^2 (nr set)
+  const uint32_t* table; // [nwin][2^w][L]
+  int nwin;
+  int w;
+  const uint64_t* exp;   // [count][exp_stride] the randomness r
+  size_t exp_stride;
+  int exp_words;
+  const uint64_t* fm_words;  // plaintexts [count][fm_stride]
+  size_t fm_stride;
+  int fm_nwords;
+  uint64_t* out;         // [count][out_stride]
+  size_t out_stride;
+  size_t count;
+};
+
+struct FixedBaseBuildArgs {
+  ModCtxDev ctx;
+  const uint64_t* base;  // hs, ctx.mod_words words
+  uint32_t* table;       // [nwin][2^w][L]
+  int nwin;
+  int w;
+};
+
+}  // namespace pgpu
+
+#endif  // PAILLIERCRYPTOLIB_AMD_CSRC_KARGS_HPP_

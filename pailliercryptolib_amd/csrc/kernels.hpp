@@ -17,108 +17,15 @@
 #ifndef PAILLIERCRYPTOLIB_AMD_CSRC_KERNELS_HPP_
 #define PAILLIERCRYPTOLIB_AMD_CSRC_KERNELS_HPP_
 
+#include "kargs.hpp"
 #include "mont_core.hpp"
 
 namespace pgpu {
-
-// Montgomery context of one odd modulus N, resident in device memory (built by the host,
-// capi.hip: build_modctx).  R = 2^(29*L) for the geometry the context was built for.
-struct ModCtxDev {
-  const uint32_t* n;    // [L]   N, 29-bit limbs
-  const uint32_t* r2;   // [L]   R^2 mod N
-  const uint32_t* one;  // [L]   R mod N
-  const uint32_t* r2s;  // [L]   R^2 * 2^(64*mod_words) mod N   (wide-base reduction)   | may be null
-  const uint32_t* fc;   // [L]   constant final multiplier, plain domain (hp, hq)       | may be null
-  const uint32_t* nr;   // [L]   n*R mod N for N = n^2 (Paillier g^m = 1 + n*m)          | may be null
-  const uint64_t* n64;  // [W64+1] N as little-endian 64-bit words, zero padded
-  // Quotient-digit shortcut.  If nhat != null the exponentiation loop runs modulo Nhat = N*k with
-  // k = -N^-1 mod 2^29, i.e. Nhat == -1 mod 2^29 and the Montgomery constant n0' is 1: the
-  // quotient digit is just the low limb (no multiply).  n / r2 / one / r2s / nr above are then
-  // all taken modulo Nhat (lazy values stay correct modulo N); the multiplication that leaves the
-  // Montgomery domain switches back to the true modulus held here.
-  const uint32_t* nhat; // [L] Nhat limbs, or null (then n is the true modulus everywhere)
-  uint32_t n0inv;       // -N^-1 mod 2^29 (true modulus)
-  int mod_words;        // 64-bit words per element of this modulus in the C-ABI layout
-};
-
-enum FinalMul : int {
-  FM_UNIT = 0,       // multiply by 1: plain modexp
-  FM_CTX_CONST = 1,  // multiply by ctx.fc
-  FM_PAILLIER_G = 2  // multiply by (1 + n*m) mod n^2, m read from fm_words
-};
-
-struct ModexpArgs {
-  ModCtxDev ctx[2];
-  int nctx;              // 1, or 2: instance i uses ctx[i % 2] and base element i / 2.  With 2 contexts a
-                         // wavefront takes instances of ONE parity (wave W: parity W & 1, elements
-                         // (W >> 1)*IPW ...), so context and exponent are wave-uniform
-  const uint64_t* base;  // [.][base_stride] (0: one shared base)
-  size_t base_stride;
-  int base_words;        // valid words per base; may be 2*mod_words (reduced on load) if ctx.r2s
-  const uint64_t* exp;   // [.][exp_stride]; exp_per_ctx: row (i % nctx), else row i (0: shared)
-  size_t exp_stride;
-  int exp_per_ctx;
-  int exp_words;
-  int exp_bits;          // max exponent bit length over the batch (mod_exp.cpp:484)
-  int window;            // fixed window width w, 1..5 (table of 2^w entries); with a schedule: 2^w ODD powers
-  // Shared exponents known to the host (key constants p-1, q-1, n) come with a sliding-window
-  // schedule per context instead of being scanned digit by digit: step k = (nsq << 6) | (idx + 1):
-  // nsq squarings, then a multiplication by base^(2*idx+1) (idx + 1 == 0: squarings only; step 0 has
-  // nsq == 0 and loads the entry).  null: fixed-window scan of exp.
-  const uint16_t* sched[2];
-  int sched_len[2];
-  int parity_waves;      // nctx == 2 only: 1 = a wavefront takes one parity (required by a schedule)
-  int final_mul;         // FinalMul
-  const uint64_t* fm_words;  // FM_PAILLIER_G: plaintexts [count][fm_stride]
-  size_t fm_stride;
-  int fm_nwords;
-  uint64_t* out;         // [count][out_stride]
-  size_t out_stride;
-  uint32_t* table;       // [count rounded up to IPW][2^w][L] workspace
-  size_t count;          // number of instances (= 2 * ciphertexts when nctx == 2)
-  uint64_t* wave_clocks; // optional diagnostics (tools/wave_spread.py): [waves][3] = start, end
-                         // (s_memtime ticks), XCC id | HW_ID << 8
-};
-
-struct ModmulArgs {
-  ModCtxDev ctx;
-  const uint64_t* a;     // [count][a_stride]
-  size_t a_stride;
-  const uint64_t* b;     // [count][b_stride]  (b_stride == 0: scalar broadcast)
-  size_t b_stride;
-  int in_words;          // valid words per operand
-  uint64_t* out;         // [count][ctx.mod_words]
-  size_t count;
-};
-
-// Second half of CRT decryption.  All constants are host-precomputed for the geometry of this
-// launch (R = 2^(29*L)); M is the auxiliary modulus 2^(29*(L-1)) - 1 (odd, coprime to p and q)
-// under which "multiply by p^-1" is an exact division and "multiply by p" an exact product.
-struct CrtArgs {
-  ModCtxDev ctxM;        // modulus M
-  ModCtxDev ctxQ;        // modulus q
-  const uint32_t* cp;    // [L] p^-1 * R mod M
-  const uint32_t* cq;    // [L] q^-1 * R mod M
-  const uint32_t* pinvR; // [L] (p^-1 mod q) * R mod q
-  const uint32_t* pRM;   // [L] p * R mod M
-  const uint64_t* hp64;  // [vw] hp
-  const uint64_t* hq64;  // [vw] hq
-  const uint64_t* p2_64; // [vw] p^2
-  const uint64_t* q2_64; // [vw] q^2
-  const uint64_t* q64;   // [vw] q (zero padded)
-  const uint64_t* v;     // [2*count][vw]: row 2i = xp*hp mod p^2, row 2i+1 = xq*hq mod q^2
-  int vw;                // words per row of v (= words of p^2)
-  uint64_t* out;         // [count][out_words]  plaintexts (< n)
-  int out_words;
-  size_t count;
-};
 
 // Workgroups are kWavesPerWG independent wavefronts (one per SIMD of a CU, for even SIMD load);
 // each wavefront owns its slice of the LDS arrays and never talks to the others, so the LDS
 // hand-off is wave-scope: LDS executes one wave's instructions in order, only the compiler must
 // not reorder across the hand-off (no s_barrier).
-constexpr int kWavesPerWG = 4;
-constexpr int kWGThreads = kWave * kWavesPerWG;
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -352,8 +259,16 @@ __global__ __launch_bounds__(kWGThreads, 2) void modexp_kernel(ModexpArgs A) {
     bool start_main = false;
     if (phase == GMUL || phase == TOMONT_HI) {
       // park the result, then run the (low-part) to-Montgomery multiplication of the base
+      if (phase == GMUL && A.ctx[0].gadd) {
+        // Montgomery-form output: the staged multiplier was n*R^2, so a = n*m*R; g^m*R = a + (R mod N)
+        uint32_t gk[K];
 #pragma unroll
-      for (int j = 0; j < K; ++j) keep[j] = a[j] + ((phase == GMUL && x == 0 && j == 0) ? 1u : 0u);   // g^m = 1 + n*m
+        for (int j = 0; j < K; ++j) gk[j] = PGPU_CTX(gadd)[x * K + j];
+        add_normalise<GEO>(a, gk);
+      }
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+        keep[j] = a[j] + ((phase == GMUL && !A.ctx[0].gadd && x == 0 && j == 0) ? 1u : 0u);   // g^m = 1 + n*m
       if (phase == GMUL && unitq) {                        // the loop itself runs modulo Nhat
 #pragma unroll
         for (int j = 0; j < K; ++j) n[j] = PGPU_CTX(nhat)[x * K + j];
@@ -494,30 +409,6 @@ __global__ __launch_bounds__(kWGThreads, 2) void modexp_kernel(ModexpArgs A) {
 // w-bit digit of r   -- nwin-1 multiplications and NO squarings (1024-bit r, w = 8: 127 instead
 // of 1259).  The table (nwin * 2^w entries of L limbs) is built once per key by fb_build_kernel and
 // lives in HBM / Infinity Cache; an entry is loaded straight into the lane-resident operand.
-struct FixedBaseArgs {
-  ModCtxDev ctx;         // modulus n^2 (nr set)
-  const uint32_t* table; // [nwin][2^w][L]
-  int nwin;
-  int w;
-  const uint64_t* exp;   // [count][exp_stride] the randomness r
-  size_t exp_stride;
-  int exp_words;
-  const uint64_t* fm_words;  // plaintexts [count][fm_stride]
-  size_t fm_stride;
-  int fm_nwords;
-  uint64_t* out;         // [count][out_stride]
-  size_t out_stride;
-  size_t count;
-};
-
-struct FixedBaseBuildArgs {
-  ModCtxDev ctx;
-  const uint64_t* base;  // hs, ctx.mod_words words
-  uint32_t* table;       // [nwin][2^w][L]
-  int nwin;
-  int w;
-};
-
 // instance i builds row i of the table: B = hs^(2^(w*i)) by w*i squarings, then T[i][d] = T[i][d-1]*B
 template <class GEO>
 __global__ __launch_bounds__(kWGThreads) void fb_build_kernel(FixedBaseBuildArgs A) {
@@ -659,7 +550,14 @@ __global__ __launch_bounds__(kWGThreads, 2) void fb_encrypt_kernel(FixedBaseArgs
     if (step == 0) {
 #pragma unroll
       for (int j = 0; j < K; ++j) gm[j] = r[j];
-      if (x == 0) gm[0] += 1;
+      if (A.ctx.gadd) {       // Montgomery-form output (see modexp_kernel GMUL): g^m*R = n*m*R + (R mod N)
+        uint32_t gk[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) gk[j] = A.ctx.gadd[x * K + j];
+        add_normalise<GEO>(gm, gk);
+      } else if (x == 0) {
+        gm[0] += 1;
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < K; ++j) acc[j] = r[j];
@@ -675,7 +573,14 @@ __global__ __launch_bounds__(kWGThreads, 2) void fb_encrypt_kernel(FixedBaseArgs
   store_canonical<GEO>(a, n, A.ctx.mod_words, bl, io, A.out, A.out_stride, first_inst, A.count, lane, g, x);
 }
 
-// out = a*b mod N: montmul(montmul(a, R^2), b) -- two Montgomery multiplications.
+// Batched modular product (CipherText::raw_add, ciphertext.cpp:135-141) in four flavours (ModmulMode):
+//   MM_PLAIN   out = a*b mod N          montmul(montmul(a, R^2), b): plain operands, plain result
+//   MM_SINGLE  out = montmul(a, b)      operands in Montgomery form -> result in Montgomery form (ONE product;
+//                                       device-resident ciphertext chains stay in the Montgomery domain)
+//   MM_BY_R2   out = montmul(a, R^2)    plain -> Montgomery form
+//   MM_BY_ONE  out = montmul(a, 1)      Montgomery form -> plain
+//   MM_GM      out = a * (1 + n*b)      CT + PT with the plaintext b (ctx.nr = n*R^2, ctx.gadd = R mod N)
+// Results are canonical (< N) in every mode.
 template <class GEO>
 __global__ __launch_bounds__(kWGThreads) void modmul_kernel(ModmulArgs A) {
   constexpr int K = GEO::K, L = GEO::L, G = GEO::G, IPW = GEO::IPW;
@@ -691,23 +596,53 @@ __global__ __launch_bounds__(kWGThreads) void modmul_kernel(ModmulArgs A) {
 #pragma unroll
   for (int j = 0; j < K; ++j) n[j] = A.ctx.n[x * K + j];
   const uint32_t n0inv = A.ctx.n0inv;
+  const int mode = A.mode;
 
-  stage_words<GEO>(io, A.a, A.a_stride, 0, A.in_words, first_inst, A.count, 1, lane);
+  if (mode == MM_GM) {
+    // CT + PT (ciphertext.cpp:75-80) without the host loop of raw_encrypt: g^m*R = m*(n*R^2)*R^-1 + (R mod N),
+    // then ONE product with the ciphertext rows -- the result has the form (Montgomery / plain) of the ciphertext
+    stage_words<GEO>(io, A.b, A.b_stride, 0, A.b_words, first_inst, A.count, 1, lane);
 #pragma unroll
-  for (int j = 0; j < K; ++j) bl[g][x * K + j] = A.ctx.r2[x * K + j];
-  wave_lds_sync();
+    for (int j = 0; j < K; ++j) bl[g][x * K + j] = A.ctx.nr[x * K + j];
+    wave_lds_sync();
 #pragma unroll
-  for (int j = 0; j < K; ++j) a[j] = limb_from_words(io[g], x * K + j);
+    for (int j = 0; j < K; ++j) a[j] = limb_from_words(io[g], x * K + j);
+    montmul<GEO>(a, a, bl[g], n, n0inv);
+    uint32_t gk[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) gk[j] = A.ctx.gadd[x * K + j];
+    add_normalise<GEO>(a, gk);
+    wave_lds_sync();
+    stage_words<GEO>(io, A.a, A.a_stride, 0, A.in_words, first_inst, A.count, 1, lane);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < K; ++j) bl[g][x * K + j] = limb_from_words(io[g], x * K + j);
+    wave_lds_sync();
+    montmul<GEO>(a, a, bl[g], n, n0inv);
+  } else {
+    stage_words<GEO>(io, A.a, A.a_stride, 0, A.in_words, first_inst, A.count, 1, lane);
+    if (mode == MM_PLAIN || mode == MM_BY_R2) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) bl[g][x * K + j] = A.ctx.r2[x * K + j];
+    } else if (mode == MM_BY_ONE) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) bl[g][x * K + j] = (x == 0 && j == 0) ? 1u : 0u;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = limb_from_words(io[g], x * K + j);
+    const int nsteps = mode == MM_PLAIN ? 2 : 1;
 #pragma unroll 1
-  for (int step = 0; step < 2; ++step) {
-    montmul<GEO>(a, a, bl[g], n, n0inv);      // step 0: a*R (any a < R); step 1: a*b mod N, lazy
-    if (step == 0) {
-      wave_lds_sync();
-      stage_words<GEO>(io, A.b, A.b_stride, 0, A.in_words, first_inst, A.count, 1, lane);
-      wave_lds_sync();
+    for (int step = 0; step < nsteps; ++step) {
+      if (mode == MM_SINGLE || step == 1) {     // the multiplier is the b operand
+        wave_lds_sync();
+        stage_words<GEO>(io, A.b, A.b_stride, 0, A.in_words, first_inst, A.count, 1, lane);
+        wave_lds_sync();
 #pragma unroll
-      for (int j = 0; j < K; ++j) bl[g][x * K + j] = limb_from_words(io[g], x * K + j);
-      wave_lds_sync();
+        for (int j = 0; j < K; ++j) bl[g][x * K + j] = limb_from_words(io[g], x * K + j);
+        wave_lds_sync();
+      }
+      montmul<GEO>(a, a, bl[g], n, n0inv);      // a*R (any a < R) / a*b*R^-1 mod N, lazy
     }
   }
   store_canonical<GEO>(a, n, A.ctx.mod_words, bl, io, A.out, (size_t)A.ctx.mod_words, first_inst, A.count, lane, g, x);

@@ -1,0 +1,32 @@
+// pailliercryptolib_amd -- host-callable launchers of the gfx950 kernels (kernels.hpp).
+// The kernels are instantiated per geometry in several translation units (k_modexp.hip compiled
+// once per PGPU_PART, k_misc.hip) so that they build in parallel and a change of the host runtime
+// does not recompile device code.  Every launcher returns false when the geometry is not compiled.
+#ifndef PAILLIERCRYPTOLIB_AMD_CSRC_LAUNCH_HPP_
+#define PAILLIERCRYPTOLIB_AMD_CSRC_LAUNCH_HPP_
+
+#include <hip/hip_runtime_api.h>
+
+#include "kargs.hpp"
+
+namespace pgpu {
+
+// modexp_kernel lives in kModexpParts translation units; launch_modexp tries each
+constexpr int kModexpParts = 4;
+bool launch_modexp_part0(int G, int K, const ModexpArgs& a, unsigned blocks, hipStream_t s);
+bool launch_modexp_part1(int G, int K, const ModexpArgs& a, unsigned blocks, hipStream_t s);
+bool launch_modexp_part2(int G, int K, const ModexpArgs& a, unsigned blocks, hipStream_t s);
+bool launch_modexp_part3(int G, int K, const ModexpArgs& a, unsigned blocks, hipStream_t s);
+inline bool launch_modexp(int G, int K, const ModexpArgs& a, unsigned blocks, hipStream_t s) {
+  return launch_modexp_part0(G, K, a, blocks, s) || launch_modexp_part1(G, K, a, blocks, s) ||
+         launch_modexp_part2(G, K, a, blocks, s) || launch_modexp_part3(G, K, a, blocks, s);
+}
+
+bool launch_modmul(int G, int K, const ModmulArgs& a, unsigned blocks, hipStream_t s);
+bool launch_crt(int G, int K, const CrtArgs& a, unsigned blocks, hipStream_t s);
+bool launch_fb_build(int G, int K, const FixedBaseBuildArgs& a, unsigned blocks, hipStream_t s);
+bool launch_fb_encrypt(int G, int K, const FixedBaseArgs& a, unsigned blocks, hipStream_t s);
+
+}  // namespace pgpu
+
+#endif  // PAILLIERCRYPTOLIB_AMD_CSRC_LAUNCH_HPP_

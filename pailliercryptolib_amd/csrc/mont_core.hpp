@@ -25,11 +25,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "kargs.hpp"
+
 namespace pgpu {
 
-constexpr int kWave = 64;
-constexpr int kLimbBits = 29;
-constexpr uint32_t kLimbMask = (1u << kLimbBits) - 1;
 
 template <int G_, int K_>
 struct Geo {

@@ -1,0 +1,584 @@
+// pailliercryptolib_amd -- device pool, worker lanes, allocator, staging copies, key replication (runtime.hpp).
+#include "runtime.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: the library is dlopen'ed (replicate over xGMI), never linked
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+
+namespace pgpu {
+namespace rt {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+namespace {
+
+std::mutex g_pool_mu;   // init / shutdown
+std::vector<std::unique_ptr<Device>> g_pool;
+bool g_init = false;
+thread_local int t_current = 0;
+size_t g_min_shard = 0;
+const char* g_transport = "single";
+
+// ---- RCCL, loaded at run time ----
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::vector<ncclComm_t> comms;
+  bool ready = false;
+  std::string note;
+} g_rccl;
+
+bool rccl_load() {
+  if (g_rccl.lib) return true;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (g_rccl.lib) break;
+  }
+  if (!g_rccl.lib) {
+    g_rccl.note = "librccl not found";
+    return false;
+  }
+#define PGPU_SYM(field, sym)                                                        \
+  g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.lib, sym)); \
+  if (!g_rccl.field) {                                                              \
+    g_rccl.note = std::string("librccl lacks ") + sym;                              \
+    return false;                                                                   \
+  }
+  PGPU_SYM(CommInitAll, "ncclCommInitAll")
+  PGPU_SYM(CommDestroy, "ncclCommDestroy")
+  PGPU_SYM(Broadcast, "ncclBroadcast")
+  PGPU_SYM(GroupStart, "ncclGroupStart")
+  PGPU_SYM(GroupEnd, "ncclGroupEnd")
+  PGPU_SYM(GetErrorString, "ncclGetErrorString")
+#undef PGPU_SYM
+  return true;
+}
+
+// one communicator per pool device (single process, ncclCommInitAll); needs distinct physical devices
+void rccl_init(const std::vector<int>& ordinals) {
+  g_rccl.ready = false;
+  const char* no = std::getenv("PGPU_NO_RCCL");
+  if (no && std::atoi(no) != 0) {
+    g_rccl.note = "disabled by PGPU_NO_RCCL";
+    return;
+  }
+  const char* force = std::getenv("PGPU_RCCL_FORCE");   // also bring it up for a pool of one (self-test)
+  if (ordinals.size() < 2 && !(force && std::atoi(force) != 0)) return;
+  if (std::set<int>(ordinals.begin(), ordinals.end()).size() != ordinals.size()) {
+    g_rccl.note = "pool entries share a physical device";
+    return;
+  }
+  if (!rccl_load()) return;
+  g_rccl.comms.assign(ordinals.size(), nullptr);
+  ncclResult_t r = g_rccl.CommInitAll(g_rccl.comms.data(), (int)ordinals.size(), ordinals.data());
+  if (r != ncclSuccess) {
+    g_rccl.note = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r);
+    g_rccl.comms.clear();
+    return;
+  }
+  g_rccl.ready = true;
+  g_rccl.note = "ok";
+}
+
+void rccl_shutdown() {
+  if (g_rccl.ready)
+    for (ncclComm_t c : g_rccl.comms)
+      if (c) (void)g_rccl.CommDestroy(c);
+  g_rccl.comms.clear();
+  g_rccl.ready = false;
+}
+
+void lane_main(Device* d, Lane* lane) {
+  (void)hipSetDevice(d->ordinal);
+  for (;;) {
+    std::function<void(Lane&)> fn;
+    {
+      std::unique_lock<std::mutex> lk(d->mu);
+      d->cv.wait(lk, [&] { return d->stop || !d->queue.empty(); });
+      if (d->queue.empty()) return;   // stop requested and nothing left
+      fn = std::move(d->queue.front());
+      d->queue.pop_front();
+    }
+    fn(*lane);
+  }
+}
+
+}  // namespace
+
+// ---------------- Workspace ----------------
+int Workspace::ensure(size_t need) {
+  if (need <= bytes) return PGPU_OK;
+  if (p) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(p));
+    p = nullptr;
+    bytes = 0;
+  }
+  HIP_TRY(hipMalloc(&p, need));
+  bytes = need;
+  return PGPU_OK;
+}
+void Workspace::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  bytes = 0;
+}
+
+// ---------------- Device ----------------
+int Device::bind() const {
+  HIP_TRY(hipSetDevice(ordinal));
+  return PGPU_OK;
+}
+
+namespace {
+constexpr size_t kGranule = 64 * 1024, kIdleCap = (size_t)4 << 30;
+}
+
+int Device::alloc(size_t bytes, hipStream_t tag, void** out) {
+  if (!out) return fail(PGPU_ERR_INVALID_PARAM, "null output pointer");
+  const size_t rounded = (std::max<size_t>(bytes, 1) + kGranule - 1) / kGranule * kGranule;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = free_blocks.find({tag, rounded});
+    if (it != free_blocks.end() && !it->second.empty()) {
+      *out = it->second.back();
+      it->second.pop_back();
+      idle_bytes -= rounded;
+      return PGPU_OK;
+    }
+  }
+  DeviceGuard g(ordinal);
+  hipError_t e = hipMalloc(out, rounded);
+  if (e != hipSuccess) {   // out of memory: drop the idle blocks and retry once
+    release_idle();
+    HIP_TRY(hipMalloc(out, rounded));
+  }
+  std::lock_guard<std::mutex> lk(mu);
+  block_size[*out] = rounded;
+  return PGPU_OK;
+}
+
+void Device::free(void* p, hipStream_t tag) {
+  if (!p) return;
+  size_t sz = 0;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = block_size.find(p);
+    if (it != block_size.end()) {
+      sz = it->second;
+      if (g_init && idle_bytes + sz <= kIdleCap) {
+        free_blocks[{tag, sz}].push_back(p);
+        idle_bytes += sz;
+        return;
+      }
+      block_size.erase(it);
+    }
+  }
+  DeviceGuard g(ordinal);
+  (void)hipFree(p);   // (synchronises the device)
+}
+
+void Device::release_idle() {
+  DeviceGuard g(ordinal);
+  (void)hipDeviceSynchronize();
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto& kv : free_blocks)
+    for (void* p : kv.second) {
+      (void)hipFree(p);
+      block_size.erase(p);
+    }
+  free_blocks.clear();
+  idle_bytes = 0;
+}
+
+StreamWork& Device::work_for(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = work.find(s);
+  if (it != work.end()) return *it->second;
+  if (work.size() >= 32 && work.size() % 32 == 0) {
+    // streams come and go (callers create and destroy them): give back the scratch memory of the idle ones.
+    // The (small) entries themselves stay, so a reference handed out earlier never dangles; an entry whose
+    // mutex is taken is in use right now and keeps its memory.
+    DeviceGuard g(ordinal);
+    (void)hipDeviceSynchronize();
+    for (auto& w : work) {
+      if (w.second->mu.try_lock()) {
+        w.second->table.release();
+        w.second->vbuf.release();
+        w.second->mu.unlock();
+      }
+    }
+  }
+  auto& slot = work[s];
+  slot.reset(new StreamWork);
+  return *slot;
+}
+
+hipEvent_t Device::pool_event() {
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!event_pool.empty()) {
+      hipEvent_t e = event_pool.back();
+      event_pool.pop_back();
+      return e;
+    }
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void Device::post(std::function<void(Lane&)> fn) {
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    queue.push_back(std::move(fn));
+  }
+  cv.notify_one();
+}
+
+// ---------------- staging copies ----------------
+void big_copy(void* dst, const void* src, size_t n) {
+  // A single thread moves ~8 GB/s between pageable memory and a pinned buffer -- less than the DMA engine behind
+  // it -- so large copies are split over a few persistent helper threads (never joined: they sleep on a
+  // condition variable and die with the process).  One job at a time; a second caller copies on its own.
+  struct Pool {
+    enum { kHelpers = 3 };
+    std::mutex job;   // held for the duration of one copy
+    std::mutex m;
+    std::condition_variable cv, done;
+    char* dst = nullptr;
+    const char* src = nullptr;
+    size_t n = 0, per = 0;
+    unsigned gen = 0;
+    int pending = 0;
+    Pool() {
+      for (int i = 0; i < kHelpers; ++i) std::thread([this, i] { run(i + 1); }).detach();
+    }
+    void run(int slice) {
+      unsigned seen = 0;
+      for (;;) {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return gen != seen; });
+        seen = gen;
+        char* d = dst;
+        const char* s = src;
+        const size_t nn = n, pp = per;
+        lk.unlock();
+        const size_t lo = std::min(nn, pp * (size_t)slice), hi = std::min(nn, pp * (size_t)(slice + 1));
+        if (hi > lo) std::memcpy(d + lo, s + lo, hi - lo);
+        lk.lock();
+        if (--pending == 0) done.notify_one();
+      }
+    }
+  };
+  static Pool* pool = new Pool();
+  if (n < ((size_t)2 << 20) || !pool->job.try_lock()) {
+    std::memcpy(dst, src, n);
+    return;
+  }
+  const size_t per = (n / (Pool::kHelpers + 1) + 63) & ~(size_t)63;
+  {
+    std::lock_guard<std::mutex> lk(pool->m);
+    pool->dst = (char*)dst;
+    pool->src = (const char*)src;
+    pool->n = n;
+    pool->per = per;
+    pool->pending = Pool::kHelpers;
+    ++pool->gen;
+  }
+  pool->cv.notify_all();
+  std::memcpy(dst, src, std::min(per, n));   // slice 0 on the calling thread
+  {
+    std::unique_lock<std::mutex> lk(pool->m);
+    pool->done.wait(lk, [&] { return pool->pending == 0; });
+  }
+  pool->job.unlock();
+}
+
+namespace {
+int ensure_stage(Lane& l) {
+  for (int i = 0; i < 2; ++i) {
+    if (!l.stage[i]) HIP_TRY(hipHostMalloc(&l.stage[i], kStageBytes, hipHostMallocDefault));
+    if (!l.stage_ev[i]) HIP_TRY(hipEventCreateWithFlags(&l.stage_ev[i], hipEventDisableTiming));
+  }
+  return PGPU_OK;
+}
+}  // namespace
+
+// host -> device: chunk i+1 is packed into the other pinned buffer while chunk i is on the wire.  The copies
+// are ordered on `s` (the stream the consumer kernels run on); nothing is waited for at the end.
+int Lane::h2d(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
+  RC_TRY(ensure_stage(*this));
+  size_t off = 0;
+  for (int i = 0; off < bytes; ++i) {
+    const int b = i & 1;
+    const size_t n = std::min(kStageBytes, bytes - off);
+    HIP_TRY(hipEventSynchronize(stage_ev[b]));   // the DMA that last used this buffer is done (no-op if never recorded)
+    big_copy(stage[b], (const char*)h_src + off, n);
+    HIP_TRY(hipMemcpyAsync((char*)d_dst + off, stage[b], n, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(stage_ev[b], s));
+    off += n;
+  }
+  return PGPU_OK;
+}
+
+// device -> host, ordered behind the work queued on `s`: chunk i+1 is on the wire while chunk i is unpacked
+int Lane::d2h(void* h_dst, const void* d_src, size_t bytes, hipStream_t s) {
+  RC_TRY(ensure_stage(*this));
+  const int chunks = (int)((bytes + kStageBytes - 1) / kStageBytes);
+  auto issue = [&](int i) -> hipError_t {
+    const size_t off = (size_t)i * kStageBytes, n = std::min(kStageBytes, bytes - off);
+    hipError_t r = hipEventSynchronize(stage_ev[i & 1]);
+    if (r == hipSuccess) r = hipMemcpyAsync(stage[i & 1], (const char*)d_src + off, n, hipMemcpyDeviceToHost, s);
+    return r == hipSuccess ? hipEventRecord(stage_ev[i & 1], s) : r;
+  };
+  hipError_t e = hipSuccess;
+  if (chunks > 0) e = issue(0);
+  for (int i = 0; i < chunks && e == hipSuccess; ++i) {
+    if (i + 1 < chunks) e = issue(i + 1);   // its buffer was unpacked in iteration i-1
+    if (e == hipSuccess) e = hipEventSynchronize(stage_ev[i & 1]);
+    if (e != hipSuccess) break;
+    const size_t off = (size_t)i * kStageBytes, n = std::min(kStageBytes, bytes - off);
+    big_copy((char*)h_dst + off, stage[i & 1], n);
+  }
+  if (e != hipSuccess) return fail(PGPU_ERR_HIP, std::string("device -> host copy failed: ") + hipGetErrorString(e));
+  return PGPU_OK;
+}
+
+// ---------------- tasks ----------------
+void TaskGroup::run(Device& d, std::function<int(Lane&)> fn) {
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    ++pending;
+  }
+  d.post([this, fn](Lane& lane) {
+    int rc = fn(lane);
+    std::lock_guard<std::mutex> lk(mu);
+    if (rc != 0 && status == 0) {
+      status = rc;
+      err = g_err;   // the lane thread's message
+    }
+    if (--pending == 0) cv.notify_all();
+  });
+}
+
+int TaskGroup::wait() {
+  std::unique_lock<std::mutex> lk(mu);
+  cv.wait(lk, [&] { return pending == 0; });
+  if (status != 0) g_err = err;
+  return status;
+}
+
+// ---------------- pool ----------------
+bool initialized() { return g_init; }
+
+int check_ready() {
+  if (!g_init) return fail(PGPU_ERR_NO_DEVICE, "pgpu_init has not been called (no GPU context)");
+  return PGPU_OK;
+}
+
+int pool_size() { return (int)g_pool.size(); }
+Device& device(int i) { return *g_pool[(size_t)i]; }
+Device& current() {
+  int i = t_current;
+  if (i < 0 || i >= (int)g_pool.size()) i = 0;
+  return *g_pool[(size_t)i];
+}
+int current_index() { return (t_current >= 0 && t_current < (int)g_pool.size()) ? t_current : 0; }
+int set_current(int index) {
+  RC_TRY(check_ready());
+  if (index < 0 || index >= (int)g_pool.size()) return fail(PGPU_ERR_INVALID_PARAM, "pool index out of range");
+  t_current = index;
+  return PGPU_OK;
+}
+const char* replicate_transport() { return g_transport; }
+
+size_t min_shard() {
+  if (g_min_shard == 0) {
+    const char* e = std::getenv("PGPU_MIN_SHARD");
+    g_min_shard = e && std::atol(e) > 0 ? (size_t)std::atol(e) : 256;
+  }
+  return g_min_shard;
+}
+void set_min_shard(size_t n) { g_min_shard = n ? n : 256; }
+int shard_devices(size_t count) {
+  const size_t D = (size_t)pool_size();
+  return (int)std::max<size_t>(1, std::min(D, count / min_shard()));
+}
+
+int pool_init(const std::vector<int>& ordinals) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (g_init) {
+    bool same = ordinals.size() == g_pool.size();
+    for (size_t i = 0; same && i < ordinals.size(); ++i) same = g_pool[i]->ordinal == ordinals[i];
+    if (same) return PGPU_OK;
+    return fail(PGPU_ERR_INVALID_PARAM, "already initialised with a different device set (call pgpu_shutdown first)");
+  }
+  int visible = 0;
+  if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0)
+    return fail(PGPU_ERR_NO_DEVICE, "no HIP device visible");
+  if (ordinals.empty()) return fail(PGPU_ERR_INVALID_PARAM, "empty device list");
+  std::vector<std::unique_ptr<Device>> pool;
+  for (size_t i = 0; i < ordinals.size(); ++i) {
+    if (ordinals[i] < 0 || ordinals[i] >= visible)
+      return fail(PGPU_ERR_INVALID_PARAM, "device ordinal out of range");
+    std::unique_ptr<Device> d(new Device);
+    d->index = (int)i;
+    d->ordinal = ordinals[i];
+    HIP_TRY(hipSetDevice(d->ordinal));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, d->ordinal));
+    d->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return fail(PGPU_ERR_NO_DEVICE, "device is not gfx950: " + d->name);
+    HIP_TRY(hipStreamCreateWithFlags(&d->bstream, hipStreamNonBlocking));
+    for (int l = 0; l < 2; ++l) {
+      std::unique_ptr<Lane> lane(new Lane);
+      lane->dev = d.get();
+      lane->id = l;
+      HIP_TRY(hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking));
+      d->lanes.push_back(std::move(lane));
+    }
+    pool.push_back(std::move(d));
+  }
+  HIP_TRY(hipSetDevice(ordinals[0]));
+  g_pool = std::move(pool);
+  for (auto& d : g_pool)
+    for (auto& lane : d->lanes) lane->th = std::thread(lane_main, d.get(), lane.get());
+  rccl_init(ordinals);
+  g_transport = g_pool.size() == 1 && !g_rccl.ready ? "single" : (g_rccl.ready ? "rccl" : "memcpy");
+  t_current = 0;
+  g_init = true;
+  return PGPU_OK;
+}
+
+void pool_shutdown() {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (!g_init) return;
+  g_init = false;
+  for (auto& d : g_pool) {
+    {
+      std::lock_guard<std::mutex> l2(d->mu);
+      d->stop = true;
+    }
+    d->cv.notify_all();
+    for (auto& lane : d->lanes)
+      if (lane->th.joinable()) lane->th.join();
+  }
+  rccl_shutdown();
+  for (auto& d : g_pool) {
+    (void)hipSetDevice(d->ordinal);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : d->work) {
+      kv.second->table.release();
+      kv.second->vbuf.release();
+    }
+    d->work.clear();
+    for (auto& kv : d->free_blocks)
+      for (void* p : kv.second) {
+        (void)hipFree(p);
+        d->block_size.erase(p);
+      }
+    d->free_blocks.clear();
+    d->idle_bytes = 0;
+    for (auto& t : d->timed) {
+      d->event_pool.push_back(t.e0);
+      d->event_pool.push_back(t.e1);
+    }
+    d->timed.clear();
+    for (hipEvent_t e : d->event_pool) (void)hipEventDestroy(e);
+    d->event_pool.clear();
+    for (auto& lane : d->lanes) {
+      for (int i = 0; i < 2; ++i) {
+        if (lane->stage[i]) (void)hipHostFree(lane->stage[i]);
+        if (lane->stage_ev[i]) (void)hipEventDestroy(lane->stage_ev[i]);
+      }
+      if (lane->stream) (void)hipStreamDestroy(lane->stream);
+    }
+    if (d->bstream) (void)hipStreamDestroy(d->bstream);
+  }
+  if (!g_pool.empty()) (void)hipSetDevice(g_pool[0]->ordinal);
+  g_pool.clear();
+  g_transport = "single";
+}
+
+// ---------------- replicated constant data ----------------
+Replicated::~Replicated() { scrub_and_free(); }
+
+void Replicated::scrub_and_free() {
+  for (size_t i = 0; i < d.size(); ++i) {
+    if (!d[i]) continue;
+    if (i < g_pool.size()) {
+      DeviceGuard g(g_pool[i]->ordinal);
+      if (secret_) (void)hipMemset(d[i], 0, bytes);   // key material does not outlive the key object
+      (void)hipFree(d[i]);
+    } else {
+      (void)hipFree(d[i]);
+    }
+  }
+  d.clear();
+  bytes = 0;
+}
+
+int Replicated::upload(const void* host, size_t nbytes, bool secret) {
+  static std::mutex collective_mu;   // one collective at a time on the pool's communicators
+  std::lock_guard<std::mutex> clk(collective_mu);
+  scrub_and_free();
+  secret_ = secret;
+  bytes = nbytes;
+  const int D = pool_size();
+  d.assign((size_t)D, nullptr);
+  for (int i = 0; i < D; ++i) {
+    DeviceGuard g(device(i).ordinal);
+    HIP_TRY(hipMalloc(&d[(size_t)i], nbytes));
+  }
+  {
+    DeviceGuard g(device(0).ordinal);
+    HIP_TRY(hipMemcpy(d[0], host, nbytes, hipMemcpyHostToDevice));
+  }
+  if (D == 1 && !g_rccl.ready) return PGPU_OK;
+  if (g_rccl.ready) {
+    // ONE broadcast from device 0 over xGMI (single process: a group call over all communicators)
+    ncclResult_t r = g_rccl.GroupStart();
+    for (int i = 0; i < D && r == ncclSuccess; ++i) {
+      DeviceGuard g(device(i).ordinal);
+      r = g_rccl.Broadcast(d[0], d[(size_t)i], nbytes, ncclUint8, 0, g_rccl.comms[(size_t)i], device(i).bstream);
+    }
+    ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r == ncclSuccess) {
+      for (int i = 0; i < D; ++i) {
+        DeviceGuard g(device(i).ordinal);
+        HIP_TRY(hipStreamSynchronize(device(i).bstream));
+      }
+      return PGPU_OK;
+    }
+    // a failed collective leaves RCCL unusable: remember it and copy per device from here on
+    g_rccl.note = std::string("ncclBroadcast: ") + g_rccl.GetErrorString(r);
+    g_rccl.ready = false;
+    g_transport = "memcpy";
+  }
+  for (int i = 1; i < D; ++i) {
+    DeviceGuard g(device(i).ordinal);
+    HIP_TRY(hipMemcpy(d[(size_t)i], host, nbytes, hipMemcpyHostToDevice));
+  }
+  return PGPU_OK;
+}
+
+std::string rccl_note() { return g_rccl.note; }
+
+}  // namespace rt
+}  // namespace pgpu
