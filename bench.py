@@ -10,15 +10,22 @@ One "step" = one pass of the hot path over one synthetic batch that is already r
 metric "2048-bit modexps/sec (encrypt+decrypt)" is quoted on; it mirrors the reference's BM_Encrypt /
 BM_Decrypt (benchmark/bench_cryptography.cpp:73-121: same key, same HS_BN, DJN on).
 
-N > 1: one process per GPU (torch.distributed, backend nccl == RCCL); the batch shards by rank
-(weak scaling: every rank processes its own 8192-element batch); the only collective is the
-broadcast of the key material from rank 0.  Timing: barrier + synchronize on both sides of
-exactly K steps, MAX over ranks.
+How N GPUs are driven:
+  * `python bench.py --gpus N` (plain): ONE process, the library's device pool (pgpu_init_all: one worker pair +
+    streams per GPU, key images replicated by one RCCL broadcast over xGMI); the global batch of N x 8192
+    elements is a sharded resident pgpu_batch, a step enqueues one launch per GPU.  This is also the N = 1 path.
+  * under torch.distributed.run (WORLD_SIZE set): one process per GPU, backend nccl == RCCL; every rank
+    processes its own 8192-element batch through the `_dev` entry points; the only collective is the broadcast
+    of the key material from rank 0.
+Both are weak scaling (8192 elements per GPU per step); timing = barrier/synchronise on both sides of exactly K
+steps, MAX over ranks.  `--config 4|5` runs BASELINE.json configs[3] / configs[4] instead: a FIXED total batch
+(65536 x 3072-bit encrypt+decrypt; 1 M x 2048-bit CT+CT and CT x PT) sharded over the N GPUs (strong scaling).
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,9 +36,9 @@ sys.path.insert(0, ROOT)
 
 BATCH = 8192
 KEY_BITS = 2048
-# measured v_mad_u64_u32 issue rate on MI355X: profiles/r01_ubench_valu_issue_rates.txt (8 waves/SIMD row)
 PEAK_TMAC32 = 39.32   # 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz: v_mad_u64_u32 is full rate (38.35 measured)
 HBM_PEAK_GBS = 8000.0
+K_MODEXP, K_MODMUL, K_CRT, K_FB = 1, 2, 3, 4
 
 
 def algorithmic_mac32(mod_bits, exp_bits):
@@ -42,125 +49,169 @@ def algorithmic_mac32(mod_bits, exp_bits):
     return (2 * s * s + s) * (exp_bits + (exp_bits + w - 1) // w + (1 << w))
 
 
+def ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def iso_key():
+    k = json.load(open(os.path.join(ROOT, "tests", "golden", "iso_kat.json")))
+    return int(k["p"], 16), int(k["q"], 16), int(k["bench_hs"], 16)
+
+
+def synth(rank, count, nw, pw):
+    rng = np.random.default_rng(1234 + rank)
+    m = np.frombuffer(rng.bytes(count * nw * 8), dtype=np.uint64).reshape(count, nw).copy()
+    m[:, -1] &= np.uint64((1 << 62) - 1)          # plaintexts < 2^(64 nw - 2) < n
+    r = np.frombuffer(rng.bytes(count * pw * 8), dtype=np.uint64).reshape(count, pw).copy()   # full-width r
+    return m, r
+
+
+def collect_timing(L, cap):
+    kinds = (ctypes.c_int * cap)()
+    kms = (ctypes.c_double * cap)()
+    n = L.pgpu_timing_collect(kinds, kms, cap)
+    per = {}
+    for i in range(n):
+        per.setdefault(kinds[i], []).append(kms[i])
+    return per
+
+
+class Batches:
+    """thin owner of pgpu_batch handles"""
+
+    def __init__(self, L, check):
+        self.L, self.check = L, check
+
+    def up(self, arr):
+        h = ctypes.c_void_p()
+        arr = np.ascontiguousarray(arr, dtype=np.uint64)
+        self.check(self.L.pgpu_batch_upload(ptr(arr), arr.shape[0], arr.shape[1], arr.shape[1], ctypes.byref(h)))
+        return h
+
+    def down(self, h):
+        out = np.empty((self.L.pgpu_batch_count(h), self.L.pgpu_batch_words(h)), dtype=np.uint64)
+        self.check(self.L.pgpu_batch_download(h, ptr(out)))
+        return out
+
+    def op(self, fn, *a):
+        h = ctypes.c_void_p()
+        self.check(fn(*a, ctypes.byref(h)))
+        return h
+
+    def free(self, *hs):
+        for h in hs:
+            if h:
+                self.L.pgpu_batch_destroy(h)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
+                    help="2: BASELINE configs[1]+[2] (default, the headline); 4 / 5: configs[3] / configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the N=1 side measurements (end-to-end, API level, non-DJN variant)")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run --nproc-per-node N")
-    # validation-only knobs (exercise the N>1 code path on a 1-GPU box): BENCH_SINGLE_DEVICE=1 puts every
-    # rank on device 0, BENCH_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU)
-    if os.environ.get("BENCH_SINGLE_DEVICE") == "1":
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        if args.gpus != world:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        return run_ranks(args, world)
+    return run_pool(args)
 
+
+# ----------------------------------------------------------------------------------------------------------------
+# plain invocation: one process, in-process device pool
+# ----------------------------------------------------------------------------------------------------------------
+def run_pool(args):
+    if os.environ.get("BENCH_SINGLE_DEVICE") == "1":      # validation of N > 1 on a 1-GPU box: entries wrap around
+        os.environ["PGPU_POOL_OVERSUBSCRIBE"] = "1"
+    try:
+        import torch                                      # one HIP runtime per process: let torch bring it up first
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        torch = None
     import pailliercryptolib_amd as pa
     from pailliercryptolib_amd import _capi
-    from pailliercryptolib_amd.limbs import ints_to_limbs, limbs_to_ints
-
-    pa.initialize(local_rank)
+    from pailliercryptolib_amd.limbs import limbs_to_ints
     L = _capi.lib()
-    nw = KEY_BITS // 64          # words of n
-    pw = nw // 2                 # words of p, q
-
-    # ---- key material: rank 0 owns it, everyone else receives it over RCCL ----
-    key_words = torch.zeros(2 * pw + 2 * nw, dtype=torch.int64, device="cuda")   # p | q | hs
-    if rank == 0:
-        k = json.load(open(os.path.join(ROOT, "tests", "golden", "iso_kat.json")))
-        p, q, hs = int(k["p"], 16), int(k["q"], 16), int(k["bench_hs"], 16)
-        flat = np.concatenate([ints_to_limbs([p], pw)[0], ints_to_limbs([q], pw)[0], ints_to_limbs([hs], 2 * nw)[0]])
-        key_words.copy_(torch.from_numpy(flat.view(np.int64)))
-    if world > 1:
-        dist.broadcast(key_words, src=0)
-    kw = key_words.cpu().numpy().view(np.uint64)
-    p = limbs_to_ints(kw[:pw])[0]
-    q = limbs_to_ints(kw[pw:2 * pw])[0]
-    hs = limbs_to_ints(kw[2 * pw:])[0]
+    N = args.gpus
+    _capi.check(L.pgpu_init_all(N))
+    pa.engine._initialized = True
+    _capi.check(L.pgpu_set_min_shard(256))
+    B = Batches(L, _capi.check)
+    if args.config != 2:
+        result = run_config45(args, pa, L, B, N)
+        print(json.dumps(result), flush=True)
+        pa.terminate()
+        return
+    p, q, hs = iso_key()
     n = p * q
+    nw, pw = KEY_BITS // 64, KEY_BITS // 128
     pk = pa.PublicKey(n, KEY_BITS, hs=hs)
     sk = pa.PrivateKey(p, q)
 
-    # ---- synthetic batch, resident in HBM before the timed region ----
-    rng = np.random.default_rng(1234 + rank)
-    m_host = np.frombuffer(rng.bytes(BATCH * nw * 8), dtype=np.uint64).reshape(BATCH, nw).copy()
-    m_host[:, -1] &= np.uint64((1 << 62) - 1)          # plaintexts < 2^2046 < n
-    r_host = np.frombuffer(rng.bytes(BATCH * pw * 8), dtype=np.uint64).reshape(BATCH, pw).copy()   # 1024-bit r
-    d_m = torch.from_numpy(m_host.view(np.int64)).cuda()
-    d_r = torch.from_numpy(r_host.view(np.int64)).cuda()
-    d_c = torch.empty((BATCH, 2 * nw), dtype=torch.int64, device="cuda")
-    d_out = torch.empty((BATCH, nw), dtype=torch.int64, device="cuda")
-    stream = torch.cuda.current_stream()
-    sptr = ctypes.c_void_p(stream.cuda_stream)
+    # ---- synthetic global batch (N x 8192), sharded over the pool, resident before the timed region ----
+    parts = [synth(g, BATCH, nw, pw) for g in range(N)]
+    m_host = np.concatenate([a for a, _ in parts])
+    r_host = np.concatenate([b for _, b in parts])
+    bm, br = B.up(m_host), B.up(r_host)
+    state = {"c": None, "out": None}
 
-    def enc():
-        _capi.check(L.pgpu_paillier_encrypt_dev(pk._h, d_m.data_ptr(), nw, nw, d_r.data_ptr(), pw, pw, 64 * pw,
-                                                d_c.data_ptr(), BATCH, sptr))
-
-    def dec():
-        _capi.check(L.pgpu_paillier_decrypt_crt_dev(sk._h, d_c.data_ptr(), d_out.data_ptr(), BATCH, sptr))
+    def step():
+        B.free(state["c"], state["out"])
+        state["c"] = B.op(L.pgpu_batch_encrypt, pk._h, bm, br, 64 * pw)
+        state["out"] = B.op(L.pgpu_batch_decrypt_crt, sk._h, state["c"])
 
     def sync_all():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        _capi.check(L.pgpu_synchronize())
+        if torch is not None and torch.cuda.is_available():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        enc()
-        dec()
+        step()
     sync_all()
-    # live per-kernel timing: the library brackets every launch with HIP events on the launch
-    # stream (no sync inside the timed region); collected after the final synchronisation
+    # live per-kernel timing: the library brackets every launch with HIP events on the launch stream (no
+    # synchronisation inside the timed region); collected after the final synchronisation (pool entry 0)
     _capi.check(L.pgpu_set_timing(1))
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        enc()
-        dec()
+    for _ in range(args.steps):
+        step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    kinds = (ctypes.c_int * (4 * args.steps + 8))()
-    kms = (ctypes.c_double * (4 * args.steps + 8))()
-    nrec = L.pgpu_timing_collect(kinds, kms, len(kinds))
+    per_kind = collect_timing(L, 4 * args.steps + 8)
     _capi.check(L.pgpu_set_timing(0))
-    per_kind = {}
-    for i in range(nrec):
-        per_kind.setdefault(kinds[i], []).append(kms[i])
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     # ---- correctness of what was timed: full-size round trip + oracle spot checks ----
-    ok = bool(torch.equal(d_out, d_m))
-    if rank == 0:
-        from oracle import paillier_oracle as orc
-        opk = orc.PublicKey(n, KEY_BITS)
-        opk.set_djn(hs)
-        c_host = d_c[:3].cpu().numpy().view(np.uint64)
-        want = opk.encrypt(limbs_to_ints(m_host[:3]), limbs_to_ints(r_host[:3]))
-        ok = ok and (limbs_to_ints(c_host) == want)
+    ok = bool(np.array_equal(B.down(state["out"]), m_host))
+    from oracle import paillier_oracle as orc
+    opk = orc.PublicKey(n, KEY_BITS)
+    opk.set_djn(hs)
+    c_all = B.down(state["c"])
+    idx = [0, 1, 2, BATCH - 1, N * BATCH - 1]
+    want = opk.encrypt(limbs_to_ints(m_host[idx]), limbs_to_ints(r_host[idx]))
+    ok = ok and (limbs_to_ints(c_all[idx]) == want)
     if not ok:
         raise SystemExit("bench: GPU results differ from the oracle / round trip failed")
 
-    K_MODEXP, K_MODMUL, K_CRT, K_FB = 1, 2, 3, 4
+    result = headline(args, N, elapsed, per_kind, nw, pw,
+                      f"in-process device pool x{N} (batch sharded; key images: {L.pgpu_pool_transport().decode()})")
+    result["config"]["secret_exponent_policy"] = ["fixed-window", "sliding"][L.pgpu_get_secret_exponent_policy()]
+    if N == 1 and not args.no_extras:
+        result.update(extras(pa, L, B, pk, sk, n, p, q, hs, m_host, r_host, per_kind))
+    if N == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(n, p, q, hs, m_host, r_host)
+    B.free(state["c"], state["out"], bm, br)
+    print(json.dumps(result), flush=True)
+    pa.terminate()
+
+
+def headline(args, world, elapsed, per_kind, nw, pw, parallelism):
+    """the contract line (metric / value / roofline of the dominant kernel) from the timed region's numbers"""
     fixed_base = K_FB in per_kind
     enc_ms = float(np.mean(per_kind[K_FB])) if fixed_base else None
     modexp_ms = per_kind.get(K_MODEXP, [])
@@ -171,94 +222,410 @@ def main():
     crt_ms = float(np.mean(per_kind[K_CRT]))
     modexps_per_step = 3 * BATCH * world
     value = modexps_per_step * args.steps / elapsed
-
-    if rank == 0:
-        mac_enc = algorithmic_mac32(2 * KEY_BITS, KEY_BITS // 2) * BATCH        # 41.48 M * 8192
-        mac_dec = 2 * algorithmic_mac32(KEY_BITS, KEY_BITS // 2) * BATCH        # 20.82 M * 8192
-        alg_bytes_dec = (2 * nw * 8 + nw * 8) * BATCH                           # c + m = 768 B/elt
-        alg_bytes_enc = (nw * 8 + pw * 8 + 2 * nw * 8) * BATCH                  # m + r + c = 896 B/elt
-        achieved = mac_dec / (dec_ms * 1e-3) / 1e12
-        pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-        # encrypt leg: with fixed-base tables the kernel EXECUTES far fewer multiplications than the
-        # canonical square-and-multiply count, so its honest ALU fraction uses the executed count
-        fbw = int(os.environ.get("PGPU_FB_WINDOW", "12"))
-        s4096 = 2 * KEY_BITS // 32
-        if fixed_base:
-            nmul = (KEY_BITS // 2 + fbw - 1) // fbw + 1            # nwin-1 table products + g^m + exit
-            mac_enc_exec = (2 * s4096 * s4096 + s4096) * nmul * BATCH
-        else:
-            mac_enc_exec = mac_enc
-        result = {
-            "metric": "2048-bit modexps/sec (encrypt+decrypt)",
-            "value": round(value, 1),
-            "unit": "modexps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u64",
-            "data": "synthetic",
-            "config": {
-                "workload": "k=2048 ISO/IEC 18033-6 key, DJN: encrypt batch=8192 (mod n^2, 4096 b, e=1024 b) "
-                            "+ CRT decrypt batch=8192 (2x mod p^2/q^2, 2048 b, e=1024 b) per GPU per step",
-                "batch_per_gpu": BATCH, "modexps_per_step_per_gpu": 3 * BATCH,
-                "parallelism": f"batch-sharded x{world} (key broadcast only)",
-                "elements_per_s": round(BATCH * world * args.steps / elapsed, 1),
-            },
-            "roofline": {
-                "bound": "int-alu",
-                "bound_note": "VALU issue rate: v_mad_u64_u32 issues at full rate, one wave64 instruction per 4 cycles per SIMD "
-                              "= 39.32 T MAC32/s at 2.4 GHz (38.35 measured, profiles/r01_ubench_mad_peak.txt); "
-                              "neither hbm nor mfma binds this path: integer carry-chain work, HBM at 1e-4 of peak",
-                "kernel": f"modexp_kernel<{geo_name(nw, KEY_BITS, 2 * BATCH)}> (CRT-decrypt leg: {2 * BATCH} half-width "
-                          "modexps per launch; the dominant kernel of the step)",
-                "achieved": round(achieved, 3),
-                "peak": PEAK_TMAC32,
-                "unit": "TMAC32/s",
-                "frac": round(achieved / PEAK_TMAC32, 4),
-                "traffic": pmc.get("modexp_decrypt_hbm_bytes_per_launch"),
-                "kernel_ms": round(dec_ms, 4),
-                "algorithmic_mac32_per_launch": mac_dec,
-                "algorithmic_bytes_per_launch": alg_bytes_dec,
-                "hbm_achieved_GBs": round(alg_bytes_dec / (dec_ms * 1e-3) / 1e9, 3),
-                "hbm_peak_GBs": HBM_PEAK_GBS,
-                "hbm_frac": round(alg_bytes_dec / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                "other_kernels": {
-                    "crt_kernel<Geo<8,9>>": {"ms": round(crt_ms, 4)},
-                    (f"fb_encrypt_kernel<{geo_name(2 * nw, 2 * KEY_BITS, BATCH)}>" if fixed_base
-                     else f"modexp_kernel<{geo_name(2 * nw, 2 * KEY_BITS, BATCH)}> (encrypt)"): {
-                        "ms": round(enc_ms, 4),
-                        "canonical_mac32_per_launch": mac_enc,
-                        "executed_mac32_per_launch": mac_enc_exec,
-                        "executed_TMAC32_per_s": round(mac_enc_exec / (enc_ms * 1e-3) / 1e12, 3),
-                        "executed_frac": round(mac_enc_exec / (enc_ms * 1e-3) / 1e12 / PEAK_TMAC32, 4),
-                        "canonical_TMAC32_per_s": round(mac_enc / (enc_ms * 1e-3) / 1e12, 3),
-                        "algorithmic_bytes_per_launch": alg_bytes_enc,
-                        "traffic": pmc.get("fb_encrypt_hbm_bytes_per_launch"),
-                        "note": ("fixed-base windowing w=%d: hs^r as %d table products, no squarings" % (fbw, nmul - 2))
-                                if fixed_base else "generic square-and-multiply",
-                    },
+    mac_enc = algorithmic_mac32(2 * KEY_BITS, KEY_BITS // 2) * BATCH        # 41.48 M * 8192
+    mac_dec = 2 * algorithmic_mac32(KEY_BITS, KEY_BITS // 2) * BATCH        # 20.82 M * 8192
+    alg_bytes_dec = (2 * nw * 8 + nw * 8) * BATCH                           # c + m = 768 B/elt
+    alg_bytes_enc = (nw * 8 + pw * 8 + 2 * nw * 8) * BATCH                  # m + r + c = 896 B/elt
+    achieved = mac_dec / (dec_ms * 1e-3) / 1e12
+    pmc = {}
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
+    # encrypt leg: with fixed-base tables the kernel EXECUTES far fewer multiplications than the
+    # canonical square-and-multiply count, so its honest ALU fraction uses the executed count
+    fbw = int(os.environ.get("PGPU_FB_WINDOW", "12"))
+    s4096 = 2 * KEY_BITS // 32
+    if fixed_base:
+        nmul = (KEY_BITS // 2 + fbw - 1) // fbw + 1            # nwin-1 table products + g^m + exit
+        mac_enc_exec = (2 * s4096 * s4096 + s4096) * nmul * BATCH
+    else:
+        mac_enc_exec = mac_enc
+    return {
+        "metric": "2048-bit modexps/sec (encrypt+decrypt)",
+        "value": round(value, 1),
+        "unit": "modexps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": "k=2048 ISO/IEC 18033-6 key, DJN: encrypt batch=8192 (mod n^2, 4096 b, e=1024 b) "
+                        "+ CRT decrypt batch=8192 (2x mod p^2/q^2, 2048 b, e=1024 b) per GPU per step",
+            "batch_per_gpu": BATCH, "modexps_per_step_per_gpu": 3 * BATCH,
+            "parallelism": parallelism,
+            "elements_per_s": round(BATCH * world * args.steps / elapsed, 1),
+        },
+        "roofline": {
+            "bound": "int-alu",
+            "bound_note": "VALU issue rate: v_mad_u64_u32 issues at full rate, one wave64 instruction per 4 cycles per SIMD "
+                          "= 39.32 T MAC32/s at 2.4 GHz (38.35 measured, profiles/r01_ubench_mad_peak.txt); "
+                          "neither hbm nor mfma binds this path: integer carry-chain work, HBM at 1e-4 of peak",
+            "kernel": f"modexp_kernel<{geo_name(nw, KEY_BITS, 2 * BATCH)}> (CRT-decrypt leg: {2 * BATCH} half-width "
+                      "modexps per launch; the dominant kernel of the step)",
+            "achieved": round(achieved, 3),
+            "peak": PEAK_TMAC32,
+            "unit": "TMAC32/s",
+            "frac": round(achieved / PEAK_TMAC32, 4),
+            "traffic": pmc.get("modexp_decrypt_hbm_bytes_per_launch"),
+            "kernel_ms": round(dec_ms, 4),
+            "algorithmic_mac32_per_launch": mac_dec,
+            "algorithmic_bytes_per_launch": alg_bytes_dec,
+            "hbm_achieved_GBs": round(alg_bytes_dec / (dec_ms * 1e-3) / 1e9, 3),
+            "hbm_peak_GBs": HBM_PEAK_GBS,
+            "hbm_frac": round(alg_bytes_dec / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+            "other_kernels": {
+                "crt_kernel<Geo<8,9>>": {"ms": round(crt_ms, 4)},
+                (f"fb_encrypt_kernel<{geo_name(2 * nw, 2 * KEY_BITS, BATCH)}>" if fixed_base
+                 else f"modexp_kernel<{geo_name(2 * nw, 2 * KEY_BITS, BATCH)}> (encrypt)"): {
+                    "ms": round(enc_ms, 4),
+                    "canonical_mac32_per_launch": mac_enc,
+                    "executed_mac32_per_launch": mac_enc_exec,
+                    "executed_TMAC32_per_s": round(mac_enc_exec / (enc_ms * 1e-3) / 1e12, 3),
+                    "executed_frac": round(mac_enc_exec / (enc_ms * 1e-3) / 1e12 / PEAK_TMAC32, 4),
+                    "canonical_TMAC32_per_s": round(mac_enc / (enc_ms * 1e-3) / 1e12, 3),
+                    "algorithmic_bytes_per_launch": alg_bytes_enc,
+                    "traffic": pmc.get("fb_encrypt_hbm_bytes_per_launch"),
+                    "note": ("fixed-base windowing w=%d: hs^r as %d table products, no squarings" % (fbw, nmul - 2))
+                            if fixed_base else "generic square-and-multiply",
                 },
             },
+        },
+        # the conservative reading of the headline: the CRT-decrypt leg alone (no fixed-base shortcut in it)
+        "decrypt_only_modexps_per_s": round(2 * BATCH / ((dec_ms + crt_ms) * 1e-3), 1),
+    }
+
+
+def best_of(fn, reps):
+    best = 1e30
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
+def extras(pa, L, B, pk, sk, n, p, q, hs, m_host, r_host, per_kind):
+    """SURVEY 8(d) side measurements, N = 1, outside the timed region (VERDICT r01 'next' item 3)."""
+    from pailliercryptolib_amd import _capi
+    nw, pw = m_host.shape[1], r_host.shape[1]
+    out = {}
+    # (1) the same step through the synchronous host-pointer entry points: H2D + kernels + D2H per call
+    c_host = np.empty((BATCH, 2 * nw), dtype=np.uint64)
+    d_host = np.empty((BATCH, nw), dtype=np.uint64)
+
+    def e2e_enc():
+        _capi.check(L.pgpu_paillier_encrypt(pk._h, ptr(m_host), nw, nw, ptr(r_host), pw, pw, 64 * pw, ptr(c_host), BATCH))
+
+    def e2e_dec():
+        _capi.check(L.pgpu_paillier_decrypt_crt(sk._h, ptr(c_host), ptr(d_host), BATCH))
+    e2e_enc(); e2e_dec()
+    te, td = best_of(e2e_enc, 5), best_of(e2e_dec, 5)
+    assert np.array_equal(d_host, m_host)
+    out["end_to_end"] = {"what": "pgpu_paillier_encrypt + pgpu_paillier_decrypt_crt on caller-owned host arrays "
+                                 "(pinned staging, H2D + kernels + D2H inside the call)",
+                         "encrypt_ms": round(te * 1e3, 3), "decrypt_ms": round(td * 1e3, 3),
+                         "modexps_per_s": round(3 * BATCH / (te + td), 1)}
+    # (2) the API-visible timing of the reference's own benchmark: ipcl::PublicKey::encrypt / PrivateKey::decrypt with
+    # std::vector<BigNumber> in and out (benchmark/bench_cryptography.cpp:73-121)
+    try:
+        out["api_level"] = api_level()
+    except Exception as e:                                  # noqa: BLE001 -- a side measurement must not sink the line
+        out["api_level"] = {"error": str(e)[:300]}
+    # (3) config 2 with the plain obfuscator r^n mod n^2 (2048-bit exponent) instead of DJN's hs^r
+    pk2 = pa.PublicKey(n, KEY_BITS)
+    rng = np.random.default_rng(99)
+    r2 = np.frombuffer(rng.bytes(BATCH * nw * 8), dtype=np.uint64).reshape(BATCH, nw).copy()
+    r2[:, -1] &= np.uint64((1 << 62) - 1)
+    bm, br2 = B.up(m_host), B.up(r2)
+    hold = {}
+
+    def nondjn():
+        B.free(hold.get("c"))
+        hold["c"] = B.op(L.pgpu_batch_encrypt, pk2._h, bm, br2, 64 * nw)
+        _capi.check(L.pgpu_synchronize())
+    nondjn()
+    tn = best_of(nondjn, 3)
+    dec = B.op(L.pgpu_batch_decrypt_crt, sk._h, hold["c"])
+    assert np.array_equal(B.down(dec), m_host)
+    mac = algorithmic_mac32(2 * KEY_BITS, KEY_BITS) * BATCH
+    out["config2_nondjn"] = {"what": "encrypt batch=8192 with the non-DJN obfuscator r^n mod n^2 (e = n, 2048 b), resident",
+                             "encrypt_ms": round(tn * 1e3, 3), "encrypts_per_s": round(BATCH / tn, 1),
+                             "frac_of_peak": round(mac / tn / 1e12 / PEAK_TMAC32, 4),
+                             "step_modexps_per_s_with_it": round(
+                                 3 * BATCH / (tn + (np.mean(per_kind[K_MODEXP]) + np.mean(per_kind[K_CRT])) * 1e-3), 1)}
+    B.free(hold.get("c"), dec, bm, br2)
+    return out
+
+
+def api_level():
+    from pailliercryptolib_amd import build
+    exe = build.build_api_bench()
+    r = subprocess.run([exe, "--json", str(BATCH)], capture_output=True, text=True, timeout=300)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr[-300:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    d["modexps_per_s"] = round(3 * BATCH / ((d["encrypt_us"] + d["decrypt_us"]) * 1e-6), 1)
+    return d
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[3] / configs[4]: fixed total, sharded over the pool
+# ----------------------------------------------------------------------------------------------------------------
+def run_config45(args, pa, L, B, N):
+    from oracle import paillier_oracle as orc
+    from pailliercryptolib_amd import _capi
+    from pailliercryptolib_amd.limbs import limbs_to_ints
+    sync = lambda: _capi.check(L.pgpu_synchronize())
+    if args.config == 4:
+        case = [c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "seeded_vectors.json")))["cases"]
+                if c["bits"] == 3072 and c["djn"]][0]
+        p, q, hs = int(case["p"], 16), int(case["q"], 16), int(case["hs"], 16)
+        n, bits, total = p * q, 3072, 65536
+        nw, pw = bits // 64, bits // 128
+        pk, sk = pa.PublicKey(n, bits, hs=hs), pa.PrivateKey(p, q)
+        m_host, r_host = synth(0, total, nw, pw)
+        bm, br = B.up(m_host), B.up(r_host)
+        st = {}
+
+        def step():
+            B.free(st.get("c"), st.get("o"))
+            st["c"] = B.op(L.pgpu_batch_encrypt, pk._h, bm, br, 64 * pw)
+            st["o"] = B.op(L.pgpu_batch_decrypt_crt, sk._h, st["c"])
+        for _ in range(max(1, args.warmup)):
+            step()
+        sync()
+        _capi.check(L.pgpu_set_timing(1))
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        elapsed = time.perf_counter() - t0
+        per = collect_timing(L, 4 * args.steps + 8)
+        _capi.check(L.pgpu_set_timing(0))
+        assert np.array_equal(B.down(st["o"]), m_host), "config 4: round trip failed"
+        opk = orc.PublicKey(n, bits)
+        opk.set_djn(hs)
+        assert limbs_to_ints(B.down(st["c"])[:2]) == opk.encrypt(limbs_to_ints(m_host[:2]), limbs_to_ints(r_host[:2]))
+        # host-buffer (PCIe-inclusive) variant of the same step
+        c_host = np.empty((total, 2 * nw), dtype=np.uint64)
+        d_host = np.empty((total, nw), dtype=np.uint64)
+
+        def e2e():
+            _capi.check(L.pgpu_paillier_encrypt(pk._h, ptr(m_host), nw, nw, ptr(r_host), pw, pw, 64 * pw, ptr(c_host), total))
+            _capi.check(L.pgpu_paillier_decrypt_crt(sk._h, ptr(c_host), ptr(d_host), total))
+        e2e()
+        t_e2e = best_of(e2e, 2)
+        assert np.array_equal(d_host, m_host)
+        shard = total // N
+        dec_ms = float(np.mean(per[K_MODEXP]))
+        mac_dec = 2 * algorithmic_mac32(bits, bits // 2) * shard
+        return {
+            "metric": "3072-bit modexps/sec (encrypt+decrypt), batch=65536 sharded over the GPUs",
+            "value": round(3 * total * args.steps / elapsed, 1), "unit": "modexps/s", "n_gpus": N, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: k=3072 DJN key, batch=65536 encrypt + CRT decrypt, sharded "
+                                   f"contiguously over {N} GPU(s) ({shard} elements each), resident",
+                       "elements_per_s": round(total * args.steps / elapsed, 1),
+                       "parallelism": f"in-process device pool x{N} (key images: {L.pgpu_pool_transport().decode()})"},
+            "roofline": {"bound": "int-alu", "kernel": f"modexp_kernel<{geo_name(nw, bits, 2 * shard)}> (CRT-decrypt leg, "
+                                                       f"{2 * shard} half-width modexps per launch per GPU)",
+                         "achieved": round(mac_dec / (dec_ms * 1e-3) / 1e12, 3), "peak": PEAK_TMAC32, "unit": "TMAC32/s",
+                         "frac": round(mac_dec / (dec_ms * 1e-3) / 1e12 / PEAK_TMAC32, 4), "traffic": None,
+                         "kernel_ms": round(dec_ms, 4),
+                         "other_kernels": {"fb_encrypt_kernel": {"ms": round(float(np.mean(per[K_FB])), 4)},
+                                           "crt_kernel": {"ms": round(float(np.mean(per[K_CRT])), 4)}}},
+            "end_to_end": {"what": "the same step from caller-owned host arrays (H2D + kernels + D2H)",
+                           "ms_per_step": round(t_e2e * 1e3, 3), "modexps_per_s": round(3 * total / t_e2e, 1)},
         }
-        if not args.no_cpu_baseline and world == 1:     # reported at N=1 only (rank 0)
-            result["cpu_baseline"] = cpu_baseline(n, p, q, hs, m_host, r_host)
-        print(json.dumps(result), flush=True)
-    if world > 1:
+    # ---- config 5: 2048-bit CT+CT and CT x PT on 1 M elements ----
+    p, q, hs = iso_key()
+    n = p * q
+    nsq = n * n
+    nw = KEY_BITS // 64
+    W = 2 * nw
+    total = 1 << 20
+    pk = pa.PublicKey(n, KEY_BITS, hs=hs)
+    rng = np.random.default_rng(5)
+    a_host = np.frombuffer(rng.bytes(total * W * 8), dtype=np.uint64).reshape(total, W).copy()
+    b_host = np.frombuffer(rng.bytes(total * W * 8), dtype=np.uint64).reshape(total, W).copy()
+    a_host[:, -1] &= np.uint64((1 << 60) - 1)        # < n^2 (top word of n^2 is > 2^61 for this key)
+    b_host[:, -1] &= np.uint64((1 << 60) - 1)
+    e_host = np.frombuffer(rng.bytes(total * 8), dtype=np.uint64).reshape(total, 1).copy() & np.uint64(0xFFFFFFFF)
+    ba_plain, bb_plain, be = B.up(a_host), B.up(b_host), B.up(e_host)
+    # a resident chain keeps its ciphertexts in the Montgomery domain: bring the operands there once, untimed
+    one = B.up(np.array([[1] + [0] * (W - 1)], dtype=np.uint64))
+    ba = B.op(L.pgpu_batch_ct_add, pk._h, ba_plain, one)
+    bb = B.op(L.pgpu_batch_ct_add, pk._h, bb_plain, one)
+    sync()
+    st = {}
+
+    def add():
+        B.free(st.get("s"))
+        st["s"] = B.op(L.pgpu_batch_ct_add, pk._h, ba, bb)
+
+    def mul():
+        B.free(st.get("t"))
+        st["t"] = B.op(L.pgpu_batch_ct_mul, pk._h, ba, be, 32)
+    add(); mul(); sync()
+    _capi.check(L.pgpu_set_timing(1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        add()
+    sync()
+    t_add = (time.perf_counter() - t0) / args.steps
+    per_add = collect_timing(L, args.steps + 8)
+    t0 = time.perf_counter()
+    for _ in range(max(1, args.steps // 4)):
+        mul()
+    sync()
+    t_mul = (time.perf_counter() - t0) / max(1, args.steps // 4)
+    per_mul = collect_timing(L, args.steps + 8)
+    _capi.check(L.pgpu_set_timing(0))
+    idx = [0, 1, total // 2, total - 1]
+    av, bv, ev = limbs_to_ints(a_host[idx]), limbs_to_ints(b_host[idx]), [int(x) for x in e_host[idx, 0]]
+    assert limbs_to_ints(B.down(st["s"])[idx]) == [x * y % nsq for x, y in zip(av, bv)], "config 5: CT+CT differs"
+    assert limbs_to_ints(B.down(st["t"])[idx]) == [pow(x, y, nsq) for x, y in zip(av, ev)], "config 5: CTxPT differs"
+    # host-buffer (PCIe-bound) variant of CT+CT
+    o_host = np.empty_like(a_host)
+    mod = np.array([(nsq >> (64 * i)) & ((1 << 64) - 1) for i in range(W)], dtype=np.uint64)
+
+    def e2e_add():
+        _capi.check(L.pgpu_modmul(ptr(a_host), ptr(b_host), W, ptr(mod), W, ptr(o_host), total))
+    e2e_add()
+    t_e2e = best_of(e2e_add, 2)
+    shard = total // N
+    mm_ms = float(np.mean(per_add[K_MODMUL]))
+    # SURVEY 8(d) / BASELINE.md: "CT add = 65 792 MAC32" = TWO canonical Montgomery products mod n^2 per element
+    # (into the domain and the product); a resident chain executes ONE, so the executed fraction is half of `frac`
+    mac_add = 2 * (2 * 128 * 128 + 128) * shard
+    mac_mul = algorithmic_mac32(2 * KEY_BITS, 32) * shard
+    me_ms = float(np.mean(per_mul[K_MODEXP]))
+    return {
+        "metric": "2048-bit CipherText add (modmul mod n^2) elements/sec, batch=1M sharded over the GPUs",
+        "value": round(total / t_add, 1), "unit": "modmuls/s", "n_gpus": N, "steps": args.steps, "warmup": 1,
+        "ms_per_step": round(t_add * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4]: k=2048, batch=1M: (i) CT+CT on resident Montgomery-domain ciphertexts "
+                               "(one product each), (ii) CT x PT with 32-bit plaintexts; sharded contiguously over "
+                               f"{N} GPU(s) ({shard} elements each)",
+                   "parallelism": f"in-process device pool x{N} (key images: {L.pgpu_pool_transport().decode()})"},
+        "roofline": {"bound": "int-alu", "kernel": f"modmul_kernel<{geo_name(W, 2 * KEY_BITS, shard)}> (CT+CT, {shard} per GPU)",
+                     "achieved": round(mac_add / (mm_ms * 1e-3) / 1e12, 3), "peak": PEAK_TMAC32, "unit": "TMAC32/s",
+                     "frac": round(mac_add / (mm_ms * 1e-3) / 1e12 / PEAK_TMAC32, 4), "traffic": None,
+                     "kernel_ms": round(mm_ms, 4), "executed_frac": round(mac_add / 2 / (mm_ms * 1e-3) / 1e12 / PEAK_TMAC32, 4),
+                     "algorithmic_bytes_per_launch": 3 * W * 8 * shard,
+                     "hbm_achieved_GBs": round(3 * W * 8 * shard / (mm_ms * 1e-3) / 1e9, 1), "hbm_peak_GBs": HBM_PEAK_GBS,
+                     "hbm_frac": round(3 * W * 8 * shard / (mm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "config5_mul_ctpt_u32": {"ms_per_step": round(t_mul * 1e3, 3), "modexps_per_s": round(total / t_mul, 1),
+                                 "kernel": f"modexp_kernel<{geo_name(W, 2 * KEY_BITS, shard)}>", "kernel_ms": round(me_ms, 3),
+                                 "frac": round(mac_mul / (me_ms * 1e-3) / 1e12 / PEAK_TMAC32, 4)},
+        "end_to_end": {"what": "CT+CT through pgpu_modmul on caller-owned host arrays (plain operands: two products, "
+                               "H2D + kernel + D2H pipelined in sub-batches over the worker lanes)",
+                       "ms_per_step": round(t_e2e * 1e3, 3), "modmuls_per_s": round(total / t_e2e, 1),
+                       "host_GBs": round(3 * W * 8 * total / t_e2e / 1e9, 2)},
+    }
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# under torch.distributed.run: one process per GPU, RCCL only for the key broadcast
+# ----------------------------------------------------------------------------------------------------------------
+def run_ranks(args, world):
+    import torch
+    import torch.distributed as dist
+    if args.config != 2:
+        raise SystemExit("--config 4|5 run through the in-process pool: invoke bench.py plainly (no torchrun)")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # validation-only knobs (exercise this path on a 1-GPU box): BENCH_SINGLE_DEVICE=1 puts every rank on
+    # device 0, BENCH_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU)
+    if os.environ.get("BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
+
+    import pailliercryptolib_amd as pa
+    from pailliercryptolib_amd import _capi
+    from pailliercryptolib_amd.limbs import ints_to_limbs, limbs_to_ints
+    pa.initialize(local_rank)
+    L = _capi.lib()
+    nw, pw = KEY_BITS // 64, KEY_BITS // 128
+
+    # ---- key material: rank 0 owns it, everyone else receives it over RCCL ----
+    key_words = torch.zeros(2 * pw + 2 * nw, dtype=torch.int64, device="cuda")   # p | q | hs
+    if rank == 0:
+        p, q, hs = iso_key()
+        flat = np.concatenate([ints_to_limbs([p], pw)[0], ints_to_limbs([q], pw)[0], ints_to_limbs([hs], 2 * nw)[0]])
+        key_words.copy_(torch.from_numpy(flat.view(np.int64)))
+    dist.broadcast(key_words, src=0)
+    kw = key_words.cpu().numpy().view(np.uint64)
+    p, q, hs = limbs_to_ints(kw[:pw])[0], limbs_to_ints(kw[pw:2 * pw])[0], limbs_to_ints(kw[2 * pw:])[0]
+    n = p * q
+    pk, sk = pa.PublicKey(n, KEY_BITS, hs=hs), pa.PrivateKey(p, q)
+
+    m_host, r_host = synth(rank, BATCH, nw, pw)
+    d_m = torch.from_numpy(m_host.view(np.int64)).cuda()
+    d_r = torch.from_numpy(r_host.view(np.int64)).cuda()
+    d_c = torch.empty((BATCH, 2 * nw), dtype=torch.int64, device="cuda")
+    d_out = torch.empty((BATCH, nw), dtype=torch.int64, device="cuda")
+    sptr = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def step():
+        _capi.check(L.pgpu_paillier_encrypt_dev(pk._h, d_m.data_ptr(), nw, nw, d_r.data_ptr(), pw, pw, 64 * pw,
+                                                d_c.data_ptr(), BATCH, sptr))
+        _capi.check(L.pgpu_paillier_decrypt_crt_dev(sk._h, d_c.data_ptr(), d_out.data_ptr(), BATCH, sptr))
+
+    def sync_all():
+        torch.cuda.synchronize()
         dist.barrier()
-        dist.destroy_process_group()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    _capi.check(L.pgpu_set_timing(1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    per_kind = collect_timing(L, 4 * args.steps + 8)
+    _capi.check(L.pgpu_set_timing(0))
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ok = bool(torch.equal(d_out, d_m))
+    if rank == 0:
+        from oracle import paillier_oracle as orc
+        opk = orc.PublicKey(n, KEY_BITS)
+        opk.set_djn(hs)
+        ok = ok and limbs_to_ints(d_c[:3].cpu().numpy().view(np.uint64)) == \
+            opk.encrypt(limbs_to_ints(m_host[:3]), limbs_to_ints(r_host[:3]))
+    if not ok:
+        raise SystemExit("bench: GPU results differ from the oracle / round trip failed")
+    if rank == 0:
+        result = headline(args, world, elapsed, per_kind, nw, pw,
+                          f"one process per GPU x{world} (torch.distributed {backend}; key broadcast only)")
+        result["config"]["secret_exponent_policy"] = ["fixed-window", "sliding"][L.pgpu_get_secret_exponent_policy()]
+        print(json.dumps(result), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
     pa.terminate()
 
 
 def geo_name(in_words, mod_bits, count):
     """modexp / fb_encrypt kernel instantiation the library launches for this shape (pgpu_kernel_geometry)."""
-    import ctypes
     from pailliercryptolib_amd import _capi
     g, k = ctypes.c_int(), ctypes.c_int()
     _capi.check(_capi.lib().pgpu_kernel_geometry(in_words, mod_bits, count, ctypes.byref(g), ctypes.byref(k)))
@@ -274,14 +641,13 @@ def cpu_baseline(n, p, q, hs, m_host, r_host):
                                      mbx_exp_mb8 path runs (a restatement, not IPP-Crypto); needs avx512ifma
       openssl BN_mod_exp_mont        the oracle of the reference's own QAT tests (BASELINE.md "B2")
       scalar  oracle/modexp_oracle.c 64-bit CIOS Montgomery + 5-bit fixed window
-    "value" is the fastest leg available on this host."""
+    Every leg is timed with all usable cores and with ONE thread.  "value" is the fastest all-core leg."""
     from oracle import c_oracle
     from oracle import paillier_oracle as orc
     from pailliercryptolib_amd.limbs import ints_to_limbs
     nw, pw = m_host.shape[1], r_host.shape[1]
     sk = orc.PrivateKey(n, p, q)
     threads = min(c_oracle.lib().orc_max_threads(), c_oracle.usable_cpus())   # honours the cgroup CPU quota
-    c_oracle.set_threads(threads)
     args = [ints_to_limbs([v], pw)[0] for v in (sk.p, sk.q, sk.hp, sk.hq, sk.pinv)]
     n_l, hs_l = ints_to_limbs([n], nw)[0], ints_to_limbs([hs], 2 * nw)[0]
 
@@ -292,8 +658,9 @@ def cpu_baseline(n, p, q, hs, m_host, r_host):
         return (lambda m, r: c_oracle.paillier_encrypt_with(backend, n_l, hs_l, m, r),
                 lambda c: c_oracle.paillier_decrypt_crt_with(backend, *args, c))
 
-    def measure(backend, target_s):
+    def measure(backend, target_s, nthreads):
         enc, dec = flows(backend)
+        c_oracle.set_threads(nthreads)
 
         def run(S):
             t0 = time.perf_counter()
@@ -301,10 +668,10 @@ def cpu_baseline(n, p, q, hs, m_host, r_host):
             dt = time.perf_counter() - t0
             assert np.array_equal(m, m_host[:S])
             return dt
-        probe = max(8 * threads, 64)
+        probe = max(8 * nthreads, 16)
         dt = run(probe)
         S = int(min(m_host.shape[0], max(probe, probe * target_s / dt)))
-        S -= S % (8 * threads) if S > 8 * threads else 0
+        S -= S % (8 * nthreads) if S > 8 * nthreads else 0
         dt = run(S)
         reps = 1
         if S == m_host.shape[0] and dt < 0.6 * target_s:      # whole batch too short: repeat it
@@ -313,11 +680,16 @@ def cpu_baseline(n, p, q, hs, m_host, r_host):
         return {"value": round(3 * S * reps / dt, 1), "elements": S * reps, "seconds": round(dt, 2)}
 
     legs = {}
+    backends = []
     if c_oracle.ifma_lib() is not None:
-        legs["ifma"] = measure(c_oracle.ifma_modexp_batch, 8.0)
+        backends.append(("ifma", c_oracle.ifma_modexp_batch, 6.0))
     if c_oracle.openssl_lib() is not None:
-        legs["openssl"] = measure(c_oracle.openssl_modexp_batch, 6.0)
-    legs["scalar"] = measure(None, 8.0)
+        backends.append(("openssl", c_oracle.openssl_modexp_batch, 4.0))
+    backends.append(("scalar", None, 5.0))
+    for name, be, target in backends:
+        legs[name] = measure(be, target, threads)
+        legs[name]["one_thread"] = measure(be, 2.0, 1)
+    c_oracle.set_threads(threads)
     best = max(legs, key=lambda k: legs[k]["value"])
     what = {"ifma": "oracle/ifma_oracle.c (8-lane AVX512-IFMA radix-2^52 restatement of the reference's mb8 path)",
             "openssl": "OpenSSL BN_mod_exp_mont", "scalar": "oracle/modexp_oracle.c (64-bit CIOS)"}[best]
@@ -326,8 +698,8 @@ def cpu_baseline(n, p, q, hs, m_host, r_host):
                       f"time target), encrypt + CRT decrypt "
                       f"({3 * legs[best]['elements']} modexps) in {legs[best]['seconds']} s; {what}, gcc -O3 "
                       f"-fopenmp; {threads} OpenMP threads = min(affinity {len(os.sched_getaffinity(0))}, "
-                      f"cgroup cpu quota {c_oracle.usable_cpus()})",
-            "leg": best, "legs": legs}
+                      f"cgroup cpu quota {c_oracle.usable_cpus()}); every leg also timed with 1 thread (legs.*.one_thread)",
+            "leg": best, "one_thread_value": legs[best]["one_thread"]["value"], "legs": legs}
 
 
 if __name__ == "__main__":

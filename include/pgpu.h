@@ -92,6 +92,13 @@ const char* pgpu_pool_transport(void);
 /* batches smaller than min_shard * k elements are spread over at most k GPUs (default 256; env
  * PGPU_MIN_SHARD) */
 int pgpu_set_min_shard(size_t min_elements_per_device);
+/* waits for everything queued on the pool's own streams (resident-batch operations, worker lanes) on every GPU */
+int pgpu_synchronize(void);
+/* The cut a batch of `count` elements receives on a pool of `pool_size` GPUs: *n_shards shards, shard i =
+ * elements [bounds[i], bounds[i+1]) on pool entry i (contiguous, in order, sizes differ by at most one;
+ * bounds has room for pool_size + 1 entries).  Pure host-side query (needs no device): this is the rule every
+ * host-pointer entry point and every pgpu_batch follows. */
+int pgpu_shard_plan(size_t count, int pool_size, int* n_shards, size_t* bounds);
 
 /* ---- generic batched modular exponentiation: out[i] = base[i]^exp[i] mod mod ----
  * Replaces mbx_exp_mb8 (mod_exp.cpp:508-516) / ippsMontExp (mod_exp.cpp:549-579) under

@@ -23,7 +23,7 @@ SYMBOLS = [
     "pgpu_set_fixed_base_window", "pgpu_set_timing", "pgpu_timing_collect",
     "pgpu_kernel_geometry",
     "pgpu_init_all", "pgpu_pool_size", "pgpu_set_device", "pgpu_get_device", "pgpu_pool_transport",
-    "pgpu_set_min_shard", "pgpu_set_secret_exponent_policy", "pgpu_get_secret_exponent_policy",
+    "pgpu_set_min_shard", "pgpu_shard_plan", "pgpu_synchronize", "pgpu_set_secret_exponent_policy", "pgpu_get_secret_exponent_policy",
     "pgpu_batch_create", "pgpu_batch_upload", "pgpu_batch_download", "pgpu_batch_destroy", "pgpu_batch_count",
     "pgpu_batch_words", "pgpu_batch_is_montgomery", "pgpu_batch_encrypt", "pgpu_batch_decrypt_crt",
     "pgpu_batch_ct_add", "pgpu_batch_ct_add_plain", "pgpu_batch_ct_mul",
@@ -97,6 +97,9 @@ def lib():
     L.pgpu_get_device.argtypes = []; L.pgpu_get_device.restype = c_int
     L.pgpu_pool_transport.argtypes = []; L.pgpu_pool_transport.restype = c_char_p
     L.pgpu_set_min_shard.argtypes = [c_size_t]; L.pgpu_set_min_shard.restype = c_int
+    L.pgpu_synchronize.argtypes = []; L.pgpu_synchronize.restype = c_int
+    L.pgpu_shard_plan.argtypes = [c_size_t, c_int, POINTER(c_int), POINTER(c_size_t)]
+    L.pgpu_shard_plan.restype = c_int
     L.pgpu_set_secret_exponent_policy.argtypes = [c_int]; L.pgpu_set_secret_exponent_policy.restype = c_int
     L.pgpu_get_secret_exponent_policy.argtypes = []; L.pgpu_get_secret_exponent_policy.restype = c_int
     L.pgpu_batch_create.argtypes = [c_size_t, c_int, POINTER(c_void_p)]; L.pgpu_batch_create.restype = c_int

@@ -90,6 +90,31 @@ def build_ipcl(force=False):
     return out
 
 
+def build_api_bench(force=False):
+    """tests/cpp/ipcl_bench.cpp -> pailliercryptolib_amd/ipcl_api_bench: the reference's google-benchmark cases restated
+    over the ipcl:: mirror; bench.py runs it with --json for the API-level number."""
+    import json
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    inc = os.path.join(cpp, "kat_vectors.inc")
+    k = json.load(open(os.path.join(ROOT, "tests", "golden", "iso_kat.json")))
+    names = {"p": "KAT_P", "q": "KAT_Q", "m0": "KAT_M0", "m1": "KAT_M1", "r0": "KAT_R0", "r1": "KAT_R1",
+             "c1": "KAT_C1", "c2": "KAT_C2", "c1c2": "KAT_C1C2", "m1m2": "KAT_M1M2",
+             "bench_hs": "KAT_BENCH_HS", "bench_r": "KAT_BENCH_R"}
+    text = "// generated from tests/golden/iso_kat.json -- do not edit\n" + "".join(
+        f'#define {macro} "{k[key]}"\n' for key, macro in names.items())
+    if not os.path.exists(inc) or open(inc).read() != text:
+        open(inc, "w").write(text)
+    out = os.path.join(HERE, "ipcl_api_bench")
+    src = os.path.join(cpp, "ipcl_bench.cpp")
+    libs = [os.path.join(HERE, "libipcl_amd.so"), os.path.join(HERE, "libpgpu.so")]
+    build_pgpu()
+    build_ipcl()
+    if force or _newer(out, [src, inc] + libs):
+        _run(["g++", "-O2", "-std=c++17", "-fopenmp", "-I" + os.path.join(ROOT, "include"), "-I" + cpp, src,
+              "-L" + HERE, "-lipcl_amd", "-lpgpu", "-Wl,-rpath,$ORIGIN", "-o", out])
+    return out
+
+
 def build_oracle(force=False):
     odir = os.path.join(ROOT, "oracle")
     out = os.path.join(odir, "libmodexp_oracle.so")
@@ -102,4 +127,5 @@ def build_oracle(force=False):
 def build_all(force=False):
     build_pgpu(force)
     build_ipcl(force)
+    build_api_bench(force)
     build_oracle(force)

@@ -847,6 +847,30 @@ int pgpu_set_min_shard(size_t n) {
   return PGPU_OK;
 }
 
+int pgpu_synchronize(void) {
+  RC_TRY(rt::check_ready());
+  for (int i = 0; i < rt::pool_size(); ++i) {
+    rt::Device& d = rt::device(i);
+    rt::DeviceGuard g(d.ordinal);
+    HIP_TRY(hipStreamSynchronize(d.bstream));
+    for (auto& lane : d.lanes) HIP_TRY(hipStreamSynchronize(lane->stream));
+  }
+  return PGPU_OK;
+}
+
+int pgpu_shard_plan(size_t count, int pool_size, int* n_shards, size_t* bounds) {
+  if (pool_size <= 0 || !n_shards || !bounds) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_shard_plan: bad argument");
+  const int D = (int)std::max<size_t>(1, std::min<size_t>((size_t)pool_size, count / rt::min_shard()));
+  *n_shards = D;
+  for (int d = 0; d < D; ++d) {
+    size_t lo, hi;
+    rt::shard_bounds(count, D, d, &lo, &hi);
+    bounds[d] = lo;
+    bounds[d + 1] = hi;
+  }
+  return PGPU_OK;
+}
+
 int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, int* limbs) {
   if (in_words <= 0 || mod_bits <= 1 || !lanes || !limbs)
     return fail(PGPU_ERR_INVALID_PARAM, "pgpu_kernel_geometry: bad argument");

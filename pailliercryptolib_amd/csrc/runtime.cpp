@@ -22,6 +22,9 @@ namespace {
 
 std::mutex g_pool_mu;   // init / shutdown
 std::vector<std::unique_ptr<Device>> g_pool;
+// Devices of earlier pools: batches, keys and buffers may outlive pgpu_shutdown (a caller's objects are destroyed
+// after terminateContext); the (small) Device records they point to are parked here instead of being deleted.
+std::vector<std::unique_ptr<Device>> g_retired;
 bool g_init = false;
 thread_local int t_current = 0;
 size_t g_min_shard = 0;
@@ -179,7 +182,7 @@ void Device::free(void* p, hipStream_t tag) {
     auto it = block_size.find(p);
     if (it != block_size.end()) {
       sz = it->second;
-      if (g_init && idle_bytes + sz <= kIdleCap) {
+      if (alive && idle_bytes + sz <= kIdleCap) {
         free_blocks[{tag, sz}].push_back(p);
         idle_bytes += sz;
         return;
@@ -415,7 +418,7 @@ size_t min_shard() {
 }
 void set_min_shard(size_t n) { g_min_shard = n ? n : 256; }
 int shard_devices(size_t count) {
-  const size_t D = (size_t)pool_size();
+  const size_t D = (size_t)std::max(1, pool_size());
   return (int)std::max<size_t>(1, std::min(D, count / min_shard()));
 }
 
@@ -511,6 +514,12 @@ void pool_shutdown() {
     if (d->bstream) (void)hipStreamDestroy(d->bstream);
   }
   if (!g_pool.empty()) (void)hipSetDevice(g_pool[0]->ordinal);
+  for (auto& d : g_pool) {
+    d->alive = false;
+    d->bstream = nullptr;
+    d->lanes.clear();
+    g_retired.push_back(std::move(d));
+  }
   g_pool.clear();
   g_transport = "single";
 }

@@ -106,6 +106,7 @@ struct Device {
   int index = 0;     // position in the pool
   int ordinal = 0;   // HIP device ordinal (several pool entries may share one when oversubscribed)
   std::string name;
+  bool alive = true;               // false once its pool has been shut down (objects may still point here)
   hipStream_t bstream = nullptr;   // resident-batch operations
   std::mutex mu;                   // allocator, work map, timing, queue
 

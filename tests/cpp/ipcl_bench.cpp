@@ -6,7 +6,9 @@
 // Prints one line per (op, batch): microseconds per call (best of N) and elements/s.
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <functional>
+#include <string>
 #include <vector>
 
 #include "ipcl/ipcl.hpp"
@@ -23,7 +25,38 @@ static double best_us(const std::function<void()>& f, int reps) {
   return best;
 }
 
+// `--json <batch>`: the API-visible timed region of the reference's BM_Encrypt / BM_Decrypt
+// (benchmark/bench_cryptography.cpp:73-121) for bench.py: std::vector<BigNumber> in, std::vector<BigNumber> out
+// (the reference's results ARE host BigNumbers, so getTexts() is inside the timed call), one JSON line.
+static int json_mode(size_t dsize) {
+  ipcl::initializeContext("default");
+  BigNumber P(KAT_P), Q(KAT_Q), n = P * Q;
+  ipcl::PublicKey pk(n, 2048, true);
+  ipcl::PrivateKey sk(pk, P, Q);
+  pk.setRandom(std::vector<BigNumber>(dsize, BigNumber(KAT_BENCH_R)));
+  pk.setHS(BigNumber(KAT_BENCH_HS));
+  std::vector<BigNumber> m(dsize);
+  for (size_t i = 0; i < dsize; i++) m[i] = P - BigNumber((unsigned int)(i * 1024));   // bench_cryptography.cpp:87
+  std::vector<BigNumber> c, d;
+  for (size_t done = 0; done < 4096 + dsize; done += dsize) c = pk.encrypt(ipcl::PlainText(m)).getTexts();   // warm-up
+  d = sk.decrypt(ipcl::CipherText(pk, c)).getTexts();
+  const double enc = best_us([&] { c = pk.encrypt(ipcl::PlainText(m)).getTexts(); }, 5);
+  const double dec = best_us([&] { d = sk.decrypt(ipcl::CipherText(pk, c)).getTexts(); }, 5);
+  bool ok = d.size() == m.size();
+  for (size_t i = 0; ok && i < dsize; ++i) ok = d[i] == m[i];
+  // resident chaining (the texts never become BigNumbers in between): encrypt -> CT+CT -> decrypt -> first element
+  ipcl::PlainText pt(m);
+  ipcl::CipherText ct2 = pk.encrypt(pt);
+  const double chain = best_us([&] { (void)sk.decrypt(pk.encrypt(pt) + ct2).getElement(0); }, 3);
+  std::printf("{\"what\": \"ipcl::PublicKey::encrypt / PrivateKey::decrypt, vector<BigNumber> in and out, batch %zu\", "
+              "\"encrypt_us\": %.1f, \"decrypt_us\": %.1f, \"chain_enc_add_dec_us\": %.1f, \"round_trip_ok\": %s}\n",
+              dsize, enc, dec, chain, ok ? "true" : "false");
+  ipcl::terminateContext();
+  return ok ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 2 && std::string(argv[1]) == "--json") return json_mode((size_t)std::atol(argv[2]));
   ipcl::initializeContext("default");
   BigNumber P(KAT_P), Q(KAT_Q), n = P * Q;
   std::vector<size_t> sizes = {16, 64, 128, 256, 512, 1024, 2048, 2100};   // bench_cryptography.cpp:12-19

