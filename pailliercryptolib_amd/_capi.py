@@ -9,7 +9,8 @@ import os
 from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p, POINTER, c_uint64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpgpu.so")
+# PGPU_LIB: an alternative build of the library (kernel A/B experiments, tools/build_variant.py)
+LIB_PATH = os.environ.get("PGPU_LIB") or os.path.join(_HERE, "libpgpu.so")
 
 # every symbol include/pgpu.h declares (tests check the built library exports all of them)
 SYMBOLS = [

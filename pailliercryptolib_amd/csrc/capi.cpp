@@ -38,9 +38,11 @@ struct GeoInfo {
 const GeoInfo kGeos[] = {{2, 9}, {4, 9}, {4, 10}, {4, 14}, {8, 9}, {8, 14}, {16, 9}, {16, 14}, {16, 18}};
 
 // (4,10): the 1024-bit class with room for unit quotient digits (R >= 256 * Nhat needs 37 bits above the
-// modulus; (4,9) offers 20).  PGPU_GEO_410=0 keeps those moduli on (4,9) with the per-row n0' multiply.
+// modulus; (4,9) offers 20).  Measured (tools/probe_geo410.py, profiles/r02_geo410.txt): the 23 % more MACs of
+// L = 40 cost more than the per-row n0' multiply they remove (65536 x 512-bit exponents: 6.7 ms vs 5.8 ms), so
+// it is OFF by default; PGPU_GEO_410=1 selects it.
 bool geo410_enabled() {
-  static const bool on = [] { const char* e = std::getenv("PGPU_GEO_410"); return !e || std::atoi(e) != 0; }();
+  static const bool on = [] { const char* e = std::getenv("PGPU_GEO_410"); return e && std::atoi(e) != 0; }();
   return on;
 }
 

@@ -26,6 +26,17 @@ namespace pgpu {
 // each wavefront owns its slice of the LDS arrays and never talks to the others, so the LDS
 // hand-off is wave-scope: LDS executes one wave's instructions in order, only the compiler must
 // not reorder across the hand-off (no s_barrier).
+// A wavefront that is alone on its SIMD (the bench's batch: 1024 wavefronts on 1024 SIMDs) issues a
+// v_mad_u64_u32 every 5.2 cycles at the default priority and every 4.65 at priority 3
+// (profiles/r02_ubench_lone_wave.txt; the CU's issue arbiter serves a raised wave sooner); with several
+// waves per SIMD all of them are raised alike and nothing changes.  Measured on the decrypt launch: -2.5 %.
+#ifndef PGPU_SETPRIO
+#define PGPU_SETPRIO 3
+#endif
+__device__ __forceinline__ void raise_wave_priority() {
+  if (PGPU_SETPRIO > 0) __builtin_amdgcn_s_setprio(PGPU_SETPRIO);
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -148,9 +159,13 @@ __device__ __forceinline__ void add_normalise(uint32_t (&a)[GEO::K], const uint3
   a[0] += dpp_from_prev(cc);
 }
 
+#ifndef PGPU_MODEXP_MIN_WAVES
+#define PGPU_MODEXP_MIN_WAVES 2
+#endif
 template <class GEO>
-__global__ __launch_bounds__(kWGThreads, 2) void modexp_kernel(ModexpArgs A) {
+__global__ __launch_bounds__(kWGThreads, PGPU_MODEXP_MIN_WAVES) void modexp_kernel(ModexpArgs A) {
   constexpr int K = GEO::K, L = GEO::L, G = GEO::G, IPW = GEO::IPW;
+  raise_wave_priority();
   __shared__ uint32_t bl_[kWavesPerWG][IPW][L];
   __shared__ uint32_t bl2_[kWavesPerWG][IPW][L];   // doubled limbs of the operand being squared
   __shared__ uint64_t io_[kWavesPerWG][IPW][GEO::W64 + 1];
@@ -481,6 +496,7 @@ __global__ __launch_bounds__(kWGThreads) void fb_build_kernel(FixedBaseBuildArgs
 template <class GEO>
 __global__ __launch_bounds__(kWGThreads, 2) void fb_encrypt_kernel(FixedBaseArgs A) {
   constexpr int K = GEO::K, L = GEO::L, G = GEO::G, IPW = GEO::IPW;
+  raise_wave_priority();
   __shared__ uint32_t bl_[kWavesPerWG][IPW][L];
   __shared__ uint64_t io_[kWavesPerWG][IPW][GEO::W64 + 1];
   const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
@@ -584,6 +600,7 @@ __global__ __launch_bounds__(kWGThreads, 2) void fb_encrypt_kernel(FixedBaseArgs
 template <class GEO>
 __global__ __launch_bounds__(kWGThreads) void modmul_kernel(ModmulArgs A) {
   constexpr int K = GEO::K, L = GEO::L, G = GEO::G, IPW = GEO::IPW;
+  raise_wave_priority();
   __shared__ uint32_t bl_[kWavesPerWG][IPW][L];
   __shared__ uint64_t io_[kWavesPerWG][IPW][GEO::W64 + 1];
   const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;

@@ -21,10 +21,11 @@ int fail(int code, const std::string& msg) {
 namespace {
 
 std::mutex g_pool_mu;   // init / shutdown
-std::vector<std::unique_ptr<Device>> g_pool;
+// (never destroyed: a process may exit without pgpu_shutdown, and worker threads must not find their Device gone)
+std::vector<std::unique_ptr<Device>>& g_pool = *new std::vector<std::unique_ptr<Device>>();
 // Devices of earlier pools: batches, keys and buffers may outlive pgpu_shutdown (a caller's objects are destroyed
 // after terminateContext); the (small) Device records they point to are parked here instead of being deleted.
-std::vector<std::unique_ptr<Device>> g_retired;
+std::vector<std::unique_ptr<Device>>& g_retired = *new std::vector<std::unique_ptr<Device>>();
 bool g_init = false;
 thread_local int t_current = 0;
 size_t g_min_shard = 0;
@@ -422,8 +423,25 @@ int shard_devices(size_t count) {
   return (int)std::max<size_t>(1, std::min(D, count / min_shard()));
 }
 
+// A process that exits without pgpu_shutdown (scripts, a crashed test) must not hang in its static destructors:
+// stop and join the worker lanes, and leave every GPU resource to the driver (the HIP runtime may already be
+// shutting down at this point, so no HIP call is made here).
+static void stop_lanes_at_exit() {
+  for (auto& d : g_pool) {
+    {
+      std::lock_guard<std::mutex> l2(d->mu);
+      d->stop = true;
+    }
+    d->cv.notify_all();
+    for (auto& lane : d->lanes)
+      if (lane->th.joinable()) lane->th.join();
+  }
+}
+
 int pool_init(const std::vector<int>& ordinals) {
   std::lock_guard<std::mutex> lk(g_pool_mu);
+  static const bool hooked = [] { return std::atexit(stop_lanes_at_exit) == 0; }();
+  (void)hooked;
   if (g_init) {
     bool same = ordinals.size() == g_pool.size();
     for (size_t i = 0; same && i < ordinals.size(); ++i) same = g_pool[i]->ordinal == ordinals[i];

@@ -140,6 +140,11 @@ def main():
         ok["mul_bcast"] = down(op(L.pgpu_batch_ct_mul, pk._h, pc2, e1, 40)) == [pow(a, e[0], nsq) for a in oc2]
         ok["dec_plain"] = down(op(L.pgpu_batch_decrypt_crt, sk._h, pc2)) == m2
         res["ok"] = ok
+    elif scenario == "no_terminate":
+        # a script that forgets pgpu_shutdown: the worker lanes must not keep the process from exiting
+        m = [rng.randrange(n) for _ in range(20)]
+        pk = pa.PublicKey(n, 2048, hs=hs)
+        res["ok"] = {"enc": len(pk.encrypt(m, [rng.getrandbits(1024) for _ in m])) == 20}
     elif scenario == "unequal_key":
         # p^2 one bit shorter than q^2, straddling the unit-quotient-digit headroom of the geometry: both contexts of
         # a decrypt launch must agree on the loop form (odd-parity waves read a null nhat otherwise)
@@ -154,8 +159,9 @@ def main():
             ok[f"enc{bits}"] = ct == orc.PublicKey(n2, bits).encrypt(m, r)
             ok[f"dec{bits}"] = pa.PrivateKey(p2, q2).decrypt(ct) == m
         res["ok"] = ok
-    print(json.dumps(res))
-    pa.terminate()
+    print(json.dumps(res), flush=True)
+    if scenario != "no_terminate":
+        pa.terminate()
 
 
 if __name__ == "__main__":

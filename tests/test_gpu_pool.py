@@ -12,10 +12,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_worker(scenario, ndev, **env):
+def run_worker(scenario, ndev, timeout=600, **env):
     e = dict(os.environ, PGPU_POOL_OVERSUBSCRIBE="1", PGPU_MIN_SHARD="8", **env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "pool_worker.py"), scenario, str(ndev)],
-                       capture_output=True, text=True, timeout=900, env=e)
+                       capture_output=True, text=True, timeout=timeout, env=e)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]   # (librccl prints a banner of its own)
     return json.loads(lines[-1])
@@ -57,3 +57,11 @@ def test_key_with_unequal_square_widths(engine, geo410):
     res = run_worker("unequal_key", 1, PGPU_GEO_410=geo410)
     bad = [k for k, v in res["ok"].items() if not v]
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_process_exits_without_shutdown(engine):
+    """A process that never calls pgpu_shutdown must still exit promptly (the worker lanes are stopped by an
+    atexit hook); a hang here would burn the whole gpurun limit."""
+    res = run_worker("no_terminate", 2, timeout=120)
+    assert res["ok"]["enc"]
