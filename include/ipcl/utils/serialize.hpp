@@ -11,11 +11,15 @@
 //   * a class with a versioned save/load/serialize writes its class version (uint32, 0 here:
 //     the reference never calls CEREAL_CLASS_VERSION) ONCE per archive, before the first
 //     instance of that type.
-// PARITY UNPINNED: no IPCL-produced byte stream exists in the reference tree to check this
-// against; what is tested is the round trip and the field order of the reference's members.
+// PARITY: pinned against hand-built byte vectors that follow cereal v1.3.2's PortableBinary framing rule by
+// rule (tests/test_serialization_layout.py for BigNumber / PlainText, tests/cpp/ipcl_api_tests.cpp for the
+// keys) -- NOT against a stream written by cereal itself: cereal is fetched from GitHub by the reference's
+// build (cmake/cereal.cmake:7-8) and exists neither in its tree nor in this image, and the tree holds no
+// serialized fixture.  Interoperability with archives of a real IPCL build therefore remains unverified.
 #ifndef PAILLIERCRYPTOLIB_AMD_IPCL_UTILS_SERIALIZE_HPP_
 #define PAILLIERCRYPTOLIB_AMD_IPCL_UTILS_SERIALIZE_HPP_
 
+#include <algorithm>   // (the reference's headers provide it transitively through cereal: test_serialization.cpp uses std::for_each)
 #include <cstdint>
 #include <cstring>
 #include <fstream>

@@ -69,6 +69,8 @@ void PrivateKey::load(serializer::InputArchive& ar) {
   BigNumber p, q;
   p.load(ar);
   q.load(ar);
+  ERROR_CHECK(!p.isNegative() && !q.isNegative() && p.IsOdd() && q.IsOdd() && p > BigNumber::Two() && q > BigNumber::Two(),
+              "PrivateKey: corrupt archive (p and q must be odd primes)");
   m_n = std::make_shared<BigNumber>(p * q);
   m_nsquare = std::make_shared<BigNumber>((*m_n) * (*m_n));
   m_g = std::make_shared<BigNumber>((*m_n) + 1);

@@ -137,6 +137,10 @@ void PublicKey::load(serializer::InputArchive& ar) {
   BigNumber n, hs;
   n.load(ar);
   hs.load(ar);
+  // a key from an archive is untrusted input: refuse what no generateKeypair / create could have produced
+  ERROR_CHECK(bits > 0 && randbits >= 0, "PublicKey: corrupt archive (bits / randbits)");
+  ERROR_CHECK(!n.isNegative() && n.IsOdd() && n > BigNumber::One(), "PublicKey: corrupt archive (n must be odd and > 1)");
+  ERROR_CHECK(!hs.isNegative(), "PublicKey: corrupt archive (negative hs)");
   if (enable_DJN) create(n, bits, hs, randbits);
   else create(n, bits);
 }

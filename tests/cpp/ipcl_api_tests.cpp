@@ -6,8 +6,10 @@
 // plus the error behaviour and container quirks listed in SURVEY.md section 4 / Appendix A.
 #include <omp.h>
 
+#include <algorithm>
 #include <climits>
 #include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <iostream>
 #include <random>
@@ -16,6 +18,7 @@
 #include <vector>
 
 #include "ipcl/ipcl.hpp"
+#include "pgpu.h"
 #include "kat_vectors.inc"  // generated from tests/golden/iso_kat.json by the pytest wrapper
 
 static int g_failed = 0, g_checks = 0;
@@ -374,6 +377,89 @@ TEST(serialization_roundtrips) {   // after test/test_serialization.cpp:13-106
   EXPECT_EQ(*from_file.getN(), *key.pub_key.getN());
   std::istringstream truncated(blob.substr(0, blob.size() / 2));
   EXPECT_THROW(ipcl::serializer::deserialize(truncated, ct_after));
+}
+
+// ---- byte layout of the keys against hand-built cereal PortableBinary framing (see tests/test_serialization_layout.py
+// for the rules; members: pub_key.hpp:133-164 "bits", "enable_DJN", "randbits", "n", "hs"; pri_key.hpp:93-101 "bits"
+// (of p), "p", "q") ----
+static void put_le(std::string& o, uint64_t v, int bytes) {
+  for (int i = 0; i < bytes; ++i) o.push_back((char)((v >> (8 * i)) & 0xff));
+}
+static void put_bn(std::string& o, const BigNumber& b) {   // vector<Ipp32u> then the sign enum
+  std::vector<Ipp32u> w;
+  b.num2vec(w);
+  put_le(o, w.size(), 8);
+  for (Ipp32u x : w) put_le(o, x, 4);
+  put_le(o, b.isNegative() ? 0 : 1, 4);
+}
+TEST(serialization_layout_keys) {
+  BigNumber P(KAT_P), Q(KAT_Q), n = P * Q, hs(KAT_BENCH_HS);
+  ipcl::PublicKey pk;
+  pk.create(n, 2048, hs, 1024);
+  std::string want;
+  put_le(want, 1, 1);        // archive header: little-endian payload
+  put_le(want, 0, 4);        // class version of ipcl::PublicKey
+  put_le(want, 2048, 4);     // bits (int)
+  put_le(want, 1, 1);        // enable_DJN (bool)
+  put_le(want, 1024, 4);     // randbits (int)
+  put_le(want, 0, 4);        // class version of BigNumber, before its first instance
+  put_bn(want, n);
+  put_bn(want, hs);
+  std::ostringstream os;
+  ipcl::serializer::serialize(os, pk);
+  EXPECT_TRUE(os.str() == want);
+  ipcl::PrivateKey sk(pk, P, Q);
+  std::string want_sk;
+  put_le(want_sk, 1, 1);
+  put_le(want_sk, 0, 4);                       // class version of ipcl::PrivateKey
+  put_le(want_sk, (uint64_t)std::min(P, Q).BitSize(), 4);   // "bits" = m_p->BitSize(), p the smaller prime
+  put_le(want_sk, 0, 4);                       // class version of BigNumber
+  put_bn(want_sk, std::min(P, Q));
+  put_bn(want_sk, std::max(P, Q));
+  std::ostringstream os2;
+  ipcl::serializer::serialize(os2, sk);
+  EXPECT_TRUE(os2.str() == want_sk);
+  // a loaded key is checked before it is used: an even n / a negative hs is a corrupt archive
+  std::string bad = want;
+  bad[1 + 4 + 4 + 1 + 4 + 4 + 8] ^= 1;        // lowest bit of n
+  ipcl::PublicKey victim;
+  std::istringstream is(bad);
+  EXPECT_THROW(ipcl::serializer::deserialize(is, victim));
+}
+
+// ---- device pool: batches are cut into contiguous shards over the pool's GPUs (one entry per GPU; the pytest wrapper
+// also runs this binary on an oversubscribed 3-entry pool with a tiny minimum shard) ----
+TEST(pool_sharded_batches_keep_order) {
+  ipcl::KeyPair& key = shared_key();
+  const size_t N = 301;   // not a multiple of any pool size in use
+  std::vector<uint32_t> a(N), b(N), e(N);
+  for (size_t i = 0; i < N; ++i) { a[i] = (uint32_t)(1000 + i); b[i] = (uint32_t)(7 * i + 3); e[i] = (uint32_t)(i % 13 + 1); }
+  ipcl::CipherText ca = key.pub_key.encrypt(ipcl::PlainText(a)), cb = key.pub_key.encrypt(ipcl::PlainText(b));
+  EXPECT_TRUE(ca.isDeviceResident());
+  ipcl::PlainText r = key.priv_key.decrypt((ca + cb) * ipcl::PlainText(e) + ipcl::PlainText(b));   // (a+b)*e + b
+  EXPECT_TRUE(r.isDeviceResident());
+  bool ok = true;
+  for (size_t i = 0; i < N; ++i) ok = ok && r.getElementVec(i)[0] == (a[i] + b[i]) * e[i] + b[i];
+  EXPECT_TRUE(ok);
+  // scalar operands are broadcast to every shard
+  ipcl::PlainText r2 = key.priv_key.decrypt(ca * ipcl::PlainText(5u) + key.pub_key.encrypt(ipcl::PlainText(9u)));
+  ok = true;
+  for (size_t i = 0; i < N; ++i) ok = ok && r2.getElementVec(i)[0] == a[i] * 5 + 9;
+  EXPECT_TRUE(ok);
+  // the host-pointer seam shards too: ipcl::modExp over one modulus
+  BigNumber m("0xf123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdf1");
+  std::vector<BigNumber> base(N), ex(N, BigNumber(65537u)), mod(N, m);
+  for (size_t i = 0; i < N; ++i) base[i] = BigNumber((Ipp32u)(i + 2));
+  std::vector<BigNumber> got = ipcl::modExp(base, ex, mod);
+  ok = true;
+  for (size_t i = 0; i < N; i += 37) {
+    BigNumber acc = base[i];                                     // base^65537 = base^(2^16) * base
+    for (int k = 0; k < 16; ++k) acc = m.ModMul(acc, acc);
+    ok = ok && got[i] == m.ModMul(acc, base[i]);
+  }
+  EXPECT_TRUE(ok);
+  const char* expect_pool = std::getenv("IPCL_EXPECT_POOL");
+  if (expect_pool) EXPECT_EQ(pgpu_pool_size(), std::atoi(expect_pool));
 }
 
 TEST(keygen_non_djn_and_3072_bit) {

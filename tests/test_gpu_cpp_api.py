@@ -48,3 +48,22 @@ def test_cpp_api_suite_on_gpu():
     print(r.stderr[-2000:])
     assert r.returncode == 0, "C++ API tests failed"
     assert " 0 failed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_api_suite_on_oversubscribed_pool():
+    """The same suite on an in-process pool of three entries (wrapped around the box's one GPU) with a tiny minimum
+    shard: every batch of the reference's test sizes is cut over three 'devices' -- shard order, broadcast operands,
+    per-device key copies and the Montgomery-domain chains all go through the multi-device code."""
+    from pailliercryptolib_amd import build as b
+    b.build_pgpu()
+    b.build_ipcl()
+    exe = build_test_binary()
+    env = dict(os.environ, PGPU_POOL_OVERSUBSCRIBE="1", IPCL_GPU_DEVICES="3", PGPU_MIN_SHARD="4", IPCL_EXPECT_POOL="3")
+    env.pop("LOCAL_RANK", None)
+    env.pop("IPCL_GPU_DEVICE", None)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
+    print(r.stdout[-6000:])
+    print(r.stderr[-2000:])
+    assert r.returncode == 0, "C++ API tests failed on the pool"
+    assert " 0 failed" in r.stdout

@@ -1,0 +1,101 @@
+"""the FULL output of every BASELINE configuration at its per-GPU size, hashed (SHA-256) and compared
+with the hash of the C oracle's output on the same inputs -- every element, not a sample.  The oracle side runs
+oracle/modexp_oracle.c's reference flows with the fastest modexp backend the host has (the AVX512-IFMA restatement,
+else OpenSSL, else the scalar port), all cores; the GPU side goes through the C-ABI `_dev` entry points."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.uint64).tobytes()).hexdigest()
+
+
+def rand_rows(rng, count, words, top_mask=None):
+    a = np.frombuffer(rng.bytes(count * words * 8), dtype=np.uint64).reshape(count, words).copy()
+    if top_mask is not None:
+        a[:, -1] &= np.uint64(top_mask)
+    return a
+
+
+@pytest.fixture(scope="module")
+def cpu():
+    """(encrypt, decrypt, modexp) of the C oracle with its fastest backend"""
+    from oracle import c_oracle
+    c_oracle.set_threads(min(c_oracle.lib().orc_max_threads(), c_oracle.usable_cpus()))
+    be = c_oracle.ifma_modexp_batch if c_oracle.ifma_lib() is not None else (
+        c_oracle.openssl_modexp_batch if c_oracle.openssl_lib() is not None else c_oracle.modexp_batch)
+    return (lambda n, hs, m, r: c_oracle.paillier_encrypt_with(be, n, hs, m, r),
+            lambda *a: c_oracle.paillier_decrypt_crt_with(be, *a), be, c_oracle)
+
+
+def key_limbs(p, q, hs, bits):
+    from oracle import paillier_oracle as orc
+    from pailliercryptolib_amd.limbs import ints_to_limbs
+    n = p * q
+    nw, pw = bits // 64, bits // 128
+    sk = orc.PrivateKey(n, p, q)
+    return (ints_to_limbs([n], nw)[0], None if hs is None else ints_to_limbs([hs], 2 * nw)[0],
+            [ints_to_limbs([v], pw)[0] for v in (sk.p, sk.q, sk.hp, sk.hq, sk.pinv)])
+
+
+@pytest.mark.parametrize("bits,count,djn,policy", [(2048, 8192, True, 0), (2048, 8192, False, 1), (3072, 8192, True, 0)])
+def test_encrypt_decrypt_full_output_hash(engine, cpu, bits, count, djn, policy):
+    """configs[1] + configs[2] (k=2048, batch 8192; DJN and the r^n variant) and one 8192-element shard of configs[3]
+    (k=3072): every ciphertext and every plaintext, fixed-window (0) and sliding (1) schedules of p-1 / q-1."""
+    from pailliercryptolib_amd import _capi, torch_ops as T
+    enc_cpu, dec_cpu, _, _ = cpu
+    if bits == 2048:
+        k = json.load(open(os.path.join(GOLD, "iso_kat.json")))
+        p, q, hs = int(k["p"], 16), int(k["q"], 16), int(k["bench_hs"], 16)
+    else:
+        case = [c for c in json.load(open(os.path.join(GOLD, "seeded_vectors.json")))["cases"]
+                if c["bits"] == bits and c["djn"]][0]
+        p, q, hs = int(case["p"], 16), int(case["q"], 16), int(case["hs"], 16)
+    if not djn:
+        hs = None
+    n = p * q
+    nw, pw = bits // 64, bits // 128
+    rng = np.random.default_rng(bits + count + djn)
+    m = rand_rows(rng, count, nw, (1 << 62) - 1)
+    r = rand_rows(rng, count, pw) if djn else rand_rows(rng, count, nw, (1 << 62) - 1)
+    pk, sk = engine.PublicKey(n, bits, hs=hs), engine.PrivateKey(p, q)
+    L = _capi.lib()
+    old = L.pgpu_get_secret_exponent_policy()
+    _capi.check(L.pgpu_set_secret_exponent_policy(policy))
+    try:
+        d_c = T.encrypt(pk, T.to_device(m), T.to_device(r))
+        c_gpu = T.to_host(d_c)
+        m_gpu = T.to_host(T.decrypt(sk, d_c))
+    finally:
+        _capi.check(L.pgpu_set_secret_exponent_policy(old))
+    n_l, hs_l, sk_l = key_limbs(p, q, hs, bits)
+    c_cpu = enc_cpu(n_l, hs_l, m, r)
+    assert sha(c_gpu) == sha(c_cpu), "ciphertext batch differs from the C oracle"
+    assert sha(m_gpu) == sha(dec_cpu(*sk_l, c_cpu)) == sha(m), "plaintext batch differs from the C oracle"
+
+
+def test_config5_full_output_hash(engine, cpu):
+    """configs[4], one GPU's 131072-element shard: CT+CT (plain operands through the C-ABI) and CT x PT with 32-bit
+    plaintexts -- all 131072 results of each against the C oracle."""
+    from pailliercryptolib_amd import torch_ops as T
+    from pailliercryptolib_amd.limbs import ints_to_limbs
+    _, _, modexp_cpu, c_oracle = cpu
+    k = json.load(open(os.path.join(GOLD, "iso_kat.json")))
+    n = int(k["p"], 16) * int(k["q"], 16)
+    nsq = n * n
+    N, W = 131072, 64
+    rng = np.random.default_rng(55)
+    a = rand_rows(rng, N, W, (1 << 60) - 1)
+    b = rand_rows(rng, N, W, (1 << 60) - 1)
+    e = rand_rows(rng, N, 1, (1 << 32) - 1)
+    mod = ints_to_limbs([nsq], W)[0]
+    d_a = T.to_device(a)
+    assert sha(T.to_host(T.mod_mul(d_a, T.to_device(b), nsq))) == sha(c_oracle.modmul_batch(a, b, mod))
+    assert sha(T.to_host(T.mod_exp(d_a, T.to_device(e), nsq, exp_bits=32))) == sha(modexp_cpu(a, e, mod))

@@ -1,0 +1,70 @@
+"""Byte layout of ipcl::serializer against hand-built vectors that follow cereal v1.3.2's
+PortableBinary framing (the reference serialises through cereal::PortableBinary{Output,Input}Archive,
+ipcl/include/ipcl/utils/serialize.hpp:25-36):
+  * archive header: one byte, 1 = little-endian payload (PortableBinaryOutputArchive's constructor);
+  * a type with a versioned save/load/serialize member writes its class version (uint32, 0: the reference never uses
+    CEREAL_CLASS_VERSION) ONCE per archive, immediately before the first instance of that type;
+  * arithmetic values little-endian at their natural size (std::size_t = 8 bytes), enums as their 32-bit underlying type;
+  * std::vector<T>: uint64 element count, then the elements (raw little-endian words for arithmetic T);
+  * name-value pairs carry no names in binary archives; base_class<B> serialises the base like a member.
+Members, in order (reference): BigNumber = {vector<Ipp32u> words (num2vec), IppsBigNumSGN sign} (bignum.h:131-153);
+BaseText = {size_t size, vector<BigNumber> texts} (base_text.hpp:108-114); PlainText = {base} (plaintext.hpp:92-98).
+The key classes are checked the same way on the GPU box (tests/cpp/ipcl_api_tests.cpp: serialization_layout), because
+constructing a key builds its device image.  NOT checked: a stream written by cereal itself (not available offline)."""
+import os
+import struct
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "pailliercryptolib_amd")
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    from pailliercryptolib_amd import build
+    build.build_pgpu()
+    build.build_ipcl()
+    exe = str(tmp_path_factory.mktemp("ser") / "ser_driver")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "bignum_driver.cpp"), "-L" + LIBDIR, "-lipcl_amd", "-lpgpu",
+                    "-Wl,-rpath," + LIBDIR, "-o", exe], check=True)
+    return exe
+
+
+def ask(driver, line):
+    return subprocess.run([driver], input=line + "\n", capture_output=True, text=True).stdout.strip()
+
+
+def words32(v):
+    out = []
+    while v:
+        out.append(v & 0xFFFFFFFF)
+        v >>= 32
+    return out
+
+
+def bn_body(v):
+    """BigNumber payload without the class-version record: vector<Ipp32u> then the sign enum"""
+    w = words32(abs(v))
+    return struct.pack("<Q", len(w)) + b"".join(struct.pack("<I", x) for x in w) + struct.pack("<I", 0 if v < 0 else 1)
+
+
+def test_bignumber_layout(driver):
+    for v in (0x10000000200000003, 5, 0xFFFFFFFF, 0x1234567890ABCDEF0123456789, -0x100000000):
+        sv = ("-" if v < 0 else "") + hex(abs(v))
+        want = b"\x01" + struct.pack("<I", 0) + bn_body(v)
+        assert ask(driver, f"ser {sv}") == want.hex(), hex(v)
+
+
+def test_plaintext_layout(driver):
+    a, b, c = 0xDEADBEEFCAFEBABE12345678, 7, 0x1FFFFFFFF
+    want = (b"\x01" + struct.pack("<I", 0)          # ipcl::PlainText class version
+            + struct.pack("<I", 0)                  # ipcl::BaseText class version (base_class<BaseText>)
+            + struct.pack("<Q", 3)                  # m_size (std::size_t)
+            + struct.pack("<Q", 3)                  # m_texts: element count
+            + struct.pack("<I", 0) + bn_body(a)     # first BigNumber: its class version precedes it
+            + bn_body(b) + bn_body(c))              # later ones: no version record
+    got = ask(driver, f"serpt {hex(a)} {hex(b)} {hex(c)}")
+    assert got == want.hex() + " ok"
