@@ -4,14 +4,6 @@
 #include <sstream>
 #include <string>
 #include "ipcl/bignum.h"
-#include "ipcl/plaintext.hpp"
-
-static std::string hexbytes(const std::string& s) {
-  static const char* d = "0123456789abcdef";
-  std::string o;
-  for (unsigned char c : s) { o += d[c >> 4]; o += d[c & 15]; }
-  return o;
-}
 
 int main() {
   std::string line;
@@ -36,16 +28,6 @@ int main() {
       else if (op == "dec") { BigNumber d(sa.c_str()); d.num2hex(out); }
       else if (op == "vec") { std::vector<Ipp32u> v; a.num2vec(v); std::ostringstream os; os << v.size(); for (auto w : v) os << " " << w; out = os.str(); }
       else if (op == "bin") { unsigned char buf[64] = {0}; BigNumber::toBin(buf, 64, a); BigNumber r; BigNumber::fromBin(r, buf, 64); r.num2hex(out); }
-      else if (op == "ser") { std::ostringstream os; ipcl::serializer::serialize(os, a); out = hexbytes(os.str()); }
-      else if (op == "serpt") {   // PlainText of {a, b, c}
-        std::ostringstream os;
-        ipcl::serializer::serialize(os, ipcl::PlainText(std::vector<BigNumber>{a, b, c}));
-        std::string bytes = os.str();
-        ipcl::PlainText back;
-        std::istringstream is(bytes);
-        ipcl::serializer::deserialize(is, back);
-        out = hexbytes(bytes) + (back.getSize() == 3 && back.getElement(0) == a && back.getElement(2) == c ? " ok" : " BAD");
-      }
       else out = "?";
       std::cout << out << "\n";
     } catch (const std::exception& e) {

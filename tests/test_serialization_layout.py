@@ -28,7 +28,7 @@ def driver(tmp_path_factory):
     build.build_ipcl()
     exe = str(tmp_path_factory.mktemp("ser") / "ser_driver")
     subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, "tests", "cpp", "bignum_driver.cpp"), "-L" + LIBDIR, "-lipcl_amd", "-lpgpu",
+                    os.path.join(ROOT, "tests", "cpp", "serialize_driver.cpp"), "-L" + LIBDIR, "-lipcl_amd", "-lpgpu",
                     "-Wl,-rpath," + LIBDIR, "-o", exe], check=True)
     return exe
 
