@@ -71,7 +71,7 @@ __global__ __launch_bounds__(512) void k(uint64_t* out) {
     return;
   }
   init_regs();
-  if (V == 9) asm volatile("s_setprio 3");
+  if (V == 9 || V == 12 || V == 13) asm volatile("s_setprio 3");
   for (int it = 0; it < NITER; ++it) {
     if (V == 0) asm volatile(R4(MAC16("s[20:21]")) ::: CLOB);                    // baseline: 64 MACs
     if (V == 1) asm volatile(R4(MAC16ROT) ::: CLOB);                              // carry-out rotates over 4 SGPR pairs
@@ -86,6 +86,10 @@ __global__ __launch_bounds__(512) void k(uint64_t* out) {
     if (V == 8) asm volatile(R2(MAC16("s[20:21]") MAC16("s[20:21]") SUP5 SUP5) ::: CLOB);   // the kernel's mix: 64 MAC + 20 support
     if (V == 9) asm volatile(R4(MAC16("s[20:21]")) ::: CLOB);                    // baseline at s_setprio 3
     if (V == 10) asm volatile(R4("ds_read_b32 v29, v28\n\t" MAC16("s[20:21]") "s_waitcnt lgkmcnt(0)\n\t") ::: CLOB);
+    if (V == 11) asm volatile(R2(MAC16("vcc") MAC16("vcc") SUP5 SUP5) ::: CLOB);            // the kernel's mix, carry-out to vcc
+    if (V == 12) asm volatile(R2(MAC16("s[20:21]") MAC16("s[20:21]") SUP5 SUP5) ::: CLOB);  // the kernel's mix at s_setprio 3
+    if (V == 13) asm volatile(R2(MAC16("vcc") MAC16("vcc") SUP5 SUP5) ::: CLOB);            // mix, vcc, s_setprio 3
+    if (V == 14) asm volatile(R2(MAC16ROT MAC16ROT SUP5 SUP5) ::: CLOB);                    // mix, rotating carry-out
                                                                                   // LDS read issued 16 MACs before its wait
   }
   uint32_t r; asm volatile("v_add_u32 %0, v32, v28" : "=v"(r));
@@ -110,6 +114,10 @@ int main(int argc, char** argv) {
       {"kernel mix: 64 MACs + 20 support ops", k<8, 0>, 84, 64, 256},
       {"64 MACs at s_setprio 3", k<9, 0>, 64, 64, 256},
       {"4 x (ds_read, 16 MACs, wait)", k<10, 0>, 72, 64, 256},
+      {"kernel mix, carry-out to vcc", k<11, 0>, 84, 64, 256},
+      {"kernel mix at s_setprio 3", k<12, 0>, 84, 64, 256},
+      {"kernel mix, vcc, s_setprio 3", k<13, 0>, 84, 64, 256},
+      {"kernel mix, rotating carry-out", k<14, 0>, 84, 64, 256},
       {"64 MACs + s_nop helper wave on the SIMD", k<0, 1>, 64, 64, 512},
       {"64 MACs + s_sleep helper wave on the SIMD", k<0, 2>, 64, 64, 512},
       {"64 MACs + SALU helper wave on the SIMD", k<0, 3>, 64, 64, 512},
