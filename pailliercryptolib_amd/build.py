@@ -46,7 +46,7 @@ def _objects():
               os.path.join(ROOT, "include", "ipcl", "utils", "serialize.hpp")]
     obj = os.path.join(HERE, "build")
     out = []
-    for part in range(4):
+    for part in range(8):
         src = os.path.join(CSRC, "k_modexp.hip")
         o = os.path.join(obj, f"k_modexp_{part}.o")
         out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src] + kdeps))

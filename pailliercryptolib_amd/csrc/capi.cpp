@@ -396,6 +396,22 @@ GeoInfo launch_geo(const GeoInfo& geo, size_t count) {
   return waves >= min_waves ? wide : geo;
 }
 
+// A launch that leaves a wavefront alone on its SIMD (at most ~1.5 wavefronts per SIMD) takes the kernel form whose
+// multiplier rows are broadcast from registers (kernels.hpp: REGROWS): nobody covers that wavefront's LDS round
+// trips.  PGPU_REGROWS=0 / 1 forces the LDS / register form (A/B measurements).
+std::atomic<int> g_row_source{-2};   // -1 auto, 0 LDS, 1 registers (-2: not read from the environment yet)
+bool use_regrows(const GeoInfo& geo, size_t waves) {
+  int mode = g_row_source.load();
+  if (mode == -2) {
+    const char* e = std::getenv("PGPU_REGROWS");
+    mode = e ? (std::atoi(e) != 0 ? 1 : 0) : -1;
+    g_row_source.store(mode);
+  }
+  if (!pgpu::modexp_has_regrows(geo.G, geo.K)) return false;
+  if (mode >= 0) return mode != 0;
+  return waves <= kSimds + kSimds / 2;
+}
+
 uint64_t* g_wave_clocks = nullptr;   // diagnostics (tools/wave_spread.py)
 
 // common launcher of modexp_kernel on device `d`, stream `s`: sizes the window table of the stream's
@@ -432,7 +448,7 @@ int run_modexp(rt::Device& d, pgpu::ModexpArgs& a, const GeoInfo& ctx_geo, hipSt
   a.wave_clocks = g_wave_clocks;
   TimerScope t(d, s, PGPU_KERNEL_MODEXP);
   const unsigned blocks = (unsigned)((waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
-  if (!pgpu::launch_modexp(geo.G, geo.K, a, blocks, s))
+  if (!pgpu::launch_modexp(geo.G, geo.K, use_regrows(geo, waves), a, blocks, s))
     return fail(PGPU_ERR_UNSUPPORTED, "modexp kernel geometry not compiled");
   HIP_TRY(hipGetLastError());
   t.stop();
@@ -903,6 +919,9 @@ int pgpu_get_secret_exponent_policy(void) { return secret_policy(); }
 // diagnostics (tools/wave_spread.py): device buffer that receives per-wave start/end clocks of the
 // next modexp_kernel launches; null switches it off.  Not part of the public header.
 void pgpu_debug_set_wave_clocks(uint64_t* d_buf) { g_wave_clocks = d_buf; }
+// tests / A-B measurements: force where modexp_kernel takes its multiplier rows from (-1 auto by wavefront count,
+// 0 LDS, 1 registers; geometries without a register form keep LDS).  Not part of the public header.
+void pgpu_debug_set_row_source(int mode) { g_row_source.store(mode < 0 ? -1 : (mode ? 1 : 0)); }
 
 int pgpu_set_timing(int enabled) {
   g_timing.store(enabled != 0);

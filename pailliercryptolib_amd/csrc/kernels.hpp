@@ -162,12 +162,15 @@ __device__ __forceinline__ void add_normalise(uint32_t (&a)[GEO::K], const uint3
 #ifndef PGPU_MODEXP_MIN_WAVES
 #define PGPU_MODEXP_MIN_WAVES 2
 #endif
-template <class GEO>
-__global__ __launch_bounds__(kWGThreads, PGPU_MODEXP_MIN_WAVES) void modexp_kernel(ModexpArgs A) {
+// REGROWS: the multiplier rows of every multiplication come from registers (DPP broadcasts, mont_core.hpp:
+// mont_block_reg) instead of LDS -- the form for launches that leave a wavefront alone on its SIMD; the host
+// picks it by wavefront count (capi.cpp: run_modexp).  Results are bit-identical.
+template <class GEO, bool REGROWS = false>
+__global__ __launch_bounds__(kWGThreads, REGROWS ? 1 : PGPU_MODEXP_MIN_WAVES) void modexp_kernel(ModexpArgs A) {
   constexpr int K = GEO::K, L = GEO::L, G = GEO::G, IPW = GEO::IPW;
   raise_wave_priority();
   __shared__ uint32_t bl_[kWavesPerWG][IPW][L];
-  __shared__ uint32_t bl2_[kWavesPerWG][IPW][L];   // doubled limbs of the operand being squared
+  __shared__ uint32_t bl2_[kWavesPerWG][REGROWS ? 1 : IPW][REGROWS ? 1 : L];   // doubled limbs of the operand being squared
   __shared__ uint64_t io_[kWavesPerWG][IPW][GEO::W64 + 1];
 
   const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
@@ -192,6 +195,24 @@ __global__ __launch_bounds__(kWGThreads, PGPU_MODEXP_MIN_WAVES) void modexp_kern
   // loop modulus: Nhat (unit quotient digits) when the context provides it, else N
   const bool unitq = A.ctx[0].nhat != nullptr;     // wave-uniform (both contexts agree)
   uint32_t n[K], a[K];
+  uint32_t mreg[REGROWS ? K : 1];   // REGROWS: the multiplier of the next multiplication (squarings use a itself)
+  // the multiplier limb j of this lane goes to its LDS row or, with REGROWS, stays in a register
+#define PGPU_STAGE(j, value)                                         \
+  do {                                                               \
+    if constexpr (REGROWS) mreg[j] = (value);                        \
+    else bl[g][x * K + (j)] = (value);                               \
+  } while (0)
+  // one multiplication a = a * multiplier (SQ: the multiplier is a itself)
+#define PGPU_MONTMUL(SQ, UQ)                                                              \
+  do {                                                                                    \
+    if constexpr (REGROWS) {                                                              \
+      if constexpr (SQ) montmul_reg<GEO, true, UQ>(a, a, a, n, n0inv);                    \
+      else montmul_reg<GEO, false, UQ>(a, a, mreg, n, n0inv);                             \
+    } else {                                                                              \
+      if constexpr (SQ) montmul<GEO, true, UQ>(a, a, bl[g], n, n0inv, bl2[g]);            \
+      else montmul<GEO, false, UQ>(a, a, bl[g], n, n0inv);                                \
+    }                                                                                     \
+  } while (0)
   // (g^m = 1 + n*m is formed under the TRUE modulus so that it stays < 2N; see GMUL below)
   const bool gm_first = A.final_mul == FM_PAILLIER_G;
 #pragma unroll
@@ -237,17 +258,17 @@ __global__ __launch_bounds__(kWGThreads, PGPU_MODEXP_MIN_WAVES) void modexp_kern
     phase = GMUL;    // keep = m * (n*R) * R^-1 = n*m mod n^2 (plain domain, lazy)
     stage_words<GEO>(io, A.fm_words, A.fm_stride, 0, A.fm_nwords, first_inst, A.count, 1, lane, istep);
 #pragma unroll
-    for (int j = 0; j < K; ++j) bl[g][x * K + j] = PGPU_CTX(nr)[x * K + j];
+    for (int j = 0; j < K; ++j) PGPU_STAGE(j, PGPU_CTX(nr)[x * K + j]);
   } else if (wide) {
     phase = TOMONT_HI;  // keep = hi(base) * 2^(64 mw) * R mod N
     stage_words<GEO>(io, A.base, A.base_stride, mw, A.base_words - mw, first_inst, A.count, nctx, lane, istep);
 #pragma unroll
-    for (int j = 0; j < K; ++j) bl[g][x * K + j] = PGPU_CTX(r2s)[x * K + j];
+    for (int j = 0; j < K; ++j) PGPU_STAGE(j, PGPU_CTX(r2s)[x * K + j]);
   } else {
     phase = TOMONT;
     stage_words<GEO>(io, A.base, A.base_stride, 0, A.base_words, first_inst, A.count, nctx, lane, istep);
 #pragma unroll
-    for (int j = 0; j < K; ++j) bl[g][x * K + j] = PGPU_CTX(r2)[x * K + j];
+    for (int j = 0; j < K; ++j) PGPU_STAGE(j, PGPU_CTX(r2)[x * K + j]);
   }
   wave_lds_sync();
 #pragma unroll
@@ -260,15 +281,15 @@ __global__ __launch_bounds__(kWGThreads, PGPU_MODEXP_MIN_WAVES) void modexp_kern
 #pragma unroll
         for (int j = 0; j < K; ++j) n[j] = PGPU_CTX(n)[x * K + j];
       }
-      montmul<GEO, false, false>(a, a, bl[g], n, n0inv);
+      PGPU_MONTMUL(false, false);
       break;
     }
     if (unitq && phase != GMUL) {
-      if (phase == SQR || phase == X2) montmul<GEO, true, true>(a, a, bl[g], n, n0inv, bl2[g]);
-      else montmul<GEO, false, true>(a, a, bl[g], n, n0inv);
+      if (phase == SQR || phase == X2) PGPU_MONTMUL(true, true);
+      else PGPU_MONTMUL(false, true);
     } else {
-      if (phase == SQR || phase == X2) montmul<GEO, true, false>(a, a, bl[g], n, n0inv, bl2[g]);
-      else montmul<GEO, false, false>(a, a, bl[g], n, n0inv);
+      if (phase == SQR || phase == X2) PGPU_MONTMUL(true, false);
+      else PGPU_MONTMUL(false, false);
     }
 
     bool start_main = false;
@@ -292,7 +313,7 @@ __global__ __launch_bounds__(kWGThreads, PGPU_MODEXP_MIN_WAVES) void modexp_kern
       stage_words<GEO>(io, A.base, A.base_stride, 0, wide ? mw : A.base_words, first_inst, A.count,
                        nctx, lane, istep);
 #pragma unroll
-      for (int j = 0; j < K; ++j) bl[g][x * K + j] = PGPU_CTX(r2)[x * K + j];
+      for (int j = 0; j < K; ++j) PGPU_STAGE(j, PGPU_CTX(r2)[x * K + j]);
       wave_lds_sync();
 #pragma unroll
       for (int j = 0; j < K; ++j) a[j] = limb_from_words(io[g], x * K + j);
@@ -326,7 +347,7 @@ __global__ __launch_bounds__(kWGThreads, PGPU_MODEXP_MIN_WAVES) void modexp_kern
         for (int j = 0; j < K; ++j) {
           tbl[L + j] = a[j];
           tbl[j] = PGPU_CTX(one)[x * K + j];
-          bl[g][x * K + j] = a[j];
+          PGPU_STAGE(j, a[j]);
         }
         wave_lds_sync();
         if (tsize > 2) phase = TABLE; else start_main = true;
@@ -335,7 +356,7 @@ __global__ __launch_bounds__(kWGThreads, PGPU_MODEXP_MIN_WAVES) void modexp_kern
       // a = base^2 * R: it becomes the staged multiplier; the running value restarts from base
       wave_lds_sync();
 #pragma unroll
-      for (int j = 0; j < K; ++j) { bl[g][x * K + j] = a[j]; a[j] = tbl[j]; }
+      for (int j = 0; j < K; ++j) { PGPU_STAGE(j, a[j]); a[j] = tbl[j]; }
       wave_lds_sync();
       e = 1;
       phase = TABLE;
@@ -374,10 +395,12 @@ __global__ __launch_bounds__(kWGThreads, PGPU_MODEXP_MIN_WAVES) void modexp_kern
 
     // ---- stage the multiplier operand of the next multiplication ----
     if (phase == SQR || phase == X2) {
-      wave_lds_sync();
+      if constexpr (!REGROWS) {     // (with REGROWS a squaring reads its rows from a: nothing to stage)
+        wave_lds_sync();
 #pragma unroll
-      for (int j = 0; j < K; ++j) { bl[g][x * K + j] = a[j]; bl2[g][x * K + j] = a[j] << 1; }
-      wave_lds_sync();
+        for (int j = 0; j < K; ++j) { bl[g][x * K + j] = a[j]; bl2[g][x * K + j] = a[j] << 1; }
+        wave_lds_sync();
+      }
     } else if (phase == MUL) {
       int d = sched_mode ? mul_idx : digit(win);
       uint32_t t[K];
@@ -385,20 +408,20 @@ __global__ __launch_bounds__(kWGThreads, PGPU_MODEXP_MIN_WAVES) void modexp_kern
       for (int j = 0; j < K; ++j) t[j] = tbl[(size_t)d * L + j];
       wave_lds_sync();
 #pragma unroll
-      for (int j = 0; j < K; ++j) bl[g][x * K + j] = t[j];
+      for (int j = 0; j < K; ++j) PGPU_STAGE(j, t[j]);
       wave_lds_sync();
     } else if (phase == FINAL) {
       // leave the Montgomery domain: multiply by 1, by the context constant, or by g^m
       wave_lds_sync();
       if (A.final_mul == FM_UNIT) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) bl[g][x * K + j] = (x == 0 && j == 0) ? 1u : 0u;
+        for (int j = 0; j < K; ++j) PGPU_STAGE(j, (x == 0 && j == 0) ? 1u : 0u);
       } else if (A.final_mul == FM_CTX_CONST) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) bl[g][x * K + j] = PGPU_CTX(fc)[x * K + j];
+        for (int j = 0; j < K; ++j) PGPU_STAGE(j, PGPU_CTX(fc)[x * K + j]);
       } else {
 #pragma unroll
-        for (int j = 0; j < K; ++j) bl[g][x * K + j] = keep[j];
+        for (int j = 0; j < K; ++j) PGPU_STAGE(j, keep[j]);
       }
       wave_lds_sync();
     }
@@ -416,6 +439,8 @@ __global__ __launch_bounds__(kWGThreads, PGPU_MODEXP_MIN_WAVES) void modexp_kern
   }
 }
 
+#undef PGPU_STAGE
+#undef PGPU_MONTMUL
 #undef PGPU_CTX
 
 // ---------------------------------------------------------------------------------------------

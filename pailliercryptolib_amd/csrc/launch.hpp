@@ -11,13 +11,21 @@
 
 namespace pgpu {
 
-// modexp_kernel lives in kModexpParts translation units; launch_modexp tries each
-constexpr int kModexpParts = 4;
+// modexp_kernel lives in eight translation units (k_modexp.hip, PGPU_PART 0..7); launch_modexp tries each.
+// regrows: the kernel form whose multiplier rows come from registers (kernels.hpp: modexp_kernel<GEO, true>).
 bool launch_modexp_part0(int G, int K, const ModexpArgs& a, unsigned blocks, hipStream_t s);
 bool launch_modexp_part1(int G, int K, const ModexpArgs& a, unsigned blocks, hipStream_t s);
 bool launch_modexp_part2(int G, int K, const ModexpArgs& a, unsigned blocks, hipStream_t s);
 bool launch_modexp_part3(int G, int K, const ModexpArgs& a, unsigned blocks, hipStream_t s);
-inline bool launch_modexp(int G, int K, const ModexpArgs& a, unsigned blocks, hipStream_t s) {
+bool launch_modexp_reg_part4(int G, int K, const ModexpArgs& a, unsigned blocks, hipStream_t s);
+bool launch_modexp_reg_part5(int G, int K, const ModexpArgs& a, unsigned blocks, hipStream_t s);
+bool launch_modexp_reg_part6(int G, int K, const ModexpArgs& a, unsigned blocks, hipStream_t s);
+bool launch_modexp_reg_part7(int G, int K, const ModexpArgs& a, unsigned blocks, hipStream_t s);
+inline bool modexp_has_regrows(int G, int K) { return G == 2 || G == 4 || (G == 16 && K <= 7); }
+inline bool launch_modexp(int G, int K, bool regrows, const ModexpArgs& a, unsigned blocks, hipStream_t s) {
+  if (regrows)
+    return launch_modexp_reg_part4(G, K, a, blocks, s) || launch_modexp_reg_part5(G, K, a, blocks, s) ||
+           launch_modexp_reg_part6(G, K, a, blocks, s) || launch_modexp_reg_part7(G, K, a, blocks, s);
   return launch_modexp_part0(G, K, a, blocks, s) || launch_modexp_part1(G, K, a, blocks, s) ||
          launch_modexp_part2(G, K, a, blocks, s) || launch_modexp_part3(G, K, a, blocks, s);
 }

@@ -67,6 +67,22 @@ __device__ __forceinline__ uint32_t bcast_lane0(uint32_t v) {
   }
 }
 
+// value held by lane S of every G-lane group, in every lane of the group (G in {2, 4, 16}: one DPP move)
+template <int G, int S>
+__device__ __forceinline__ uint32_t bcast_lane(uint32_t v) {
+  static_assert(G == 2 || G == 4 || G == 16, "one-instruction broadcast exists for 2-, 4- and 16-lane groups");
+  static_assert(S >= 0 && S < G, "lane index inside the group");
+  // (mov_dpp, not update_dpp: every lane reads a valid source, so there is no "old" value to materialise)
+  if constexpr (G == 16) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x150 + S /*row_newbcast:S*/, 0xf, 0xf, true);
+  } else if constexpr (G == 4) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, S | (S << 2) | (S << 4) | (S << 6) /*quad_perm:[S,S,S,S]*/, 0xf, 0xf, true);
+  } else {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, S | (S << 2) | ((2 + S) << 4) | ((2 + S) << 6), 0xf, 0xf,
+                                              true);   // quad_perm:[S,S,2+S,2+S]
+  }
+}
+
 // ---- fused DPP + mask (one VALU slot: v_and_b32_dpp) ----
 // m must live in a VGPR (callers launder it through an empty asm): with a register mask hipcc's DPP
 // combiner folds the v_and into the DPP move, schedules it freely and inserts the "VALU write -> DPP
@@ -103,18 +119,13 @@ __device__ __forceinline__ uint32_t and_bcast_lane0(uint32_t v, uint32_t m) {
 // j < r, against the doubled row limb (brow2 = 2*brow), plus the diagonal j == r once:
 //   sum_{X,S} [ sum_{j<r} 2 a_X[j] a_S[r] + sum_r a_X[r] a_S[r] ] = a^2   (rename X<->S, j<->r)
 // K(K+1)/2 MACs instead of K^2, identical instruction stream in every lane and block.
+// b / b2: the K multiplier rows of this block (b2 = 2*b, squarings only), in registers.
 template <class GEO, bool SQR, bool UNITQ>
-__device__ __forceinline__ void mont_block(uint64_t (&LOWC)[GEO::K], uint64_t (&UPC)[GEO::K],
-                                           const uint32_t (&a)[GEO::K], const uint32_t (&n)[GEO::K],
-                                           uint32_t n0inv, const uint32_t* __restrict__ brow,
-                                           const uint32_t* __restrict__ brow2) {
+__device__ __forceinline__ void mont_block_rows(uint64_t (&LOWC)[GEO::K], uint64_t (&UPC)[GEO::K],
+                                                const uint32_t (&a)[GEO::K], const uint32_t (&n)[GEO::K],
+                                                uint32_t n0inv, const uint32_t (&b)[GEO::K],
+                                                const uint32_t (&b2)[GEO::K]) {
   constexpr int K = GEO::K;
-  uint32_t b[K], b2[K];
-#pragma unroll
-  for (int r = 0; r < K; ++r) {
-    b[r] = brow[r];
-    if constexpr (SQR) b2[r] = brow2[r]; else b2[r] = 0;
-  }
   // phase A: acc += a_chunk * b_rows  (v_mad_u64_u32 only, no carries)
 #pragma unroll
   for (int r = 0; r < K; ++r) {
@@ -194,22 +205,47 @@ __device__ __forceinline__ void mont_block(uint64_t (&LOWC)[GEO::K], uint64_t (&
   for (int j = 0; j < K; ++j) LOWC[j] = 0;
 }
 
-// r = a * b * R^-1 mod N (lazy: inputs < 4N -> output < 2N), b read from LDS at bl[0..L).
-// Output limbs are < 2^29 except limbs 0 and 1 of a lane, which hold an unrippled carry (see pass 2).
-template <class GEO, bool SQR = false, bool UNITQ = false>
-__device__ __forceinline__ void montmul(uint32_t (&r)[GEO::K], const uint32_t (&a)[GEO::K],
-                                        const uint32_t* __restrict__ bl,
-                                        const uint32_t (&n)[GEO::K], uint32_t n0inv,
-                                        const uint32_t* __restrict__ bl2 = nullptr) {
+// rows staged in LDS by the caller (group-broadcast reads): the form for launches with several wavefronts per
+// SIMD, where somebody else's instructions cover the LDS round trip
+template <class GEO, bool SQR, bool UNITQ>
+__device__ __forceinline__ void mont_block(uint64_t (&LOWC)[GEO::K], uint64_t (&UPC)[GEO::K],
+                                           const uint32_t (&a)[GEO::K], const uint32_t (&n)[GEO::K],
+                                           uint32_t n0inv, const uint32_t* __restrict__ brow,
+                                           const uint32_t* __restrict__ brow2) {
   constexpr int K = GEO::K;
-  uint64_t c0[K], c1[K];
+  uint32_t b[K], b2[K];
 #pragma unroll
-  for (int j = 0; j < K; ++j) { c0[j] = 0; c1[j] = 0; }
-#pragma unroll 1
-  for (int s = 0; s < GEO::G; s += 2) {
-    mont_block<GEO, SQR, UNITQ>(c0, c1, a, n, n0inv, bl + s * K, bl2 + s * K);
-    mont_block<GEO, SQR, UNITQ>(c1, c0, a, n, n0inv, bl + (s + 1) * K, bl2 + (s + 1) * K);
+  for (int r = 0; r < K; ++r) {
+    b[r] = brow[r];
+    if constexpr (SQR) b2[r] = brow2[r]; else b2[r] = 0;
   }
+  mont_block_rows<GEO, SQR, UNITQ>(LOWC, UPC, a, n, n0inv, b, b2);
+}
+
+// rows taken straight from the registers of lane S of the group (m: the multiplier's limbs, lane-distributed like
+// a): one DPP broadcast per row limb, one shift per doubled limb, no LDS.  A wavefront that is ALONE on its SIMD
+// (the bench's CRT-decrypt launch, every small batch) pays every LDS round trip in full -- ~110 exposed cycles
+// per block plus ~25 ds_read / s_waitcnt issue slots and the staging writes of every multiplication -- which is
+// more than these 2K cheap VALU instructions; with several wavefronts per SIMD the LDS form wins
+// (profiles/r02_ubench_lone_wave.txt).
+template <class GEO, bool SQR, bool UNITQ, int S>
+__device__ __forceinline__ void mont_block_reg(uint64_t (&LOWC)[GEO::K], uint64_t (&UPC)[GEO::K],
+                                               const uint32_t (&a)[GEO::K], const uint32_t (&n)[GEO::K],
+                                               uint32_t n0inv, const uint32_t (&m)[GEO::K]) {
+  constexpr int K = GEO::K;
+  uint32_t b[K], b2[K];
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    b[r] = bcast_lane<GEO::G, S>(m[r]);
+    if constexpr (SQR) b2[r] = b[r] << 1; else b2[r] = 0;
+  }
+  mont_block_rows<GEO, SQR, UNITQ>(LOWC, UPC, a, n, n0inv, b, b2);
+}
+
+// Epilogue of a multiplication: the K finished columns -> relaxed 29-bit limbs.
+template <class GEO>
+__device__ __forceinline__ void montmul_finish(uint32_t (&r)[GEO::K], const uint64_t (&c0)[GEO::K]) {
+  constexpr int K = GEO::K;
   // pass 1: local carry propagation
   uint64_t c = 0;
 #pragma unroll
@@ -229,6 +265,50 @@ __device__ __forceinline__ void montmul(uint32_t (&r)[GEO::K], const uint32_t (&
   r[0] += dpp_from_prev((uint32_t)c) & maskv;
   r[1] += dpp_from_prev((uint32_t)(c >> kLimbBits));
 }
+
+// r = a * b * R^-1 mod N (lazy: inputs < 4N -> output < 2N), b read from LDS at bl[0..L).
+// Output limbs are < 2^29 except limbs 0 and 1 of a lane, which hold an unrippled carry (see pass 2).
+template <class GEO, bool SQR = false, bool UNITQ = false>
+__device__ __forceinline__ void montmul(uint32_t (&r)[GEO::K], const uint32_t (&a)[GEO::K],
+                                        const uint32_t* __restrict__ bl,
+                                        const uint32_t (&n)[GEO::K], uint32_t n0inv,
+                                        const uint32_t* __restrict__ bl2 = nullptr) {
+  constexpr int K = GEO::K;
+  uint64_t c0[K], c1[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) { c0[j] = 0; c1[j] = 0; }
+#pragma unroll 1
+  for (int s = 0; s < GEO::G; s += 2) {
+    mont_block<GEO, SQR, UNITQ>(c0, c1, a, n, n0inv, bl + s * K, bl2 + s * K);
+    mont_block<GEO, SQR, UNITQ>(c1, c0, a, n, n0inv, bl + (s + 1) * K, bl2 + (s + 1) * K);
+  }
+  montmul_finish<GEO>(r, c0);
+}
+
+// The same multiplication with the multiplier rows broadcast from registers (mont_block_reg): m holds the
+// multiplier's limbs, lane-distributed like a (a squaring passes a itself).  All G blocks are inline.
+template <class GEO, bool SQR, bool UNITQ, int S>
+__device__ __forceinline__ void montmul_reg_blocks(uint64_t (&c0)[GEO::K], uint64_t (&c1)[GEO::K],
+                                                   const uint32_t (&a)[GEO::K], const uint32_t (&n)[GEO::K],
+                                                   uint32_t n0inv, const uint32_t (&m)[GEO::K]) {
+  if constexpr (S < GEO::G) {
+    mont_block_reg<GEO, SQR, UNITQ, S>(c0, c1, a, n, n0inv, m);
+    mont_block_reg<GEO, SQR, UNITQ, S + 1>(c1, c0, a, n, n0inv, m);
+    montmul_reg_blocks<GEO, SQR, UNITQ, S + 2>(c0, c1, a, n, n0inv, m);
+  }
+}
+template <class GEO, bool SQR = false, bool UNITQ = false>
+__device__ __forceinline__ void montmul_reg(uint32_t (&r)[GEO::K], const uint32_t (&a)[GEO::K],
+                                            const uint32_t (&m)[GEO::K], const uint32_t (&n)[GEO::K],
+                                            uint32_t n0inv) {
+  constexpr int K = GEO::K;
+  uint64_t c0[K], c1[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) { c0[j] = 0; c1[j] = 0; }
+  montmul_reg_blocks<GEO, SQR, UNITQ, 0>(c0, c1, a, n, n0inv, m);
+  montmul_finish<GEO>(r, c0);
+}
+
 
 // Fully canonical limbs (< 2^29 everywhere).  Data-dependent trip count (<= G+1); used only
 // outside the multiplication loop.  Values may carry a signed borrow in r[] limbs on entry?  No:

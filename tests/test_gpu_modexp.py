@@ -152,3 +152,63 @@ def test_modexp_small_batches_latency_split(engine, mod_bits, count):
     assert engine.mod_exp(base, exp, mod) == [pow(b, e, mod) for b, e in zip(base, exp)]
     e = rng.getrandbits(1024)
     assert engine.mod_exp(base, [e], mod) == [pow(b, e, mod) for b in base]
+
+
+@pytest.mark.parametrize("row_source", [0, 1])
+def test_both_kernel_forms_agree_with_pow(engine, row_source):
+    """modexp_kernel exists in two forms per geometry -- multiplier rows read from LDS, or broadcast from registers
+    (the form for launches that leave a wavefront alone on its SIMD) -- normally picked by the wavefront count.
+    Force each form over every geometry class, several batch sizes, squarings and table products, fixed-window scan
+    and (shared exponent through the host API) sliding schedule; everything against CPython pow."""
+    import ctypes
+    from pailliercryptolib_amd import _capi
+    L = _capi.lib()
+    L.pgpu_debug_set_row_source.argtypes = [ctypes.c_int]
+    L.pgpu_debug_set_row_source.restype = None
+    rng = random.Random(900 + row_source)
+    L.pgpu_debug_set_row_source(row_source)
+    try:
+        for bits, ebits, count in ((512, 70, 33), (1024, 300, 200), (1536, 129, 70), (2048, 1024, 40), (2048, 64, 300),
+                                   (3072, 200, 24), (4096, 96, 40)):
+            mod = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+            base = [rng.randrange(mod) for _ in range(count)]
+            exp = [rng.getrandbits(ebits) for _ in range(count)]
+            assert engine.mod_exp(base, exp, mod) == [pow(b, e, mod) for b, e in zip(base, exp)], (bits, ebits, count)
+            e1 = rng.getrandbits(ebits) | 1
+            assert engine.mod_exp(base, [e1], mod) == [pow(b, e1, mod) for b in base], (bits, "shared", count)
+    finally:
+        L.pgpu_debug_set_row_source(-1)
+
+
+@pytest.mark.parametrize("row_source", [0, 1])
+@pytest.mark.parametrize("policy", [0, 1])
+def test_both_kernel_forms_in_crt_decrypt(engine, row_source, policy):
+    """The two-context decrypt launch (p^2 / q^2 sides, fixed-window scan or sliding schedules with parity waves) in
+    both kernel forms, for 1024-, 2048- and 3072-bit keys and batch sizes on either side of the latency-geometry
+    switch; ciphertexts come from the oracle, the plaintexts must come back."""
+    import ctypes
+    import json
+    import os
+    from pailliercryptolib_amd import _capi
+    L = _capi.lib()
+    L.pgpu_debug_set_row_source.argtypes = [ctypes.c_int]
+    L.pgpu_debug_set_row_source.restype = None
+    gold = os.path.join(os.path.dirname(__file__), "golden", "seeded_vectors.json")
+    rng = random.Random(77 + 2 * row_source + policy)
+    old = L.pgpu_get_secret_exponent_policy()
+    L.pgpu_debug_set_row_source(row_source)
+    _capi.check(L.pgpu_set_secret_exponent_policy(policy))
+    try:
+        for case in [c for c in json.load(open(gold))["cases"] if c["djn"]]:
+            p, q, hs, bits = int(case["p"], 16), int(case["q"], 16), int(case["hs"], 16), case["bits"]
+            n = p * q
+            opk = orc.PublicKey(n, bits)
+            opk.set_djn(hs)
+            sk = engine.PrivateKey(p, q)
+            for count in (3, 70):
+                m = [rng.randrange(n) for _ in range(count)]
+                ct = opk.encrypt(m, [rng.getrandbits(bits // 2) for _ in range(count)])
+                assert sk.decrypt(ct) == m, (bits, count)
+    finally:
+        L.pgpu_debug_set_row_source(-1)
+        _capi.check(L.pgpu_set_secret_exponent_policy(old))
