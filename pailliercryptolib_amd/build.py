@@ -8,6 +8,7 @@
 import os
 import shutil
 import subprocess
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -22,7 +23,7 @@ def _newer(target, sources):
 
 
 def _run(cmd, cwd=None):
-    print("[build]", " ".join(cmd), flush=True)
+    print("[build]", " ".join(cmd), file=sys.stderr, flush=True)   # (stdout belongs to the caller: bench.py's JSON line)
     subprocess.run(cmd, check=True, cwd=cwd)
 
 
