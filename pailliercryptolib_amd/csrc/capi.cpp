@@ -396,9 +396,10 @@ GeoInfo launch_geo(const GeoInfo& geo, size_t count) {
   return waves >= min_waves ? wide : geo;
 }
 
-// A launch that leaves a wavefront alone on its SIMD (at most ~1.5 wavefronts per SIMD) takes the kernel form whose
-// multiplier rows are broadcast from registers (kernels.hpp: REGROWS): nobody covers that wavefront's LDS round
-// trips.  PGPU_REGROWS=0 / 1 forces the LDS / register form (A/B measurements).
+// A launch of at most one wavefront per SIMD takes the kernel form whose multiplier rows are broadcast from registers
+// (kernels.hpp: REGROWS): nobody covers a lone wavefront's LDS round trips.  That form holds one wavefront per
+// SIMD (it parks a few values in AGPRs), so anything larger runs the LDS form at two per SIMD.
+// PGPU_REGROWS=0 / 1 forces the LDS / register form (A/B measurements).
 std::atomic<int> g_row_source{-2};   // -1 auto, 0 LDS, 1 registers (-2: not read from the environment yet)
 bool use_regrows(const GeoInfo& geo, size_t waves) {
   int mode = g_row_source.load();
@@ -409,7 +410,7 @@ bool use_regrows(const GeoInfo& geo, size_t waves) {
   }
   if (!pgpu::modexp_has_regrows(geo.G, geo.K)) return false;
   if (mode >= 0) return mode != 0;
-  return waves <= kSimds + kSimds / 2;
+  return waves <= kSimds;
 }
 
 uint64_t* g_wave_clocks = nullptr;   // diagnostics (tools/wave_spread.py)

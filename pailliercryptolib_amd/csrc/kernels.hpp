@@ -170,12 +170,10 @@ __global__ __launch_bounds__(kWGThreads, REGROWS ? 1 : PGPU_MODEXP_MIN_WAVES) vo
   constexpr int K = GEO::K, L = GEO::L, G = GEO::G, IPW = GEO::IPW;
   raise_wave_priority();
   __shared__ uint32_t bl_[kWavesPerWG][IPW][L];
-  __shared__ uint32_t bl2_[kWavesPerWG][REGROWS ? 1 : IPW][REGROWS ? 1 : L];   // doubled limbs of the operand being squared
   __shared__ uint64_t io_[kWavesPerWG][IPW][GEO::W64 + 1];
 
   const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
   auto& bl = bl_[wv];
-  auto& bl2 = bl2_[wv];
   auto& io = io_[wv];
   const int g = lane / G, x = lane % G;
   const int nctx = A.nctx;
@@ -209,7 +207,7 @@ __global__ __launch_bounds__(kWGThreads, REGROWS ? 1 : PGPU_MODEXP_MIN_WAVES) vo
       if constexpr (SQ) montmul_reg<GEO, true, UQ>(a, a, a, n, n0inv);                    \
       else montmul_reg<GEO, false, UQ>(a, a, mreg, n, n0inv);                             \
     } else {                                                                              \
-      if constexpr (SQ) montmul<GEO, true, UQ>(a, a, bl[g], n, n0inv, bl2[g]);            \
+      if constexpr (SQ) montmul<GEO, true, UQ>(a, a, bl[g], n, n0inv);                    \
       else montmul<GEO, false, UQ>(a, a, bl[g], n, n0inv);                                \
     }                                                                                     \
   } while (0)
@@ -398,7 +396,7 @@ __global__ __launch_bounds__(kWGThreads, REGROWS ? 1 : PGPU_MODEXP_MIN_WAVES) vo
       if constexpr (!REGROWS) {     // (with REGROWS a squaring reads its rows from a: nothing to stage)
         wave_lds_sync();
 #pragma unroll
-        for (int j = 0; j < K; ++j) { bl[g][x * K + j] = a[j]; bl2[g][x * K + j] = a[j] << 1; }
+        for (int j = 0; j < K; ++j) bl[g][x * K + j] = a[j];
         wave_lds_sync();
       }
     } else if (phase == MUL) {

@@ -27,6 +27,10 @@
 
 #include "kargs.hpp"
 
+#ifndef PGPU_REG_RECVMAC
+#define PGPU_REG_RECVMAC 1   // register-row form: hand-over limb added by a multiply-accumulate by one (see mont_block_rows)
+#endif
+
 namespace pgpu {
 
 
@@ -116,15 +120,18 @@ __device__ __forceinline__ uint32_t and_bcast_lane0(uint32_t v, uint32_t m) {
 // SQR = true: the multiplier rows ARE the multiplicand (a squaring).  Every cross product
 // a_X[j]*a_S[r] (lane chunk X, row block S) then occurs twice in the full square -- once in block
 // (X,S), once in block (S,X) at the same column -- so each block computes only the pairs with
-// j < r, against the doubled row limb (brow2 = 2*brow), plus the diagonal j == r once:
+// j < r, with one factor doubled (a2 = 2*a), plus the diagonal j == r once:
 //   sum_{X,S} [ sum_{j<r} 2 a_X[j] a_S[r] + sum_r a_X[r] a_S[r] ] = a^2   (rename X<->S, j<->r)
 // K(K+1)/2 MACs instead of K^2, identical instruction stream in every lane and block.
-// b / b2: the K multiplier rows of this block (b2 = 2*b, squarings only), in registers.
-template <class GEO, bool SQR, bool UNITQ>
+// b: the K multiplier rows of this block, in registers; a2 = 2*a (squarings only: the doubled cross products take
+// the doubling on the multiplicand side, computed once per multiplication instead of once per row and block).
+// RECVMAC: the received limb joins its column through a multiply-accumulate by one instead of a 64-bit add (the
+// register-row form: its register allocation otherwise spends a v_mov per row on the zero high half of the addend).
+template <class GEO, bool SQR, bool UNITQ, bool RECVMAC = false>
 __device__ __forceinline__ void mont_block_rows(uint64_t (&LOWC)[GEO::K], uint64_t (&UPC)[GEO::K],
-                                                const uint32_t (&a)[GEO::K], const uint32_t (&n)[GEO::K],
-                                                uint32_t n0inv, const uint32_t (&b)[GEO::K],
-                                                const uint32_t (&b2)[GEO::K]) {
+                                                const uint32_t (&a)[GEO::K], const uint32_t (&a2)[GEO::K],
+                                                const uint32_t (&n)[GEO::K], uint32_t n0inv,
+                                                const uint32_t (&b)[GEO::K]) {
   constexpr int K = GEO::K;
   // phase A: acc += a_chunk * b_rows  (v_mad_u64_u32 only, no carries)
 #pragma unroll
@@ -134,7 +141,7 @@ __device__ __forceinline__ void mont_block_rows(uint64_t (&LOWC)[GEO::K], uint64
       uint64_t p;
       if constexpr (SQR) {
         if (j > r) continue;
-        p = (uint64_t)a[j] * (j < r ? b2[r] : b[r]);
+        p = (uint64_t)(j < r ? a2[j] : a[j]) * b[r];
       } else {
         p = (uint64_t)a[j] * b[r];
       }
@@ -156,6 +163,12 @@ __device__ __forceinline__ void mont_block_rows(uint64_t (&LOWC)[GEO::K], uint64
     else UPC[r + j - K] += (uint64_t)n[j] * q;
   };
   uint32_t recv = 0, qprev = 0;
+  uint32_t onev = 1;
+  if constexpr (RECVMAC) asm("" : "+v"(onev));   // a VGPR holding 1 (keeps the product a v_mad_u64_u32)
+  auto add_recv = [&](uint64_t& col) {
+    if constexpr (RECVMAC) col += (uint64_t)recv * onev;
+    else col += recv;
+  };
 #pragma unroll
   for (int r = 0; r < K; ++r) {
     // UNITQ: the modulus is == -1 mod 2^29 (capi.hip: build_modctx scales it), so n0' = 1
@@ -170,7 +183,7 @@ __device__ __forceinline__ void mont_block_rows(uint64_t (&LOWC)[GEO::K], uint64
     if (r > 0) {
 #pragma unroll
       for (int j = J3; j < K; ++j) mac(r - 1, j, qprev);
-      UPC[r - 1] += recv;
+      add_recv(UPC[r - 1]);
     }
     __builtin_amdgcn_sched_barrier(kNoValuCross);
 #pragma unroll
@@ -199,7 +212,7 @@ __device__ __forceinline__ void mont_block_rows(uint64_t (&LOWC)[GEO::K], uint64
   }
 #pragma unroll
   for (int j = J3; j < K; ++j) mac(K - 1, j, qprev);
-  UPC[K - 1] += recv;
+  add_recv(UPC[K - 1]);
   // the low half is consumed; it becomes the (zero) upper half of the next block
 #pragma unroll
   for (int j = 0; j < K; ++j) LOWC[j] = 0;
@@ -209,37 +222,32 @@ __device__ __forceinline__ void mont_block_rows(uint64_t (&LOWC)[GEO::K], uint64
 // SIMD, where somebody else's instructions cover the LDS round trip
 template <class GEO, bool SQR, bool UNITQ>
 __device__ __forceinline__ void mont_block(uint64_t (&LOWC)[GEO::K], uint64_t (&UPC)[GEO::K],
-                                           const uint32_t (&a)[GEO::K], const uint32_t (&n)[GEO::K],
-                                           uint32_t n0inv, const uint32_t* __restrict__ brow,
-                                           const uint32_t* __restrict__ brow2) {
+                                           const uint32_t (&a)[GEO::K], const uint32_t (&a2)[GEO::K],
+                                           const uint32_t (&n)[GEO::K], uint32_t n0inv,
+                                           const uint32_t* __restrict__ brow) {
   constexpr int K = GEO::K;
-  uint32_t b[K], b2[K];
+  uint32_t b[K];
 #pragma unroll
-  for (int r = 0; r < K; ++r) {
-    b[r] = brow[r];
-    if constexpr (SQR) b2[r] = brow2[r]; else b2[r] = 0;
-  }
-  mont_block_rows<GEO, SQR, UNITQ>(LOWC, UPC, a, n, n0inv, b, b2);
+  for (int r = 0; r < K; ++r) b[r] = brow[r];
+  mont_block_rows<GEO, SQR, UNITQ>(LOWC, UPC, a, a2, n, n0inv, b);
 }
 
 // rows taken straight from the registers of lane S of the group (m: the multiplier's limbs, lane-distributed like
-// a): one DPP broadcast per row limb, one shift per doubled limb, no LDS.  A wavefront that is ALONE on its SIMD
+// a): one DPP broadcast per row limb, no LDS.  A wavefront that is ALONE on its SIMD
 // (the bench's CRT-decrypt launch, every small batch) pays every LDS round trip in full -- ~110 exposed cycles
 // per block plus ~25 ds_read / s_waitcnt issue slots and the staging writes of every multiplication -- which is
-// more than these 2K cheap VALU instructions; with several wavefronts per SIMD the LDS form wins
+// more than these K cheap VALU instructions; with several wavefronts per SIMD the LDS form wins
 // (profiles/r02_ubench_lone_wave.txt).
 template <class GEO, bool SQR, bool UNITQ, int S>
 __device__ __forceinline__ void mont_block_reg(uint64_t (&LOWC)[GEO::K], uint64_t (&UPC)[GEO::K],
-                                               const uint32_t (&a)[GEO::K], const uint32_t (&n)[GEO::K],
-                                               uint32_t n0inv, const uint32_t (&m)[GEO::K]) {
+                                               const uint32_t (&a)[GEO::K], const uint32_t (&a2)[GEO::K],
+                                               const uint32_t (&n)[GEO::K], uint32_t n0inv,
+                                               const uint32_t (&m)[GEO::K]) {
   constexpr int K = GEO::K;
-  uint32_t b[K], b2[K];
+  uint32_t b[K];
 #pragma unroll
-  for (int r = 0; r < K; ++r) {
-    b[r] = bcast_lane<GEO::G, S>(m[r]);
-    if constexpr (SQR) b2[r] = b[r] << 1; else b2[r] = 0;
-  }
-  mont_block_rows<GEO, SQR, UNITQ>(LOWC, UPC, a, n, n0inv, b, b2);
+  for (int r = 0; r < K; ++r) b[r] = bcast_lane<GEO::G, S>(m[r]);
+  mont_block_rows<GEO, SQR, UNITQ, PGPU_REG_RECVMAC != 0>(LOWC, UPC, a, a2, n, n0inv, b);
 }
 
 // Epilogue of a multiplication: the K finished columns -> relaxed 29-bit limbs.
@@ -271,16 +279,20 @@ __device__ __forceinline__ void montmul_finish(uint32_t (&r)[GEO::K], const uint
 template <class GEO, bool SQR = false, bool UNITQ = false>
 __device__ __forceinline__ void montmul(uint32_t (&r)[GEO::K], const uint32_t (&a)[GEO::K],
                                         const uint32_t* __restrict__ bl,
-                                        const uint32_t (&n)[GEO::K], uint32_t n0inv,
-                                        const uint32_t* __restrict__ bl2 = nullptr) {
+                                        const uint32_t (&n)[GEO::K], uint32_t n0inv) {
   constexpr int K = GEO::K;
   uint64_t c0[K], c1[K];
+  uint32_t a2[K];
 #pragma unroll
-  for (int j = 0; j < K; ++j) { c0[j] = 0; c1[j] = 0; }
+  for (int j = 0; j < K; ++j) {
+    c0[j] = 0;
+    c1[j] = 0;
+    a2[j] = SQR ? a[j] << 1 : 0;
+  }
 #pragma unroll 1
   for (int s = 0; s < GEO::G; s += 2) {
-    mont_block<GEO, SQR, UNITQ>(c0, c1, a, n, n0inv, bl + s * K, bl2 + s * K);
-    mont_block<GEO, SQR, UNITQ>(c1, c0, a, n, n0inv, bl + (s + 1) * K, bl2 + (s + 1) * K);
+    mont_block<GEO, SQR, UNITQ>(c0, c1, a, a2, n, n0inv, bl + s * K);
+    mont_block<GEO, SQR, UNITQ>(c1, c0, a, a2, n, n0inv, bl + (s + 1) * K);
   }
   montmul_finish<GEO>(r, c0);
 }
@@ -289,12 +301,13 @@ __device__ __forceinline__ void montmul(uint32_t (&r)[GEO::K], const uint32_t (&
 // multiplier's limbs, lane-distributed like a (a squaring passes a itself).  All G blocks are inline.
 template <class GEO, bool SQR, bool UNITQ, int S>
 __device__ __forceinline__ void montmul_reg_blocks(uint64_t (&c0)[GEO::K], uint64_t (&c1)[GEO::K],
-                                                   const uint32_t (&a)[GEO::K], const uint32_t (&n)[GEO::K],
-                                                   uint32_t n0inv, const uint32_t (&m)[GEO::K]) {
+                                                   const uint32_t (&a)[GEO::K], const uint32_t (&a2)[GEO::K],
+                                                   const uint32_t (&n)[GEO::K], uint32_t n0inv,
+                                                   const uint32_t (&m)[GEO::K]) {
   if constexpr (S < GEO::G) {
-    mont_block_reg<GEO, SQR, UNITQ, S>(c0, c1, a, n, n0inv, m);
-    mont_block_reg<GEO, SQR, UNITQ, S + 1>(c1, c0, a, n, n0inv, m);
-    montmul_reg_blocks<GEO, SQR, UNITQ, S + 2>(c0, c1, a, n, n0inv, m);
+    mont_block_reg<GEO, SQR, UNITQ, S>(c0, c1, a, a2, n, n0inv, m);
+    mont_block_reg<GEO, SQR, UNITQ, S + 1>(c1, c0, a, a2, n, n0inv, m);
+    montmul_reg_blocks<GEO, SQR, UNITQ, S + 2>(c0, c1, a, a2, n, n0inv, m);
   }
 }
 template <class GEO, bool SQR = false, bool UNITQ = false>
@@ -303,12 +316,16 @@ __device__ __forceinline__ void montmul_reg(uint32_t (&r)[GEO::K], const uint32_
                                             uint32_t n0inv) {
   constexpr int K = GEO::K;
   uint64_t c0[K], c1[K];
+  uint32_t a2[K];
 #pragma unroll
-  for (int j = 0; j < K; ++j) { c0[j] = 0; c1[j] = 0; }
-  montmul_reg_blocks<GEO, SQR, UNITQ, 0>(c0, c1, a, n, n0inv, m);
+  for (int j = 0; j < K; ++j) {
+    c0[j] = 0;
+    c1[j] = 0;
+    a2[j] = SQR ? a[j] << 1 : 0;
+  }
+  montmul_reg_blocks<GEO, SQR, UNITQ, 0>(c0, c1, a, a2, n, n0inv, m);
   montmul_finish<GEO>(r, c0);
 }
-
 
 // Fully canonical limbs (< 2^29 everywhere).  Data-dependent trip count (<= G+1); used only
 // outside the multiplication loop.  Values may carry a signed borrow in r[] limbs on entry?  No:
