@@ -540,6 +540,13 @@ int new_batch(size_t count, int words, std::unique_ptr<pgpu_batch>* out) {
   return PGPU_OK;
 }
 
+// A Montgomery-form batch fits a key when it was produced under the same modulus and geometry -- the same key
+// object, or another object built from the same n (copies of an ipcl::PublicKey each own a device key).
+bool same_domain(const std::shared_ptr<ModCtx>& batch_ctx, const std::shared_ptr<ModCtx>& key_ctx) {
+  if (!batch_ctx || batch_ctx == key_ctx) return true;
+  return batch_ctx->geo.L() == key_ctx->geo.L() && batch_ctx->geo.G == key_ctx->geo.G && batch_ctx->N == key_ctx->N;
+}
+
 // operands of one operation must be cut the same way (they are, unless min_shard changed in between)
 int same_layout(const pgpu_batch* a, const pgpu_batch* b) {
   if (b->count == 1 && a->count != 1) return PGPU_OK;   // broadcast operand: a copy everywhere (or on device 0)
@@ -1354,8 +1361,7 @@ int pgpu_batch_is_montgomery(const pgpu_batch* b) { return b && b->mont ? 1 : 0;
 int pgpu_batch_upload(const uint64_t* host, size_t count, int words, size_t stride, pgpu_batch** out) {
   RC_TRY(rt::check_ready());
   if (!host || !out) return fail(PGPU_ERR_INVALID_PARAM, "null pointer");
-  if (stride < (size_t)words) return fail(PGPU_ERR_INVALID_PARAM, "stride smaller than the row width");
-  if (stride != (size_t)words) return fail(PGPU_ERR_UNSUPPORTED, "batch upload needs densely packed rows");
+  if (words <= 0 || stride < (size_t)words) return fail(PGPU_ERR_INVALID_PARAM, "stride smaller than the row width");
   std::unique_ptr<pgpu_batch> b;
   RC_TRY(new_batch(count, words, &b));
   rt::TaskGroup tg;
@@ -1365,7 +1371,16 @@ int pgpu_batch_upload(const uint64_t* host, size_t count, int words, size_t stri
       size_t lo, hi;
       bp->bounds(d, &lo, &hi);
       hipStream_t s = lane.dev->bstream;
-      RC_TRY(lane.h2d(bp->ptr(d), host + lo * (size_t)words, (hi - lo) * (size_t)words * 8, s));
+      if (stride == (size_t)words) {
+        RC_TRY(lane.h2d(bp->ptr(d), host + lo * (size_t)words, (hi - lo) * (size_t)words * 8, s));
+      } else {   // rows padded to a wider stride on the host: the device batch is dense
+        std::vector<uint64_t> dense((hi - lo) * (size_t)words);
+        for (size_t i = lo; i < hi; ++i)
+          std::memcpy(dense.data() + (i - lo) * (size_t)words, host + i * stride, (size_t)words * 8);
+        RC_TRY(lane.h2d(bp->ptr(d), dense.data(), dense.size() * 8, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return PGPU_OK;
+      }
       HIP_TRY(hipStreamSynchronize(s));   // the caller may reuse `host` as soon as we return
       return PGPU_OK;
     });
@@ -1464,8 +1479,8 @@ int pgpu_batch_ct_add(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_ba
   const int W = 2 * key->n_words;
   if (a->words != W || b->words != W) return fail(PGPU_ERR_INVALID_PARAM, "CT + CT error: width mismatch");
   if (b->count != a->count && b->count != 1) return fail(PGPU_ERR_INVALID_PARAM, "CT + CT error: Size mismatch!");
-  if ((a->mont && a->mont != key->nsq) || (b->mont && b->mont != key->nsq))
-    return fail(PGPU_ERR_INVALID_PARAM, "CT + CT error: batch belongs to a different key object");
+  if (!same_domain(a->mont, key->nsq) || !same_domain(b->mont, key->nsq))
+    return fail(PGPU_ERR_INVALID_PARAM, "CT + CT error: 2 different public keys detected!");
   // both operands in the Montgomery domain -> ONE product per element, result stays there
   RC_TRY(same_layout(a, b));
   std::unique_ptr<pgpu_batch> ta, tb;
@@ -1499,12 +1514,12 @@ int pgpu_batch_ct_add_plain(const pgpu_pubkey* key, const pgpu_batch* a, const p
   const int W = 2 * key->n_words;
   if (a->words != W || m->words > W) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: width mismatch");
   if (m->count != a->count && m->count != 1) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: Size mismatch!");
-  if (a->mont && a->mont != key->nsq) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: batch belongs to a different key object");
+  if (!same_domain(a->mont, key->nsq)) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: batch belongs to a different key");
   if (m->mont) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: plaintext batch in Montgomery form");
   RC_TRY(same_layout(a, m));
   std::unique_ptr<pgpu_batch> o;
   RC_TRY(new_batch(a->count, W, &o));
-  o->mont = a->mont;   // the product keeps the form of the ciphertext
+  o->mont = a->mont ? key->nsq : nullptr;   // the product keeps the form of the ciphertext
   const bool bcast = m->count == 1 && a->count != 1;
   for (int d = 0; d < o->ndev; ++d) {
     size_t lo, hi;
@@ -1526,7 +1541,7 @@ int pgpu_batch_ct_mul(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_ba
   if (a->words != W) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: width mismatch");
   if (e->count != a->count && e->count != 1) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: Size mismatch!");
   if (e->mont) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: exponent batch in Montgomery form");
-  if (a->mont && a->mont != key->nsq) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: batch belongs to a different key object");
+  if (!same_domain(a->mont, key->nsq)) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: batch belongs to a different key");
   if (e_bits < 0 || e_bits > 64 * e->words) return fail(PGPU_ERR_INVALID_PARAM, "exp_bits/exp_words inconsistent");
   RC_TRY(same_layout(a, e));
   std::unique_ptr<pgpu_batch> o;

@@ -2,6 +2,12 @@
 // RDSEED / RDRAND / IPP-PRNG chain.  Randomness never reaches the GPU path except as data.
 #include "ipcl/utils/common.hpp"
 
+#include <sys/random.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstddef>
+#include <cstring>
 #include <random>
 
 #include "detail.hpp"
@@ -9,10 +15,30 @@
 
 namespace ipcl {
 
-void rand32u(std::vector<Ipp32u>& addr) {
-  std::random_device dev;
-  for (auto& x : addr) x = dev();
+namespace detail {
+// n bytes from the kernel CSPRNG in as few system calls as possible (a batch of 8192 DJN obfuscator exponents is
+// 1 MiB: one std::random_device call per 32-bit word used to be the slowest part of a real encrypt)
+void fill_random(void* dst, std::size_t n) {
+  unsigned char* p = static_cast<unsigned char*>(dst);
+  while (n > 0) {
+    ssize_t got = getrandom(p, n, 0);
+    if (got < 0) {
+      if (errno == EINTR) continue;
+      std::random_device dev;            // (no getrandom: fall back to the C++ source, word by word)
+      for (; n >= 4; n -= 4, p += 4) {
+        unsigned v = dev();
+        std::memcpy(p, &v, 4);
+      }
+      for (; n > 0; --n, ++p) *p = (unsigned char)dev();
+      return;
+    }
+    p += got;
+    n -= (std::size_t)got;
+  }
 }
+}  // namespace detail
+
+void rand32u(std::vector<Ipp32u>& addr) { detail::fill_random(addr.data(), addr.size() * sizeof(Ipp32u)); }
 
 BigNumber getRandomBN(int bits) {
   ERROR_CHECK(bits > 0, "getRandomBN: bit length must be positive");
@@ -24,23 +50,32 @@ BigNumber getRandomBN(int bits) {
 
 namespace detail {
 
+// BigNumber <-> flat limb arrays.  Deliberately serial: an OpenMP team was measured SLOWER here (fork/join of a
+// sleeping team costs more than the ~0.3 ms a conversion of 8192 elements takes, and OpenMP's default team of one
+// thread per visible CPU turns each region into hundreds of milliseconds on a 256-thread host under a 16-core quota).
+
 int max_bits(const std::vector<BigNumber>& v) {
   int b = 0;
-  for (const auto& x : v) b = std::max(b, x.isZero() ? 0 : x.BitSize());
+  const std::ptrdiff_t n = (std::ptrdiff_t)v.size();
+  for (std::ptrdiff_t i = 0; i < n; ++i) b = std::max(b, v[(size_t)i].isZero() ? 0 : v[(size_t)i].BitSize());
   return b;
 }
 
 std::vector<uint64_t> pack(const std::vector<BigNumber>& v, int words) {
   std::vector<uint64_t> flat(v.size() * (size_t)words);
-  for (size_t i = 0; i < v.size(); ++i)
-    ERROR_CHECK(v[i].toLimbs64(flat.data() + i * (size_t)words, (size_t)words),
-                "pack: value wider than the batch stride");
+  const std::ptrdiff_t n = (std::ptrdiff_t)v.size();
+  bool fits = true;
+  for (std::ptrdiff_t i = 0; i < n; ++i)
+    fits = fits && v[(size_t)i].toLimbs64(flat.data() + (size_t)i * (size_t)words, (size_t)words);
+  ERROR_CHECK(fits, "pack: value wider than the batch stride");
   return flat;
 }
 
 std::vector<BigNumber> unpack(const std::vector<uint64_t>& flat, std::size_t count, int words) {
   std::vector<BigNumber> v(count);
-  for (size_t i = 0; i < count; ++i) v[i] = BigNumber::fromLimbs64(flat.data() + i * (size_t)words, (size_t)words);
+  const std::ptrdiff_t n = (std::ptrdiff_t)count;
+  for (std::ptrdiff_t i = 0; i < n; ++i)
+    v[(size_t)i] = BigNumber::fromLimbs64(flat.data() + (size_t)i * (size_t)words, (size_t)words);
   return v;
 }
 

@@ -22,6 +22,7 @@ inline int words_for_bits(int bits) { return bits <= 0 ? 1 : (bits + 63) / 64; }
 std::vector<uint64_t> pack(const std::vector<BigNumber>& v, int words);
 std::vector<BigNumber> unpack(const std::vector<uint64_t>& flat, std::size_t count, int words);
 int max_bits(const std::vector<BigNumber>& v);
+void fill_random(void* dst, std::size_t n);   // kernel CSPRNG, bulk
 
 // A batch resident in GPU memory: [count][words] little-endian 64-bit limbs, cut into contiguous shards over
 // the device pool (pgpu_batch).  Immutable once produced (results are always written to fresh batches), so

@@ -4,6 +4,9 @@
 // plaintexts and the randomness are marshalled once and ONE fused GPU call returns the ciphertexts.
 #include "ipcl/pub_key.hpp"
 
+#include <algorithm>
+#include <cstddef>
+
 #include "detail.hpp"
 #include "ipcl/ciphertext.hpp"
 #include "ipcl/mod_exp.hpp"
@@ -100,12 +103,22 @@ std::shared_ptr<detail::PubKeyDevice> PublicKey::device() const {
 std::vector<BigNumber> PublicKey::drawRandom(std::size_t sz) const {
   if (m_testv) return m_r;  // used as is: size is checked by the caller like ippMBModExp does
   std::vector<BigNumber> r(sz);
-  if (m_enable_DJN) {
-    for (auto& x : r) x = getRandomBN(m_randbits);
-  } else {
-    const BigNumber nm1 = *m_n - 1;
-    for (auto& x : r) x = getRandomBN(m_bits) % nm1 + 1;
+  // one bulk read of the kernel CSPRNG for the whole batch
+  const int bits = m_enable_DJN ? m_randbits : m_bits;
+  ERROR_CHECK(bits > 0, "getRandomBN: bit length must be positive");
+  const std::size_t w32 = (std::size_t)BITSIZE_WORD(bits);
+  std::vector<Ipp32u> pool(sz * w32);
+  detail::fill_random(pool.data(), pool.size() * sizeof(Ipp32u));
+  const BigNumber nm1 = *m_n - 1;
+  const bool djn = m_enable_DJN;
+  const std::ptrdiff_t n = (std::ptrdiff_t)sz;
+  for (std::ptrdiff_t i = 0; i < n; ++i) {
+    Ipp32u* w = pool.data() + (std::size_t)i * w32;
+    if (bits % 32) w[w32 - 1] &= (1u << (bits % 32)) - 1;
+    BigNumber x(w, (int)w32);
+    r[(std::size_t)i] = djn ? x : x % nm1 + 1;
   }
+  std::fill(pool.begin(), pool.end(), 0u);
   return r;
 }
 

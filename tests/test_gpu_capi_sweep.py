@@ -82,3 +82,60 @@ def test_invalid_calls_return_error_codes(engine):
     assert L.pgpu_paillier_encrypt(None, ptr(one), 1, 1, ptr(one), 1, 1, 1, ptr(out), 1) == -1  # null key
     assert b"" != L.pgpu_last_error()
     assert L.pgpu_set_fixed_base_window(13) == -1
+
+
+def test_batch_api_errors_and_strided_upload(engine):
+    """pgpu_batch entry points: argument errors come back as status codes (never exit / abort), a padded host stride is
+    accepted, batches of different keys or sizes are refused."""
+    import json
+    import os
+    from pailliercryptolib_amd import _capi
+    from pailliercryptolib_amd.limbs import ints_to_limbs, limbs_to_ints
+    L = _capi.lib()
+    k = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "iso_kat.json")))
+    p, q, hs = int(k["p"], 16), int(k["q"], 16), int(k["bench_hs"], 16)
+    n = p * q
+    pk, sk = engine.PublicKey(n, 2048, hs=hs), engine.PrivateKey(p, q)
+    rng = random.Random(4)
+    h = ctypes.c_void_p()
+
+    def up(vals, words, stride=None):
+        stride = stride or words
+        a = np.zeros((len(vals), stride), dtype=np.uint64)
+        a[:, :words] = ints_to_limbs(vals, words)
+        a[:, words:] = np.uint64(0xDEADBEEF)          # padding must be ignored
+        b = ctypes.c_void_p()
+        _capi.check(L.pgpu_batch_upload(ptr(a), len(vals), words, stride, ctypes.byref(b)))
+        return b
+
+    def down(b):
+        out = np.empty((L.pgpu_batch_count(b), L.pgpu_batch_words(b)), dtype=np.uint64)
+        _capi.check(L.pgpu_batch_download(b, ptr(out)))
+        return limbs_to_ints(out)
+    m = [rng.randrange(n) for _ in range(9)]
+    r = [rng.getrandbits(1024) for _ in range(9)]
+    bm, br = up(m, 32, stride=40), up(r, 16, stride=17)
+    assert down(bm) == m and L.pgpu_batch_words(bm) == 32 and L.pgpu_batch_count(br) == 9
+    assert L.pgpu_batch_upload(ptr(np.zeros((2, 2), dtype=np.uint64)), 2, 2, 1, ctypes.byref(h)) == -1    # stride < words
+    assert L.pgpu_batch_upload(None, 2, 2, 2, ctypes.byref(h)) == -1
+    assert L.pgpu_batch_create(0, 4, ctypes.byref(h)) == -1                                             # empty batch
+    assert L.pgpu_batch_encrypt(pk._h, bm, up(r[:5], 16), 1024, ctypes.byref(h)) == -1                   # size mismatch
+    c = ctypes.c_void_p()
+    _capi.check(L.pgpu_batch_encrypt(pk._h, bm, br, 1024, ctypes.byref(c)))
+    assert L.pgpu_batch_is_montgomery(c) == 1 and L.pgpu_batch_is_montgomery(bm) == 0
+    assert L.pgpu_batch_encrypt(pk._h, c, br, 1024, ctypes.byref(h)) == -1                               # Montgomery-form "plaintext"
+    assert L.pgpu_batch_decrypt_crt(sk._h, bm, ctypes.byref(h)) == -1                                    # wrong width
+    assert L.pgpu_batch_ct_add(pk._h, c, up(m[:4], 64), ctypes.byref(h)) == -1                           # size mismatch
+    assert L.pgpu_batch_ct_mul(pk._h, c, c, 32, ctypes.byref(h)) == -1                                   # exponents in Montgomery form
+    assert L.pgpu_batch_ct_mul(pk._h, c, up([3] * 9, 1), 65, ctypes.byref(h)) == -1                      # e_bits > 64 * words
+    # a ciphertext batch of ANOTHER key size is refused by decrypt; one of an equal modulus (a second key object) is fine
+    pk2 = engine.PublicKey(n, 2048, hs=hs)
+    s = ctypes.c_void_p()
+    _capi.check(L.pgpu_batch_ct_add(pk2._h, c, c, ctypes.byref(s)))
+    d = ctypes.c_void_p()
+    _capi.check(L.pgpu_batch_decrypt_crt(sk._h, s, ctypes.byref(d)))
+    assert down(d) == [2 * x % n for x in m]
+    assert L.pgpu_batch_download(None, None) == -1
+    for b in (bm, br, c, s, d):
+        L.pgpu_batch_destroy(b)
+    L.pgpu_batch_destroy(None)
