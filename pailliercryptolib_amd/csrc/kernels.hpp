@@ -282,13 +282,32 @@ __global__ __launch_bounds__(kWGThreads, REGROWS ? 1 : PGPU_MODEXP_MIN_WAVES) vo
       PGPU_MONTMUL(false, false);
       break;
     }
+    // A run of squarings (83 % of all multiplications) is a tight loop around ONE call site: nothing between two
+    // squarings but the counter -- and, in the LDS form, the re-staging of the operand.  (Routing every squaring
+    // through the phase machine below cost 50-100 instructions of register shuffling and scalar bookkeeping each,
+    // and a scalar instruction is a 6-18 cycle issue slot for a wavefront that is alone on its SIMD.)
+#define PGPU_SQUARING_RUN(UQ)                                                  \
+  do {                                                                          \
+    int run_ = (phase == X2) ? 1 : sq;                                          \
+    for (;;) {                                                                  \
+      PGPU_MONTMUL(true, UQ);                                                   \
+      if (--run_ == 0) break;                                                   \
+      if constexpr (!REGROWS) {                                                 \
+        wave_lds_sync();                                                        \
+        _Pragma("unroll") for (int j = 0; j < K; ++j) bl[g][x * K + j] = a[j];  \
+        wave_lds_sync();                                                        \
+      }                                                                         \
+    }                                                                           \
+    if (phase == SQR) sq = 0;                                                   \
+  } while (0)
     if (unitq && phase != GMUL) {
-      if (phase == SQR || phase == X2) PGPU_MONTMUL(true, true);
+      if (phase == SQR || phase == X2) PGPU_SQUARING_RUN(true);
       else PGPU_MONTMUL(false, true);
     } else {
-      if (phase == SQR || phase == X2) PGPU_MONTMUL(true, false);
+      if (phase == SQR || phase == X2) PGPU_SQUARING_RUN(false);
       else PGPU_MONTMUL(false, false);
     }
+#undef PGPU_SQUARING_RUN
 
     bool start_main = false;
     if (phase == GMUL || phase == TOMONT_HI) {
@@ -362,10 +381,8 @@ __global__ __launch_bounds__(kWGThreads, REGROWS ? 1 : PGPU_MODEXP_MIN_WAVES) vo
 #pragma unroll
       for (int j = 0; j < K; ++j) tbl[(size_t)e * L + j] = a[j];
       if (++e == tsize) start_main = true;
-    } else if (phase == SQR) {
-      if (--sq == 0) {
-        if (!sched_mode || mul_idx >= 0) phase = MUL; else next_step();
-      }
+    } else if (phase == SQR) {   // the whole run of squarings is done (sq == 0)
+      if (!sched_mode || mul_idx >= 0) phase = MUL; else next_step();
     } else {  // MUL
       if (sched_mode) next_step();
       else if (--win < 0) phase = FINAL; else { phase = SQR; sq = w; }
