@@ -415,6 +415,20 @@ bool use_regrows(const GeoInfo& geo, size_t waves) {
 
 uint64_t* g_wave_clocks = nullptr;   // diagnostics (tools/wave_spread.py)
 
+// CRT decrypt: exponentiation modulo p^2 / q^2 in split form (hensel.hpp) where it is compiled for the key size;
+// PGPU_HENSEL=0 keeps the full-width modexp_kernel (A/B measurements, parity tests of both paths).
+std::atomic<int> g_hensel{-2};
+bool hensel_enabled() {
+  int mode = g_hensel.load();
+  if (mode == -2) {
+    const char* e = std::getenv("PGPU_HENSEL");
+    mode = (e && std::atoi(e) == 0) ? 0 : 1;
+    g_hensel.store(mode);
+  }
+  return mode != 0;
+}
+bool hensel_forced() { return g_hensel.load() == 2; }   // tests: also for batches that would take the latency geometry
+
 // common launcher of modexp_kernel on device `d`, stream `s`: sizes the window table of the stream's
 // workspace and fills the shared fields.  sched: per-context sliding-window schedules (device arrays) or null.
 struct SchedRef {
@@ -503,6 +517,11 @@ struct pgpu_privkey {
   rt::Replicated d_crt32;       // cp | cq | pinvR | pRM  (29-bit limbs, CRT geometry)
   rt::Replicated d_crt64;       // hp | hq | p^2 | q^2 | q   (n_words words each)
   int nsq_rbits = 0;            // R of the n^2 context: Montgomery-form ciphertexts carry this factor
+  // split-form exponentiation (hensel.hpp); hk == 0: not compiled for this key size
+  int hk = 0;                   // limbs per lane (a quad of 4 lanes per ciphertext side)
+  int h_chunk_words = 0, h_nchunks = 0;
+  rt::Replicated d_hensel;      // per side: P | p | h (2K limbs each) | pair one | pairs conv | pairs conv (Montgomery input)
+  uint32_t h_n0inv[2] = {0, 0}, h_k[2] = {0, 0};
 };
 
 // sharded device-resident batch
@@ -734,9 +753,62 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
   rt::StreamWork& w = d.work_for(s);
   std::lock_guard<std::mutex> lk(w.mu);   // the hand-over buffer is ours until both stages are queued
   RC_TRY(w.vbuf.ensure(2 * count * (size_t)nw * 8));
+  const bool lat = use_latency_geo(key->geo_lat, key->geo_exp, 2 * count);
+  const bool sliding = secret_policy() == PGPU_EXP_SLIDING && key->sched[0].dev.bytes;
+  bool have_m = false;
+  if (key->hk && hensel_enabled() && (!lat || hensel_forced())) {
+    // stage 1, split form: M[2i] = mp, M[2i+1] = mq  (hensel.hpp)
+    const int K = key->hk, nch = key->h_nchunks;
+    const size_t side_words = (size_t)6 * K + 4 * K + (size_t)2 * nch * 4 * K;
+    const uint32_t* blob = (const uint32_t*)key->d_hensel.d[(size_t)d.index];
+    pgpu::HenselArgs h{};
+    for (int sd = 0; sd < 2; ++sd) {
+      const uint32_t* b = blob + sd * side_words;
+      h.ctx[sd].nhat = b;
+      h.ctx[sd].n = b + 2 * K;
+      h.ctx[sd].h = b + 4 * K;
+      h.ctx[sd].one = b + 6 * K;
+      h.ctx[sd].conv = b + 10 * K + (in_mont ? (size_t)nch * 4 * K : 0);
+      h.ctx[sd].n0inv = key->h_n0inv[sd];
+      h.ctx[sd].k = key->h_k[sd];
+    }
+    h.ct = d_c;
+    h.ct_stride = (size_t)2 * nw;
+    h.ct_words = 2 * nw;
+    h.chunk_words = key->h_chunk_words;
+    h.nchunks = nch;
+    h.exp = (const uint64_t*)key->d_exps.d[(size_t)d.index];
+    h.exp_stride = (size_t)key->pq_words;
+    h.exp_words = key->pq_words;
+    h.exp_bits = key->exp_bits;
+    size_t entries;
+    if (sliding) {
+      for (int i = 0; i < 2; ++i) {
+        h.sched[i] = (const uint16_t*)key->sched[i].dev.d[(size_t)d.index];
+        h.sched_len[i] = key->sched[i].len;
+      }
+      h.window = key->sched[0].w;
+      entries = (size_t)1 << (h.window - 1);
+    } else {
+      h.window = pick_window(h.exp_bits);
+      entries = (size_t)1 << h.window;
+    }
+    h.out = (uint64_t*)w.vbuf.p;
+    h.out_stride = (size_t)key->pq_words;
+    h.out_words = key->pq_words;
+    h.count = count;
+    const size_t waves = 2 * ((count + 15) / 16);
+    const unsigned blocks = (unsigned)((waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
+    RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * 16 * entries * 4 * K * sizeof(uint32_t)));
+    h.table = (uint32_t*)w.table.p;
+    TimerScope t(d, s, PGPU_KERNEL_MODEXP);
+    if (!pgpu::launch_hensel(K, h, blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "split-form kernel not compiled");
+    HIP_TRY(hipGetLastError());
+    t.stop();
+    have_m = true;
+  }
   // stage 1: V[2i] = c^(p-1)*hp mod p^2, V[2i+1] = c^(q-1)*hq mod q^2   (2*count instances)
   pgpu::ModexpArgs a{};
-  const bool lat = use_latency_geo(key->geo_lat, key->geo_exp, 2 * count);
   const int vf = in_mont ? VF_BASE_MONT : VF_NONE;
   a.ctx[0] = (lat ? key->p2l : key->p2)->view(d.index, vf);
   a.ctx[1] = (lat ? key->q2l : key->q2)->view(d.index, vf);
@@ -754,7 +826,6 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
   a.out_stride = (size_t)nw;
   a.count = 2 * count;
   SchedRef sr;
-  const bool sliding = secret_policy() == PGPU_EXP_SLIDING && key->sched[0].dev.bytes;
   if (sliding) {
     for (int i = 0; i < 2; ++i) {
       sr.p[i] = (const uint16_t*)key->sched[i].dev.d[(size_t)d.index];
@@ -762,7 +833,7 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
     }
     sr.w = key->sched[0].w;
   }
-  RC_TRY(run_modexp(d, a, lat ? key->geo_lat : key->geo_exp, s, sliding ? &sr : nullptr, &w));
+  if (!have_m) RC_TRY(run_modexp(d, a, lat ? key->geo_lat : key->geo_exp, s, sliding ? &sr : nullptr, &w));
   // stage 2: L function, CRT
   const int Lc = key->geo_crt.L(), pad = key->geo_crt.w64() + 1;
   pgpu::CrtArgs c{};
@@ -780,7 +851,8 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
   c.q2_64 = c64 + 3 * pad;
   c.q64 = c64 + 4 * pad;
   c.v = (const uint64_t*)w.vbuf.p;
-  c.vw = nw;
+  c.vw = have_m ? key->pq_words : nw;
+  c.have_m = have_m ? 1 : 0;
   c.out = d_m;
   c.out_words = nw;
   c.count = count;
@@ -930,6 +1002,9 @@ void pgpu_debug_set_wave_clocks(uint64_t* d_buf) { g_wave_clocks = d_buf; }
 // tests / A-B measurements: force where modexp_kernel takes its multiplier rows from (-1 auto by wavefront count,
 // 0 LDS, 1 registers; geometries without a register form keep LDS).  Not part of the public header.
 void pgpu_debug_set_row_source(int mode) { g_row_source.store(mode < 0 ? -1 : (mode ? 1 : 0)); }
+// tests / A-B measurements: 0 = CRT decrypt through the full-width modexp_kernel, 1 = split form where compiled
+// (batches beyond the latency geometry's range), 2 = split form for every batch size
+void pgpu_debug_set_hensel(int mode) { g_hensel.store(mode < 0 ? 0 : (mode > 2 ? 2 : mode)); }
 
 int pgpu_set_timing(int enabled) {
   g_timing.store(enabled != 0);
@@ -1197,6 +1272,59 @@ int pgpu_paillier_encrypt(const pgpu_pubkey* key, const uint64_t* m, size_t m_st
 }
 
 // ===================== Paillier private key / CRT decrypt =====================
+namespace {
+// Constants of the split-form exponentiation (hensel.hpp) for both sides of the key.  A residue z modulo P^2 is
+// the pair (a, b) with z == a - P*b: a = z mod P, b = (P - z div P) mod P.
+int build_hensel(pgpu_privkey* k, const BigNumber& p, const BigNumber& q, const BigNumber& hp, const BigNumber& hq) {
+  const int bits_lo = std::min(p.BitSize(), q.BitSize()), bits_hi = std::max(p.BitSize(), q.BitSize());
+  // R = 2^(58K) >= 256 * P, P = prime * k < 2^(bits + 29)
+  const int K = (bits_hi + 29 + 8 + 2 * pgpu::kLimbBits - 1) / (2 * pgpu::kLimbBits);
+  if (!pgpu::hensel_has(K)) return PGPU_OK;
+  // a ciphertext enters in chunks z < 2^(64*cw) <= 2P (P >= prime > 2^(bits-1))
+  const int cw = std::min(k->pq_words, bits_lo / 64);
+  if (cw <= 0) return PGPU_OK;
+  const int ct_words = 2 * k->n_words;
+  const int nch = (ct_words + cw - 1) / cw;
+  const BigNumber R = pow2(2 * K * pgpu::kLimbBits);
+  const size_t side_words = (size_t)6 * K + 4 * K + (size_t)2 * nch * 4 * K;
+  std::vector<uint32_t> h(2 * side_words, 0);
+  for (int sd = 0; sd < 2; ++sd) {
+    const BigNumber& pr = sd ? q : p;
+    uint32_t n0 = (uint32_t)(pr.limbs64()[0] & pgpu::kLimbMask), inv = n0;
+    for (int i = 0; i < 5; ++i) inv *= 2u - n0 * inv;
+    const uint32_t n0inv = (0u - inv) & pgpu::kLimbMask;
+    const BigNumber P = pr * BigNumber((Ipp32u)n0inv);
+    const BigNumber P2 = P * P;
+    uint32_t* b = h.data() + sd * side_words;
+    auto put_pair = [&](uint32_t* dst, const BigNumber& z) {
+      const BigNumber zr = z % P2;
+      const BigNumber f = zr / P;
+      to_limbs29(zr % P, 2 * K, dst);
+      to_limbs29(f.isZero() ? f : P - f, 2 * K, dst + 2 * K);
+    };
+    to_limbs29(P, 2 * K, b);
+    to_limbs29(pr, 2 * K, b + 2 * K);
+    to_limbs29(sd ? hq : hp, 2 * K, b + 4 * K);
+    const BigNumber Rm = R % P2, R2 = (Rm * Rm) % P2;
+    put_pair(b + 6 * K, Rm);
+    const BigNumber R2m = (R2 * P2.InverseMul(pow2(k->nsq_rbits) % P2)) % P2;   // cancels the R of the n^2 context
+    for (int i = 0; i < nch; ++i) {
+      const BigNumber sh = pow2(64 * cw * i) % P2;
+      put_pair(b + 10 * K + (size_t)i * 4 * K, (R2 * sh) % P2);
+      put_pair(b + 10 * K + (size_t)(nch + i) * 4 * K, (R2m * sh) % P2);
+    }
+    k->h_n0inv[sd] = n0inv;
+    k->h_k[sd] = n0inv;   // P = prime * (-prime^-1 mod 2^29)
+  }
+  RC_TRY(k->d_hensel.upload(h.data(), h.size() * sizeof(uint32_t), true));
+  std::fill(h.begin(), h.end(), 0u);
+  k->hk = K;
+  k->h_chunk_words = cw;
+  k->h_nchunks = nch;
+  return PGPU_OK;
+}
+}  // namespace
+
 int pgpu_privkey_create(const uint64_t* p_in, const uint64_t* q_in, int pq_words,
                         pgpu_privkey** out) {
   RC_TRY(rt::check_ready());
@@ -1269,6 +1397,8 @@ int pgpu_privkey_create(const uint64_t* p_in, const uint64_t* q_in, int pq_words
     RC_TRY(make_schedule(pm1, sw, &k->sched[0], true));
     RC_TRY(make_schedule(qm1, sw, &k->sched[1], true));
   }
+
+  RC_TRY(build_hensel(k.get(), p, q, hp, hq));
 
   // recombination: auxiliary modulus M = 2^(29*(L-1)) - 1 must exceed n (exact u*p product)
   const GeoInfo* gc = nullptr;

@@ -1,0 +1,322 @@
+// pailliercryptolib_amd -- CRT-decrypt exponentiation modulo a SQUARE (p^2, q^2) in split form.
+//
+// Replaces the two half-width exponentiations of PrivateKey::decryptCRT and the L-function / *hp step behind them
+// (ipcl/pri_key.cpp:122-157; the reference hands c^(p-1) mod p^2 to ippMBModExp as a 2048-bit black box).
+// A residue modulo P^2 is kept as a PAIR of half-width numbers
+//        x  ==  a - P*b   (mod P^2),      0 <= a, b < 2P  (lazy),
+// and the Montgomery product of two pairs costs three half-width products and two half-width reductions
+// instead of one full-width product and one full-width reduction (5 s^2 instead of 8 s^2 limb products; a
+// squaring 4 s^2 -- here: 4 K^2 per lane -- instead of 6 s^2):
+//        a*c = t*R - q*P            (Montgomery reduction modulo P: t = (a*c + q*P)/R, q = the quotient digits)
+//   =>   (a - P*b)(c - P*d) == t*R - P*(a*d + b*c + q)            (mod P^2)
+//   =>   x*y*R^-1 == t - P*w,   w = (a*d + b*c + q) * R^-1 mod P  (a second Montgomery reduction modulo P)
+// -- the quotient digits of the first reduction are exactly the correction the second one needs, and with the
+// negated coefficient (a - P*b rather than a + P*b) every term is added, never subtracted.  R = 2^(29*2K) is the
+// Montgomery radix of the HALF width.  tests/test_hensel_model.py restates this with Python integers.
+//
+// Lanes: a 4-lane quad holds one exponentiation; quad lanes 0,1 ("half A") hold a, lanes 2,3 ("half B") hold b,
+// K 29-bit limbs per lane: two Geo<2,K> groups side by side that run ONE instruction stream.  The multiplier rows
+// of both halves are limbs of half A of an operand (c, then a), broadcast to the whole quad by one
+// v_mov_b32_dpp quad_perm:[S,S,S,S] each; half A accumulates a*c while half B accumulates b*c + d*a; the K-row
+// reduction blocks of mont_core.hpp run in both halves at once, half B's low lane receiving half A's digit first
+// (mont_reduce_rows<.., PAIR>).  The loop modulus is P = p*k == -1 (mod 2^29) (unit quotient digits); the
+// multiplication that leaves the Montgomery domain switches to the true prime: (a, k*b) is a pair modulo p^2.
+// With u = c^(p-1) == 1 (mod p) that last product, by (hp, 0), leaves  a' in {hp, hp + p}  and the plaintext half
+//        mp = L_p(u) * hp mod p  =  ([a' >= p] - b') mod p
+// directly -- the L function costs a comparison, and crt_kernel receives mp and mq instead of u*hp mod p^2.
+#ifndef PAILLIERCRYPTOLIB_AMD_CSRC_HENSEL_HPP_
+#define PAILLIERCRYPTOLIB_AMD_CSRC_HENSEL_HPP_
+
+#include "kernels.hpp"
+
+namespace pgpu {
+
+// One K-row block of a pair product.  mc: this lane's multiplicand limbs for the rows `crow` (half A: a,
+// half B: b; a squaring doubles half B's); md / arow: the second product of half B (d times the rows of a; md is
+// zero in half A, unused in a squaring).
+template <int K, bool SQR, bool UNITQ, int S>
+__device__ __forceinline__ void pair_block(uint64_t (&LOWC)[K], uint64_t (&UPC)[K], const uint32_t (&mc)[K],
+                                           const uint32_t (&md)[K], const uint32_t (&own)[K],
+                                           const uint32_t (&m)[K], const uint32_t (&n)[K], uint32_t n0inv,
+                                           uint32_t selB) {
+  using GEO = Geo<2, K>;
+  uint32_t crow[K];
+#pragma unroll
+  for (int r = 0; r < K; ++r) crow[r] = bcast_lane<4, S>(SQR ? own[r] : m[r]);
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const uint64_t p = (uint64_t)mc[j] * crow[r];
+      if (r + j < K) LOWC[r + j] += p;
+      else UPC[r + j - K] += p;
+    }
+  }
+  if constexpr (!SQR) {
+    uint32_t arow[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) arow[r] = bcast_lane<4, S>(own[r]);
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const uint64_t p = (uint64_t)md[j] * arow[r];
+        if (r + j < K) LOWC[r + j] += p;
+        else UPC[r + j - K] += p;
+      }
+    }
+  }
+  mont_reduce_rows<GEO, UNITQ, true, true>(LOWC, UPC, n, n0inv, selB);
+}
+
+// r = own (x) m: the Montgomery product of two pairs (lazy: inputs < 8P -> outputs < 2P).  own, m, r: this lane's
+// K limbs (half A: the a part, half B: the b part).  halfB: 1 in quad lanes 2,3; selB: 1 in quad lane 2.
+template <int K, bool SQR, bool UNITQ>
+__device__ __forceinline__ void pairmul(uint32_t (&r)[K], const uint32_t (&own)[K], const uint32_t (&m)[K],
+                                        const uint32_t (&n)[K], uint32_t n0inv, uint32_t halfB, uint32_t selB) {
+  static_assert(3 * K + 6 < 64, "a column of half B receives 3K products (+ relaxed limbs): must stay below 2^64");
+  using GEO = Geo<2, K>;
+  uint64_t c0[K], c1[K];
+  uint32_t mc[K], md[K];
+  const uint32_t maskB = 0u - halfB;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    c0[j] = 0;
+    c1[j] = 0;
+    mc[j] = SQR ? own[j] << halfB : own[j];   // squaring: half B accumulates 2*a*b
+    md[j] = SQR ? 0 : m[j] & maskB;
+  }
+  pair_block<K, SQR, UNITQ, 0>(c0, c1, mc, md, own, m, n, n0inv, selB);
+  pair_block<K, SQR, UNITQ, 1>(c1, c0, mc, md, own, m, n, n0inv, selB);
+  montmul_finish<GEO>(r, c0);
+}
+
+// d = r - s limb-wise (canonical limbs in, canonical limbs out, modulo 2^(29*L)); returns the final borrow
+// (1: r < s), known to every lane of the group.
+template <class GEO>
+__device__ __forceinline__ uint32_t sub_limbs(uint32_t (&d)[GEO::K], const uint32_t (&r)[GEO::K],
+                                              const uint32_t (&s)[GEO::K], int x, int lane) {
+  constexpr int K = GEO::K, G = GEO::G;
+  const int top_lane = (lane / G) * G + (G - 1);
+  uint32_t b = 0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    uint32_t t = r[j] - s[j] - b;
+    d[j] = t & kLimbMask;
+    b = t >> 31;
+  }
+  uint32_t top_borrow = b;
+  for (;;) {
+    uint32_t bin = dpp_from_prev(b);
+    if (x == 0) bin = 0;
+    if (__ballot(bin != 0) == 0) break;
+    b = bin;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      uint32_t t = d[j] - b;
+      d[j] = t & kLimbMask;
+      b = t >> 31;
+    }
+    top_borrow |= b;
+  }
+  return (uint32_t)__shfl((int)top_borrow, top_lane);
+}
+
+// One wavefront = 16 quads = 16 ciphertexts of ONE side (wave parity: even = p, odd = q), so context, exponent and
+// schedule are wave-uniform.  Output: row 2i = mp, row 2i+1 = mq (canonical words) for crt_kernel (have_m).
+template <int K>
+__global__ __launch_bounds__(kWGThreads, 1) void hensel_decrypt_kernel(HenselArgs A) {
+  using HG = Geo<2, K>;
+  constexpr int IPW = kWave / 4, L2 = 2 * K, LQ = 4 * K, W64 = HG::W64;
+  raise_wave_priority();
+  __shared__ uint32_t bl_[kWavesPerWG][IPW][L2];
+  __shared__ uint64_t io_[kWavesPerWG][IPW][W64 + 1];
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  auto& bl = bl_[wv];
+  auto& io = io_[wv];
+  const int q4 = lane / 4, x4 = lane % 4, x = x4 & 1;
+  const uint32_t halfB = (uint32_t)(x4 >> 1);
+  uint32_t selB = x4 == 2 ? 1u : 0u;
+  asm("" : "+v"(selB));   // opaque, so that "digit * selB" stays ONE v_mad_u64_u32 (not a select and a 64-bit add)
+  const size_t wave_id = (size_t)blockIdx.x * kWavesPerWG + wv;
+  const int side = __builtin_amdgcn_readfirstlane((int)(wave_id & 1));
+  const size_t first_elem = (wave_id >> 1) * IPW;
+  size_t elem = first_elem + q4;
+  if (elem >= A.count) elem = A.count - 1;   // padded quads recompute the last element
+#define HCTX(field) (side ? A.ctx[1].field : A.ctx[0].field)
+
+  uint32_t n[K], own[K], mreg[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) n[j] = HCTX(nhat)[x * K + j];
+  uint32_t n0inv = 0;   // unit quotient digits until the exit multiplication
+
+  const bool sched_mode = A.sched[0] != nullptr;
+  const uint16_t* sch = side ? A.sched[1] : A.sched[0];
+  const int nsteps = side ? A.sched_len[1] : A.sched_len[0];
+  const int w = A.window;
+  const int tsize = sched_mode ? 1 << (w - 1) : 1 << w;
+  uint32_t* tbl = A.table + (wave_id * IPW + q4) * (size_t)tsize * LQ + x4 * K;
+  const uint64_t* ep = A.exp + (size_t)side * A.exp_stride;
+  const int nwin = (A.exp_bits + w - 1) / w;
+  auto digit = [&](int i) -> int {
+    int bit = i * w;
+    int word = bit >> 6, sh = bit & 63;
+    uint64_t v = (word < A.exp_words) ? ep[word] >> sh : 0;
+    if (sh + w > 64 && word + 1 < A.exp_words) v |= ep[word + 1] << (64 - sh);
+    return (int)(v & (uint64_t)(tsize - 1));
+  };
+
+  // ---- c * R as a pair: sum over the ciphertext's chunks z_i (half-width, so (z_i, 0) is a pair) of
+  //      (z_i, 0) (x) pair(2^(64*cw*i) * R^2); a schedule adds one trip that squares the sum (its table holds the
+  //      odd powers and is built by multiplying with base^2) ----
+  uint32_t acc[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) acc[j] = 0;
+  {
+    const uint64_t* row = A.ct + elem * A.ct_stride;
+    const uint32_t* conv = HCTX(conv);
+    const int trips = A.nchunks + ((sched_mode && tsize > 1) ? 1 : 0);
+#pragma unroll 1
+    for (int i = 0; i < trips; ++i) {
+      if (i < A.nchunks) {
+        wave_lds_sync();
+        const int first = i * A.chunk_words;
+        const int words = min(A.chunk_words, A.ct_words - first);
+        for (int t = x4; t <= W64; t += 4) io[q4][t] = (t < words) ? row[first + t] : 0;
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          own[j] = halfB ? 0u : limb_from_words(io[q4], x * K + j);
+          mreg[j] = conv[(size_t)i * LQ + x4 * K + j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) own[j] = mreg[j] = acc[j];
+      }
+      pairmul<K, false, true>(own, own, mreg, n, n0inv, halfB, selB);
+      if (i < A.nchunks) add_normalise<HG>(acc, own);
+    }
+  }
+
+  // ---- window table.  Fixed window: all powers 0 .. 2^w-1, entry e = entry e-1 times the base;
+  //      schedule: the odd powers, entry e = entry e-1 times base^2 ----
+  {
+    int e;
+    if (sched_mode) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        tbl[j] = acc[j];
+        mreg[j] = own[j];      // base^2 (the extra trip above; unused if the table has one entry)
+        own[j] = acc[j];
+      }
+      e = 1;
+    } else {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        tbl[LQ + j] = acc[j];
+        tbl[j] = HCTX(one)[x4 * K + j];
+        mreg[j] = own[j] = acc[j];
+      }
+      e = 2;
+    }
+#pragma unroll 1
+    for (; e < tsize; ++e) {
+      pairmul<K, false, true>(own, own, mreg, n, n0inv, halfB, selB);
+#pragma unroll
+      for (int j = 0; j < K; ++j) tbl[(size_t)e * LQ + j] = own[j];
+    }
+  }
+
+  // ---- main loop: steps of (nsq squarings, one multiplication by a table entry) ----
+  // fixed window: nsq = w, entry = the next exponent digit (always multiplies, also by entry 0 = 1);
+  // schedule: the steps the host built (kargs.hpp: ModexpArgs::sched)
+  int win;
+  bool any = true;
+  if (sched_mode) {
+    if (nsteps == 0) any = false;
+    win = 1;
+  } else {
+    if (nwin == 0) any = false;
+    win = nwin - 2;
+  }
+  if (any) {
+    const int d0 = sched_mode ? (__builtin_amdgcn_readfirstlane((int)sch[0]) & 63) - 1 : digit(nwin - 1);
+#pragma unroll
+    for (int j = 0; j < K; ++j) own[j] = tbl[(size_t)d0 * LQ + j];   // (this lane's own earlier stores)
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j) own[j] = HCTX(one)[x4 * K + j];
+  }
+#pragma unroll 1
+  for (;;) {
+    int nsq, idx;
+    if (sched_mode) {
+      if (!any || win >= nsteps) break;
+      const int st = __builtin_amdgcn_readfirstlane((int)sch[win++]);
+      nsq = st >> 6;
+      idx = (st & 63) - 1;
+    } else {
+      if (!any || win < 0) break;
+      nsq = w;
+      idx = digit(win--);
+    }
+    const bool mul = !sched_mode || idx >= 0;
+    if (mul) {   // the entry travels while the squarings run
+#pragma unroll
+      for (int j = 0; j < K; ++j) mreg[j] = tbl[(size_t)idx * LQ + j];
+    }
+#pragma unroll 1
+    for (int i = 0; i < nsq; ++i) pairmul<K, true, true>(own, own, own, n, n0inv, halfB, selB);
+    if (mul) pairmul<K, false, true>(own, own, mreg, n, n0inv, halfB, selB);
+  }
+
+  // ---- leave the Montgomery domain under the TRUE prime: (a, k*b) is a pair modulo p^2; multiply by (hp, 0) ----
+  {
+    uint64_t col[K];
+    const uint32_t kk = halfB ? HCTX(k) : 1u;
+#pragma unroll
+    for (int j = 0; j < K; ++j) col[j] = (uint64_t)own[j] * kk;
+    montmul_finish<HG>(own, col);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      n[j] = HCTX(n)[x * K + j];
+      mreg[j] = halfB ? 0u : HCTX(h)[x * K + j];
+    }
+    n0inv = HCTX(n0inv);
+    pairmul<K, false, false>(own, own, mreg, n, n0inv, halfB, selB);
+  }
+  // half A: a' in {hp, hp + p};  half B: b' < 2p.   mp = ([a' >= p] - b') mod p
+  full_normalise<HG>(own, x);
+  uint32_t d[K];
+  const uint32_t below = sub_limbs<HG>(d, own, n, x, lane);          // half A: a' < p ?   half B: b' < p ?
+  const uint32_t jflag = (uint32_t)__shfl((int)(below ^ 1u), (lane & ~3) + 1);   // half A's verdict, quad-wide
+  if (!below) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) own[j] = d[j];                       // half B: b'' = b' mod p  (half A: unused)
+  }
+  (void)sub_limbs<HG>(d, n, own, x, lane);                           // p - b''  in (0, p]
+  if (x == 0) d[0] += jflag;
+  full_normalise<HG>(d, x);                                          // p - b'' + j  in (0, p + 1]
+  const uint32_t small = sub_limbs<HG>(own, d, n, x, lane);          // >= p: take the difference
+  if (small) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) own[j] = d[j];
+  }
+  wave_lds_sync();
+  if (halfB) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) bl[q4][x * K + j] = own[j];
+  }
+  wave_lds_sync();
+  const int ow = A.out_words;
+  for (int t = lane; t < IPW * ow; t += kWave) {
+    const int gg = t / ow, ww = t % ow;
+    const size_t oe = first_elem + gg;
+    if (oe < A.count) A.out[(2 * oe + side) * A.out_stride + ww] = ww < W64 ? word_from_limbs(bl[gg], L2, ww) : 0;
+  }
+#undef HCTX
+}
+
+}  // namespace pgpu
+
+#endif  // PAILLIERCRYPTOLIB_AMD_CSRC_HENSEL_HPP_

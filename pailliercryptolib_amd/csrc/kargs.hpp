@@ -117,9 +117,44 @@ struct CrtArgs {
   const uint64_t* q64;   // [vw] q (zero padded)
   const uint64_t* v;     // [2*count][vw]: row 2i = xp*hp mod p^2, row 2i+1 = xq*hq mod q^2
   int vw;                // words per row of v (= words of p^2)
+  int have_m;            // 1: the rows of v already hold mp (row 2i) and mq (row 2i+1), canonical (hensel.hpp)
   uint64_t* out;         // [count][out_words]  plaintexts (< n)
   int out_words;
   size_t count;
+};
+
+// CRT-decrypt exponentiation in split form (hensel.hpp): one side (p or q) of the key.  "pair" arrays hold 4K
+// limbs in quad-lane order: the 2K limbs of a, then the 2K limbs of b, for x == a - P*b (mod P^2).
+struct HenselCtxDev {
+  const uint32_t* nhat;  // [2K]  P = p * k == -1 mod 2^29: the loop modulus
+  const uint32_t* n;     // [2K]  p
+  const uint32_t* one;   // pair  R mod P^2                      (R = 2^(29*2K))
+  const uint32_t* conv;  // [nchunks] pairs  2^(64*chunk_words*i) * R^2 mod P^2  (divided by the R of the n^2
+                         //       context when the ciphertexts arrive in its Montgomery form)
+  const uint32_t* h;     // [2K]  hp (hq): the constant multiplier of pri_key.cpp:153-154
+  uint32_t n0inv;        // -p^-1 mod 2^29
+  uint32_t k;            // P / p
+};
+
+struct HenselArgs {
+  HenselCtxDev ctx[2];   // p side (even wavefronts), q side (odd wavefronts)
+  const uint64_t* ct;    // [count][ct_stride] ciphertexts
+  size_t ct_stride;
+  int ct_words;          // valid words per ciphertext
+  int chunk_words;       // a ciphertext enters as nchunks chunks of chunk_words words (each < 4P)
+  int nchunks;
+  const uint64_t* exp;   // [2][exp_stride]: p-1, q-1
+  size_t exp_stride;
+  int exp_words;
+  int exp_bits;
+  int window;            // as ModexpArgs::window
+  const uint16_t* sched[2];   // as ModexpArgs::sched (null: fixed-window scan)
+  int sched_len[2];
+  uint64_t* out;         // [2*count][out_stride]: row 2i = mp, row 2i+1 = mq
+  size_t out_stride;
+  int out_words;
+  uint32_t* table;       // [wavefronts * 16][entries][4K] workspace
+  size_t count;          // ciphertexts
 };
 
 struct FixedBaseArgs {

@@ -735,6 +735,15 @@ __global__ __launch_bounds__(kWGThreads) void crt_kernel(CrtArgs A) {
     const ModCtxDev& C = (step == 2) ? A.ctxQ : A.ctxM;
     const uint32_t* mulc = (step == 0) ? A.cp : (step == 1) ? A.cq : (step == 2) ? A.pinvR : A.pRM;
     wave_lds_sync();
+    if (A.have_m && step < 2) {   // the exponentiation kernel delivered mp / mq themselves (hensel.hpp)
+      const uint64_t* V = A.v + (2 * inst + step) * (size_t)vw;
+      uint64_t* dst = step ? tmp[g] : ymp[g];
+      for (int t = x; t <= W64; t += G) {
+        dst[t] = (t < vw) ? V[t] : 0;
+        io[g][t] = 0;   // (step 2 writes vw words of the difference and reads limbs from all of them)
+      }
+      continue;
+    }
     if (step < 2) {
       // io = (V - h) mod sq, exactly divisible by the prime
       const uint64_t* V = A.v + (2 * inst + step) * (size_t)vw;

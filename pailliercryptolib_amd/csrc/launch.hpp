@@ -30,6 +30,10 @@ inline bool launch_modexp(int G, int K, bool regrows, const ModexpArgs& a, unsig
          launch_modexp_part2(G, K, a, blocks, s) || launch_modexp_part3(G, K, a, blocks, s);
 }
 
+// hensel_decrypt_kernel (hensel.hpp, k_hensel.hip): K limbs per lane of a 4-lane quad
+inline bool hensel_has(int K) { return K == 10 || K == 19; }
+bool launch_hensel(int K, const HenselArgs& a, unsigned blocks, hipStream_t s);
+
 bool launch_modmul(int G, int K, const ModmulArgs& a, unsigned blocks, hipStream_t s);
 bool launch_crt(int G, int K, const CrtArgs& a, unsigned blocks, hipStream_t s);
 bool launch_fb_build(int G, int K, const FixedBaseBuildArgs& a, unsigned blocks, hipStream_t s);

@@ -127,29 +127,13 @@ __device__ __forceinline__ uint32_t and_bcast_lane0(uint32_t v, uint32_t m) {
 // the doubling on the multiplicand side, computed once per multiplication instead of once per row and block).
 // RECVMAC: the received limb joins its column through a multiply-accumulate by one instead of a 64-bit add (the
 // register-row form: its register allocation otherwise spends a v_mov per row on the zero high half of the addend).
-template <class GEO, bool SQR, bool UNITQ, bool RECVMAC = false>
-__device__ __forceinline__ void mont_block_rows(uint64_t (&LOWC)[GEO::K], uint64_t (&UPC)[GEO::K],
-                                                const uint32_t (&a)[GEO::K], const uint32_t (&a2)[GEO::K],
-                                                const uint32_t (&n)[GEO::K], uint32_t n0inv,
-                                                const uint32_t (&b)[GEO::K]) {
+// PAIR (hensel.hpp): the 2-lane group is one half of a 4-lane quad; the quotient digit of the quad's lower half
+// (lanes 0,1) is also added to column r of the upper half's low lane (selB = 1 in quad lane 2, else 0) before the
+// upper half takes its own digit.
+template <class GEO, bool UNITQ, bool RECVMAC, bool PAIR = false>
+__device__ __forceinline__ void mont_reduce_rows(uint64_t (&LOWC)[GEO::K], uint64_t (&UPC)[GEO::K],
+                                                 const uint32_t (&n)[GEO::K], uint32_t n0inv, uint32_t selB = 0) {
   constexpr int K = GEO::K;
-  // phase A: acc += a_chunk * b_rows  (v_mad_u64_u32 only, no carries)
-#pragma unroll
-  for (int r = 0; r < K; ++r) {
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      uint64_t p;
-      if constexpr (SQR) {
-        if (j > r) continue;
-        p = (uint64_t)(j < r ? a2[j] : a[j]) * b[r];
-      } else {
-        p = (uint64_t)a[j] * b[r];
-      }
-      if (r + j < K) LOWC[r + j] += p;
-      else UPC[r + j - K] += p;
-    }
-  }
-  // phase B: K quotient digits, each followed by acc += n_chunk * q
   uint32_t maskv = kLimbMask;
   asm("" : "+v"(maskv));   // keep the mask in a VGPR (v_and_b32_dpp takes no literal)
   // The dependent chain of a row is q -> MAC (columns r, r+1) -> carry -> q of the next row.  A lone
@@ -173,6 +157,11 @@ __device__ __forceinline__ void mont_block_rows(uint64_t (&LOWC)[GEO::K], uint64
   for (int r = 0; r < K; ++r) {
     // UNITQ: the modulus is == -1 mod 2^29 (capi.hip: build_modctx scales it), so n0' = 1
     __builtin_amdgcn_sched_barrier(kNoValuCross);
+    if constexpr (PAIR) {
+      static_assert(GEO::G == 2, "a pair is two 2-lane halves of a quad");
+      const uint32_t qa = bcast_lane<4, 0>(UNITQ ? (uint32_t)LOWC[r] : (uint32_t)LOWC[r] * n0inv) & maskv;
+      LOWC[r] += (uint64_t)qa * selB;
+    }
     uint32_t q = and_bcast_lane0<GEO::G>(UNITQ ? (uint32_t)LOWC[r] : (uint32_t)LOWC[r] * n0inv, maskv);
     // fillers between the broadcast and its first use: the last two MACs of the previous row, and
     // the hand-over of column r-1, final since the previous row: its 29-bit limb belongs to lane x-1,
@@ -216,6 +205,32 @@ __device__ __forceinline__ void mont_block_rows(uint64_t (&LOWC)[GEO::K], uint64
   // the low half is consumed; it becomes the (zero) upper half of the next block
 #pragma unroll
   for (int j = 0; j < K; ++j) LOWC[j] = 0;
+}
+
+template <class GEO, bool SQR, bool UNITQ, bool RECVMAC = false>
+__device__ __forceinline__ void mont_block_rows(uint64_t (&LOWC)[GEO::K], uint64_t (&UPC)[GEO::K],
+                                                const uint32_t (&a)[GEO::K], const uint32_t (&a2)[GEO::K],
+                                                const uint32_t (&n)[GEO::K], uint32_t n0inv,
+                                                const uint32_t (&b)[GEO::K]) {
+  constexpr int K = GEO::K;
+  // phase A: acc += a_chunk * b_rows  (v_mad_u64_u32 only, no carries)
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      uint64_t p;
+      if constexpr (SQR) {
+        if (j > r) continue;
+        p = (uint64_t)(j < r ? a2[j] : a[j]) * b[r];
+      } else {
+        p = (uint64_t)a[j] * b[r];
+      }
+      if (r + j < K) LOWC[r + j] += p;
+      else UPC[r + j - K] += p;
+    }
+  }
+  // phase B: K quotient digits, each followed by acc += n_chunk * q
+  mont_reduce_rows<GEO, UNITQ, RECVMAC>(LOWC, UPC, n, n0inv);
 }
 
 // rows staged in LDS by the caller (group-broadcast reads): the form for launches with several wavefronts per

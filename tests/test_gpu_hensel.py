@@ -1,0 +1,137 @@
+"""CRT decrypt through the split-form exponentiation (csrc/hensel.hpp: residues modulo p^2 as pairs a - P*b) against
+the full-width kernel and the oracle: same bits for every key class it is compiled for, both exponent policies,
+ragged batch sizes, the KAT and the seeded fixtures, ciphertexts that are not encryptions, and Montgomery-form
+(device-resident) ciphertexts."""
+import ctypes
+import json
+import os
+import random
+
+import pytest
+
+from oracle import paillier_oracle as orc
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _lib():
+    from pailliercryptolib_amd import _capi
+    L = _capi.lib()
+    L.pgpu_debug_set_hensel.argtypes = [ctypes.c_int]
+    L.pgpu_debug_set_hensel.restype = None
+    return L
+
+
+@pytest.fixture()
+def hensel(engine):
+    L = _lib()
+    yield L.pgpu_debug_set_hensel
+    L.pgpu_debug_set_hensel(1)   # the library default
+
+
+def _kat():
+    k = json.load(open(os.path.join(GOLD, "iso_kat.json")))
+    return {key: (int(v, 16) if isinstance(v, str) and v.startswith("0x") else v) for key, v in k.items()}
+
+
+def test_kat_and_fixtures_through_split_form(engine, hensel):
+    hensel(2)    # every batch size
+    kat = _kat()
+    sk = engine.PrivateKey(kat["p"], kat["q"])
+    num = kat["num_values"]
+    m = [kat["m0"]] * num
+    m[1] = kat["m1"]
+    c = [kat["c1"]] * num
+    c[1] = kat["c2"]
+    assert sk.decrypt(c) == m
+    assert sk.decrypt([kat["c1c2"]]) == [kat["m1m2"]]
+    data = json.load(open(os.path.join(GOLD, "seeded_vectors.json")))
+    ran = 0
+    for case in data["cases"]:
+        p, q = int(case["p"], 16), int(case["q"], 16)
+        sk = engine.PrivateKey(p, q)
+        assert sk.decrypt([int(v, 16) for v in case["c"]]) == [int(v, 16) for v in case["m"]], case["bits"]
+        ran += 1
+    assert ran
+
+
+@pytest.mark.parametrize("bits,count", [(1024, 37), (1024, 2311), (2048, 1), (2048, 16), (2048, 17), (2048, 2500)])
+@pytest.mark.parametrize("policy", ["fixed", "sliding"])
+def test_split_form_equals_full_width(engine, hensel, bits, count, policy):
+    """Random elements of Z_{n^2} (mostly NOT encryptions, so L_p(c^(p-1)) has no structure to hide behind)."""
+    from pailliercryptolib_amd import _capi
+    rng = random.Random(bits * 7 + count)
+    if bits == 2048:
+        kat = _kat()
+        p, q = kat["p"], kat["q"]
+    else:
+        case = next(c for c in json.load(open(os.path.join(GOLD, "seeded_vectors.json")))["cases"] if c["bits"] == bits)
+        p, q = int(case["p"], 16), int(case["q"], 16)
+    n = p * q
+    _capi.check(_capi.lib().pgpu_set_secret_exponent_policy(1 if policy == "sliding" else 0))
+    try:
+        sk = engine.PrivateKey(p, q)
+        c = [rng.randrange(1, n * n) for _ in range(count)]
+        c[0] = 1
+        if count > 2:
+            c[1] = n * n - 1
+            c[2] = n + 1
+        hensel(0)
+        ref = sk.decrypt(c)
+        hensel(2)
+        got = sk.decrypt(c)
+        assert got == ref
+        osk = orc.PrivateKey(n, p, q)
+        for i in sorted(set([0, 1 % count, 2 % count, count - 1, count // 2])):
+            assert got[i] == osk.decrypt([c[i]])[0]
+    finally:
+        _capi.check(_capi.lib().pgpu_set_secret_exponent_policy(0))
+
+
+def test_split_form_roundtrip_and_resident_chain(engine, hensel):
+    """enc -> dec at a size that takes the split form by default, and the device-resident chain
+    encrypt -> CT+CT -> decrypt, whose ciphertexts reach decrypt in the Montgomery form of n^2."""
+    import numpy as np
+    from pailliercryptolib_amd import _capi
+    from pailliercryptolib_amd.limbs import ints_to_limbs, limbs_to_ints
+    L = _capi.lib()
+    kat = _kat()
+    p, q = kat["p"], kat["q"]
+    n = p * q
+    nw = 32
+    rng = random.Random(11)
+    pk = engine.PublicKey(n, 2048, hs=kat["bench_hs"])
+    sk = engine.PrivateKey(p, q)
+    count = 3000
+    m1 = [rng.getrandbits(64) for _ in range(count)]
+    m2 = [rng.getrandbits(64) for _ in range(count)]
+    r1 = [rng.getrandbits(1024) for _ in range(count)]
+    r2 = [rng.getrandbits(1024) for _ in range(count)]
+    hensel(1)
+    assert sk.decrypt(pk.encrypt(m1, r1)) == m1
+
+    def ptr(a):
+        return a.ctypes.data_as(ctypes.c_void_p)
+
+    def up(vals, words):
+        h = ctypes.c_void_p()
+        a = ints_to_limbs(vals, words)
+        _capi.check(L.pgpu_batch_upload(ptr(a), len(vals), words, words, ctypes.byref(h)))
+        return h
+
+    def op(fn, *a):
+        h = ctypes.c_void_p()
+        _capi.check(fn(*a, ctypes.byref(h)))
+        return h
+    hs = [up(m1, nw), up(m2, nw), up(r1, 16), up(r2, 16)]
+    c1 = op(L.pgpu_batch_encrypt, pk._h, hs[0], hs[2], 1024)
+    c2 = op(L.pgpu_batch_encrypt, pk._h, hs[1], hs[3], 1024)
+    assert L.pgpu_batch_is_montgomery(c1)
+    sm = op(L.pgpu_batch_ct_add, pk._h, c1, c2)
+    d = op(L.pgpu_batch_decrypt_crt, sk._h, sm)
+    out = np.empty((L.pgpu_batch_count(d), L.pgpu_batch_words(d)), dtype=np.uint64)
+    _capi.check(L.pgpu_batch_download(d, ptr(out)))
+    assert limbs_to_ints(out) == [a + b for a, b in zip(m1, m2)]
+    for h in hs + [c1, c2, sm, d]:
+        L.pgpu_batch_destroy(h)

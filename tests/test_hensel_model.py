@@ -1,0 +1,100 @@
+"""Integer model of the split-form arithmetic of csrc/hensel.hpp (CPU test, no GPU): residues modulo P^2 as pairs
+x == a - P*b, the pair Montgomery product built from two half-width reductions, the chunked entry of a
+ciphertext, the fixed-window exponentiation, and the exit under the true prime that yields
+mp = L_p(c^(p-1) mod p^2) * hp mod p (ipcl/pri_key.cpp:136-157) without a division.  The lazy bounds the kernel
+relies on (every component below 2P) are asserted on the way."""
+import json
+import os
+import random
+
+import pytest
+
+LB = 29
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def setup(p, K):
+    k = (-pow(p, -1, 1 << LB)) % (1 << LB)
+    P = k * p
+    assert P % (1 << LB) == (1 << LB) - 1            # unit quotient digits
+    R = 1 << (LB * 2 * K)
+    assert R >= 256 * P
+    return k, P, R
+
+
+def to_pair(z, P):
+    z %= P * P
+    a, f = z % P, z // P
+    return (a, (P - f) % P)
+
+
+def val(pr, P):
+    return (pr[0] - P * pr[1]) % (P * P)
+
+
+def redc(T, P, R):
+    q = (T * (-pow(P, -1, R))) % R
+    return (T + q * P) // R, q
+
+
+def pmul(x, y, P, R):
+    (a, b), (c, d) = x, y
+    t, q = redc(a * c, P, R)
+    w, _ = redc(a * d + b * c + q, P, R)
+    assert t < 2 * P and w < 2 * P
+    return (t, w)
+
+
+def cases():
+    out = []
+    for case in json.load(open(os.path.join(GOLD, "seeded_vectors.json")))["cases"]:
+        if case["bits"] in (1024, 2048):
+            out.append((int(case["p"], 16), int(case["q"], 16)))
+    return out[:2]
+
+
+@pytest.mark.parametrize("side", [0, 1])
+def test_pair_exponentiation_matches_reference_formula(side):
+    rng = random.Random(3 + side)
+    for p, q in cases():
+        if side:
+            p, q = q, p
+        bits = p.bit_length()
+        K = (bits + 37 + 2 * LB - 1) // (2 * LB)
+        k, P, R = setup(p, K)
+        n = p * q
+        cw = min((bits + 63) // 64, bits // 64)
+        nch = (2 * ((n.bit_length() + 63) // 64) + cw - 1) // cw
+        conv = [to_pair((1 << (64 * cw * i)) * R * R, P) for i in range(nch)]
+        hp = pow(((pow(n + 1, p - 1, p * p) - 1) // p), -1, p)        # computeHfun, pri_key.cpp:159-167
+        for c in (1, n + 1, n * n - 1, rng.randrange(n * n), rng.randrange(n * n)):
+            acc = (0, 0)
+            for i in range(nch):
+                z = (c >> (64 * cw * i)) & ((1 << (64 * cw)) - 1)
+                assert z < 2 * P
+                t = pmul((z, 0), conv[i], P, R)
+                acc = (acc[0] + t[0], acc[1] + t[1])
+            assert val(acc, P) == c * R % (P * P)
+            w = 5
+            tbl = [to_pair(R, P), acc]
+            for _ in range(2, 1 << w):
+                tbl.append(pmul(tbl[-1], acc, P, R))
+            e = p - 1
+            nwin = (e.bit_length() + w - 1) // w
+            x = tbl[(e >> (w * (nwin - 1))) & 31]
+            for i in range(nwin - 2, -1, -1):
+                for _ in range(w):
+                    x = pmul(x, x, P, R)
+                x = pmul(x, tbl[(e >> (w * i)) & 31], P, R)
+            u = pow(c, p - 1, p * p)
+            assert val(x, P) % (p * p) == u * R % (p * p)
+            # exit: (a, k*b) is a pair modulo p^2; product with (hp, 0) under the true prime
+            a, B = x[0], k * x[1]
+            n0 = (-pow(p, -1, R)) % R
+            q1 = a * hp * n0 % R
+            t = (a * hp + q1 * p) // R
+            q2 = (B * hp + q1) * n0 % R
+            w2 = (B * hp + q1 + q2 * p) // R
+            assert t < 2 * p and w2 < 2 * p and t % p == hp
+            j = 1 if t >= p else 0
+            assert (j - w2) % p == ((u - 1) // p) * hp % p          # pri_key.cpp:142, 154-157
