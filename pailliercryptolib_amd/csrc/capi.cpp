@@ -427,7 +427,6 @@ bool hensel_enabled() {
   }
   return mode != 0;
 }
-bool hensel_forced() { return g_hensel.load() == 2; }   // tests: also for batches that would take the latency geometry
 
 // common launcher of modexp_kernel on device `d`, stream `s`: sizes the window table of the stream's
 // workspace and fills the shared fields.  sched: per-context sliding-window schedules (device arrays) or null.
@@ -517,11 +516,16 @@ struct pgpu_privkey {
   rt::Replicated d_crt32;       // cp | cq | pinvR | pRM  (29-bit limbs, CRT geometry)
   rt::Replicated d_crt64;       // hp | hq | p^2 | q^2 | q   (n_words words each)
   int nsq_rbits = 0;            // R of the n^2 context: Montgomery-form ciphertexts carry this factor
-  // split-form exponentiation (hensel.hpp); hk == 0: not compiled for this key size
-  int hk = 0;                   // limbs per lane (a quad of 4 lanes per ciphertext side)
-  int h_chunk_words = 0, h_nchunks = 0;
-  rt::Replicated d_hensel;      // per side: P | p | h (2K limbs each) | pair one | pairs conv | pairs conv (Montgomery input)
-  uint32_t h_n0inv[2] = {0, 0}, h_k[2] = {0, 0};
+  // split-form exponentiation (hensel.hpp): the forms compiled for this key size, most lanes per ciphertext
+  // (shortest serial chain) first; a launch takes the first one that still puts at most one wavefront on a SIMD
+  struct HenselSet {
+    int H = 0, K = 0;           // 2H lanes per ciphertext side, K limbs per lane; L2 = H*K limbs per half
+    int chunk_words = 0, nchunks = 0;
+    rt::Replicated blob;        // per side: P | p | h | k*R mod p (L2 limbs each) | pair one | pairs conv | pairs conv (Montgomery input)
+    uint32_t n0inv[2] = {0, 0};
+    size_t side_words() const { return (size_t)H * K * (6 + 4 * (size_t)nchunks); }
+  };
+  std::vector<std::unique_ptr<HenselSet>> hs;
 };
 
 // sharded device-resident batch
@@ -756,26 +760,39 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
   const bool lat = use_latency_geo(key->geo_lat, key->geo_exp, 2 * count);
   const bool sliding = secret_policy() == PGPU_EXP_SLIDING && key->sched[0].dev.bytes;
   bool have_m = false;
-  if (key->hk && hensel_enabled() && (!lat || hensel_forced())) {
+  const pgpu_privkey::HenselSet* hset = nullptr;
+  if (hensel_enabled() && !key->hs.empty()) {
+    const int mode = g_hensel.load();   // 1: by batch size; 2 / 3 (tests): always the form of fewest / most lanes
+    if (mode == 2) hset = key->hs.back().get();
+    else if (mode == 3) hset = key->hs.front().get();
+    else {
+      hset = key->hs.back().get();
+      for (const auto& f : key->hs) {
+        const size_t ipw = 64 / (2 * (size_t)f->H);
+        if (2 * ((count + ipw - 1) / ipw) <= kSimds) { hset = f.get(); break; }
+      }
+    }
+  }
+  if (hset) {
     // stage 1, split form: M[2i] = mp, M[2i+1] = mq  (hensel.hpp)
-    const int K = key->hk, nch = key->h_nchunks;
-    const size_t side_words = (size_t)6 * K + 4 * K + (size_t)2 * nch * 4 * K;
-    const uint32_t* blob = (const uint32_t*)key->d_hensel.d[(size_t)d.index];
+    const int L2 = hset->H * hset->K, nch = hset->nchunks, ipw = 64 / (2 * hset->H);
+    const size_t side_words = hset->side_words();
+    const uint32_t* blob = (const uint32_t*)hset->blob.d[(size_t)d.index];
     pgpu::HenselArgs h{};
     for (int sd = 0; sd < 2; ++sd) {
       const uint32_t* b = blob + sd * side_words;
       h.ctx[sd].nhat = b;
-      h.ctx[sd].n = b + 2 * K;
-      h.ctx[sd].h = b + 4 * K;
-      h.ctx[sd].one = b + 6 * K;
-      h.ctx[sd].conv = b + 10 * K + (in_mont ? (size_t)nch * 4 * K : 0);
-      h.ctx[sd].n0inv = key->h_n0inv[sd];
-      h.ctx[sd].k = key->h_k[sd];
+      h.ctx[sd].n = b + L2;
+      h.ctx[sd].h = b + 2 * L2;
+      h.ctx[sd].kr = b + 3 * L2;
+      h.ctx[sd].one = b + 4 * L2;
+      h.ctx[sd].conv = b + 6 * L2 + (in_mont ? (size_t)nch * 2 * L2 : 0);
+      h.ctx[sd].n0inv = hset->n0inv[sd];
     }
     h.ct = d_c;
     h.ct_stride = (size_t)2 * nw;
     h.ct_words = 2 * nw;
-    h.chunk_words = key->h_chunk_words;
+    h.chunk_words = hset->chunk_words;
     h.nchunks = nch;
     h.exp = (const uint64_t*)key->d_exps.d[(size_t)d.index];
     h.exp_stride = (size_t)key->pq_words;
@@ -797,12 +814,13 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
     h.out_stride = (size_t)key->pq_words;
     h.out_words = key->pq_words;
     h.count = count;
-    const size_t waves = 2 * ((count + 15) / 16);
+    const size_t waves = 2 * ((count + ipw - 1) / ipw);
     const unsigned blocks = (unsigned)((waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
-    RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * 16 * entries * 4 * K * sizeof(uint32_t)));
+    RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * ipw * entries * 2 * L2 * sizeof(uint32_t)));
     h.table = (uint32_t*)w.table.p;
     TimerScope t(d, s, PGPU_KERNEL_MODEXP);
-    if (!pgpu::launch_hensel(K, h, blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "split-form kernel not compiled");
+    if (!pgpu::launch_hensel(hset->H, hset->K, h, blocks, s))
+      return fail(PGPU_ERR_UNSUPPORTED, "split-form kernel not compiled");
     HIP_TRY(hipGetLastError());
     t.stop();
     have_m = true;
@@ -1003,8 +1021,8 @@ void pgpu_debug_set_wave_clocks(uint64_t* d_buf) { g_wave_clocks = d_buf; }
 // 0 LDS, 1 registers; geometries without a register form keep LDS).  Not part of the public header.
 void pgpu_debug_set_row_source(int mode) { g_row_source.store(mode < 0 ? -1 : (mode ? 1 : 0)); }
 // tests / A-B measurements: 0 = CRT decrypt through the full-width modexp_kernel, 1 = split form where compiled
-// (batches beyond the latency geometry's range), 2 = split form for every batch size
-void pgpu_debug_set_hensel(int mode) { g_hensel.store(mode < 0 ? 0 : (mode > 2 ? 2 : mode)); }
+// (throughput or latency form by batch size), 2 / 3 = always its throughput / latency form
+void pgpu_debug_set_hensel(int mode) { g_hensel.store(mode < 0 ? 0 : (mode > 3 ? 3 : mode)); }
 
 int pgpu_set_timing(int enabled) {
   g_timing.store(enabled != 0);
@@ -1275,18 +1293,21 @@ int pgpu_paillier_encrypt(const pgpu_pubkey* key, const uint64_t* m, size_t m_st
 namespace {
 // Constants of the split-form exponentiation (hensel.hpp) for both sides of the key.  A residue z modulo P^2 is
 // the pair (a, b) with z == a - P*b: a = z mod P, b = (P - z div P) mod P.
-int build_hensel(pgpu_privkey* k, const BigNumber& p, const BigNumber& q, const BigNumber& hp, const BigNumber& hq) {
-  const int bits_lo = std::min(p.BitSize(), q.BitSize()), bits_hi = std::max(p.BitSize(), q.BitSize());
-  // R = 2^(58K) >= 256 * P, P = prime * k < 2^(bits + 29)
-  const int K = (bits_hi + 29 + 8 + 2 * pgpu::kLimbBits - 1) / (2 * pgpu::kLimbBits);
-  if (!pgpu::hensel_has(K)) return PGPU_OK;
+int build_hensel_set(pgpu_privkey* k, pgpu_privkey::HenselSet* hs, int H, int K, const BigNumber& p,
+                     const BigNumber& q, const BigNumber& hp, const BigNumber& hq) {
+  const int L2 = H * K;
+  const int bits_lo = std::min(p.BitSize(), q.BitSize());
   // a ciphertext enters in chunks z < 2^(64*cw) <= 2P (P >= prime > 2^(bits-1))
   const int cw = std::min(k->pq_words, bits_lo / 64);
-  if (cw <= 0) return PGPU_OK;
+  if (cw <= 0) return PGPU_OK;   // (leaves hs->H == 0: no split form for this key)
   const int ct_words = 2 * k->n_words;
   const int nch = (ct_words + cw - 1) / cw;
-  const BigNumber R = pow2(2 * K * pgpu::kLimbBits);
-  const size_t side_words = (size_t)6 * K + 4 * K + (size_t)2 * nch * 4 * K;
+  const BigNumber R = pow2(L2 * pgpu::kLimbBits);
+  hs->H = H;
+  hs->K = K;
+  hs->chunk_words = cw;
+  hs->nchunks = nch;
+  const size_t side_words = hs->side_words();
   std::vector<uint32_t> h(2 * side_words, 0);
   for (int sd = 0; sd < 2; ++sd) {
     const BigNumber& pr = sd ? q : p;
@@ -1299,28 +1320,39 @@ int build_hensel(pgpu_privkey* k, const BigNumber& p, const BigNumber& q, const 
     auto put_pair = [&](uint32_t* dst, const BigNumber& z) {
       const BigNumber zr = z % P2;
       const BigNumber f = zr / P;
-      to_limbs29(zr % P, 2 * K, dst);
-      to_limbs29(f.isZero() ? f : P - f, 2 * K, dst + 2 * K);
+      to_limbs29(zr % P, L2, dst);
+      to_limbs29(f.isZero() ? f : P - f, L2, dst + L2);
     };
-    to_limbs29(P, 2 * K, b);
-    to_limbs29(pr, 2 * K, b + 2 * K);
-    to_limbs29(sd ? hq : hp, 2 * K, b + 4 * K);
+    to_limbs29(P, L2, b);
+    to_limbs29(pr, L2, b + L2);
+    to_limbs29(sd ? hq : hp, L2, b + 2 * L2);
+    to_limbs29((R % pr) * BigNumber((Ipp32u)n0inv) % pr, L2, b + 3 * L2);   // P = prime * (-prime^-1 mod 2^29)
     const BigNumber Rm = R % P2, R2 = (Rm * Rm) % P2;
-    put_pair(b + 6 * K, Rm);
+    put_pair(b + 4 * L2, Rm);
     const BigNumber R2m = (R2 * P2.InverseMul(pow2(k->nsq_rbits) % P2)) % P2;   // cancels the R of the n^2 context
     for (int i = 0; i < nch; ++i) {
       const BigNumber sh = pow2(64 * cw * i) % P2;
-      put_pair(b + 10 * K + (size_t)i * 4 * K, (R2 * sh) % P2);
-      put_pair(b + 10 * K + (size_t)(nch + i) * 4 * K, (R2m * sh) % P2);
+      put_pair(b + 6 * L2 + (size_t)i * 2 * L2, (R2 * sh) % P2);
+      put_pair(b + 6 * L2 + (size_t)(nch + i) * 2 * L2, (R2m * sh) % P2);
     }
-    k->h_n0inv[sd] = n0inv;
-    k->h_k[sd] = n0inv;   // P = prime * (-prime^-1 mod 2^29)
+    hs->n0inv[sd] = n0inv;
   }
-  RC_TRY(k->d_hensel.upload(h.data(), h.size() * sizeof(uint32_t), true));
+  const int rc = hs->blob.upload(h.data(), h.size() * sizeof(uint32_t), true);
   std::fill(h.begin(), h.end(), 0u);
-  k->hk = K;
-  k->h_chunk_words = cw;
-  k->h_nchunks = nch;
+  return rc;
+}
+int build_hensel(pgpu_privkey* k, const BigNumber& p, const BigNumber& q, const BigNumber& hp, const BigNumber& hq) {
+  // R = 2^(29*H*K) >= 256 * P, P = prime * k < 2^(bits + 29): per lane count the smallest compiled form with
+  // enough limbs
+  const int need = std::max(p.BitSize(), q.BitSize()) + 29 + 8;
+  for (int H : {8, 4, 2})
+    for (int K = 1; K <= 19; ++K)
+      if (pgpu::hensel_has(H, K) && pgpu::kLimbBits * H * K >= need) {
+        std::unique_ptr<pgpu_privkey::HenselSet> set(new pgpu_privkey::HenselSet);
+        RC_TRY(build_hensel_set(k, set.get(), H, K, p, q, hp, hq));
+        if (set->H) k->hs.push_back(std::move(set));
+        break;
+      }
   return PGPU_OK;
 }
 }  // namespace

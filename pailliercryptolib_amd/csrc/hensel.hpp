@@ -14,13 +14,14 @@
 // negated coefficient (a - P*b rather than a + P*b) every term is added, never subtracted.  R = 2^(29*2K) is the
 // Montgomery radix of the HALF width.  tests/test_hensel_model.py restates this with Python integers.
 //
-// Lanes: a 4-lane quad holds one exponentiation; quad lanes 0,1 ("half A") hold a, lanes 2,3 ("half B") hold b,
-// K 29-bit limbs per lane: two Geo<2,K> groups side by side that run ONE instruction stream.  The multiplier rows
-// of both halves are limbs of half A of an operand (c, then a), broadcast to the whole quad by one
-// v_mov_b32_dpp quad_perm:[S,S,S,S] each; half A accumulates a*c while half B accumulates b*c + d*a; the K-row
+// Lanes: a group of 2H lanes holds one exponentiation (H = 2: a quad; 4; 8: a DPP row); its lanes 0..H-1
+// ("half A") hold a, lanes H..2H-1 ("half B") hold b, K 29-bit limbs per lane: two Geo<H,K> groups side by side
+// that run ONE instruction stream.  The multiplier rows of both halves are limbs of half A of an operand (c, then
+// a), broadcast to the whole group by one v_mov_b32_dpp each (quad_perm:[S,S,S,S] / row_newbcast:S; two bank-masked
+// ones for H = 4); half A accumulates a*c while half B accumulates b*c + d*a; the K-row
 // reduction blocks of mont_core.hpp run in both halves at once, half B's low lane receiving half A's digit first
 // (mont_reduce_rows<.., PAIR>).  The loop modulus is P = p*k == -1 (mod 2^29) (unit quotient digits); the
-// multiplication that leaves the Montgomery domain switches to the true prime: (a, k*b) is a pair modulo p^2.
+// multiplication that leaves the Montgomery domain switches to the true prime: (a, k*b mod p) is a pair modulo p^2.
 // With u = c^(p-1) == 1 (mod p) that last product, by (hp, 0), leaves  a' in {hp, hp + p}  and the plaintext half
 //        mp = L_p(u) * hp mod p  =  ([a' >= p] - b') mod p
 // directly -- the L function costs a comparison, and crt_kernel receives mp and mq instead of u*hp mod p^2.
@@ -31,18 +32,38 @@
 
 namespace pgpu {
 
-// One K-row block of a pair product.  mc: this lane's multiplicand limbs for the rows `crow` (half A: a,
-// half B: b; a squaring doubles half B's); md / arow: the second product of half B (d times the rows of a; md is
+// Row source of a pair product: the limbs of half A of an operand, readable by ONE broadcast per row in both halves.
+// H = 2 (quad_perm:[S,S,S,S]) and H = 8 (row_newbcast:S) broadcast straight from half A; an 8-lane group would need
+// two bank-masked moves per row, so for H = 4 the upper quad first takes a copy of the lower quad's limbs (one
+// row_shr:4 move per limb and multiplication) and every quad broadcasts from its own lane S.
+template <int H, int K>
+__device__ __forceinline__ void pair_row_source(uint32_t (&src)[K], const uint32_t (&v)[K]) {
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    if constexpr (H == 4)
+      src[j] = (uint32_t)__builtin_amdgcn_update_dpp((int)v[j], (int)v[j], 0x114 /*row_shr:4*/, 0xf, 0xa, false);
+    else
+      src[j] = v[j];
+  }
+}
+template <int H, int S>
+__device__ __forceinline__ uint32_t pair_row(uint32_t src) {
+  if constexpr (H == 8) return bcast_lane<16, S>(src);
+  else return bcast_lane<4, S>(src);
+}
+
+// One K-row block of a pair product.  mc: this lane's multiplicand limbs for the rows of csrc (half A: a,
+// half B: b; a squaring doubles half B's); md / asrc: the second product of half B (d times the rows of a; md is
 // zero in half A, unused in a squaring).
-template <int K, bool SQR, bool UNITQ, int S>
+template <int H, int K, bool SQR, bool UNITQ, int S>
 __device__ __forceinline__ void pair_block(uint64_t (&LOWC)[K], uint64_t (&UPC)[K], const uint32_t (&mc)[K],
-                                           const uint32_t (&md)[K], const uint32_t (&own)[K],
-                                           const uint32_t (&m)[K], const uint32_t (&n)[K], uint32_t n0inv,
+                                           const uint32_t (&md)[K], const uint32_t (&csrc)[K],
+                                           const uint32_t (&asrc)[K], const uint32_t (&n)[K], uint32_t n0inv,
                                            uint32_t selB) {
-  using GEO = Geo<2, K>;
+  using GEO = Geo<H, K>;
   uint32_t crow[K];
 #pragma unroll
-  for (int r = 0; r < K; ++r) crow[r] = bcast_lane<4, S>(SQR ? own[r] : m[r]);
+  for (int r = 0; r < K; ++r) crow[r] = pair_row<H, S>(csrc[r]);
 #pragma unroll
   for (int r = 0; r < K; ++r) {
 #pragma unroll
@@ -55,7 +76,7 @@ __device__ __forceinline__ void pair_block(uint64_t (&LOWC)[K], uint64_t (&UPC)[
   if constexpr (!SQR) {
     uint32_t arow[K];
 #pragma unroll
-    for (int r = 0; r < K; ++r) arow[r] = bcast_lane<4, S>(own[r]);
+    for (int r = 0; r < K; ++r) arow[r] = pair_row<H, S>(asrc[r]);
 #pragma unroll
     for (int r = 0; r < K; ++r) {
 #pragma unroll
@@ -70,15 +91,29 @@ __device__ __forceinline__ void pair_block(uint64_t (&LOWC)[K], uint64_t (&UPC)[
 }
 
 // r = own (x) m: the Montgomery product of two pairs (lazy: inputs < 8P -> outputs < 2P).  own, m, r: this lane's
-// K limbs (half A: the a part, half B: the b part).  halfB: 1 in quad lanes 2,3; selB: 1 in quad lane 2.
-template <int K, bool SQR, bool UNITQ>
+// K limbs (half A: the a part, half B: the b part).  halfB: 1 in the upper H lanes; selB: 1 in lane H of the group.
+template <int H, int K, bool SQR, bool UNITQ, int S>
+__device__ __forceinline__ void pair_blocks(uint64_t (&c0)[K], uint64_t (&c1)[K], const uint32_t (&mc)[K],
+                                            const uint32_t (&md)[K], const uint32_t (&csrc)[K],
+                                            const uint32_t (&asrc)[K], const uint32_t (&n)[K], uint32_t n0inv,
+                                            uint32_t selB) {
+  if constexpr (S < H) {
+    pair_block<H, K, SQR, UNITQ, S>(c0, c1, mc, md, csrc, asrc, n, n0inv, selB);
+    pair_block<H, K, SQR, UNITQ, S + 1>(c1, c0, mc, md, csrc, asrc, n, n0inv, selB);
+    pair_blocks<H, K, SQR, UNITQ, S + 2>(c0, c1, mc, md, csrc, asrc, n, n0inv, selB);
+  }
+}
+template <int H, int K, bool SQR, bool UNITQ>
 __device__ __forceinline__ void pairmul(uint32_t (&r)[K], const uint32_t (&own)[K], const uint32_t (&m)[K],
                                         const uint32_t (&n)[K], uint32_t n0inv, uint32_t halfB, uint32_t selB) {
   static_assert(3 * K + 6 < 64, "a column of half B receives 3K products (+ relaxed limbs): must stay below 2^64");
-  using GEO = Geo<2, K>;
+  static_assert(H == 2 || H == 4 || H == 8, "two halves inside one 16-lane DPP row");
+  using GEO = Geo<H, K>;
   uint64_t c0[K], c1[K];
-  uint32_t mc[K], md[K];
+  uint32_t mc[K], md[K], csrc[K], asrc[K];
   const uint32_t maskB = 0u - halfB;
+  pair_row_source<H, K>(asrc, own);                     // rows of a (a squaring: the only rows)
+  if constexpr (!SQR) pair_row_source<H, K>(csrc, m);   // rows of c
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     c0[j] = 0;
@@ -86,8 +121,8 @@ __device__ __forceinline__ void pairmul(uint32_t (&r)[K], const uint32_t (&own)[
     mc[j] = SQR ? own[j] << halfB : own[j];   // squaring: half B accumulates 2*a*b
     md[j] = SQR ? 0 : m[j] & maskB;
   }
-  pair_block<K, SQR, UNITQ, 0>(c0, c1, mc, md, own, m, n, n0inv, selB);
-  pair_block<K, SQR, UNITQ, 1>(c1, c0, mc, md, own, m, n, n0inv, selB);
+  if constexpr (SQR) pair_blocks<H, K, SQR, UNITQ, 0>(c0, c1, mc, md, asrc, asrc, n, n0inv, selB);
+  else pair_blocks<H, K, SQR, UNITQ, 0>(c0, c1, mc, md, csrc, asrc, n, n0inv, selB);
   montmul_finish<GEO>(r, c0);
 }
 
@@ -122,21 +157,24 @@ __device__ __forceinline__ uint32_t sub_limbs(uint32_t (&d)[GEO::K], const uint3
   return (uint32_t)__shfl((int)top_borrow, top_lane);
 }
 
-// One wavefront = 16 quads = 16 ciphertexts of ONE side (wave parity: even = p, odd = q), so context, exponent and
-// schedule are wave-uniform.  Output: row 2i = mp, row 2i+1 = mq (canonical words) for crt_kernel (have_m).
-template <int K>
-__global__ __launch_bounds__(kWGThreads, 1) void hensel_decrypt_kernel(HenselArgs A) {
-  using HG = Geo<2, K>;
-  constexpr int IPW = kWave / 4, L2 = 2 * K, LQ = 4 * K, W64 = HG::W64;
+// One wavefront = 64/(2H) groups = that many ciphertexts of ONE side (wave parity: even = p, odd = q), so context,
+// exponent and schedule are wave-uniform.  Output: row 2i = mp, row 2i+1 = mq (canonical words) for crt_kernel
+// (have_m).  H = 2: the throughput form (16 ciphertexts per wavefront); H = 8: the latency form for small batches
+// (the serial chain of a multiplication is its H*K quotient rows, and a row shrinks with K).
+// (up to 14 limbs per lane the kernel fits the 256 registers that let two wavefronts share a SIMD)
+template <int H, int K>
+__global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : 1) void hensel_decrypt_kernel(HenselArgs A) {
+  using HG = Geo<H, K>;
+  constexpr int GS = 2 * H, IPW = kWave / GS, L2 = H * K, LQ = 2 * H * K, W64 = HG::W64;
   raise_wave_priority();
   __shared__ uint32_t bl_[kWavesPerWG][IPW][L2];
   __shared__ uint64_t io_[kWavesPerWG][IPW][W64 + 1];
   const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
   auto& bl = bl_[wv];
   auto& io = io_[wv];
-  const int q4 = lane / 4, x4 = lane % 4, x = x4 & 1;
-  const uint32_t halfB = (uint32_t)(x4 >> 1);
-  uint32_t selB = x4 == 2 ? 1u : 0u;
+  const int q4 = lane / GS, x4 = lane % GS, x = x4 % H;   // group, lane in the group, lane in its half
+  const uint32_t halfB = (uint32_t)(x4 / H);
+  uint32_t selB = x4 == H ? 1u : 0u;
   asm("" : "+v"(selB));   // opaque, so that "digit * selB" stays ONE v_mad_u64_u32 (not a select and a 64-bit add)
   const size_t wave_id = (size_t)blockIdx.x * kWavesPerWG + wv;
   const int side = __builtin_amdgcn_readfirstlane((int)(wave_id & 1));
@@ -182,7 +220,7 @@ __global__ __launch_bounds__(kWGThreads, 1) void hensel_decrypt_kernel(HenselArg
         wave_lds_sync();
         const int first = i * A.chunk_words;
         const int words = min(A.chunk_words, A.ct_words - first);
-        for (int t = x4; t <= W64; t += 4) io[q4][t] = (t < words) ? row[first + t] : 0;
+        for (int t = x4; t <= W64; t += GS) io[q4][t] = (t < words) ? row[first + t] : 0;
         wave_lds_sync();
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -193,7 +231,7 @@ __global__ __launch_bounds__(kWGThreads, 1) void hensel_decrypt_kernel(HenselArg
 #pragma unroll
         for (int j = 0; j < K; ++j) own[j] = mreg[j] = acc[j];
       }
-      pairmul<K, false, true>(own, own, mreg, n, n0inv, halfB, selB);
+      pairmul<H, K, false, true>(own, own, mreg, n, n0inv, halfB, selB);
       if (i < A.nchunks) add_normalise<HG>(acc, own);
     }
   }
@@ -221,7 +259,7 @@ __global__ __launch_bounds__(kWGThreads, 1) void hensel_decrypt_kernel(HenselArg
     }
 #pragma unroll 1
     for (; e < tsize; ++e) {
-      pairmul<K, false, true>(own, own, mreg, n, n0inv, halfB, selB);
+      pairmul<H, K, false, true>(own, own, mreg, n, n0inv, halfB, selB);
 #pragma unroll
       for (int j = 0; j < K; ++j) tbl[(size_t)e * LQ + j] = own[j];
     }
@@ -266,30 +304,33 @@ __global__ __launch_bounds__(kWGThreads, 1) void hensel_decrypt_kernel(HenselArg
       for (int j = 0; j < K; ++j) mreg[j] = tbl[(size_t)idx * LQ + j];
     }
 #pragma unroll 1
-    for (int i = 0; i < nsq; ++i) pairmul<K, true, true>(own, own, own, n, n0inv, halfB, selB);
-    if (mul) pairmul<K, false, true>(own, own, mreg, n, n0inv, halfB, selB);
+    for (int i = 0; i < nsq; ++i) pairmul<H, K, true, true>(own, own, own, n, n0inv, halfB, selB);
+    if (mul) pairmul<H, K, false, true>(own, own, mreg, n, n0inv, halfB, selB);
   }
 
-  // ---- leave the Montgomery domain under the TRUE prime: (a, k*b) is a pair modulo p^2; multiply by (hp, 0) ----
+  // ---- leave the Montgomery domain under the TRUE prime: (a, k*b mod p) is a pair modulo p^2 (only b's residue
+  //      modulo p matters); multiply by (hp, 0) ----
   {
-    uint64_t col[K];
-    const uint32_t kk = halfB ? HCTX(k) : 1u;
-#pragma unroll
-    for (int j = 0; j < K; ++j) col[j] = (uint64_t)own[j] * kk;
-    montmul_finish<HG>(own, col);
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       n[j] = HCTX(n)[x * K + j];
-      mreg[j] = halfB ? 0u : HCTX(h)[x * K + j];
+      mreg[j] = HCTX(kr)[x * K + j];      // k*R mod p: a half-width Montgomery product by it multiplies by k
     }
     n0inv = HCTX(n0inv);
-    pairmul<K, false, false>(own, own, mreg, n, n0inv, halfB, selB);
+    uint32_t kb[K];
+    montmul_reg<HG, false, false>(kb, own, mreg, n, n0inv);   // (both halves run it; half A keeps a)
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      if (halfB) own[j] = kb[j];
+      mreg[j] = halfB ? 0u : HCTX(h)[x * K + j];
+    }
+    pairmul<H, K, false, false>(own, own, mreg, n, n0inv, halfB, selB);
   }
   // half A: a' in {hp, hp + p};  half B: b' < 2p.   mp = ([a' >= p] - b') mod p
   full_normalise<HG>(own, x);
   uint32_t d[K];
   const uint32_t below = sub_limbs<HG>(d, own, n, x, lane);          // half A: a' < p ?   half B: b' < p ?
-  const uint32_t jflag = (uint32_t)__shfl((int)(below ^ 1u), (lane & ~3) + 1);   // half A's verdict, quad-wide
+  const uint32_t jflag = (uint32_t)__shfl((int)(below ^ 1u), (lane / GS) * GS);   // half A's verdict, group-wide
   if (!below) {
 #pragma unroll
     for (int j = 0; j < K; ++j) own[j] = d[j];                       // half B: b'' = b' mod p  (half A: unused)

@@ -1,19 +1,35 @@
-// pailliercryptolib_amd -- instantiations of the split-form CRT-decrypt exponentiation (hensel.hpp).
+// pailliercryptolib_amd -- instantiations of the split-form CRT-decrypt exponentiation (hensel.hpp), split over
+// PGPU_PART = 0..2 so that they compile in parallel.
 #include "hensel.hpp"
 #include "launch.hpp"
 
+#ifndef PGPU_PART
+#error "compile with -DPGPU_PART=0..2"
+#endif
+
 namespace pgpu {
 
-bool launch_hensel(int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
-  if (K == 10) {
-    hipLaunchKernelGGL((hensel_decrypt_kernel<10>), dim3(blocks), dim3(kWGThreads), 0, s, a);
-    return true;
+#define PGPU_HENSEL_ONE(h, k)                                                                             \
+  if (H == h && K == k) {                                                                                 \
+    hipLaunchKernelGGL((hensel_decrypt_kernel<h, k>), dim3(blocks), dim3(kWGThreads), 0, s, a);           \
+    return true;                                                                                          \
   }
-  if (K == 19) {
-    hipLaunchKernelGGL((hensel_decrypt_kernel<19>), dim3(blocks), dim3(kWGThreads), 0, s, a);
-    return true;
-  }
+
+#if PGPU_PART == 0
+bool launch_hensel_part0(int H, int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
+  PGPU_HENSEL_ONE(2, 19) PGPU_HENSEL_ONE(2, 10) PGPU_HENSEL_ONE(4, 5)
   return false;
 }
+#elif PGPU_PART == 1
+bool launch_hensel_part1(int H, int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
+  PGPU_HENSEL_ONE(4, 18) PGPU_HENSEL_ONE(4, 14) PGPU_HENSEL_ONE(4, 10)
+  return false;
+}
+#else
+bool launch_hensel_part2(int H, int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
+  PGPU_HENSEL_ONE(8, 3) PGPU_HENSEL_ONE(8, 5) PGPU_HENSEL_ONE(8, 7) PGPU_HENSEL_ONE(8, 9)
+  return false;
+}
+#endif
 
 }  // namespace pgpu

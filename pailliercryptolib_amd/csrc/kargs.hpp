@@ -123,17 +123,18 @@ struct CrtArgs {
   size_t count;
 };
 
-// CRT-decrypt exponentiation in split form (hensel.hpp): one side (p or q) of the key.  "pair" arrays hold 4K
-// limbs in quad-lane order: the 2K limbs of a, then the 2K limbs of b, for x == a - P*b (mod P^2).
+// CRT-decrypt exponentiation in split form (hensel.hpp): one side (p or q) of the key.  L2 = H*K limbs per half;
+// "pair" arrays hold 2*L2 limbs in group-lane order: the L2 limbs of a, then the L2 limbs of b, for
+// x == a - P*b (mod P^2).
 struct HenselCtxDev {
-  const uint32_t* nhat;  // [2K]  P = p * k == -1 mod 2^29: the loop modulus
-  const uint32_t* n;     // [2K]  p
-  const uint32_t* one;   // pair  R mod P^2                      (R = 2^(29*2K))
+  const uint32_t* nhat;  // [L2]  P = p * k == -1 mod 2^29: the loop modulus
+  const uint32_t* n;     // [L2]  p
+  const uint32_t* one;   // pair  R mod P^2                      (R = 2^(29*L2))
   const uint32_t* conv;  // [nchunks] pairs  2^(64*chunk_words*i) * R^2 mod P^2  (divided by the R of the n^2
                          //       context when the ciphertexts arrive in its Montgomery form)
-  const uint32_t* h;     // [2K]  hp (hq): the constant multiplier of pri_key.cpp:153-154
+  const uint32_t* h;     // [L2]  hp (hq): the constant multiplier of pri_key.cpp:153-154
+  const uint32_t* kr;    // [L2]  (P / p) * R mod p
   uint32_t n0inv;        // -p^-1 mod 2^29
-  uint32_t k;            // P / p
 };
 
 struct HenselArgs {
@@ -153,7 +154,7 @@ struct HenselArgs {
   uint64_t* out;         // [2*count][out_stride]: row 2i = mp, row 2i+1 = mq
   size_t out_stride;
   int out_words;
-  uint32_t* table;       // [wavefronts * 16][entries][4K] workspace
+  uint32_t* table;       // [wavefronts * 64/(2H)][entries][2*L2] workspace
   size_t count;          // ciphertexts
 };
 

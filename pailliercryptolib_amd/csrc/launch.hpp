@@ -30,9 +30,21 @@ inline bool launch_modexp(int G, int K, bool regrows, const ModexpArgs& a, unsig
          launch_modexp_part2(G, K, a, blocks, s) || launch_modexp_part3(G, K, a, blocks, s);
 }
 
-// hensel_decrypt_kernel (hensel.hpp, k_hensel.hip): K limbs per lane of a 4-lane quad
-inline bool hensel_has(int K) { return K == 10 || K == 19; }
-bool launch_hensel(int K, const HenselArgs& a, unsigned blocks, hipStream_t s);
+// hensel_decrypt_kernel (hensel.hpp; k_hensel.hip compiled once per PGPU_PART): 2H lanes per ciphertext side, K limbs
+// per lane, H*K >= limbs of (prime * 2^37).  Per key class the forms from few lanes (throughput) to many (latency:
+// batches that leave SIMDs idle): 1024-bit keys (2,10) (4,5) (8,3); 2048: (2,19) (4,10) (8,5); 3072: (4,14) (8,7);
+// 4096: (4,18) (8,9).
+inline bool hensel_has(int H, int K) {
+  return (H == 2 && (K == 10 || K == 19)) || (H == 4 && (K == 5 || K == 10 || K == 14 || K == 18)) ||
+         (H == 8 && (K == 3 || K == 5 || K == 7 || K == 9));
+}
+bool launch_hensel_part0(int H, int K, const HenselArgs& a, unsigned blocks, hipStream_t s);
+bool launch_hensel_part1(int H, int K, const HenselArgs& a, unsigned blocks, hipStream_t s);
+bool launch_hensel_part2(int H, int K, const HenselArgs& a, unsigned blocks, hipStream_t s);
+inline bool launch_hensel(int H, int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
+  return launch_hensel_part0(H, K, a, blocks, s) || launch_hensel_part1(H, K, a, blocks, s) ||
+         launch_hensel_part2(H, K, a, blocks, s);
+}
 
 bool launch_modmul(int G, int K, const ModmulArgs& a, unsigned blocks, hipStream_t s);
 bool launch_crt(int G, int K, const CrtArgs& a, unsigned blocks, hipStream_t s);

@@ -55,6 +55,12 @@ __device__ __forceinline__ uint32_t dpp_from_next(uint32_t v) {
 __device__ __forceinline__ uint32_t dpp_from_prev(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
 }
+// value of lane x-D (same 16-lane row); 0 in the first D lanes of the row.
+template <int D>
+__device__ __forceinline__ uint32_t dpp_from_below(uint32_t v) {
+  static_assert(D >= 1 && D <= 15, "row_shr distance");
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + D /*row_shr:D*/, 0xf, 0xf, true);
+}
 // broadcast the value held by lane 0 of every G-lane group to the whole group.
 template <int G>
 __device__ __forceinline__ uint32_t bcast_lane0(uint32_t v) {
@@ -71,13 +77,17 @@ __device__ __forceinline__ uint32_t bcast_lane0(uint32_t v) {
   }
 }
 
-// value held by lane S of every G-lane group, in every lane of the group (G in {2, 4, 16}: one DPP move)
+// value held by lane S of every G-lane group, in every lane of the group (G in {2, 4, 16}: one DPP move; G = 8:
+// two bank-masked row broadcasts into one register)
 template <int G, int S>
 __device__ __forceinline__ uint32_t bcast_lane(uint32_t v) {
-  static_assert(G == 2 || G == 4 || G == 16, "one-instruction broadcast exists for 2-, 4- and 16-lane groups");
+  static_assert(G == 2 || G == 4 || G == 8 || G == 16, "group must sit inside a DPP row");
   static_assert(S >= 0 && S < G, "lane index inside the group");
   // (mov_dpp, not update_dpp: every lane reads a valid source, so there is no "old" value to materialise)
-  if constexpr (G == 16) {
+  if constexpr (G == 8) {
+    int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x150 + S /*row_newbcast:S*/, 0xf, 0x3, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x150 + 8 + S /*row_newbcast:8+S*/, 0xf, 0xc, false);
+  } else if constexpr (G == 16) {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x150 + S /*row_newbcast:S*/, 0xf, 0xf, true);
   } else if constexpr (G == 4) {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, S | (S << 2) | (S << 4) | (S << 6) /*quad_perm:[S,S,S,S]*/, 0xf, 0xf, true);
@@ -127,9 +137,9 @@ __device__ __forceinline__ uint32_t and_bcast_lane0(uint32_t v, uint32_t m) {
 // the doubling on the multiplicand side, computed once per multiplication instead of once per row and block).
 // RECVMAC: the received limb joins its column through a multiply-accumulate by one instead of a 64-bit add (the
 // register-row form: its register allocation otherwise spends a v_mov per row on the zero high half of the addend).
-// PAIR (hensel.hpp): the 2-lane group is one half of a 4-lane quad; the quotient digit of the quad's lower half
-// (lanes 0,1) is also added to column r of the upper half's low lane (selB = 1 in quad lane 2, else 0) before the
-// upper half takes its own digit.
+// PAIR (hensel.hpp): the G-lane group is one half of a 2G-lane group; the quotient digit of the lower half is also
+// added to column r of the upper half's low lane (selB = 1 in lane G of the 2G lanes, else 0) before the upper half
+// takes its own digit.
 template <class GEO, bool UNITQ, bool RECVMAC, bool PAIR = false>
 __device__ __forceinline__ void mont_reduce_rows(uint64_t (&LOWC)[GEO::K], uint64_t (&UPC)[GEO::K],
                                                  const uint32_t (&n)[GEO::K], uint32_t n0inv, uint32_t selB = 0) {
@@ -158,8 +168,9 @@ __device__ __forceinline__ void mont_reduce_rows(uint64_t (&LOWC)[GEO::K], uint6
     // UNITQ: the modulus is == -1 mod 2^29 (capi.hip: build_modctx scales it), so n0' = 1
     __builtin_amdgcn_sched_barrier(kNoValuCross);
     if constexpr (PAIR) {
-      static_assert(GEO::G == 2, "a pair is two 2-lane halves of a quad");
-      const uint32_t qa = bcast_lane<4, 0>(UNITQ ? (uint32_t)LOWC[r] : (uint32_t)LOWC[r] * n0inv) & maskv;
+      static_assert(GEO::G <= 8, "a pair is two G-lane halves of a 2G-lane group inside a DPP row");
+      // lane G of the group takes the digit from lane 0, G lanes below it (the other lanes multiply theirs by 0)
+      const uint32_t qa = dpp_from_below<GEO::G>(UNITQ ? (uint32_t)LOWC[r] : (uint32_t)LOWC[r] * n0inv) & maskv;
       LOWC[r] += (uint64_t)qa * selB;
     }
     uint32_t q = and_bcast_lane0<GEO::G>(UNITQ ? (uint32_t)LOWC[r] : (uint32_t)LOWC[r] * n0inv, maskv);

@@ -35,8 +35,9 @@ def _kat():
     return {key: (int(v, 16) if isinstance(v, str) and v.startswith("0x") else v) for key, v in k.items()}
 
 
-def test_kat_and_fixtures_through_split_form(engine, hensel):
-    hensel(2)    # every batch size
+@pytest.mark.parametrize("form", [2, 3])
+def test_kat_and_fixtures_through_split_form(engine, hensel, form):
+    hensel(form)    # 2: the throughput form, 3: the latency form, whatever the batch size
     kat = _kat()
     sk = engine.PrivateKey(kat["p"], kat["q"])
     num = kat["num_values"]
@@ -56,15 +57,20 @@ def test_kat_and_fixtures_through_split_form(engine, hensel):
     assert ran
 
 
-@pytest.mark.parametrize("bits,count", [(1024, 37), (1024, 2311), (2048, 1), (2048, 16), (2048, 17), (2048, 2500)])
+@pytest.mark.parametrize("bits,count", [(1024, 37), (1024, 2311), (2048, 1), (2048, 16), (2048, 17), (2048, 2500), (3072, 5), (3072, 2100),
+                                        (4096, 3), (4096, 2051)])
 @pytest.mark.parametrize("policy", ["fixed", "sliding"])
-def test_split_form_equals_full_width(engine, hensel, bits, count, policy):
+@pytest.mark.parametrize("form", [2, 3])
+def test_split_form_equals_full_width(engine, hensel, bits, count, policy, form):
     """Random elements of Z_{n^2} (mostly NOT encryptions, so L_p(c^(p-1)) has no structure to hide behind)."""
     from pailliercryptolib_amd import _capi
     rng = random.Random(bits * 7 + count)
     if bits == 2048:
         kat = _kat()
         p, q = kat["p"], kat["q"]
+    elif bits == 4096:
+        k4 = json.load(open(os.path.join(GOLD, "primes_4096.json")))
+        p, q = int(k4["p"], 16), int(k4["q"], 16)
     else:
         case = next(c for c in json.load(open(os.path.join(GOLD, "seeded_vectors.json")))["cases"] if c["bits"] == bits)
         p, q = int(case["p"], 16), int(case["q"], 16)
@@ -79,7 +85,7 @@ def test_split_form_equals_full_width(engine, hensel, bits, count, policy):
             c[2] = n + 1
         hensel(0)
         ref = sk.decrypt(c)
-        hensel(2)
+        hensel(form)
         got = sk.decrypt(c)
         assert got == ref
         osk = orc.PrivateKey(n, p, q)

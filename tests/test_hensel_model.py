@@ -88,8 +88,9 @@ def test_pair_exponentiation_matches_reference_formula(side):
                 x = pmul(x, tbl[(e >> (w * i)) & 31], P, R)
             u = pow(c, p - 1, p * p)
             assert val(x, P) % (p * p) == u * R % (p * p)
-            # exit: (a, k*b) is a pair modulo p^2; product with (hp, 0) under the true prime
-            a, B = x[0], k * x[1]
+            # exit: (a, k*b mod p) is a pair modulo p^2; product with (hp, 0) under the true prime
+            a, B = x[0], redc(x[1] * (k * R % p), p, R)[0]            # k*b mod p (lazy) by a half-width product
+            assert B < 2 * p and (B - k * x[1]) % p == 0
             n0 = (-pow(p, -1, R)) % R
             q1 = a * hp * n0 % R
             t = (a * hp + q1 * p) // R
