@@ -227,6 +227,11 @@ int pgpu_timing_collect(int* kinds, double* ms, int max_entries);
  * per lane (modexp_kernel; small batches take a 16-lane latency split, large ones the wide split).  Pure
  * host-side query (needs no device); lets a profile be labelled with the kernel instantiation that ran.  PGPU_ERR_UNSUPPORTED when no compiled geometry is wide enough. */
 int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, int* limbs);
+/* Exponentiation kernel a CRT decrypt of `count` ciphertexts (per device) runs under this key: *split = 1:
+ * hensel_decrypt_kernel<*lanes / 2, *limbs> -- residues modulo p^2 / q^2 as pairs of half-width numbers (DESIGN.md
+ * section 3; compiled for 1024- to 4096-bit keys; PGPU_HENSEL=0 turns it off); *split = 0: the full-width
+ * modexp_kernel<Geo<*lanes, *limbs>>.  Host-side query. */
+int pgpu_decrypt_kernel_form(const pgpu_privkey* key, size_t count, int* split, int* lanes, int* limbs);
 
 #ifdef __cplusplus
 }

@@ -750,6 +750,20 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
   return run_modexp(d, a, key->nsq->geo, s, sr.p[0] ? &sr : nullptr);
 }
 
+// split form of the CRT-decrypt exponentiation for a batch of `count` ciphertexts on one device (null: the
+// full-width modexp_kernel)
+const pgpu_privkey::HenselSet* pick_hensel(const pgpu_privkey* key, size_t count) {
+  if (!hensel_enabled() || key->hs.empty()) return nullptr;
+  const int mode = g_hensel.load();   // 1: by batch size; 2 / 3 (tests): always the form of fewest / most lanes
+  if (mode == 2) return key->hs.back().get();
+  if (mode == 3) return key->hs.front().get();
+  for (const auto& f : key->hs) {
+    const size_t ipw = 64 / (2 * (size_t)f->H);
+    if (2 * ((count + ipw - 1) / ipw) <= kSimds) return f.get();
+  }
+  return key->hs.back().get();
+}
+
 // fused CRT decrypt on one device; in_mont: ciphertexts arrive in the Montgomery domain of n^2
 int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m, size_t count,
                hipStream_t s, bool in_mont) {
@@ -760,19 +774,7 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
   const bool lat = use_latency_geo(key->geo_lat, key->geo_exp, 2 * count);
   const bool sliding = secret_policy() == PGPU_EXP_SLIDING && key->sched[0].dev.bytes;
   bool have_m = false;
-  const pgpu_privkey::HenselSet* hset = nullptr;
-  if (hensel_enabled() && !key->hs.empty()) {
-    const int mode = g_hensel.load();   // 1: by batch size; 2 / 3 (tests): always the form of fewest / most lanes
-    if (mode == 2) hset = key->hs.back().get();
-    else if (mode == 3) hset = key->hs.front().get();
-    else {
-      hset = key->hs.back().get();
-      for (const auto& f : key->hs) {
-        const size_t ipw = 64 / (2 * (size_t)f->H);
-        if (2 * ((count + ipw - 1) / ipw) <= kSimds) { hset = f.get(); break; }
-      }
-    }
-  }
+  const pgpu_privkey::HenselSet* hset = pick_hensel(key, count);
   if (hset) {
     // stage 1, split form: M[2i] = mp, M[2i+1] = mq  (hensel.hpp)
     const int L2 = hset->H * hset->K, nch = hset->nchunks, ipw = 64 / (2 * hset->H);
@@ -994,6 +996,22 @@ int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, i
   if (!geo) return fail(PGPU_ERR_UNSUPPORTED, "modulus wider than the compiled kernel geometries");
   const GeoInfo lat = latency_geo(*geo);
   const GeoInfo g = use_latency_geo(lat, *geo, count) ? lat : launch_geo(*geo, count);
+  *lanes = g.G;
+  *limbs = g.K;
+  return PGPU_OK;
+}
+
+int pgpu_decrypt_kernel_form(const pgpu_privkey* key, size_t count, int* split, int* lanes, int* limbs) {
+  if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_decrypt_kernel_form: bad argument");
+  if (const pgpu_privkey::HenselSet* f = pick_hensel(key, count)) {
+    *split = 1;
+    *lanes = 2 * f->H;
+    *limbs = f->K;
+    return PGPU_OK;
+  }
+  const bool lat = use_latency_geo(key->geo_lat, key->geo_exp, 2 * count);
+  const GeoInfo g = lat ? key->geo_lat : launch_geo(key->geo_exp, 2 * count);
+  *split = 0;
   *lanes = g.G;
   *limbs = g.K;
   return PGPU_OK;

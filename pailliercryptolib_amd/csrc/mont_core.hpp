@@ -27,6 +27,20 @@
 
 #include "kargs.hpp"
 
+// pair form (mont_reduce_rows<.., PAIR>): MACs of a row held back as fillers of the next row's opening -- FA of them
+// between the lower half's digit going up and its MAC, FB between that MAC and the digit broadcast, FC behind it.
+// Measured on the bench's decrypt launch (tools/build_variant.py, tools/run_variants_h.sh; same box): none held back
+// beyond the usual two 5.15-5.20 ms, (3,4,1) 4.79-4.85, (2,3,3) 4.82-4.84, FC = 0 5.05: a lone wavefront has nobody
+// else's instructions to cover the two dependent cross-lane steps.
+#ifndef PGPU_PAIR_FA
+#define PGPU_PAIR_FA 3
+#endif
+#ifndef PGPU_PAIR_FB
+#define PGPU_PAIR_FB 4
+#endif
+#ifndef PGPU_PAIR_FC
+#define PGPU_PAIR_FC 1
+#endif
 #ifndef PGPU_REG_RECVMAC
 #define PGPU_REG_RECVMAC 1   // register-row form: hand-over limb added by a multiply-accumulate by one (see mont_block_rows)
 #endif
@@ -151,7 +165,12 @@ __device__ __forceinline__ void mont_reduce_rows(uint64_t (&LOWC)[GEO::K], uint6
   // q | 4 MACs | limb hand-over + carry shift | 2 MACs | carry add | remaining MACs, pinned with VALU
   // scheduling barriers (memory and scalar instructions may still cross).
   constexpr int kNoValuCross = 0x3fc;
-  constexpr int J1 = K < 4 ? K : 4, J2 = K < 6 ? K : 6, J3 = K - 2 > J2 ? K - 2 : J2;
+  // (PAIR: two dependent cross-lane steps open a row -- the lower half's digit goes up, then both digits are
+  // broadcast -- so more of the previous row's MACs are held back as fillers: two between the steps, the rest after)
+  constexpr bool kSpread = PAIR && K >= 12;
+  constexpr int kFA = kSpread ? PGPU_PAIR_FA : 0, kFB = kSpread ? PGPU_PAIR_FB : 0;
+  constexpr int kHeld = kSpread ? kFA + kFB + PGPU_PAIR_FC : 2;
+  constexpr int J1 = K < 4 ? K : 4, J2 = K < 6 ? K : 6, J3 = K - kHeld > J2 ? K - kHeld : J2;
   auto mac = [&](int r, int j, uint32_t q) {
     if (r + j < K) LOWC[r + j] += (uint64_t)n[j] * q;
     else UPC[r + j - K] += (uint64_t)n[j] * q;
@@ -167,11 +186,30 @@ __device__ __forceinline__ void mont_reduce_rows(uint64_t (&LOWC)[GEO::K], uint6
   for (int r = 0; r < K; ++r) {
     // UNITQ: the modulus is == -1 mod 2^29 (capi.hip: build_modctx scales it), so n0' = 1
     __builtin_amdgcn_sched_barrier(kNoValuCross);
+    int jf = J3;   // next held-back MAC of the previous row
     if constexpr (PAIR) {
       static_assert(GEO::G <= 8, "a pair is two G-lane halves of a 2G-lane group inside a DPP row");
       // lane G of the group takes the digit from lane 0, G lanes below it (the other lanes multiply theirs by 0)
       const uint32_t qa = dpp_from_below<GEO::G>(UNITQ ? (uint32_t)LOWC[r] : (uint32_t)LOWC[r] * n0inv) & maskv;
+      if constexpr (kFA > 0) {
+        __builtin_amdgcn_sched_barrier(kNoValuCross);
+        if (r > 0) {
+#pragma unroll
+          for (int t = 0; t < kFA; ++t) mac(r - 1, jf + t, qprev);
+          jf += kFA;
+        }
+        __builtin_amdgcn_sched_barrier(kNoValuCross);
+      }
       LOWC[r] += (uint64_t)qa * selB;
+      if constexpr (kFB > 0) {
+        __builtin_amdgcn_sched_barrier(kNoValuCross);
+        if (r > 0) {
+#pragma unroll
+          for (int t = 0; t < kFB; ++t) mac(r - 1, jf + t, qprev);
+          jf += kFB;
+        }
+        __builtin_amdgcn_sched_barrier(kNoValuCross);
+      }
     }
     uint32_t q = and_bcast_lane0<GEO::G>(UNITQ ? (uint32_t)LOWC[r] : (uint32_t)LOWC[r] * n0inv, maskv);
     // fillers between the broadcast and its first use: the last two MACs of the previous row, and
@@ -182,7 +220,7 @@ __device__ __forceinline__ void mont_reduce_rows(uint64_t (&LOWC)[GEO::K], uint6
     __builtin_amdgcn_sched_barrier(kNoValuCross);
     if (r > 0) {
 #pragma unroll
-      for (int j = J3; j < K; ++j) mac(r - 1, j, qprev);
+      for (int j = jf; j < K; ++j) mac(r - 1, j, qprev);
       add_recv(UPC[r - 1]);
     }
     __builtin_amdgcn_sched_barrier(kNoValuCross);

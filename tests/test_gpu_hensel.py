@@ -58,7 +58,7 @@ def test_kat_and_fixtures_through_split_form(engine, hensel, form):
 
 
 @pytest.mark.parametrize("bits,count", [(1024, 37), (1024, 2311), (2048, 1), (2048, 16), (2048, 17), (2048, 2500), (3072, 5), (3072, 2100),
-                                        (4096, 3), (4096, 2051)])
+                                        (4096, 3), (4096, 2051), (2037, 9), (2037, 2200)])
 @pytest.mark.parametrize("policy", ["fixed", "sliding"])
 @pytest.mark.parametrize("form", [2, 3])
 def test_split_form_equals_full_width(engine, hensel, bits, count, policy, form):
@@ -68,8 +68,8 @@ def test_split_form_equals_full_width(engine, hensel, bits, count, policy, form)
     if bits == 2048:
         kat = _kat()
         p, q = kat["p"], kat["q"]
-    elif bits == 4096:
-        k4 = json.load(open(os.path.join(GOLD, "primes_4096.json")))
+    elif bits in (4096, 2037):     # 2037: a 1013-bit and a 1024-bit prime (five ciphertext chunks per side)
+        k4 = json.load(open(os.path.join(GOLD, "primes_4096.json" if bits == 4096 else "primes_uneven.json")))
         p, q = int(k4["p"], 16), int(k4["q"], 16)
     else:
         case = next(c for c in json.load(open(os.path.join(GOLD, "seeded_vectors.json")))["cases"] if c["bits"] == bits)

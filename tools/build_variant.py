@@ -1,5 +1,6 @@
 """Kernel A/B experiments: builds pailliercryptolib_amd/libpgpu_<name>.so from the regular objects, with the
 modexp part(s) recompiled under extra -D flags.  usage: build_variant.py <name> <part,part,..> <flags...>
+(part: N = k_modexp.hip part N, hN = k_hensel.hip part N)
 Run a benchmark against it with PGPU_LIB=<path>.  (tools/, diagnostics only)"""
 import os
 import subprocess
@@ -10,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from pailliercryptolib_amd import build  # noqa: E402
 
-name, parts, flags = sys.argv[1], [int(x) for x in sys.argv[2].split(",")], sys.argv[3:]
+name, parts, flags = sys.argv[1], sys.argv[2].split(","), sys.argv[3:]
 build.build_pgpu()
 objs = build._objects()
 vdir = os.path.join(build.HERE, "build", "variant_" + name)
@@ -18,7 +19,8 @@ os.makedirs(vdir, exist_ok=True)
 link, jobs = [], []
 for o, cmd, _ in objs:
     base = os.path.basename(o)
-    part = int(base.split("_")[-1][0]) if base.startswith("k_modexp_") else -1
+    part = base.split("_")[-1][0] if base.startswith("k_modexp_") else \
+        "h" + base.split("_")[-1][0] if base.startswith("k_hensel_") else None
     if part in parts:
         vo = os.path.join(vdir, base)
         jobs.append(cmd[:-1] + [vo] + flags)        # (cmd ends with "-o", o)

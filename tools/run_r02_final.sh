@@ -5,6 +5,8 @@ OUT=$REPO/gpurun_out/r02final
 mkdir -p $OUT
 cd $REPO
 timeout 300 python3 bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err; echo "n1 rc=$?"
+PGPU_HENSEL=0 timeout 200 python3 bench.py --no-extras --no-cpu-baseline > $OUT/bench_n1_fullwidth_decrypt.json 2> $OUT/bench_n1_fullwidth_decrypt.err; echo "n1 full-width rc=$?"
+PGPU_HENSEL=0 timeout 300 ./pailliercryptolib_amd/ipcl_api_bench > $OUT/ipcl_api_bench_fullwidth_decrypt.txt 2>&1; echo "api bench full-width rc=$?"
 BENCH_SINGLE_DEVICE=1 timeout 200 python3 bench.py --gpus 2 --steps 10 > $OUT/bench_n2_pool_1dev.json 2> $OUT/bench_n2_pool_1dev.err; echo "n2 pool rc=$?"
 BENCH_SINGLE_DEVICE=1 BENCH_DIST_BACKEND=gloo timeout 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 10 > $OUT/bench_n2_torchrun_1dev.json 2> $OUT/bench_n2_torchrun_1dev.err; echo "n2 torchrun rc=$?"
 timeout 300 python3 bench.py --config 4 --steps 3 --warmup 1 > $OUT/bench_config4_n1.json 2> $OUT/bench_config4_n1.err; echo "c4 rc=$?"

@@ -5,7 +5,7 @@ src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 
 def short(name):
-    for k in ("modexp_kernel", "crt_kernel", "modmul_kernel", "fixedbase", "fb_"):
+    for k in ("modexp_kernel", "hensel_decrypt_kernel", "crt_kernel", "modmul_kernel", "fixedbase", "fb_"):
         if k in name:
             return name.split("(")[0].replace("void pgpu::", "")
     return None
@@ -55,9 +55,12 @@ for s, cs in agg.items():
 json.dump(out, open(f"profiles/{tag}_pmc_counters.json", "w"), indent=1)
 summary = {"source": f"profiles/{tag}_pmc_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                      "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, the x2 on FETCH per MI355X_MICROARCH.md (HBM)"}
-dec = next((v for k, v in out.items() if k.startswith("modexp_kernel<")), None)   # the bench launches one shape
+# the CRT-decrypt exponentiation of the bench: the split form (hensel.hpp) or the full-width modexp_kernel
+dec_name = next((k for k in out if k.startswith("hensel_decrypt_kernel<")), None) or \
+    next((k for k in out if k.startswith("modexp_kernel<")), None)
+dec = out.get(dec_name)
 if dec and "hbm_bytes_fetch_x2_corrected" in dec:
-    summary["modexp_decrypt_kernel"] = next(k for k in out if k.startswith("modexp_kernel<"))
+    summary["modexp_decrypt_kernel"] = dec_name
     summary["modexp_decrypt_hbm_bytes_per_launch"] = dec["hbm_bytes_fetch_x2_corrected"]
     summary["modexp_decrypt_hbm_bytes_per_launch_raw"] = dec["hbm_bytes_raw"]
 fb = next((v for k, v in out.items() if k.startswith("fb_encrypt_kernel<")), None)
