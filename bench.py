@@ -202,7 +202,8 @@ def run_pool(args):
 
     result = headline(args, N, elapsed, per_kind, nw, pw,
                       f"in-process device pool x{N} (batch sharded; key images: {L.pgpu_pool_transport().decode()})",
-                      decrypt_kernel(sk, BATCH, nw, KEY_BITS))
+                      decrypt_kernel(sk, BATCH, nw, KEY_BITS),
+                      encrypt_kernel(pk, BATCH, nw, KEY_BITS, int(os.environ.get("PGPU_FB_WINDOW", "12"))))
     result["config"]["secret_exponent_policy"] = ["fixed-window", "sliding"][L.pgpu_get_secret_exponent_policy()]
     if N == 1 and not args.no_extras:
         result.update(extras(pa, L, B, pk, sk, n, p, q, hs, m_host, r_host, per_kind))
@@ -236,7 +237,27 @@ def decrypt_kernel(sk, count, nw, key_bits):
     return f"hensel_decrypt_kernel<{lanes.value // 2},{limbs.value}>", nsq * 4 * l2 * l2 + nmul * 6 * l2 * l2
 
 
-def headline(args, world, elapsed, per_kind, nw, pw, parallelism, dec_kernel=None):
+def encrypt_kernel(pk, count, nw, key_bits, fbw):
+    """(name, executed MAC32 per element, note) of the fixed-base DJN encrypt kernel: full-width products (2 s^2 + s,
+    s = 4096/32) or pair products of the split form (6 L2^2 limb products each, plus the way back to a full-width
+    residue: two products in Montgomery form)."""
+    from pailliercryptolib_amd import _capi
+    split, lanes, limbs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _capi.check(_capi.lib().pgpu_encrypt_kernel_form(pk._h, nw, count, ctypes.byref(split), ctypes.byref(lanes),
+                                                     ctypes.byref(limbs)))
+    nprod = (key_bits // 2 + fbw - 1) // fbw - 1           # table products
+    s = 2 * key_bits // 32
+    if not split.value:
+        return (f"fb_encrypt_kernel<Geo<{lanes.value},{limbs.value}>>", (2 * s * s + s) * (nprod + 2),
+                "fixed-base windowing w=%d: hs^r as %d table products, no squarings" % (fbw, nprod))
+    l2 = lanes.value // 2 * limbs.value
+    return (f"hensel_fb_encrypt_kernel<{lanes.value // 2},{limbs.value}>",
+            6 * l2 * l2 * (nprod + 1) + 2 * l2 * l2 + 2 * (2 * s * s + s),
+            "fixed-base windowing w=%d in split form: hs^r as %d pair products (no squarings), exit by 1 + n*m, two "
+            "full-width products back to c*R mod n^2" % (fbw, nprod))
+
+
+def headline(args, world, elapsed, per_kind, nw, pw, parallelism, dec_kernel=None, enc_kernel=None):
     """the contract line (metric / value / roofline of the dominant kernel) from the timed region's numbers"""
     fixed_base = K_FB in per_kind
     enc_ms = float(np.mean(per_kind[K_FB])) if fixed_base else None
@@ -266,8 +287,15 @@ def headline(args, world, elapsed, per_kind, nw, pw, parallelism, dec_kernel=Non
     if fixed_base:
         nmul = (KEY_BITS // 2 + fbw - 1) // fbw + 1            # nwin-1 table products + g^m + exit
         mac_enc_exec = (2 * s4096 * s4096 + s4096) * nmul * BATCH
+        enc_name = f"fb_encrypt_kernel<{geo_name(2 * nw, 2 * KEY_BITS, BATCH)}>"
+        enc_note = "fixed-base windowing w=%d: hs^r as %d table products, no squarings" % (fbw, nmul - 2)
+        if enc_kernel:
+            enc_name, per_elt, enc_note = enc_kernel
+            mac_enc_exec = per_elt * BATCH
     else:
         mac_enc_exec = mac_enc
+        enc_name = f"modexp_kernel<{geo_name(2 * nw, 2 * KEY_BITS, BATCH)}> (encrypt)"
+        enc_note = "generic square-and-multiply"
     return {
         "metric": "2048-bit modexps/sec (encrypt+decrypt)",
         "value": round(value, 1),
@@ -312,8 +340,7 @@ def headline(args, world, elapsed, per_kind, nw, pw, parallelism, dec_kernel=Non
             "hbm_frac": round(alg_bytes_dec / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
             "other_kernels": {
                 "crt_kernel<Geo<8,9>>": {"ms": round(crt_ms, 4)},
-                (f"fb_encrypt_kernel<{geo_name(2 * nw, 2 * KEY_BITS, BATCH)}>" if fixed_base
-                 else f"modexp_kernel<{geo_name(2 * nw, 2 * KEY_BITS, BATCH)}> (encrypt)"): {
+                enc_name: {
                     "ms": round(enc_ms, 4),
                     "canonical_mac32_per_launch": mac_enc,
                     "executed_mac32_per_launch": mac_enc_exec,
@@ -322,8 +349,7 @@ def headline(args, world, elapsed, per_kind, nw, pw, parallelism, dec_kernel=Non
                     "canonical_TMAC32_per_s": round(mac_enc / (enc_ms * 1e-3) / 1e12, 3),
                     "algorithmic_bytes_per_launch": alg_bytes_enc,
                     "traffic": pmc.get("fb_encrypt_hbm_bytes_per_launch"),
-                    "note": ("fixed-base windowing w=%d: hs^r as %d table products, no squarings" % (fbw, nmul - 2))
-                            if fixed_base else "generic square-and-multiply",
+                    "note": enc_note,
                 },
             },
         },
@@ -682,7 +708,8 @@ def run_ranks(args, world):
     if rank == 0:
         result = headline(args, world, elapsed, per_kind, nw, pw,
                           f"one process per GPU x{world} (torch.distributed {backend}; key broadcast only)",
-                          decrypt_kernel(sk, BATCH, nw, KEY_BITS))
+                          decrypt_kernel(sk, BATCH, nw, KEY_BITS),
+                      encrypt_kernel(pk, BATCH, nw, KEY_BITS, int(os.environ.get("PGPU_FB_WINDOW", "12"))))
         result["config"]["secret_exponent_policy"] = ["fixed-window", "sliding"][L.pgpu_get_secret_exponent_policy()]
         print(json.dumps(result), flush=True)
     dist.barrier()

@@ -232,6 +232,10 @@ int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, i
  * section 3; compiled for 1024- to 4096-bit keys; PGPU_HENSEL=0 turns it off); *split = 0: the full-width
  * modexp_kernel<Geo<*lanes, *limbs>>.  Host-side query. */
 int pgpu_decrypt_kernel_form(const pgpu_privkey* key, size_t count, int* split, int* lanes, int* limbs);
+/* The same for an encrypt of `count` plaintext rows of m_words words: *split = 1: hensel_fb_encrypt_kernel<*lanes / 2,
+ * *limbs> (DJN keys with a fixed-base window, 2048-bit keys, plaintext rows no wider than n); *split = 0:
+ * fb_encrypt_kernel / modexp_kernel <Geo<*lanes, *limbs>>. */
+int pgpu_encrypt_kernel_form(const pgpu_pubkey* key, int m_words, size_t count, int* split, int* lanes, int* limbs);
 
 #ifdef __cplusplus
 }

@@ -489,15 +489,21 @@ struct pgpu_pubkey {
   mutable std::mutex mu;
   mutable std::vector<std::deque<FbTable>> fb;   // [device]; entries never move once handed out
   mutable size_t fb_elems = 0;  // elements encrypted with this key so far (window policy)
+  // split form of n^2 = (n)^2 (hensel.hpp) for the fixed-base DJN encrypt; hH == 0: not available for this key
+  int hH = 0, hK = 0, h_chunk_words = 0, h_nchunks = 0;
+  rt::Replicated d_hpub;        // P | n | k*R mod n (L2 limbs each) | pair one | pairs conv
+  uint32_t h_n0inv = 0;
+  mutable std::vector<std::deque<FbTable>> fbh;   // [device]: fixed-base tables of pairs
   ~pgpu_pubkey() {
-    for (size_t d = 0; d < fb.size(); ++d) {
-      if (fb[d].empty() || (int)d >= rt::pool_size()) continue;
-      rt::DeviceGuard g(rt::device((int)d).ordinal);
-      for (FbTable& t : fb[d]) {
-        if (t.ready) (void)hipEventDestroy(t.ready);
-        if (t.p) (void)hipFree(t.p);
+    for (auto* lists : {&fb, &fbh})
+      for (size_t d = 0; d < lists->size(); ++d) {
+        if ((*lists)[d].empty() || (int)d >= rt::pool_size()) continue;
+        rt::DeviceGuard g(rt::device((int)d).ordinal);
+        for (FbTable& t : (*lists)[d]) {
+          if (t.ready) (void)hipEventDestroy(t.ready);
+          if (t.p) (void)hipFree(t.p);
+        }
       }
-    }
   }
 };
 
@@ -668,6 +674,55 @@ int fb_table_for(const pgpu_pubkey* key, rt::Device& d, int w, int nwin, hipStre
 }
 
 // fused encrypt on one device; out_mont: ciphertexts leave in the Montgomery domain of n^2
+pgpu::HenselPubDev hensel_pub_view(const pgpu_pubkey* key, int dev) {
+  const int L2 = key->hH * key->hK;
+  const uint32_t* b = (const uint32_t*)key->d_hpub.d[(size_t)dev];
+  pgpu::HenselPubDev v{};
+  v.nhat = b;
+  v.n = b + L2;
+  v.kr = b + 2 * L2;
+  v.one = b + 3 * L2;
+  v.conv = b + 5 * L2;
+  v.n0inv = key->h_n0inv;
+  return v;
+}
+// the fixed-base table of pairs (hensel.hpp: hensel_fb_build_kernel); same size as the full-width one
+int fb_table_for_split(const pgpu_pubkey* key, rt::Device& d, int w, int nwin, hipStream_t s, const FbTable** out) {
+  std::lock_guard<std::mutex> lk(key->mu);
+  if (key->fbh.size() < (size_t)rt::pool_size()) key->fbh.resize((size_t)rt::pool_size());
+  auto& list = key->fbh[(size_t)d.index];
+  for (const FbTable& t : list)
+    if (t.w == w && t.nwin >= nwin) {
+      HIP_TRY(hipStreamWaitEvent(s, t.ready, 0));
+      *out = &t;
+      return PGPU_OK;
+    }
+  const int H = key->hH, K = key->hK;
+  FbTable t;
+  t.w = w;
+  t.nwin = nwin;
+  HIP_TRY(hipMalloc(&t.p, (size_t)nwin * ((size_t)1 << w) * 2 * H * K * sizeof(uint32_t)));
+  HIP_TRY(hipEventCreateWithFlags(&t.ready, hipEventDisableTiming));
+  pgpu::HenselFbBuildArgs b{};
+  b.ctx = hensel_pub_view(key, d.index);
+  b.base = (const uint64_t*)key->d_hs.d[(size_t)d.index];
+  b.base_words = 2 * key->n_words;
+  b.chunk_words = key->h_chunk_words;
+  b.nchunks = key->h_nchunks;
+  b.table = (uint32_t*)t.p;
+  b.nwin = nwin;
+  b.w = w;
+  const int ipw = 64 / (2 * H);
+  const unsigned blocks = (unsigned)((((size_t)nwin + ipw - 1) / ipw + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
+  if (!pgpu::launch_hensel_fb_build(H, K, b, blocks, s))
+    return fail(PGPU_ERR_UNSUPPORTED, "split-form fixed-base build kernel not compiled");
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(t.ready, s));
+  list.push_back(t);
+  *out = &list.back();
+  return PGPU_OK;
+}
+
 int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_t m_stride, int m_words,
                const uint64_t* d_r, size_t r_stride, int r_words, int r_bits, uint64_t* d_c, size_t count,
                hipStream_t s, bool out_mont, size_t total_count) {
@@ -689,6 +744,39 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
     const GeoInfo& geo = key->nsq->geo;
     const int nwin = std::max(1, (r_bits + fbw - 1) / fbw);
     const FbTable* tab = nullptr;
+    // split form (hensel.hpp): pairs modulo (n*k)^2; needs m < 2n to form the pair of 1 + n*m, i.e. plaintext rows
+    // no wider than n, and a batch that fills the chip in 8-lane groups no worse than the full-width kernel does
+    if (key->hH && hensel_enabled() && 64 * m_words <= key->n.BitSize()) {
+      RC_TRY(fb_table_for_split(key, d, fbw, nwin, s, &tab));
+      const pgpu::ModCtxDev full = key->nsq->view(d.index, vflags);
+      pgpu::HenselFbArgs f{};
+      f.ctx = hensel_pub_view(key, d.index);
+      f.full_n = full.n;
+      f.full_nr = full.nr;                       // n*R' (plain result) or n*R'^2 (Montgomery-form result)
+      f.full_r2 = out_mont ? full.r2 : nullptr;
+      f.full_n0inv = full.n0inv;
+      f.mod_words = W;
+      f.table = (const uint32_t*)tab->p;
+      f.nwin = nwin;
+      f.w = fbw;
+      f.exp = d_r;
+      f.exp_stride = r_stride;
+      f.exp_words = r_words;
+      f.fm_words = d_m;
+      f.fm_stride = m_stride;
+      f.fm_nwords = m_words;
+      f.out = d_c;
+      f.out_stride = (size_t)W;
+      f.count = count;
+      TimerScope t(d, s, PGPU_KERNEL_FB_ENCRYPT);
+      const int ipw = 64 / (2 * key->hH);
+      const unsigned blocks = (unsigned)(((count + ipw - 1) / ipw + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
+      if (!pgpu::launch_hensel_fb_encrypt(key->hH, key->hK, f, blocks, s))
+        return fail(PGPU_ERR_UNSUPPORTED, "split-form fixed-base kernel not compiled");
+      HIP_TRY(hipGetLastError());
+      t.stop();
+      return PGPU_OK;
+    }
     RC_TRY(fb_table_for(key, d, fbw, nwin, s, &tab));
     pgpu::FixedBaseArgs f{};
     f.ctx = key->nsq->view(d.index, vflags);
@@ -1001,6 +1089,21 @@ int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, i
   return PGPU_OK;
 }
 
+int pgpu_encrypt_kernel_form(const pgpu_pubkey* key, int m_words, size_t count, int* split, int* lanes, int* limbs) {
+  if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_encrypt_kernel_form: bad argument");
+  if (key->djn && fixed_base_window() > 0 && key->hH && hensel_enabled() && 64 * m_words <= key->n.BitSize()) {
+    *split = 1;
+    *lanes = 2 * key->hH;
+    *limbs = key->hK;
+    return PGPU_OK;
+  }
+  const GeoInfo g = launch_geo(key->nsq->geo, count);
+  *split = 0;
+  *lanes = g.G;
+  *limbs = g.K;
+  return PGPU_OK;
+}
+
 int pgpu_decrypt_kernel_form(const pgpu_privkey* key, size_t count, int* split, int* lanes, int* limbs) {
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_decrypt_kernel_form: bad argument");
   if (const pgpu_privkey::HenselSet* f = pick_hensel(key, count)) {
@@ -1227,6 +1330,48 @@ int pgpu_modmul(const uint64_t* a, const uint64_t* b, size_t b_stride, const uin
 }
 
 // ===================== Paillier public key / encrypt =====================
+namespace {
+// Constants of the split form of n^2 (hensel.hpp) for the fixed-base DJN encrypt.  Available when a fixed-base form
+// (H, K) is compiled whose full-width twin Geo<2H, K> is the geometry of the key's n^2 context (the way back to a
+// full-width residue reuses that context's constants): 2048-bit keys, (4,18) <-> Geo<8,18>.
+int build_hensel_pub(pgpu_pubkey* k) {
+  GeoInfo fg = k->nsq->geo;
+  if (fg.K == 9 && fg.G >= 4) fg = GeoInfo{fg.G / 2, 18};   // the wide split of the same context (launch_geo)
+  const int H = fg.G / 2, K = fg.K, L2 = H * K;
+  if (fg.G < 4 || !pgpu::hensel_fb_has(H, K) || !k->nsq->unit) return PGPU_OK;
+  if (pgpu::kLimbBits * L2 < k->n.BitSize() + 29 + 8) return PGPU_OK;
+  const int cw = std::min(k->n_words, k->n.BitSize() / 64);
+  if (cw <= 0) return PGPU_OK;
+  const int nch = (2 * k->n_words + cw - 1) / cw;
+  const BigNumber& n = k->n;
+  uint32_t n0 = (uint32_t)(n.limbs64()[0] & pgpu::kLimbMask), inv = n0;
+  for (int i = 0; i < 5; ++i) inv *= 2u - n0 * inv;
+  const uint32_t n0inv = (0u - inv) & pgpu::kLimbMask;
+  const BigNumber P = n * BigNumber((Ipp32u)n0inv), P2 = P * P;
+  const BigNumber R = pow2(L2 * pgpu::kLimbBits);
+  std::vector<uint32_t> h((size_t)L2 * (5 + 2 * (size_t)nch), 0);
+  auto put_pair = [&](uint32_t* dst, const BigNumber& z) {
+    const BigNumber zr = z % P2;
+    const BigNumber f = zr / P;
+    to_limbs29(zr % P, L2, dst);
+    to_limbs29(f.isZero() ? f : P - f, L2, dst + L2);
+  };
+  to_limbs29(P, L2, h.data());
+  to_limbs29(n, L2, h.data() + L2);
+  to_limbs29((R % n) * BigNumber((Ipp32u)n0inv) % n, L2, h.data() + 2 * L2);
+  const BigNumber Rm = R % P2, R2 = (Rm * Rm) % P2;
+  put_pair(h.data() + 3 * L2, Rm);
+  for (int i = 0; i < nch; ++i) put_pair(h.data() + 5 * L2 + (size_t)i * 2 * L2, (R2 * (pow2(64 * cw * i) % P2)) % P2);
+  RC_TRY(k->d_hpub.upload(h.data(), h.size() * sizeof(uint32_t), false));
+  k->hH = H;
+  k->hK = K;
+  k->h_chunk_words = cw;
+  k->h_nchunks = nch;
+  k->h_n0inv = n0inv;
+  return PGPU_OK;
+}
+}  // namespace
+
 int pgpu_pubkey_create(const uint64_t* n, int n_words, const uint64_t* hs_or_null,
                        pgpu_pubkey** out) {
   RC_TRY(rt::check_ready());
@@ -1249,6 +1394,8 @@ int pgpu_pubkey_create(const uint64_t* n, int n_words, const uint64_t* hs_or_nul
   RC_TRY(k->d_n.upload(n, (size_t)n_words * 8, false));
   if (sliding_enabled()) RC_TRY(make_schedule(k->n, pick_sliding_window(k->n.BitSize()), &k->sched_n, false));
   k->fb.resize((size_t)rt::pool_size());
+  k->fbh.resize((size_t)rt::pool_size());
+  if (k->djn) RC_TRY(build_hensel_pub(k.get()));
   *out = k.release();
   return PGPU_OK;
 }

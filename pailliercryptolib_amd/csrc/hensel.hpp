@@ -358,6 +358,218 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : 1) void hensel_decrypt_ke
 #undef HCTX
 }
 
+// value of lane x+D (same 16-lane row); 0 in the last D lanes of the row.
+template <int D>
+__device__ __forceinline__ uint32_t dpp_from_above(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + D /*row_shl:D*/, 0xf, 0xf, true);
+}
+
+// own = words * R as a pair: sum over the chunks z_i of (z_i, 0) (x) pair(2^(64*cw*i) * R^2).  iorow: the group's
+// W64+1 words of LDS; x4: lane in the group.
+template <int H, int K>
+__device__ __forceinline__ void pair_from_words(uint32_t (&own)[K], const uint64_t* row, int nwords, int chunk_words,
+                                                int nchunks, const uint32_t* conv, uint64_t* iorow,
+                                                const uint32_t (&n)[K], uint32_t halfB, uint32_t selB, int x4) {
+  using HG = Geo<H, K>;
+  constexpr int GS = 2 * H, LQ = 2 * H * K, W64 = HG::W64;
+  const int x = x4 % H;
+  uint32_t acc[K], mreg[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) acc[j] = 0;
+#pragma unroll 1
+  for (int i = 0; i < nchunks; ++i) {
+    wave_lds_sync();
+    const int first = i * chunk_words;
+    const int words = min(chunk_words, nwords - first);
+    for (int t = x4; t <= W64; t += GS) iorow[t] = (t < words) ? row[first + t] : 0;
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      own[j] = halfB ? 0u : limb_from_words(iorow, x * K + j);
+      mreg[j] = conv[(size_t)i * LQ + x4 * K + j];
+    }
+    pairmul<H, K, false, true>(own, own, mreg, n, 0, halfB, selB);
+    add_normalise<HG>(acc, own);
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) own[j] = acc[j];
+}
+
+// Fixed-base table of pairs for the DJN obfuscator hs^r (kernels.hpp: fb_build_kernel is the full-width twin):
+// group i builds row i, T[i][d] = hs^(d * 2^(w*i)) * R as a pair.
+template <int H, int K>
+__global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : 1) void hensel_fb_build_kernel(HenselFbBuildArgs A) {
+  using HG = Geo<H, K>;
+  constexpr int GS = 2 * H, IPW = kWave / GS, LQ = 2 * H * K, W64 = HG::W64;
+  __shared__ uint64_t io_[kWavesPerWG][IPW][W64 + 1];
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  auto& io = io_[wv];
+  const int q4 = lane / GS, x4 = lane % GS, x = x4 % H;
+  const uint32_t halfB = (uint32_t)(x4 / H);
+  uint32_t selB = x4 == H ? 1u : 0u;
+  asm("" : "+v"(selB));
+  const size_t first_inst = ((size_t)blockIdx.x * kWavesPerWG + wv) * IPW;
+  size_t inst = first_inst + q4;
+  const bool live = inst < (size_t)A.nwin;
+  if (!live) inst = (size_t)A.nwin - 1;
+  uint32_t n[K], own[K], mreg[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) n[j] = A.ctx.nhat[x * K + j];
+  pair_from_words<H, K>(own, A.base, A.base_words, A.chunk_words, A.nchunks, A.ctx.conv, io[q4], n, halfB, selB, x4);
+  const int tsize = 1 << A.w;
+  // every group runs the squaring count of the LAST live row of its wavefront (uniform control flow); a group stops
+  // updating once its own count is reached
+  const int my_sq = A.w * (int)inst;
+  size_t last = first_inst + IPW - 1;
+  if (last >= (size_t)A.nwin) last = (size_t)A.nwin - 1;
+  const int wave_sq = A.w * (int)last;
+#pragma unroll 1
+  for (int step = 1; step <= wave_sq; ++step) {
+    uint32_t r[K];
+    pairmul<H, K, true, true>(r, own, own, n, 0, halfB, selB);
+    if (step <= my_sq) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) own[j] = r[j];
+    }
+  }
+  uint32_t* row = A.table + inst * (size_t)tsize * LQ + x4 * K;
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      row[j] = A.ctx.one[x4 * K + j];
+      row[LQ + j] = own[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) mreg[j] = own[j];
+#pragma unroll 1
+  for (int d = 2; d < tsize; ++d) {
+    pairmul<H, K, false, true>(own, own, mreg, n, 0, halfB, selB);
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) row[(size_t)d * LQ + j] = own[j];
+    }
+  }
+}
+
+// DJN encrypt c = (1 + n*m) * hs^r mod n^2 (pub_key.cpp:51-64, 88-105) in split form: hs^r as nwin-1 pair products
+// of table entries, the exit product under the true modulus n by the pair (1, -m) = 1 + n*m, then back to a
+// full-width residue: for canonical a, b < n the pair is c = a + n*b (< n^2), one full-width Montgomery product in
+// the geometry Geo<2H,K> of the n^2 context (two for a Montgomery-form result).
+template <int H, int K>
+__global__ __launch_bounds__(kWGThreads, 1) void hensel_fb_encrypt_kernel(HenselFbArgs A) {
+  using HG = Geo<H, K>;
+  using FG = Geo<2 * H, K>;
+  constexpr int GS = 2 * H, IPW = kWave / GS, LQ = 2 * H * K;
+  raise_wave_priority();
+  __shared__ uint32_t bl_[kWavesPerWG][IPW][FG::L];
+  __shared__ uint64_t io_[kWavesPerWG][IPW][FG::W64 + 1];
+  __shared__ uint32_t rows_[kWavesPerWG][2][FG::L];     // n*R' (n*R'^2) and R'^2 as multiplier rows
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  auto& bl = bl_[wv];
+  auto& io = io_[wv];
+  auto& rows = rows_[wv];
+  const int q4 = lane / GS, x4 = lane % GS, x = x4 % H;
+  const uint32_t halfB = (uint32_t)(x4 / H);
+  uint32_t selB = x4 == H ? 1u : 0u;
+  asm("" : "+v"(selB));
+  const size_t first_inst = ((size_t)blockIdx.x * kWavesPerWG + wv) * IPW;
+  size_t inst = first_inst + q4;
+  if (inst >= A.count) inst = A.count - 1;
+  for (int t = lane; t < FG::L; t += kWave) {
+    rows[0][t] = A.full_nr[t];
+    rows[1][t] = A.full_r2 ? A.full_r2[t] : 0;
+  }
+  uint32_t n[K], own[K], mreg[K], nxt[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) n[j] = A.ctx.nhat[x * K + j];
+  const int w = A.w, tsize = 1 << w;
+  const uint64_t* ep = A.exp + inst * A.exp_stride;
+  auto digit = [&](int i) -> int {
+    int bit = i * w;
+    int word = bit >> 6, sh = bit & 63;
+    uint64_t v = (word < A.exp_words) ? ep[word] >> sh : 0;
+    if (sh + w > 64 && word + 1 < A.exp_words) v |= ep[word + 1] << (64 - sh);
+    return (int)(v & (uint64_t)(tsize - 1));
+  };
+  auto load_entry = [&](uint32_t (&dst)[K], int i) {
+    const uint32_t* e = A.table + ((size_t)i * tsize + digit(i)) * LQ + x4 * K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) dst[j] = e[j];
+  };
+  load_entry(own, 0);
+  if (A.nwin > 1) load_entry(mreg, 1);
+  // the entry of the next step is fetched before the product of this one (latency hidden)
+#pragma unroll 1
+  for (int i = 1; i < A.nwin; ++i) {
+    if (i + 1 < A.nwin) load_entry(nxt, i + 1);
+    pairmul<H, K, false, true>(own, own, mreg, n, 0, halfB, selB);
+#pragma unroll
+    for (int j = 0; j < K; ++j) mreg[j] = nxt[j];
+  }
+  // ---- exit under the true modulus: (a, k*b mod n) (x) (1, 2n - m): 1 + n*m == 1 - n*(2n - m) (mod n^2) ----
+  stage_words<FG>(io, A.fm_words, A.fm_stride, 0, A.fm_nwords, first_inst, A.count, 1, lane);
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    n[j] = A.ctx.n[x * K + j];
+    mreg[j] = A.ctx.kr[x * K + j];
+  }
+  const uint32_t n0inv = A.ctx.n0inv;
+  {
+    uint32_t kb[K];
+    montmul_reg<HG, false, false>(kb, own, mreg, n, n0inv);
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+      if (halfB) own[j] = kb[j];
+  }
+  wave_lds_sync();
+  uint32_t d[K], e[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    e[j] = limb_from_words(io[q4], x * K + j);     // m (both halves compute it; half B uses it)
+    d[j] = 2 * n[j];
+  }
+  full_normalise<HG>(d, x);
+  (void)sub_limbs<HG>(mreg, d, e, x, lane);        // 2n - m  (m < 2^(64*words of n) <= 2n)
+#pragma unroll
+  for (int j = 0; j < K; ++j)
+    if (!halfB) mreg[j] = (x4 == 0 && j == 0) ? 1u : 0u;
+  pairmul<H, K, false, false>(own, own, mreg, n, n0inv, halfB, selB);
+  // ---- canonical pair: a'' = a' mod n, b'' = ([a' >= n] - b') mod n;  c = a'' + n*b'' ----
+  full_normalise<HG>(own, x);
+  const uint32_t below = sub_limbs<HG>(d, own, n, x, lane);
+  const uint32_t jflag = (uint32_t)__shfl((int)(below ^ 1u), (lane / GS) * GS);
+  if (!below) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) own[j] = d[j];
+  }
+  (void)sub_limbs<HG>(d, n, own, x, lane);          // half B: n - (b' mod n) in (0, n]
+  if (x == 0) d[0] += jflag;
+  full_normalise<HG>(d, x);
+  const uint32_t small = sub_limbs<HG>(e, d, n, x, lane);
+  // full-width operands in the lane layout of Geo<2H,K>: lane x4 holds limbs [x4*K, x4*K + K); both sit in the low half
+  uint32_t X[K], Y[K], nf[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const uint32_t bc = small ? d[j] : e[j];
+    const uint32_t down = dpp_from_above<H>(bc);
+    X[j] = halfB ? 0u : own[j];
+    Y[j] = halfB ? 0u : down;
+    nf[j] = A.full_n[x4 * K + j];
+  }
+  wave_lds_sync();
+  uint32_t t[K];
+  montmul<FG, false, false>(t, Y, rows[0], nf, A.full_n0inv);     // n * b''   (its Montgomery form: n*R' * b'')
+  if (A.full_r2) {
+    uint32_t u[K];
+    montmul<FG, false, false>(u, X, rows[1], nf, A.full_n0inv);   // a'' * R'
+    add_normalise<FG>(t, u);
+  } else {
+    add_normalise<FG>(t, X);
+  }
+  store_canonical<FG>(t, nf, A.mod_words, bl, io, A.out, A.out_stride, first_inst, A.count, lane, q4, x4);
+}
+
 }  // namespace pgpu
 
 #endif  // PAILLIERCRYPTOLIB_AMD_CSRC_HENSEL_HPP_

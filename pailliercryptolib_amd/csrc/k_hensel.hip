@@ -1,10 +1,10 @@
 // pailliercryptolib_amd -- instantiations of the split-form CRT-decrypt exponentiation (hensel.hpp), split over
-// PGPU_PART = 0..2 so that they compile in parallel.
+// PGPU_PART = 0..3 so that they compile in parallel (3: the fixed-base DJN encrypt).
 #include "hensel.hpp"
 #include "launch.hpp"
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..2"
+#error "compile with -DPGPU_PART=0..3"
 #endif
 
 namespace pgpu {
@@ -23,6 +23,21 @@ bool launch_hensel_part0(int H, int K, const HenselArgs& a, unsigned blocks, hip
 #elif PGPU_PART == 1
 bool launch_hensel_part1(int H, int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
   PGPU_HENSEL_ONE(4, 18) PGPU_HENSEL_ONE(4, 14) PGPU_HENSEL_ONE(4, 10)
+  return false;
+}
+#elif PGPU_PART == 3
+bool launch_hensel_fb_build(int H, int K, const HenselFbBuildArgs& a, unsigned blocks, hipStream_t s) {
+  if (H == 4 && K == 18) {
+    hipLaunchKernelGGL((hensel_fb_build_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  return false;
+}
+bool launch_hensel_fb_encrypt(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
+  if (H == 4 && K == 18) {
+    hipLaunchKernelGGL((hensel_fb_encrypt_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
   return false;
 }
 #else

@@ -158,6 +158,50 @@ struct HenselArgs {
   size_t count;          // ciphertexts
 };
 
+// Split form (hensel.hpp) of the public modulus n^2 = (n)^2: DJN encrypt with fixed-base tables of pairs.
+struct HenselPubDev {
+  const uint32_t* nhat;  // [L2]  P = n * k == -1 mod 2^29
+  const uint32_t* n;     // [L2]  n
+  const uint32_t* kr;    // [L2]  k * R mod n          (R = 2^(29*L2))
+  const uint32_t* one;   // pair  R mod P^2
+  const uint32_t* conv;  // [nchunks] pairs  2^(64*chunk_words*i) * R^2 mod P^2
+  uint32_t n0inv;        // -n^-1 mod 2^29
+};
+
+struct HenselFbBuildArgs {
+  HenselPubDev ctx;
+  const uint64_t* base;  // hs, base_words words
+  int base_words;
+  int chunk_words;
+  int nchunks;
+  uint32_t* table;       // [nwin][2^w] pairs
+  int nwin;
+  int w;
+};
+
+struct HenselFbArgs {
+  HenselPubDev ctx;
+  // the way back to a full-width residue modulo n^2, in the geometry Geo<2H,K> of the n^2 context (R' = 2^(29*2*L2)):
+  // c = a + n*b for canonical a, b < n is  montmul(b, n*R') + a;  its Montgomery form montmul(b, n*R'^2) + montmul(a, R'^2)
+  const uint32_t* full_n;    // [2*L2] n^2
+  const uint32_t* full_nr;   // [2*L2] n*R' mod n^2   (Montgomery-form output: n*R'^2 mod n^2)
+  const uint32_t* full_r2;   // [2*L2] R'^2 mod (a multiple of n^2); null: plain output
+  uint32_t full_n0inv;       // -(n^2)^-1 mod 2^29
+  int mod_words;             // 64-bit words per ciphertext
+  const uint32_t* table;     // [nwin][2^w] pairs
+  int nwin;
+  int w;
+  const uint64_t* exp;       // [count][exp_stride] the randomness r
+  size_t exp_stride;
+  int exp_words;
+  const uint64_t* fm_words;  // plaintexts [count][fm_stride], fm_nwords <= words of n
+  size_t fm_stride;
+  int fm_nwords;
+  uint64_t* out;             // [count][out_stride]
+  size_t out_stride;
+  size_t count;
+};
+
 struct FixedBaseArgs {
   ModCtxDev ctx;         // modulus n^2 (nr set)
   const uint32_t* table; // [nwin][2^w][L]

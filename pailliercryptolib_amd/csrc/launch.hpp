@@ -30,7 +30,7 @@ inline bool launch_modexp(int G, int K, bool regrows, const ModexpArgs& a, unsig
          launch_modexp_part2(G, K, a, blocks, s) || launch_modexp_part3(G, K, a, blocks, s);
 }
 
-// hensel_decrypt_kernel (hensel.hpp; k_hensel.hip compiled once per PGPU_PART): 2H lanes per ciphertext side, K limbs
+// hensel_decrypt_kernel (hensel.hpp; k_hensel.hip compiled once per PGPU_PART 0..2): 2H lanes per ciphertext side, K limbs
 // per lane, H*K >= limbs of (prime * 2^37).  Per key class the forms from few lanes (throughput) to many (latency:
 // batches that leave SIMDs idle): 1024-bit keys (2,10) (4,5) (8,3); 2048: (2,19) (4,10) (8,5); 3072: (4,14) (8,7);
 // 4096: (4,18) (8,9).
@@ -45,6 +45,11 @@ inline bool launch_hensel(int H, int K, const HenselArgs& a, unsigned blocks, hi
   return launch_hensel_part0(H, K, a, blocks, s) || launch_hensel_part1(H, K, a, blocks, s) ||
          launch_hensel_part2(H, K, a, blocks, s);
 }
+
+// split-form fixed-base DJN encrypt (hensel.hpp: hensel_fb_build_kernel / hensel_fb_encrypt_kernel; k_hensel.hip part 3)
+inline bool hensel_fb_has(int H, int K) { return H == 4 && K == 18; }
+bool launch_hensel_fb_build(int H, int K, const HenselFbBuildArgs& a, unsigned blocks, hipStream_t s);
+bool launch_hensel_fb_encrypt(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
 
 bool launch_modmul(int G, int K, const ModmulArgs& a, unsigned blocks, hipStream_t s);
 bool launch_crt(int G, int K, const CrtArgs& a, unsigned blocks, hipStream_t s);

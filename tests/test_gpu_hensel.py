@@ -141,3 +141,68 @@ def test_split_form_roundtrip_and_resident_chain(engine, hensel):
     assert limbs_to_ints(out) == [a + b for a, b in zip(m1, m2)]
     for h in hs + [c1, c2, sm, d]:
         L.pgpu_batch_destroy(h)
+
+
+@pytest.mark.parametrize("fbw", [4, 12])
+def test_split_form_djn_encrypt_equals_full_width(engine, hensel, fbw):
+    """DJN encrypt through the split-form fixed-base kernel (hensel_fb_encrypt_kernel) against the full-width
+    fb_encrypt_kernel and the oracle: edge plaintexts (0, 1, n-1, >= n up to the row width), edge randomness
+    (0, 1, short, full width), plain and Montgomery-form (device-resident) results."""
+    import numpy as np
+    from pailliercryptolib_amd import _capi
+    from pailliercryptolib_amd.limbs import ints_to_limbs, limbs_to_ints
+    L = _capi.lib()
+    kat = _kat()
+    p, q = kat["p"], kat["q"]
+    n = p * q
+    nw = 32
+    assert n.bit_length() == 64 * nw                         # the split form needs plaintext rows no wider than n
+    rng = random.Random(fbw)
+    count = 203
+    m = [0, 1, n - 1, n, n + 5, (1 << 2048) - 1] + [rng.randrange(n) for _ in range(count - 6)]
+    r = [0, 1, 3, (1 << 1024) - 1, 1 << 1023, rng.getrandbits(17)] + [rng.getrandbits(1024) for _ in range(count - 6)]
+    opk = orc.PublicKey(n, 2048)
+    opk.set_djn(kat["bench_hs"])
+    want = opk.encrypt(m, r)
+    _capi.check(L.pgpu_set_fixed_base_window(fbw))
+    try:
+        pk = engine.PublicKey(n, 2048, hs=kat["bench_hs"])
+        split, lanes, limbs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        hensel(1)
+        _capi.check(L.pgpu_encrypt_kernel_form(pk._h, nw, count, ctypes.byref(split), ctypes.byref(lanes),
+                                               ctypes.byref(limbs)))
+        assert (split.value, lanes.value, limbs.value) == (1, 8, 18)
+        got = pk.encrypt(m, r)
+        assert got == want
+        hensel(0)
+        _capi.check(L.pgpu_encrypt_kernel_form(pk._h, nw, count, ctypes.byref(split), ctypes.byref(lanes),
+                                               ctypes.byref(limbs)))
+        assert split.value == 0
+        assert pk.encrypt(m, r) == want
+        # Montgomery-form result of a resident batch, downloaded (leaves the domain) and decrypted in place
+        hensel(1)
+
+        def ptr(a):
+            return a.ctypes.data_as(ctypes.c_void_p)
+
+        def up(vals, words):
+            h = ctypes.c_void_p()
+            a = ints_to_limbs(vals, words)
+            _capi.check(L.pgpu_batch_upload(ptr(a), len(vals), words, words, ctypes.byref(h)))
+            return h
+        bm, br, c = up(m, nw), up(r, 16), ctypes.c_void_p()
+        _capi.check(L.pgpu_batch_encrypt(pk._h, bm, br, 1024, ctypes.byref(c)))
+        assert L.pgpu_batch_is_montgomery(c)
+        out = np.empty((count, 2 * nw), dtype=np.uint64)
+        _capi.check(L.pgpu_batch_download(c, ptr(out)))
+        assert limbs_to_ints(out) == want
+        sk = engine.PrivateKey(p, q)
+        d = ctypes.c_void_p()
+        _capi.check(L.pgpu_batch_decrypt_crt(sk._h, c, ctypes.byref(d)))
+        dm = np.empty((count, nw), dtype=np.uint64)
+        _capi.check(L.pgpu_batch_download(d, ptr(dm)))
+        assert limbs_to_ints(dm) == [v % n for v in m]
+        for h in (bm, br, c, d):
+            L.pgpu_batch_destroy(h)
+    finally:
+        _capi.check(L.pgpu_set_fixed_base_window(12))
