@@ -457,7 +457,7 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : 1) void hensel_fb_build_k
 // full-width residue: for canonical a, b < n the pair is c = a + n*b (< n^2), one full-width Montgomery product in
 // the geometry Geo<2H,K> of the n^2 context (two for a Montgomery-form result).
 template <int H, int K>
-__global__ __launch_bounds__(kWGThreads, 1) void hensel_fb_encrypt_kernel(HenselFbArgs A) {
+__global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : 1) void hensel_fb_encrypt_kernel(HenselFbArgs A) {
   using HG = Geo<H, K>;
   using FG = Geo<2 * H, K>;
   constexpr int GS = 2 * H, IPW = kWave / GS, LQ = 2 * H * K;

@@ -1,10 +1,10 @@
 // pailliercryptolib_amd -- instantiations of the split-form CRT-decrypt exponentiation (hensel.hpp), split over
-// PGPU_PART = 0..3 so that they compile in parallel (3: the fixed-base DJN encrypt).
+// PGPU_PART = 0..4 so that they compile in parallel (3, 4: the fixed-base DJN encrypt).
 #include "hensel.hpp"
 #include "launch.hpp"
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..3"
+#error "compile with -DPGPU_PART=0..4"
 #endif
 
 namespace pgpu {
@@ -25,17 +25,26 @@ bool launch_hensel_part1(int H, int K, const HenselArgs& a, unsigned blocks, hip
   PGPU_HENSEL_ONE(4, 18) PGPU_HENSEL_ONE(4, 14) PGPU_HENSEL_ONE(4, 10)
   return false;
 }
-#elif PGPU_PART == 3
-bool launch_hensel_fb_build(int H, int K, const HenselFbBuildArgs& a, unsigned blocks, hipStream_t s) {
-  if (H == 4 && K == 18) {
-    hipLaunchKernelGGL((hensel_fb_build_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+#elif PGPU_PART == 3 || PGPU_PART == 4
+#if PGPU_PART == 3
+#define PGPU_FB_H 4
+#define PGPU_FB_K 18
+#define PGPU_FB_NAME(f) f##_part3
+#else
+#define PGPU_FB_H 8
+#define PGPU_FB_K 14
+#define PGPU_FB_NAME(f) f##_part4
+#endif
+bool PGPU_FB_NAME(launch_hensel_fb_build)(int H, int K, const HenselFbBuildArgs& a, unsigned blocks, hipStream_t s) {
+  if (H == PGPU_FB_H && K == PGPU_FB_K) {
+    hipLaunchKernelGGL((hensel_fb_build_kernel<PGPU_FB_H, PGPU_FB_K>), dim3(blocks), dim3(kWGThreads), 0, s, a);
     return true;
   }
   return false;
 }
-bool launch_hensel_fb_encrypt(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
-  if (H == 4 && K == 18) {
-    hipLaunchKernelGGL((hensel_fb_encrypt_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+bool PGPU_FB_NAME(launch_hensel_fb_encrypt)(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
+  if (H == PGPU_FB_H && K == PGPU_FB_K) {
+    hipLaunchKernelGGL((hensel_fb_encrypt_kernel<PGPU_FB_H, PGPU_FB_K>), dim3(blocks), dim3(kWGThreads), 0, s, a);
     return true;
   }
   return false;

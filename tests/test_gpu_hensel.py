@@ -168,10 +168,17 @@ def test_split_form_djn_encrypt_equals_full_width(engine, hensel, fbw):
     try:
         pk = engine.PublicKey(n, 2048, hs=kat["bench_hs"])
         split, lanes, limbs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-        hensel(1)
-        _capi.check(L.pgpu_encrypt_kernel_form(pk._h, nw, count, ctypes.byref(split), ctypes.byref(lanes),
+        hensel(1)      # by batch size: the split form from 8192 elements per device up
+        _capi.check(L.pgpu_encrypt_kernel_form(pk._h, nw, 8192, ctypes.byref(split), ctypes.byref(lanes),
                                                ctypes.byref(limbs)))
         assert (split.value, lanes.value, limbs.value) == (1, 8, 18)
+        _capi.check(L.pgpu_encrypt_kernel_form(pk._h, nw, count, ctypes.byref(split), ctypes.byref(lanes),
+                                               ctypes.byref(limbs)))
+        assert split.value == 0
+        hensel(2)      # forced for this small batch
+        _capi.check(L.pgpu_encrypt_kernel_form(pk._h, nw, count, ctypes.byref(split), ctypes.byref(lanes),
+                                               ctypes.byref(limbs)))
+        assert split.value == 1
         got = pk.encrypt(m, r)
         assert got == want
         hensel(0)
@@ -180,7 +187,7 @@ def test_split_form_djn_encrypt_equals_full_width(engine, hensel, fbw):
         assert split.value == 0
         assert pk.encrypt(m, r) == want
         # Montgomery-form result of a resident batch, downloaded (leaves the domain) and decrypted in place
-        hensel(1)
+        hensel(2)
 
         def ptr(a):
             return a.ctypes.data_as(ctypes.c_void_p)
