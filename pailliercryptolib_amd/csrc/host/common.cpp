@@ -1,5 +1,5 @@
-// Host randomness (reference ipcl/utils/common.cpp): the OS CSPRNG replaces the
-// RDSEED / RDRAND / IPP-PRNG chain.  Randomness never reaches the GPU path except as data.
+// Host randomness (reference ipcl/utils/common.cpp): the OS CSPRNG (expanded by ChaCha20 for bulk requests) replaces
+// the RDSEED / RDRAND / IPP-PRNG chain.  Randomness never reaches the GPU path except as data.
 #include "ipcl/utils/common.hpp"
 
 #include <sys/random.h>
@@ -10,15 +10,16 @@
 #include <cstring>
 #include <random>
 
+#include "chacha20.hpp"
 #include "detail.hpp"
 #include "ipcl/utils/util.hpp"
 
 namespace ipcl {
 
 namespace detail {
-// n bytes from the kernel CSPRNG in as few system calls as possible (a batch of 8192 DJN obfuscator exponents is
-// 1 MiB: one std::random_device call per 32-bit word used to be the slowest part of a real encrypt)
-void fill_random(void* dst, std::size_t n) {
+namespace {
+// n bytes straight from the kernel CSPRNG
+void os_random(void* dst, std::size_t n) {
   unsigned char* p = static_cast<unsigned char*>(dst);
   while (n > 0) {
     ssize_t got = getrandom(p, n, 0);
@@ -35,6 +36,25 @@ void fill_random(void* dst, std::size_t n) {
     p += got;
     n -= (std::size_t)got;
   }
+}
+}  // namespace
+
+// Random bytes for obfuscator exponents and key material.  Small requests come straight from the kernel CSPRNG; a
+// bulk request (a batch of 8192 DJN exponents is 1 MiB, ~3 ms through getrandom(): three times the GPU kernel it
+// feeds) is the ChaCha20 key stream of a fresh 256-bit key and 96-bit nonce drawn from the kernel for this request
+// alone -- the arc4random / randombytes construction; nothing is kept between calls.  (Blocks are 64 bytes and the
+// counter is 32 bits: requests beyond 256 GiB would wrap, far above any batch.)
+void fill_random(void* dst, std::size_t n) {
+  constexpr std::size_t kBulk = 4096;
+  if (n < kBulk) {
+    os_random(dst, n);
+    return;
+  }
+  unsigned char seed[44];
+  os_random(seed, sizeof(seed));
+  chacha20_stream(seed, seed + 32, 0, static_cast<unsigned char*>(dst), n);
+  volatile unsigned char* w = seed;
+  for (std::size_t i = 0; i < sizeof(seed); ++i) w[i] = 0;
 }
 }  // namespace detail
 
