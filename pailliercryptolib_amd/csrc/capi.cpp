@@ -683,7 +683,7 @@ bool use_split_encrypt(const pgpu_pubkey* key, int m_words, size_t count) {
   const GeoInfo g = launch_geo(key->nsq->geo, count);
   return g.G == 2 * key->hH && g.K == key->hK;
 }
-pgpu::HenselPubDev hensel_pub_view(const pgpu_pubkey* key, int dev) {
+pgpu::HenselPubDev hensel_pub_view(const pgpu_pubkey* key, int dev, bool base_mont = false) {
   const int L2 = key->hH * key->hK;
   const uint32_t* b = (const uint32_t*)key->d_hpub.d[(size_t)dev];
   pgpu::HenselPubDev v{};
@@ -691,9 +691,88 @@ pgpu::HenselPubDev hensel_pub_view(const pgpu_pubkey* key, int dev) {
   v.n = b + L2;
   v.kr = b + 2 * L2;
   v.one = b + 3 * L2;
-  v.conv = b + 5 * L2;
+  v.conv = b + 5 * L2 + (base_mont ? (size_t)key->h_nchunks * 2 * L2 : 0);
   v.n0inv = key->h_n0inv;
   return v;
+}
+pgpu::HenselFullDev hensel_full_view(const pgpu_pubkey* key, int dev, bool out_mont) {
+  const pgpu::ModCtxDev full = key->nsq->view(dev, out_mont ? VF_GM_MONT : VF_NONE);
+  pgpu::HenselFullDev f{};
+  f.n = full.n;
+  f.nr = full.nr;                         // n*R' (plain result) or n*R'^2 (Montgomery-form result)
+  f.r2 = out_mont ? full.r2 : nullptr;
+  f.n0inv = full.n0inv;
+  f.mod_words = 2 * key->n_words;
+  return f;
+}
+
+// base^exp modulo n^2 in split form (hensel.hpp: hensel_modexp_kernel): the form with 8 lanes per half (4 elements per
+// wavefront) while it fills no more than the chip, else the key's throughput form.  Returns false when the key has no
+// split form.  (PGPU_SPLIT_MODEXP_MAX_WAVES: larger launches take the full-width kernel -- A/B measurements; a
+// 1 M-element CT x PT batch: 60.0 ms full width, 48.4 ms split.)
+bool split_modexp_form(const pgpu_pubkey* key, size_t count, int* H, int* K) {
+  if (!key->hH || !hensel_enabled()) return false;
+  const int L2 = key->hH * key->hK;
+  static const size_t max_waves = [] {
+    const char* e = std::getenv("PGPU_SPLIT_MODEXP_MAX_WAVES");
+    return e && std::atol(e) > 0 ? (size_t)std::atol(e) : ~(size_t)0;
+  }();
+  if (L2 % 8 == 0 && pgpu::hensel_modexp_has(8, L2 / 8) && (count + 3) / 4 <= kSimds) {
+    *H = 8;
+    *K = L2 / 8;
+    return true;
+  }
+  const size_t ipw = 64 / (2 * (size_t)key->hH);
+  if (!pgpu::hensel_modexp_has(key->hH, key->hK) || (count + ipw - 1) / ipw > max_waves) return false;
+  *H = key->hH;
+  *K = key->hK;
+  return true;
+}
+int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, int H, int K, const uint64_t* d_base, size_t base_stride,
+                    int base_words, bool base_mont, const uint64_t* d_exp, size_t exp_stride, int exp_words,
+                    int exp_bits, const SchedRef* sched, int final_mul, const uint64_t* d_m, size_t m_stride,
+                    int m_words, uint64_t* d_out, bool out_mont, size_t count, hipStream_t s) {
+  pgpu::HenselModexpArgs a{};
+  a.ctx = hensel_pub_view(key, d.index, base_mont);
+  a.full = hensel_full_view(key, d.index, out_mont);
+  a.base = d_base;
+  a.base_stride = base_stride;
+  a.base_words = base_words;
+  a.chunk_words = key->h_chunk_words;
+  a.nchunks = (base_words + key->h_chunk_words - 1) / key->h_chunk_words;
+  a.exp = d_exp;
+  a.exp_stride = exp_stride;
+  a.exp_words = exp_words;
+  a.exp_bits = exp_bits;
+  size_t entries;
+  if (sched && sched->p[0]) {
+    a.sched = sched->p[0];
+    a.sched_len = sched->len[0];
+    a.window = sched->w;
+    entries = (size_t)1 << (a.window - 1);
+  } else {
+    a.window = pick_window(exp_bits);
+    entries = (size_t)1 << a.window;
+  }
+  a.final_mul = final_mul;
+  a.fm_words = d_m;
+  a.fm_stride = m_stride;
+  a.fm_nwords = m_words;
+  a.out = d_out;
+  a.out_stride = (size_t)2 * key->n_words;
+  a.count = count;
+  const size_t ipw = 64 / (2 * (size_t)H);
+  const size_t waves = (count + ipw - 1) / ipw;
+  const unsigned blocks = (unsigned)((waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
+  rt::StreamWork& w = d.work_for(s);
+  std::lock_guard<std::mutex> lk(w.mu);
+  RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * ipw * entries * 2 * H * K * sizeof(uint32_t)));
+  a.table = (uint32_t*)w.table.p;
+  TimerScope t(d, s, PGPU_KERNEL_MODEXP);
+  if (!pgpu::launch_hensel_modexp(H, K, a, blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "split-form modexp kernel not compiled");
+  HIP_TRY(hipGetLastError());
+  t.stop();
+  return PGPU_OK;
 }
 // the fixed-base table of pairs (hensel.hpp: hensel_fb_build_kernel); same size as the full-width one
 int fb_table_for_split(const pgpu_pubkey* key, rt::Device& d, int w, int nwin, hipStream_t s, const FbTable** out) {
@@ -757,14 +836,9 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
     // no wider than n, and a batch that fills the chip in 8-lane groups no worse than the full-width kernel does
     if (use_split_encrypt(key, m_words, count)) {
       RC_TRY(fb_table_for_split(key, d, fbw, nwin, s, &tab));
-      const pgpu::ModCtxDev full = key->nsq->view(d.index, vflags);
       pgpu::HenselFbArgs f{};
       f.ctx = hensel_pub_view(key, d.index);
-      f.full_n = full.n;
-      f.full_nr = full.nr;                       // n*R' (plain result) or n*R'^2 (Montgomery-form result)
-      f.full_r2 = out_mont ? full.r2 : nullptr;
-      f.full_n0inv = full.n0inv;
-      f.mod_words = W;
+      f.full = hensel_full_view(key, d.index, out_mont);
       f.table = (const uint32_t*)tab->p;
       f.nwin = nwin;
       f.w = fbw;
@@ -822,6 +896,19 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
     a.exp_bits = r_bits;
   } else {         // r^n: per-element base, shared exponent n (pub_key.cpp:66-80)
     if (r_words > W) return fail(PGPU_ERR_INVALID_PARAM, "random wider than n^2");
+    int sh = 0, sk = 0;
+    if (64 * m_words <= key->n.BitSize() && split_modexp_form(key, count, &sh, &sk)) {
+      SchedRef srn;
+      if (key->sched_n.dev.bytes) {
+        srn.p[0] = (const uint16_t*)key->sched_n.dev.d[(size_t)d.index];
+        srn.len[0] = key->sched_n.len;
+        srn.w = key->sched_n.w;
+      }
+      return modexp_split_on(d, key, sh, sk, d_r, r_stride, r_words, false,
+                             (const uint64_t*)key->d_n.d[(size_t)d.index], 0, key->n_words, key->n.BitSize(),
+                             srn.p[0] ? &srn : nullptr, pgpu::FM_PAILLIER_G, d_m, m_stride, m_words, d_c, out_mont,
+                             count, s);
+    }
     a.base = d_r;
     a.base_stride = r_stride;
     a.base_words = r_words;
@@ -1358,7 +1445,7 @@ int build_hensel_pub(pgpu_pubkey* k) {
   const uint32_t n0inv = (0u - inv) & pgpu::kLimbMask;
   const BigNumber P = n * BigNumber((Ipp32u)n0inv), P2 = P * P;
   const BigNumber R = pow2(L2 * pgpu::kLimbBits);
-  std::vector<uint32_t> h((size_t)L2 * (5 + 2 * (size_t)nch), 0);
+  std::vector<uint32_t> h((size_t)L2 * (5 + 4 * (size_t)nch), 0);
   auto put_pair = [&](uint32_t* dst, const BigNumber& z) {
     const BigNumber zr = z % P2;
     const BigNumber f = zr / P;
@@ -1370,7 +1457,13 @@ int build_hensel_pub(pgpu_pubkey* k) {
   to_limbs29((R % n) * BigNumber((Ipp32u)n0inv) % n, L2, h.data() + 2 * L2);
   const BigNumber Rm = R % P2, R2 = (Rm * Rm) % P2;
   put_pair(h.data() + 3 * L2, Rm);
-  for (int i = 0; i < nch; ++i) put_pair(h.data() + 5 * L2 + (size_t)i * 2 * L2, (R2 * (pow2(64 * cw * i) % P2)) % P2);
+  // (second set: bases that arrive as c*R' mod n^2, R' the radix of the n^2 context -- resident ciphertexts)
+  const BigNumber R2m = (R2 * P2.InverseMul(pow2(k->nsq->geo.rbits()) % P2)) % P2;
+  for (int i = 0; i < nch; ++i) {
+    const BigNumber sh = pow2(64 * cw * i) % P2;
+    put_pair(h.data() + 5 * L2 + (size_t)i * 2 * L2, (R2 * sh) % P2);
+    put_pair(h.data() + 5 * L2 + (size_t)(nch + i) * 2 * L2, (R2m * sh) % P2);
+  }
   RC_TRY(k->d_hpub.upload(h.data(), h.size() * sizeof(uint32_t), false));
   k->hH = H;
   k->hK = K;
@@ -1404,7 +1497,7 @@ int pgpu_pubkey_create(const uint64_t* n, int n_words, const uint64_t* hs_or_nul
   if (sliding_enabled()) RC_TRY(make_schedule(k->n, pick_sliding_window(k->n.BitSize()), &k->sched_n, false));
   k->fb.resize((size_t)rt::pool_size());
   k->fbh.resize((size_t)rt::pool_size());
-  if (k->djn) RC_TRY(build_hensel_pub(k.get()));
+  RC_TRY(build_hensel_pub(k.get()));
   *out = k.release();
   return PGPU_OK;
 }
@@ -1891,6 +1984,13 @@ int pgpu_batch_ct_mul(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_ba
     o->bounds(d, &lo, &hi);
     rt::Device& dev = rt::device(d);
     rt::DeviceGuard g(dev.ordinal);
+    int sh = 0, sk = 0;
+    if (split_modexp_form(key, hi - lo, &sh, &sk)) {
+      RC_TRY(modexp_split_on(dev, key, sh, sk, a->ptr(d), (size_t)W, W, a->mont != nullptr,
+                             e->ptr(e->replicated ? d : (bcast ? 0 : d)), bcast ? 0 : (size_t)e->words, e->words, e_bits,
+                             nullptr, pgpu::FM_UNIT, nullptr, 0, 0, o->ptr(d), true, hi - lo, dev.bstream));
+      continue;
+    }
     RC_TRY(modexp_on(dev, a->ptr(d), (size_t)W, e->ptr(e->replicated ? d : (bcast ? 0 : d)),
                      bcast ? 0 : (size_t)e->words, e->words, e_bits, mod.data(), W, o->ptr(d), hi - lo, dev.bstream,
                      nullptr, a->mont != nullptr, true, key->nsq));

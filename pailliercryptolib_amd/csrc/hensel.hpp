@@ -395,6 +395,95 @@ __device__ __forceinline__ void pair_from_words(uint32_t (&own)[K], const uint64
   for (int j = 0; j < K; ++j) own[j] = acc[j];
 }
 
+// Leaves the Montgomery domain of a pair x*R modulo (n*k)^2 and stores the residue modulo n^2 as 64-bit words:
+// the exit product runs under the true modulus n on (a, k*b mod n), by (1, 0) or -- with_gm -- by the pair
+// (1, 2n - m) of 1 + n*m (1 + n*m == 1 - n*(2n - m) mod n^2; m < 2^(64 * words of n) <= 2n); the canonical pair
+// a'' = a' mod n, b'' = ([a' >= n] - b') mod n is the residue c = a'' + n*b'' < n^2, formed by one full-width Montgomery
+// product in Geo<2H,K> (two for a Montgomery-form result, HenselFullDev).  bl / io: the wavefront's LDS arrays in the
+// full-width geometry; rows: [2][FG::L] LDS, filled here.
+template <int H, int K>
+__device__ __forceinline__ void pair_exit_store(uint32_t (&own)[K], const HenselPubDev& C, const HenselFullDev& F,
+                                                bool with_gm, const uint64_t* fm_words, size_t fm_stride, int fm_nwords,
+                                                uint64_t* out, size_t out_stride, size_t first_inst, size_t count,
+                                                uint32_t (*bl)[2 * H * K], uint64_t (*io)[Geo<2 * H, K>::W64 + 1],
+                                                uint32_t (*rows)[2 * H * K], int lane, int q4, int x4, uint32_t halfB,
+                                                uint32_t selB) {
+  using HG = Geo<H, K>;
+  using FG = Geo<2 * H, K>;
+  constexpr int GS = 2 * H;
+  const int x = x4 % H;
+  for (int t = lane; t < FG::L; t += kWave) {
+    rows[0][t] = F.nr[t];
+    rows[1][t] = F.r2 ? F.r2[t] : 0;
+  }
+  if (with_gm) stage_words<FG>(io, fm_words, fm_stride, 0, fm_nwords, first_inst, count, 1, lane);
+  uint32_t n[K], mreg[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    n[j] = C.n[x * K + j];
+    mreg[j] = C.kr[x * K + j];
+  }
+  const uint32_t n0inv = C.n0inv;
+  {
+    uint32_t kb[K];
+    montmul_reg<HG, false, false>(kb, own, mreg, n, n0inv);
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+      if (halfB) own[j] = kb[j];
+  }
+  wave_lds_sync();
+  uint32_t d[K], e[K];
+  if (with_gm) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      e[j] = limb_from_words(io[q4], x * K + j);     // m (both halves compute it; half B uses it)
+      d[j] = 2 * n[j];
+    }
+    full_normalise<HG>(d, x);
+    (void)sub_limbs<HG>(mreg, d, e, x, lane);        // 2n - m
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j) mreg[j] = 0;
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j)
+    if (!halfB) mreg[j] = (x4 == 0 && j == 0) ? 1u : 0u;
+  pairmul<H, K, false, false>(own, own, mreg, n, n0inv, halfB, selB);
+  // ---- canonical pair ----
+  full_normalise<HG>(own, x);
+  const uint32_t below = sub_limbs<HG>(d, own, n, x, lane);
+  const uint32_t jflag = (uint32_t)__shfl((int)(below ^ 1u), (lane / GS) * GS);
+  if (!below) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) own[j] = d[j];
+  }
+  (void)sub_limbs<HG>(d, n, own, x, lane);          // half B: n - (b' mod n) in (0, n]
+  if (x == 0) d[0] += jflag;
+  full_normalise<HG>(d, x);
+  const uint32_t small = sub_limbs<HG>(e, d, n, x, lane);
+  // full-width operands in the lane layout of Geo<2H,K>: lane x4 holds limbs [x4*K, x4*K + K); both sit in the low half
+  uint32_t X[K], Y[K], nf[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const uint32_t bc = small ? d[j] : e[j];
+    const uint32_t down = dpp_from_above<H>(bc);
+    X[j] = halfB ? 0u : own[j];
+    Y[j] = halfB ? 0u : down;
+    nf[j] = F.n[x4 * K + j];
+  }
+  wave_lds_sync();
+  uint32_t t[K];
+  montmul<FG, false, false>(t, Y, rows[0], nf, F.n0inv);     // n * b''   (its Montgomery form: n*R' * b'')
+  if (F.r2) {
+    uint32_t u[K];
+    montmul<FG, false, false>(u, X, rows[1], nf, F.n0inv);   // a'' * R'
+    add_normalise<FG>(t, u);
+  } else {
+    add_normalise<FG>(t, X);
+  }
+  store_canonical<FG>(t, nf, F.mod_words, bl, io, out, out_stride, first_inst, count, lane, q4, x4);
+}
+
 // Fixed-base table of pairs for the DJN obfuscator hs^r (kernels.hpp: fb_build_kernel is the full-width twin):
 // group i builds row i, T[i][d] = hs^(d * 2^(w*i)) * R as a pair.
 template <int H, int K>
@@ -476,10 +565,6 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : 1) void hensel_fb_encrypt
   const size_t first_inst = ((size_t)blockIdx.x * kWavesPerWG + wv) * IPW;
   size_t inst = first_inst + q4;
   if (inst >= A.count) inst = A.count - 1;
-  for (int t = lane; t < FG::L; t += kWave) {
-    rows[0][t] = A.full_nr[t];
-    rows[1][t] = A.full_r2 ? A.full_r2[t] : 0;
-  }
   uint32_t n[K], own[K], mreg[K], nxt[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) n[j] = A.ctx.nhat[x * K + j];
@@ -507,67 +592,128 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : 1) void hensel_fb_encrypt
 #pragma unroll
     for (int j = 0; j < K; ++j) mreg[j] = nxt[j];
   }
-  // ---- exit under the true modulus: (a, k*b mod n) (x) (1, 2n - m): 1 + n*m == 1 - n*(2n - m) (mod n^2) ----
-  stage_words<FG>(io, A.fm_words, A.fm_stride, 0, A.fm_nwords, first_inst, A.count, 1, lane);
+  pair_exit_store<H, K>(own, A.ctx, A.full, true, A.fm_words, A.fm_stride, A.fm_nwords, A.out, A.out_stride, first_inst,
+                        A.count, bl, io, rows, lane, q4, x4, halfB, selB);
+}
+
+// base[i]^exp[i] modulo n^2 in split form -- CT x PT (ciphertext.cpp:143-162: per-element exponents, fixed window) and
+// the non-DJN obfuscator r^n with its g^m product (pub_key.cpp:66-80, 88-105: shared exponent n, the host's schedule).
+// Same structure as modexp_kernel; entry as in hensel_decrypt_kernel, exit as in hensel_fb_encrypt_kernel.
+// (18 limbs per lane squeezed into the 256 registers of two wavefronts per SIMD spill a few set-up values to scratch,
+// none in the loops: a 1 M-element CT x PT batch 55.8 -> 48.4 ms, launches of one wavefront per SIMD unchanged)
+#ifndef PGPU_HM_WAVES18
+#define PGPU_HM_WAVES18 2
+#endif
+template <int H, int K>
+__global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : PGPU_HM_WAVES18) void hensel_modexp_kernel(HenselModexpArgs A) {
+  using HG = Geo<H, K>;
+  using FG = Geo<2 * H, K>;
+  constexpr int GS = 2 * H, IPW = kWave / GS, LQ = 2 * H * K;
+  raise_wave_priority();
+  __shared__ uint32_t bl_[kWavesPerWG][IPW][FG::L];
+  __shared__ uint64_t io_[kWavesPerWG][IPW][FG::W64 + 1];
+  __shared__ uint32_t rows_[kWavesPerWG][2][FG::L];
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  auto& bl = bl_[wv];
+  auto& io = io_[wv];
+  auto& rows = rows_[wv];
+  const int q4 = lane / GS, x4 = lane % GS, x = x4 % H;
+  const uint32_t halfB = (uint32_t)(x4 / H);
+  uint32_t selB = x4 == H ? 1u : 0u;
+  asm("" : "+v"(selB));
+  const size_t wave_id = (size_t)blockIdx.x * kWavesPerWG + wv;
+  const size_t first_inst = wave_id * IPW;
+  size_t inst = first_inst + q4;
+  if (inst >= A.count) inst = A.count - 1;
+  uint32_t n[K], own[K], mreg[K];
 #pragma unroll
-  for (int j = 0; j < K; ++j) {
-    n[j] = A.ctx.n[x * K + j];
-    mreg[j] = A.ctx.kr[x * K + j];
-  }
-  const uint32_t n0inv = A.ctx.n0inv;
+  for (int j = 0; j < K; ++j) n[j] = A.ctx.nhat[x * K + j];
+
+  const bool sched_mode = A.sched != nullptr;
+  const uint16_t* sch = A.sched;
+  const int nsteps = A.sched_len;
+  const int w = A.window;
+  const int tsize = sched_mode ? 1 << (w - 1) : 1 << w;
+  uint32_t* tbl = A.table + (wave_id * IPW + q4) * (size_t)tsize * LQ + x4 * K;
+  const uint64_t* ep = A.exp + inst * A.exp_stride;
+  const int nwin = (A.exp_bits + w - 1) / w;
+  auto digit = [&](int i) -> int {
+    int bit = i * w;
+    int word = bit >> 6, sh = bit & 63;
+    uint64_t v = (word < A.exp_words) ? ep[word] >> sh : 0;
+    if (sh + w > 64 && word + 1 < A.exp_words) v |= ep[word + 1] << (64 - sh);
+    return (int)(v & (uint64_t)(tsize - 1));
+  };
+
+  // (the FG-sized row of io holds more than the W64+1 words of a half-width chunk)
+  pair_from_words<H, K>(own, A.base + inst * A.base_stride, A.base_words, A.chunk_words, A.nchunks, A.ctx.conv,
+                        io[q4], n, halfB, selB, x4);
+  // ---- window table (fixed window: all powers; schedule: the odd powers, built with base^2) ----
   {
-    uint32_t kb[K];
-    montmul_reg<HG, false, false>(kb, own, mreg, n, n0inv);
+    int e;
+    if (sched_mode) {
 #pragma unroll
-    for (int j = 0; j < K; ++j)
-      if (halfB) own[j] = kb[j];
+      for (int j = 0; j < K; ++j) tbl[j] = own[j];
+      if (tsize > 1) pairmul<H, K, false, true>(mreg, own, own, n, 0, halfB, selB);
+      e = 1;
+    } else {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        tbl[LQ + j] = own[j];
+        tbl[j] = A.ctx.one[x4 * K + j];
+        mreg[j] = own[j];
+      }
+      e = 2;
+    }
+#pragma unroll 1
+    for (; e < tsize; ++e) {
+      pairmul<H, K, false, true>(own, own, mreg, n, 0, halfB, selB);
+#pragma unroll
+      for (int j = 0; j < K; ++j) tbl[(size_t)e * LQ + j] = own[j];
+    }
   }
-  wave_lds_sync();
-  uint32_t d[K], e[K];
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    e[j] = limb_from_words(io[q4], x * K + j);     // m (both halves compute it; half B uses it)
-    d[j] = 2 * n[j];
-  }
-  full_normalise<HG>(d, x);
-  (void)sub_limbs<HG>(mreg, d, e, x, lane);        // 2n - m  (m < 2^(64*words of n) <= 2n)
-#pragma unroll
-  for (int j = 0; j < K; ++j)
-    if (!halfB) mreg[j] = (x4 == 0 && j == 0) ? 1u : 0u;
-  pairmul<H, K, false, false>(own, own, mreg, n, n0inv, halfB, selB);
-  // ---- canonical pair: a'' = a' mod n, b'' = ([a' >= n] - b') mod n;  c = a'' + n*b'' ----
-  full_normalise<HG>(own, x);
-  const uint32_t below = sub_limbs<HG>(d, own, n, x, lane);
-  const uint32_t jflag = (uint32_t)__shfl((int)(below ^ 1u), (lane / GS) * GS);
-  if (!below) {
-#pragma unroll
-    for (int j = 0; j < K; ++j) own[j] = d[j];
-  }
-  (void)sub_limbs<HG>(d, n, own, x, lane);          // half B: n - (b' mod n) in (0, n]
-  if (x == 0) d[0] += jflag;
-  full_normalise<HG>(d, x);
-  const uint32_t small = sub_limbs<HG>(e, d, n, x, lane);
-  // full-width operands in the lane layout of Geo<2H,K>: lane x4 holds limbs [x4*K, x4*K + K); both sit in the low half
-  uint32_t X[K], Y[K], nf[K];
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    const uint32_t bc = small ? d[j] : e[j];
-    const uint32_t down = dpp_from_above<H>(bc);
-    X[j] = halfB ? 0u : own[j];
-    Y[j] = halfB ? 0u : down;
-    nf[j] = A.full_n[x4 * K + j];
-  }
-  wave_lds_sync();
-  uint32_t t[K];
-  montmul<FG, false, false>(t, Y, rows[0], nf, A.full_n0inv);     // n * b''   (its Montgomery form: n*R' * b'')
-  if (A.full_r2) {
-    uint32_t u[K];
-    montmul<FG, false, false>(u, X, rows[1], nf, A.full_n0inv);   // a'' * R'
-    add_normalise<FG>(t, u);
+  // ---- main loop: steps of (nsq squarings, one multiplication by a table entry), as in hensel_decrypt_kernel ----
+  int win;
+  bool any = true;
+  if (sched_mode) {
+    if (nsteps == 0) any = false;
+    win = 1;
   } else {
-    add_normalise<FG>(t, X);
+    if (nwin == 0) any = false;
+    win = nwin - 2;
   }
-  store_canonical<FG>(t, nf, A.mod_words, bl, io, A.out, A.out_stride, first_inst, A.count, lane, q4, x4);
+  if (any) {
+    const int d0 = sched_mode ? (__builtin_amdgcn_readfirstlane((int)sch[0]) & 63) - 1 : digit(nwin - 1);
+#pragma unroll
+    for (int j = 0; j < K; ++j) own[j] = tbl[(size_t)d0 * LQ + j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j) own[j] = A.ctx.one[x4 * K + j];
+  }
+#pragma unroll 1
+  for (;;) {
+    int nsq, idx;
+    if (sched_mode) {
+      if (!any || win >= nsteps) break;
+      const int st = __builtin_amdgcn_readfirstlane((int)sch[win++]);
+      nsq = st >> 6;
+      idx = (st & 63) - 1;
+    } else {
+      if (!any || win < 0) break;
+      nsq = w;
+      idx = digit(win--);
+    }
+    const bool mul = !sched_mode || idx >= 0;
+    if (mul) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) mreg[j] = tbl[(size_t)idx * LQ + j];
+    }
+#pragma unroll 1
+    for (int i = 0; i < nsq; ++i) pairmul<H, K, true, true>(own, own, own, n, 0, halfB, selB);
+    if (mul) pairmul<H, K, false, true>(own, own, mreg, n, 0, halfB, selB);
+  }
+  pair_exit_store<H, K>(own, A.ctx, A.full, A.final_mul == FM_PAILLIER_G, A.fm_words, A.fm_stride, A.fm_nwords, A.out,
+                        A.out_stride, first_inst, A.count, bl, io, rows, lane, q4, x4, halfB, selB);
 }
 
 }  // namespace pgpu

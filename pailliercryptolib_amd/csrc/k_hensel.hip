@@ -1,10 +1,10 @@
 // pailliercryptolib_amd -- instantiations of the split-form CRT-decrypt exponentiation (hensel.hpp), split over
-// PGPU_PART = 0..4 so that they compile in parallel (3, 4: the fixed-base DJN encrypt).
+// PGPU_PART = 0..6 so that they compile in parallel (3, 4: the fixed-base DJN encrypt; 5, 6: the generic modexp).
 #include "hensel.hpp"
 #include "launch.hpp"
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..4"
+#error "compile with -DPGPU_PART=0..6"
 #endif
 
 namespace pgpu {
@@ -45,6 +45,22 @@ bool PGPU_FB_NAME(launch_hensel_fb_build)(int H, int K, const HenselFbBuildArgs&
 bool PGPU_FB_NAME(launch_hensel_fb_encrypt)(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
   if (H == PGPU_FB_H && K == PGPU_FB_K) {
     hipLaunchKernelGGL((hensel_fb_encrypt_kernel<PGPU_FB_H, PGPU_FB_K>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  return false;
+}
+#elif PGPU_PART == 5
+bool launch_hensel_modexp_part5(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
+  if (H == 4 && K == 18) {
+    hipLaunchKernelGGL((hensel_modexp_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  return false;
+}
+#elif PGPU_PART == 6
+bool launch_hensel_modexp_part6(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
+  if (H == 8 && K == 9) {
+    hipLaunchKernelGGL((hensel_modexp_kernel<8, 9>), dim3(blocks), dim3(kWGThreads), 0, s, a);
     return true;
   }
   return false;

@@ -179,15 +179,20 @@ struct HenselFbBuildArgs {
   int w;
 };
 
+// The way back from a canonical pair (a, b), a, b < n, to the full-width residue c = a + n*b modulo n^2, in the
+// geometry Geo<2H,K> of the n^2 context (R' = 2^(29*2*L2)):  c = montmul(b, n*R') + a;  its Montgomery form
+// c*R' = montmul(b, n*R'^2) + montmul(a, R'^2).
+struct HenselFullDev {
+  const uint32_t* n;     // [2*L2] n^2
+  const uint32_t* nr;    // [2*L2] n*R' mod n^2   (Montgomery-form result: n*R'^2 mod n^2)
+  const uint32_t* r2;    // [2*L2] R'^2 mod (a multiple of n^2); null: plain result
+  uint32_t n0inv;        // -(n^2)^-1 mod 2^29
+  int mod_words;         // 64-bit words per residue
+};
+
 struct HenselFbArgs {
   HenselPubDev ctx;
-  // the way back to a full-width residue modulo n^2, in the geometry Geo<2H,K> of the n^2 context (R' = 2^(29*2*L2)):
-  // c = a + n*b for canonical a, b < n is  montmul(b, n*R') + a;  its Montgomery form montmul(b, n*R'^2) + montmul(a, R'^2)
-  const uint32_t* full_n;    // [2*L2] n^2
-  const uint32_t* full_nr;   // [2*L2] n*R' mod n^2   (Montgomery-form output: n*R'^2 mod n^2)
-  const uint32_t* full_r2;   // [2*L2] R'^2 mod (a multiple of n^2); null: plain output
-  uint32_t full_n0inv;       // -(n^2)^-1 mod 2^29
-  int mod_words;             // 64-bit words per ciphertext
+  HenselFullDev full;
   const uint32_t* table;     // [nwin][2^w] pairs
   int nwin;
   int w;
@@ -199,6 +204,32 @@ struct HenselFbArgs {
   int fm_nwords;
   uint64_t* out;             // [count][out_stride]
   size_t out_stride;
+  size_t count;
+};
+
+// base[i]^exp[i] modulo n^2 in split form (hensel.hpp: hensel_modexp_kernel): CT x PT and the non-DJN obfuscator r^n.
+struct HenselModexpArgs {
+  HenselPubDev ctx;          // ctx.conv: the chunk constants for the form the bases arrive in (plain, or c*R' mod n^2)
+  HenselFullDev full;
+  const uint64_t* base;      // [count][base_stride]
+  size_t base_stride;
+  int base_words;
+  int chunk_words;
+  int nchunks;
+  const uint64_t* exp;       // [count][exp_stride]; exp_stride == 0: one shared exponent
+  size_t exp_stride;
+  int exp_words;
+  int exp_bits;
+  int window;                // as ModexpArgs::window
+  const uint16_t* sched;     // as ModexpArgs::sched (shared exponents the host knows), or null
+  int sched_len;
+  int final_mul;             // FM_UNIT, or FM_PAILLIER_G: times 1 + n*m, m from fm_words (rows no wider than n)
+  const uint64_t* fm_words;
+  size_t fm_stride;
+  int fm_nwords;
+  uint64_t* out;             // [count][out_stride]
+  size_t out_stride;
+  uint32_t* table;           // [wavefronts * 64/(2H)][entries][2*L2] workspace
   size_t count;
 };
 

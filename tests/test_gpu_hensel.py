@@ -213,3 +213,71 @@ def test_split_form_djn_encrypt_equals_full_width(engine, hensel, fbw):
             L.pgpu_batch_destroy(h)
     finally:
         _capi.check(L.pgpu_set_fixed_base_window(12))
+
+
+@pytest.mark.parametrize("count", [37, 4200])
+def test_split_form_ct_mul_and_plain_obfuscator_equal_full_width(engine, hensel, count):
+    """The generic split-form exponentiation modulo n^2 (hensel_modexp_kernel: 8 lanes per half for small batches, 4
+    beyond 4096 elements) against the full-width modexp_kernel and the oracle: CT x PT with per-element exponents of
+    every width on plain and on Montgomery-form (resident) ciphertexts, a broadcast scalar exponent, and the non-DJN
+    encrypt r^n * (1 + n*m) with edge plaintexts."""
+    import numpy as np
+    from pailliercryptolib_amd import _capi
+    from pailliercryptolib_amd.limbs import ints_to_limbs, limbs_to_ints
+    L = _capi.lib()
+    kat = _kat()
+    p, q = kat["p"], kat["q"]
+    n = p * q
+    nsq = n * n
+    nw = 32
+    rng = random.Random(count)
+    c = [rng.randrange(1, nsq) for _ in range(count)]
+    c[0], c[1] = 1, nsq - 1
+    widths = [0, 1, 2, 31, 32, 33, 64, 100, 2048]
+    e = [rng.getrandbits(widths[i % len(widths)]) for i in range(count)]
+    m = [0, 1, n - 1, n + 7, (1 << 2048) - 1] + [rng.randrange(n) for _ in range(count - 5)]
+    r = [1, 2, n - 1] + [rng.randrange(1, n) for _ in range(count - 3)]
+    # the oracle on a sample (all of a small batch); the rest of a large batch is compared between the two kernels
+    idx = list(range(count)) if count <= 64 else list(range(48)) + list(range(count - 16, count))
+    want_mul = {i: pow(c[i], e[i], nsq) for i in idx}
+    want_scalar = {i: pow(c[i], 65537, nsq) for i in idx}
+    opk = orc.PublicKey(n, 2048)
+    want_enc = {i: opk.encrypt([m[i]], [r[i]])[0] for i in idx}
+    seen = {}
+
+    def check(name, got, want, mode):
+        assert all(got[i] == want[i] for i in idx), (name, mode)
+        assert seen.setdefault(name, got) == got, (name, "split form and full-width kernel differ")
+
+    def ptr(a):
+        return a.ctypes.data_as(ctypes.c_void_p)
+
+    def up(vals, words):
+        h = ctypes.c_void_p()
+        a = ints_to_limbs(vals, words)
+        _capi.check(L.pgpu_batch_upload(ptr(a), len(vals), words, words, ctypes.byref(h)))
+        return h
+
+    def down(h):
+        out = np.empty((L.pgpu_batch_count(h), L.pgpu_batch_words(h)), dtype=np.uint64)
+        _capi.check(L.pgpu_batch_download(h, ptr(out)))
+        return limbs_to_ints(out)
+
+    pk = engine.PublicKey(n, 2048)                      # non-DJN: r^n
+    for mode in (1, 0):
+        hensel(mode)
+        check("enc", pk.encrypt(m, r), want_enc, mode)
+        bc, be, bs = up(c, 2 * nw), up(e, nw), up([65537], 1)
+        t = ctypes.c_void_p()
+        _capi.check(L.pgpu_batch_ct_mul(pk._h, bc, be, 2048, ctypes.byref(t)))       # plain ciphertexts in
+        assert L.pgpu_batch_is_montgomery(t)
+        got_mul = down(t)
+        check("mul", got_mul, want_mul, mode)
+        u = ctypes.c_void_p()
+        _capi.check(L.pgpu_batch_ct_mul(pk._h, t, bs, 17, ctypes.byref(u)))          # Montgomery form in, scalar
+        check("mul2", down(u), {i: pow(want_mul[i], 65537, nsq) for i in idx}, mode)
+        v = ctypes.c_void_p()
+        _capi.check(L.pgpu_batch_ct_mul(pk._h, bc, bs, 17, ctypes.byref(v)))
+        check("scalar", down(v), want_scalar, mode)
+        for h in (bc, be, bs, t, u, v):
+            L.pgpu_batch_destroy(h)
