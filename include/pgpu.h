@@ -236,6 +236,9 @@ int pgpu_decrypt_kernel_form(const pgpu_privkey* key, size_t count, int* split, 
  * *limbs> (DJN keys with a fixed-base window, 2048-bit keys, plaintext rows no wider than n); *split = 0:
  * fb_encrypt_kernel / modexp_kernel <Geo<*lanes, *limbs>>. */
 int pgpu_encrypt_kernel_form(const pgpu_pubkey* key, int m_words, size_t count, int* split, int* lanes, int* limbs);
+/* The same for the exponentiations modulo n^2 with per-element bases (CT x PT of a resident batch, the non-DJN
+ * obfuscator r^n): *split = 1: hensel_modexp_kernel<*lanes / 2, *limbs>; *split = 0: modexp_kernel<Geo<*lanes, *limbs>>. */
+int pgpu_modexp_n2_kernel_form(const pgpu_pubkey* key, size_t count, int* split, int* lanes, int* limbs);
 
 #ifdef __cplusplus
 }

@@ -1200,6 +1200,23 @@ int pgpu_encrypt_kernel_form(const pgpu_pubkey* key, int m_words, size_t count, 
   return PGPU_OK;
 }
 
+int pgpu_modexp_n2_kernel_form(const pgpu_pubkey* key, size_t count, int* split, int* lanes, int* limbs) {
+  if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_modexp_n2_kernel_form: bad argument");
+  int H = 0, K = 0;
+  if (split_modexp_form(key, count, &H, &K)) {
+    *split = 1;
+    *lanes = 2 * H;
+    *limbs = K;
+    return PGPU_OK;
+  }
+  const GeoInfo lat = latency_geo(key->nsq->geo);
+  const GeoInfo g = use_latency_geo(lat, key->nsq->geo, count) ? lat : launch_geo(key->nsq->geo, count);
+  *split = 0;
+  *lanes = g.G;
+  *limbs = g.K;
+  return PGPU_OK;
+}
+
 int pgpu_decrypt_kernel_form(const pgpu_privkey* key, size_t count, int* split, int* lanes, int* limbs) {
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_decrypt_kernel_form: bad argument");
   if (const pgpu_privkey::HenselSet* f = pick_hensel(key, count)) {
