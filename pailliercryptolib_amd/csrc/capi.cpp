@@ -1005,7 +1005,7 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
     RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * ipw * entries * 2 * L2 * sizeof(uint32_t)));
     h.table = (uint32_t*)w.table.p;
     TimerScope t(d, s, PGPU_KERNEL_MODEXP);
-    if (!pgpu::launch_hensel(hset->H, hset->K, h, blocks, s))
+    if (!pgpu::launch_hensel(hset->H, hset->K, waves > kSimds, h, blocks, s))
       return fail(PGPU_ERR_UNSUPPORTED, "split-form kernel not compiled");
     HIP_TRY(hipGetLastError());
     t.stop();

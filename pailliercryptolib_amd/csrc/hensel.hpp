@@ -161,9 +161,12 @@ __device__ __forceinline__ uint32_t sub_limbs(uint32_t (&d)[GEO::K], const uint3
 // exponent and schedule are wave-uniform.  Output: row 2i = mp, row 2i+1 = mq (canonical words) for crt_kernel
 // (have_m).  H = 2: the throughput form (16 ciphertexts per wavefront); H = 8: the latency form for small batches
 // (the serial chain of a multiplication is its H*K quotient rows, and a row shrinks with K).
-// (up to 14 limbs per lane the kernel fits the 256 registers that let two wavefronts share a SIMD)
-template <int H, int K>
-__global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : 1) void hensel_decrypt_kernel(HenselArgs A) {
+// MINW: wavefronts per SIMD the register budget is set for.  Up to 14 limbs per lane the kernel fits the 256
+// registers of two wavefronts anyway; (2,19) is compiled both ways: with the full budget for launches of at most one
+// wavefront per SIMD (no scratch at all) and squeezed into 256 registers (a few set-up values in scratch, none in the
+// loops) for larger batches, where the second wavefront buys 7 % (32768 ciphertexts: 4.76 -> 4.41 ms per 8192).
+template <int H, int K, int MINW = (K <= 14 ? 2 : 1)>
+__global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_kernel(HenselArgs A) {
   using HG = Geo<H, K>;
   constexpr int GS = 2 * H, IPW = kWave / GS, L2 = H * K, LQ = 2 * H * K, W64 = HG::W64;
   raise_wave_priority();

@@ -41,7 +41,10 @@ inline bool hensel_has(int H, int K) {
 bool launch_hensel_part0(int H, int K, const HenselArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_part1(int H, int K, const HenselArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_part2(int H, int K, const HenselArgs& a, unsigned blocks, hipStream_t s);
-inline bool launch_hensel(int H, int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
+bool launch_hensel_part7(int H, int K, const HenselArgs& a, unsigned blocks, hipStream_t s);   // (2,19) for two waves per SIMD
+// packed: the launch puts more than one wavefront on a SIMD
+inline bool launch_hensel(int H, int K, bool packed, const HenselArgs& a, unsigned blocks, hipStream_t s) {
+  if (packed && launch_hensel_part7(H, K, a, blocks, s)) return true;
   return launch_hensel_part0(H, K, a, blocks, s) || launch_hensel_part1(H, K, a, blocks, s) ||
          launch_hensel_part2(H, K, a, blocks, s);
 }
