@@ -1,7 +1,11 @@
-// pailliercryptolib_amd -- CRT-decrypt exponentiation modulo a SQUARE (p^2, q^2) in split form.
+// pailliercryptolib_amd -- exponentiation modulo a SQUARE (p^2, q^2, n^2) in split form.
 //
-// Replaces the two half-width exponentiations of PrivateKey::decryptCRT and the L-function / *hp step behind them
-// (ipcl/pri_key.cpp:122-157; the reference hands c^(p-1) mod p^2 to ippMBModExp as a 2048-bit black box).
+// Every modulus of the Paillier path is a square whose root the caller knows: p^2 / q^2 in
+// PrivateKey::decryptCRT (ipcl/pri_key.cpp:122-157; the reference hands c^(p-1) mod p^2 to ippMBModExp as a
+// 2048-bit black box) and n^2 in PublicKey::encrypt and CipherText * PlainText (pub_key.cpp:51-105,
+// ciphertext.cpp:143-162).  Kernels here: hensel_decrypt_kernel (replaces the two half-width exponentiations of
+// decryptCRT and the L-function / *hp step behind them), hensel_fb_build_kernel / hensel_fb_encrypt_kernel (DJN
+// encrypt with a fixed-base table), hensel_modexp_kernel (per-element bases: CT x PT, the non-DJN obfuscator).
 // A residue modulo P^2 is kept as a PAIR of half-width numbers
 //        x  ==  a - P*b   (mod P^2),      0 <= a, b < 2P  (lazy),
 // and the Montgomery product of two pairs costs three half-width products and two half-width reductions
@@ -17,8 +21,8 @@
 // Lanes: a group of 2H lanes holds one exponentiation (H = 2: a quad; 4; 8: a DPP row); its lanes 0..H-1
 // ("half A") hold a, lanes H..2H-1 ("half B") hold b, K 29-bit limbs per lane: two Geo<H,K> groups side by side
 // that run ONE instruction stream.  The multiplier rows of both halves are limbs of half A of an operand (c, then
-// a), broadcast to the whole group by one v_mov_b32_dpp each (quad_perm:[S,S,S,S] / row_newbcast:S; two bank-masked
-// ones for H = 4); half A accumulates a*c while half B accumulates b*c + d*a; the K-row
+// a), broadcast to the whole group by one v_mov_b32_dpp each (quad_perm:[S,S,S,S] / row_newbcast:S; H = 4: from a
+// per-quad copy, pair_row_source); half A accumulates a*c while half B accumulates b*c + d*a; the K-row
 // reduction blocks of mont_core.hpp run in both halves at once, half B's low lane receiving half A's digit first
 // (mont_reduce_rows<.., PAIR>).  The loop modulus is P = p*k == -1 (mod 2^29) (unit quotient digits); the
 // multiplication that leaves the Montgomery domain switches to the true prime: (a, k*b mod p) is a pair modulo p^2.
