@@ -177,6 +177,27 @@ CipherText PublicKey::encrypt(const PlainText& pt, bool make_secure) const {
 
   // One fused GPU launch; plaintexts may already be resident (e.g. the output of decrypt), the
   // ciphertexts stay resident until somebody asks for their BigNumbers.
+  if (m_enable_DJN && !m_testv && m_randbits > 0) {
+    // DJN exponents are plain randbits-bit strings (pub_key.cpp:59-61): drawn straight into the limb batch the GPU
+    // reads, without a BigNumber per element in between
+    auto dev = device();
+    const int nw = detail::words_for_bits(m_n->BitSize());
+    const int mw = pt.isDeviceResident() ? 0 : std::min(2 * nw, detail::words_for_bits(pt.maxBitsHint()));
+    std::shared_ptr<detail::DeviceBatch> dm = pt.isDeviceResident() ? pt.m_dev : pt.deviceBatch(mw, m_n.get());
+    const int rw = detail::words_for_bits(m_randbits);
+    std::vector<uint64_t> flat(sz * (std::size_t)rw);
+    detail::fill_random(flat.data(), flat.size() * sizeof(uint64_t));
+    if (m_randbits % 64) {
+      const uint64_t top = (~(uint64_t)0) >> (64 - m_randbits % 64);
+      for (std::size_t i = 0; i < sz; ++i) flat[i * (std::size_t)rw + (std::size_t)rw - 1] &= top;
+    }
+    auto dr = detail::DeviceBatch::upload(flat, sz, rw);
+    volatile uint64_t* wipe = flat.data();
+    for (std::size_t i = 0; i < flat.size(); ++i) wipe[i] = 0;
+    pgpu_batch* c = nullptr;
+    IPCL_GPU_CHECK(pgpu_batch_encrypt(dev->h, dm->h, dr->h, m_randbits, &c), "encrypt");
+    return CipherText(*this, detail::DeviceBatch::adopt(c));
+  }
   std::vector<BigNumber> r = drawRandom(sz);
   ERROR_CHECK(r.size() == sz, "ippMBModExp: input vector size error");  // reference mod_exp.cpp:452-454
   for (auto& x : r) ERROR_CHECK(!x.isNegative(), "encrypt: negative random value");
