@@ -281,3 +281,26 @@ def test_split_form_ct_mul_and_plain_obfuscator_equal_full_width(engine, hensel,
         check("scalar", down(v), want_scalar, mode)
         for h in (bc, be, bs, t, u, v):
             L.pgpu_batch_destroy(h)
+
+
+@pytest.mark.parametrize("pbits", [256, 384, 640, 768, 1280])
+def test_split_form_odd_key_sizes(engine, hensel, pbits):
+    """Keys between the standard classes take the smallest compiled form with enough limbs (a 1536-bit key runs the
+    2048-bit forms): CRT decrypt through every form against the full-width kernel and the oracle."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import gen_primes
+    rng = random.Random(pbits)
+    p, q = gen_primes.prime(pbits, rng, top2=False), gen_primes.prime(pbits - 3, rng, top2=False)
+    n = p * q
+    sk = engine.PrivateKey(p, q)
+    osk = orc.PrivateKey(n, p, q)
+    for count in (6, 2100):
+        c = [rng.randrange(1, n * n) for _ in range(count)]
+        hensel(0)
+        ref = sk.decrypt(c)
+        for form in (1, 2, 3):
+            hensel(form)
+            assert sk.decrypt(c) == ref, (pbits, count, form)
+        for i in (0, count - 1):
+            assert ref[i] == osk.decrypt([c[i]])[0]
