@@ -607,11 +607,191 @@ int modmul_on(rt::Device& d, const ModCtx& ctx, int mode, const uint64_t* a, con
   return PGPU_OK;
 }
 
+// ---------- perfect-square moduli through the generic seam ----------
+// ipcl::modExp is the seam the reference's own encrypt / decrypt / CT x PT reach with moduli n^2, p^2, q^2
+// (pub_key.cpp:51-80, pri_key.cpp:128-134, ciphertext.cpp:143-162): a modulus that is a perfect square of an odd
+// root takes the split form (hensel.hpp: hensel_modexp_kernel) here too, whoever calls.  One throughput and one latency
+// form per root size; the way back to a full-width residue has constants of its own (geometry Geo<2H,K>), so no
+// relation to the full-width context of the modulus is needed.
+struct SquareForm {
+  int H = 0, K = 0, chunk_words = 0, nchunks = 0;
+  rt::Replicated pub;    // P | root | k*R mod root (L2 limbs each) | pair one | pairs conv
+  rt::Replicated full;   // N | root*R' mod N   (2*L2 limbs each)
+  uint32_t n0inv_root = 0, n0inv_full = 0;
+};
+struct SquareCtx {
+  int mod_words = 0;
+  std::vector<std::unique_ptr<SquareForm>> forms;   // most lanes per element (shortest serial chain) first
+};
+std::mutex g_sq_mu;
+std::map<std::vector<uint64_t>, std::shared_ptr<SquareCtx>> g_sq_cache;   // null entry: not a (supported) square
+
+// floor(sqrt(N)) by Newton's iteration from above
+BigNumber isqrt(const BigNumber& N) {
+  if (N.isZero()) return N;
+  BigNumber x = pow2((N.BitSize() + 1) / 2);
+  for (;;) {
+    BigNumber y = (x + N / x) / BigNumber((Ipp32u)2);
+    if (y >= x) return x;
+    x = y;
+  }
+}
+
+int build_square_form(const BigNumber& N, const BigNumber& root, int mod_words, int H, int K,
+                      std::unique_ptr<SquareForm>* out) {
+  const int L2 = H * K;
+  const int cw = std::min(mod_words, root.BitSize() / 64);
+  if (cw <= 0) return PGPU_OK;
+  const int nch = (mod_words + cw - 1) / cw;
+  std::unique_ptr<SquareForm> f(new SquareForm);
+  f->H = H;
+  f->K = K;
+  f->chunk_words = cw;
+  f->nchunks = nch;
+  auto n0inv_of = [](const BigNumber& v) {
+    uint32_t n0 = (uint32_t)(v.limbs64()[0] & pgpu::kLimbMask), inv = n0;
+    for (int i = 0; i < 5; ++i) inv *= 2u - n0 * inv;
+    return (0u - inv) & pgpu::kLimbMask;
+  };
+  f->n0inv_root = n0inv_of(root);
+  f->n0inv_full = n0inv_of(N);
+  const BigNumber P = root * BigNumber((Ipp32u)f->n0inv_root), P2 = P * P;
+  const BigNumber R = pow2(L2 * pgpu::kLimbBits);
+  std::vector<uint32_t> h((size_t)L2 * (5 + 2 * (size_t)nch), 0);
+  auto put_pair = [&](uint32_t* dst, const BigNumber& z) {
+    const BigNumber zr = z % P2;
+    const BigNumber q = zr / P;
+    to_limbs29(zr % P, L2, dst);
+    to_limbs29(q.isZero() ? q : P - q, L2, dst + L2);
+  };
+  to_limbs29(P, L2, h.data());
+  to_limbs29(root, L2, h.data() + L2);
+  to_limbs29((R % root) * BigNumber((Ipp32u)f->n0inv_root) % root, L2, h.data() + 2 * L2);
+  const BigNumber Rm = R % P2, R2 = (Rm * Rm) % P2;
+  put_pair(h.data() + 3 * L2, Rm);
+  for (int i = 0; i < nch; ++i) put_pair(h.data() + 5 * L2 + (size_t)i * 2 * L2, (R2 * (pow2(64 * cw * i) % P2)) % P2);
+  RC_TRY(f->pub.upload(h.data(), h.size() * sizeof(uint32_t), false));
+  std::vector<uint32_t> g((size_t)4 * L2, 0);
+  to_limbs29(N, 2 * L2, g.data());
+  to_limbs29((root * (pow2(2 * L2 * pgpu::kLimbBits) % N)) % N, 2 * L2, g.data() + 2 * L2);
+  RC_TRY(f->full.upload(g.data(), g.size() * sizeof(uint32_t), false));
+  *out = std::move(f);
+  return PGPU_OK;
+}
+
+// the split-form description of a modulus, or null (not an odd perfect square, or no compiled form fits its root)
+int get_square_ctx(const uint64_t* mod, int mod_words, std::shared_ptr<SquareCtx>* out) {
+  out->reset();
+  if (!hensel_enabled() || !(mod[0] & 1)) return PGPU_OK;
+  std::vector<uint64_t> key(mod, mod + mod_words);
+  std::lock_guard<std::mutex> lk(g_sq_mu);
+  auto it = g_sq_cache.find(key);
+  if (it != g_sq_cache.end()) {
+    *out = it->second;
+    return PGPU_OK;
+  }
+  std::shared_ptr<SquareCtx> ctx;
+  const BigNumber N = BigNumber::fromLimbs64(mod, (size_t)mod_words);
+  // (a square is 0, 1, 4 or 9 mod 16 -- an odd one is 1 or 9: cheap rejection of almost every other modulus)
+  const unsigned low = (unsigned)(mod[0] & 15);
+  if ((low == 1 || low == 9) && N.BitSize() > 128) {
+    const BigNumber root = isqrt(N);
+    if (root * root == N && root.IsOdd()) {
+      const int need = root.BitSize() + 29 + 8;
+      ctx = std::make_shared<SquareCtx>();
+      ctx->mod_words = mod_words;
+      for (int H : {8, 4, 2})   // per lane count the smallest compiled form with enough limbs
+        for (int K = 1; K <= 19; ++K)
+          if (pgpu::hensel_modexp_has(H, K) && pgpu::kLimbBits * H * K >= need &&
+              2 * pgpu::kLimbBits * H * K >= N.BitSize() + 8) {
+            std::unique_ptr<SquareForm> f;
+            RC_TRY(build_square_form(N, root, mod_words, H, K, &f));
+            if (f) ctx->forms.push_back(std::move(f));
+            break;
+          }
+      if (ctx->forms.empty()) ctx.reset();
+    }
+  }
+  if (g_sq_cache.size() > 64) g_sq_cache.clear();
+  g_sq_cache[key] = ctx;
+  *out = ctx;
+  return PGPU_OK;
+}
+
+int modexp_square_on(rt::Device& d, const SquareCtx& sq, const uint64_t* d_base, size_t base_stride,
+                     const uint64_t* d_exp, size_t exp_stride, int exp_words, int exp_bits, uint64_t* d_out,
+                     size_t count, hipStream_t s, const SchedRef* sched, size_t total_count) {
+  // total_count: the batch this launch is a sub-batch of (sub-batches of one call run side by side on the chip)
+  const SquareForm* f = sq.forms.back().get();
+  for (const auto& c : sq.forms) {   // the form with the most lanes per element that still fits one wavefront per SIMD
+    const size_t ipw = 64 / (2 * (size_t)c->H);
+    if ((total_count + ipw - 1) / ipw <= kSimds) { f = c.get(); break; }
+  }
+  const int L2 = f->H * f->K;
+  const uint32_t* pb = (const uint32_t*)f->pub.d[(size_t)d.index];
+  const uint32_t* fb = (const uint32_t*)f->full.d[(size_t)d.index];
+  pgpu::HenselModexpArgs a{};
+  a.ctx.nhat = pb;
+  a.ctx.n = pb + L2;
+  a.ctx.kr = pb + 2 * L2;
+  a.ctx.one = pb + 3 * L2;
+  a.ctx.conv = pb + 5 * L2;
+  a.ctx.n0inv = f->n0inv_root;
+  a.full.n = fb;
+  a.full.nr = fb + 2 * L2;
+  a.full.r2 = nullptr;
+  a.full.n0inv = f->n0inv_full;
+  a.full.mod_words = sq.mod_words;
+  a.base = d_base;
+  a.base_stride = base_stride;
+  a.base_words = sq.mod_words;
+  a.chunk_words = f->chunk_words;
+  a.nchunks = f->nchunks;
+  a.exp = d_exp;
+  a.exp_stride = exp_stride;
+  a.exp_words = exp_words;
+  a.exp_bits = exp_bits;
+  size_t entries;
+  if (sched && sched->p[0]) {
+    a.sched = sched->p[0];
+    a.sched_len = sched->len[0];
+    a.window = sched->w;
+    entries = (size_t)1 << (a.window - 1);
+  } else {
+    a.window = pick_window(exp_bits);
+    entries = (size_t)1 << a.window;
+  }
+  a.final_mul = pgpu::FM_UNIT;
+  a.out = d_out;
+  a.out_stride = (size_t)sq.mod_words;
+  a.count = count;
+  const size_t ipw = 64 / (2 * (size_t)f->H);
+  const size_t waves = (count + ipw - 1) / ipw;
+  const unsigned blocks = (unsigned)((waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
+  rt::StreamWork& w = d.work_for(s);
+  std::lock_guard<std::mutex> lk(w.mu);
+  RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * ipw * entries * 2 * L2 * sizeof(uint32_t)));
+  a.table = (uint32_t*)w.table.p;
+  TimerScope t(d, s, PGPU_KERNEL_MODEXP);
+  if (!pgpu::launch_hensel_modexp(f->H, f->K, a, blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "split-form modexp kernel not compiled");
+  HIP_TRY(hipGetLastError());
+  t.stop();
+  return PGPU_OK;
+}
+
 // generic modexp on one device (bases / result plain or in the context's Montgomery form)
 int modexp_on(rt::Device& d, const uint64_t* d_base, size_t base_stride, const uint64_t* d_exp, size_t exp_stride,
               int exp_words, int exp_bits, const uint64_t* h_mod, int mod_words, uint64_t* d_out, size_t count,
-              hipStream_t s, const SchedRef* sched, bool in_mont, bool out_mont, std::shared_ptr<ModCtx> ctx_in) {
+              hipStream_t s, const SchedRef* sched, bool in_mont, bool out_mont, std::shared_ptr<ModCtx> ctx_in,
+              size_t total_count = 0) {
   std::shared_ptr<ModCtx> ctx = ctx_in;
+  if (!in_mont && !out_mont) {   // the key-less seam (plain in, plain out): a perfect-square modulus takes the split form
+    std::shared_ptr<SquareCtx> sq;
+    RC_TRY(get_square_ctx(h_mod, mod_words, &sq));
+    if (sq)
+      return modexp_square_on(d, *sq, d_base, base_stride, d_exp, exp_stride, exp_words, exp_bits, d_out, count, s, sched,
+                              std::max(count, total_count));
+  }
   if (!ctx) RC_TRY(get_modctx(h_mod, mod_words, true, &ctx));
   GeoInfo run_geo = ctx->geo;
   const GeoInfo lat = latency_geo(ctx->geo);
@@ -1395,7 +1575,7 @@ int pgpu_modexp(const uint64_t* base, size_t base_stride, const uint64_t* exp, s
       sr.w = sched_w;
     }
     RC_TRY(modexp_on(d, (const uint64_t*)db.p, base_stride, (const uint64_t*)de.p, exp_stride, exp_words, exp_bits,
-                     mod, mod_words, (uint64_t*)dout.p, n, s, sr.p[0] ? &sr : nullptr, false, false, ctx));
+                     mod, mod_words, (uint64_t*)dout.p, n, s, sr.p[0] ? &sr : nullptr, false, false, ctx, count));
     return lane.d2h(out + lo * (size_t)mod_words, dout.p, n * (size_t)mod_words * 8, s);
   });
 }

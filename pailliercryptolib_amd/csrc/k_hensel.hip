@@ -1,11 +1,11 @@
 // pailliercryptolib_amd -- instantiations of the split-form CRT-decrypt exponentiation (hensel.hpp), split over
-// PGPU_PART = 0..7 so that they compile in parallel (3, 4: the fixed-base DJN encrypt; 5, 6: the generic modexp; 7: the
-// two-wavefronts-per-SIMD build of the (2,19) decrypt form).
+// PGPU_PART = 0..8 so that they compile in parallel (3, 4: the fixed-base DJN encrypt; 5, 6, 8: the generic modexp; 7:
+// the two-wavefronts-per-SIMD build of the (2,19) decrypt form).
 #include "hensel.hpp"
 #include "launch.hpp"
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..7"
+#error "compile with -DPGPU_PART=0..8"
 #endif
 
 namespace pgpu {
@@ -46,6 +46,22 @@ bool PGPU_FB_NAME(launch_hensel_fb_build)(int H, int K, const HenselFbBuildArgs&
 bool PGPU_FB_NAME(launch_hensel_fb_encrypt)(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
   if (H == PGPU_FB_H && K == PGPU_FB_K) {
     hipLaunchKernelGGL((hensel_fb_encrypt_kernel<PGPU_FB_H, PGPU_FB_K>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  return false;
+}
+#elif PGPU_PART == 8
+bool launch_hensel_modexp_part8(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
+  if (H == 2 && K == 19) {
+    hipLaunchKernelGGL((hensel_modexp_kernel<2, 19>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  if (H == 8 && K == 5) {
+    hipLaunchKernelGGL((hensel_modexp_kernel<8, 5>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  if (H == 4 && K == 10) {
+    hipLaunchKernelGGL((hensel_modexp_kernel<4, 10>), dim3(blocks), dim3(kWGThreads), 0, s, a);
     return true;
   }
   return false;

@@ -64,12 +64,17 @@ inline bool launch_hensel_fb_encrypt(int H, int K, const HenselFbArgs& a, unsign
   return launch_hensel_fb_encrypt_part3(H, K, a, blocks, s) || launch_hensel_fb_encrypt_part4(H, K, a, blocks, s);
 }
 
-// split-form generic modexp modulo n^2 (hensel.hpp: hensel_modexp_kernel; k_hensel.hip parts 5, 6): 2048-bit keys
-inline bool hensel_modexp_has(int H, int K) { return (H == 4 && K == 18) || (H == 8 && K == 9); }
+// split-form generic modexp modulo a square (hensel.hpp: hensel_modexp_kernel; k_hensel.hip parts 5, 6, 8): roots of up
+// to 2048 bits -- (4,18) / (8,9) -- and of up to 1024 bits -- (2,19) / (4,10) / (8,5) (fewest to most lanes)
+inline bool hensel_modexp_has(int H, int K) {
+  return (H == 4 && (K == 18 || K == 10)) || (H == 8 && (K == 9 || K == 5)) || (H == 2 && K == 19);
+}
 bool launch_hensel_modexp_part5(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_modexp_part6(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
+bool launch_hensel_modexp_part8(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
 inline bool launch_hensel_modexp(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
-  return launch_hensel_modexp_part5(H, K, a, blocks, s) || launch_hensel_modexp_part6(H, K, a, blocks, s);
+  return launch_hensel_modexp_part5(H, K, a, blocks, s) || launch_hensel_modexp_part6(H, K, a, blocks, s) ||
+         launch_hensel_modexp_part8(H, K, a, blocks, s);
 }
 
 bool launch_modmul(int G, int K, const ModmulArgs& a, unsigned blocks, hipStream_t s);

@@ -304,3 +304,31 @@ def test_split_form_odd_key_sizes(engine, hensel, pbits):
             assert sk.decrypt(c) == ref, (pbits, count, form)
         for i in (0, count - 1):
             assert ref[i] == osk.decrypt([c[i]])[0]
+
+
+@pytest.mark.parametrize("count", [5, 4300])
+def test_perfect_square_moduli_through_the_generic_seam(engine, hensel, count):
+    """pgpu_modexp (the ipcl::modExp seam) detects a modulus that is the square of an odd root and runs the split form
+    for it: n^2 and p^2 of the KAT key, an odd root size in between, bases above the modulus, exponent 0 / 1 / wide,
+    a shared (scalar) exponent; bit-identical to the full-width kernel and to pow.  A modulus that only looks like
+    a square modulo 16 takes the full-width kernel as before."""
+    kat = _kat()
+    p, q = kat["p"], kat["q"]
+    n = p * q
+    rng = random.Random(count)
+    root3 = rng.getrandbits(1500) | (1 << 1499) | 1
+    for mod in (n * n, p * p, root3 * root3, n * n + 16):
+        bits = mod.bit_length()
+        base = [rng.randrange(mod) for _ in range(count)]
+        base[0] = 0
+        base[1] = mod + 5 if (mod + 5).bit_length() <= 64 * ((bits + 63) // 64) else mod - 1
+        exp = [rng.getrandbits([0, 1, 32, 64, 300][i % 5]) for i in range(count)]
+        idx = list(range(count)) if count <= 64 else list(range(24)) + list(range(count - 8, count))
+        hensel(0)
+        ref = engine.mod_exp(base, exp, mod)
+        ref_s = engine.mod_exp(base, [65537] * count, mod)
+        hensel(1)
+        assert engine.mod_exp(base, exp, mod) == ref, bits
+        assert engine.mod_exp(base, [65537] * count, mod) == ref_s, bits
+        for i in idx:
+            assert ref[i] == pow(base[i], exp[i], mod) and ref_s[i] == pow(base[i], 65537, mod), (bits, i)
