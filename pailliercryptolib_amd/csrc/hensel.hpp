@@ -179,15 +179,15 @@ __global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_kernel(Hensel
   const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
   auto& bl = bl_[wv];
   auto& io = io_[wv];
-  const int q4 = lane / GS, x4 = lane % GS, x = x4 % H;   // group, lane in the group, lane in its half
-  const uint32_t halfB = (uint32_t)(x4 / H);
-  uint32_t selB = x4 == H ? 1u : 0u;
+  const int grp = lane / GS, xg = lane % GS, x = xg % H;   // group (one exponentiation), lane in the group, lane in its half
+  const uint32_t halfB = (uint32_t)(xg / H);
+  uint32_t selB = xg == H ? 1u : 0u;
   asm("" : "+v"(selB));   // opaque, so that "digit * selB" stays ONE v_mad_u64_u32 (not a select and a 64-bit add)
   const size_t wave_id = (size_t)blockIdx.x * kWavesPerWG + wv;
   const int side = __builtin_amdgcn_readfirstlane((int)(wave_id & 1));
   const size_t first_elem = (wave_id >> 1) * IPW;
-  size_t elem = first_elem + q4;
-  if (elem >= A.count) elem = A.count - 1;   // padded quads recompute the last element
+  size_t elem = first_elem + grp;
+  if (elem >= A.count) elem = A.count - 1;   // padded groups recompute the last element
 #define HCTX(field) (side ? A.ctx[1].field : A.ctx[0].field)
 
   uint32_t n[K], own[K], mreg[K];
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_kernel(Hensel
   const int nsteps = side ? A.sched_len[1] : A.sched_len[0];
   const int w = A.window;
   const int tsize = sched_mode ? 1 << (w - 1) : 1 << w;
-  uint32_t* tbl = A.table + (wave_id * IPW + q4) * (size_t)tsize * LQ + x4 * K;
+  uint32_t* tbl = A.table + (wave_id * IPW + grp) * (size_t)tsize * LQ + xg * K;
   const uint64_t* ep = A.exp + (size_t)side * A.exp_stride;
   const int nwin = (A.exp_bits + w - 1) / w;
   auto digit = [&](int i) -> int {
@@ -227,12 +227,12 @@ __global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_kernel(Hensel
         wave_lds_sync();
         const int first = i * A.chunk_words;
         const int words = min(A.chunk_words, A.ct_words - first);
-        for (int t = x4; t <= W64; t += GS) io[q4][t] = (t < words) ? row[first + t] : 0;
+        for (int t = xg; t <= W64; t += GS) io[grp][t] = (t < words) ? row[first + t] : 0;
         wave_lds_sync();
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-          own[j] = halfB ? 0u : limb_from_words(io[q4], x * K + j);
-          mreg[j] = conv[(size_t)i * LQ + x4 * K + j];
+          own[j] = halfB ? 0u : limb_from_words(io[grp], x * K + j);
+          mreg[j] = conv[(size_t)i * LQ + xg * K + j];
         }
       } else {
 #pragma unroll
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_kernel(Hensel
 #pragma unroll
       for (int j = 0; j < K; ++j) {
         tbl[LQ + j] = acc[j];
-        tbl[j] = HCTX(one)[x4 * K + j];
+        tbl[j] = HCTX(one)[xg * K + j];
         mreg[j] = own[j] = acc[j];
       }
       e = 2;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_kernel(Hensel
     for (int j = 0; j < K; ++j) own[j] = tbl[(size_t)d0 * LQ + j];   // (this lane's own earlier stores)
   } else {
 #pragma unroll
-    for (int j = 0; j < K; ++j) own[j] = HCTX(one)[x4 * K + j];
+    for (int j = 0; j < K; ++j) own[j] = HCTX(one)[xg * K + j];
   }
 #pragma unroll 1
   for (;;) {
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_kernel(Hensel
   wave_lds_sync();
   if (halfB) {
 #pragma unroll
-    for (int j = 0; j < K; ++j) bl[q4][x * K + j] = own[j];
+    for (int j = 0; j < K; ++j) bl[grp][x * K + j] = own[j];
   }
   wave_lds_sync();
   const int ow = A.out_words;
@@ -372,14 +372,14 @@ __device__ __forceinline__ uint32_t dpp_from_above(uint32_t v) {
 }
 
 // own = words * R as a pair: sum over the chunks z_i of (z_i, 0) (x) pair(2^(64*cw*i) * R^2).  iorow: the group's
-// W64+1 words of LDS; x4: lane in the group.
+// W64+1 words of LDS; xg: lane in the group.
 template <int H, int K>
 __device__ __forceinline__ void pair_from_words(uint32_t (&own)[K], const uint64_t* row, int nwords, int chunk_words,
                                                 int nchunks, const uint32_t* conv, uint64_t* iorow,
-                                                const uint32_t (&n)[K], uint32_t halfB, uint32_t selB, int x4) {
+                                                const uint32_t (&n)[K], uint32_t halfB, uint32_t selB, int xg) {
   using HG = Geo<H, K>;
   constexpr int GS = 2 * H, LQ = 2 * H * K, W64 = HG::W64;
-  const int x = x4 % H;
+  const int x = xg % H;
   uint32_t acc[K], mreg[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) acc[j] = 0;
@@ -388,12 +388,12 @@ __device__ __forceinline__ void pair_from_words(uint32_t (&own)[K], const uint64
     wave_lds_sync();
     const int first = i * chunk_words;
     const int words = min(chunk_words, nwords - first);
-    for (int t = x4; t <= W64; t += GS) iorow[t] = (t < words) ? row[first + t] : 0;
+    for (int t = xg; t <= W64; t += GS) iorow[t] = (t < words) ? row[first + t] : 0;
     wave_lds_sync();
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       own[j] = halfB ? 0u : limb_from_words(iorow, x * K + j);
-      mreg[j] = conv[(size_t)i * LQ + x4 * K + j];
+      mreg[j] = conv[(size_t)i * LQ + xg * K + j];
     }
     pairmul<H, K, false, true>(own, own, mreg, n, 0, halfB, selB);
     add_normalise<HG>(acc, own);
@@ -413,12 +413,12 @@ __device__ __forceinline__ void pair_exit_store(uint32_t (&own)[K], const Hensel
                                                 bool with_gm, const uint64_t* fm_words, size_t fm_stride, int fm_nwords,
                                                 uint64_t* out, size_t out_stride, size_t first_inst, size_t count,
                                                 uint32_t (*bl)[2 * H * K], uint64_t (*io)[Geo<2 * H, K>::W64 + 1],
-                                                uint32_t (*rows)[2 * H * K], int lane, int q4, int x4, uint32_t halfB,
+                                                uint32_t (*rows)[2 * H * K], int lane, int grp, int xg, uint32_t halfB,
                                                 uint32_t selB) {
   using HG = Geo<H, K>;
   using FG = Geo<2 * H, K>;
   constexpr int GS = 2 * H;
-  const int x = x4 % H;
+  const int x = xg % H;
   for (int t = lane; t < FG::L; t += kWave) {
     rows[0][t] = F.nr[t];
     rows[1][t] = F.r2 ? F.r2[t] : 0;
@@ -443,7 +443,7 @@ __device__ __forceinline__ void pair_exit_store(uint32_t (&own)[K], const Hensel
   if (with_gm) {
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      e[j] = limb_from_words(io[q4], x * K + j);     // m (both halves compute it; half B uses it)
+      e[j] = limb_from_words(io[grp], x * K + j);     // m (both halves compute it; half B uses it)
       d[j] = 2 * n[j];
     }
     full_normalise<HG>(d, x);
@@ -454,7 +454,7 @@ __device__ __forceinline__ void pair_exit_store(uint32_t (&own)[K], const Hensel
   }
 #pragma unroll
   for (int j = 0; j < K; ++j)
-    if (!halfB) mreg[j] = (x4 == 0 && j == 0) ? 1u : 0u;
+    if (!halfB) mreg[j] = (xg == 0 && j == 0) ? 1u : 0u;
   pairmul<H, K, false, false>(own, own, mreg, n, n0inv, halfB, selB);
   // ---- canonical pair ----
   full_normalise<HG>(own, x);
@@ -468,7 +468,7 @@ __device__ __forceinline__ void pair_exit_store(uint32_t (&own)[K], const Hensel
   if (x == 0) d[0] += jflag;
   full_normalise<HG>(d, x);
   const uint32_t small = sub_limbs<HG>(e, d, n, x, lane);
-  // full-width operands in the lane layout of Geo<2H,K>: lane x4 holds limbs [x4*K, x4*K + K); both sit in the low half
+  // full-width operands in the lane layout of Geo<2H,K>: lane xg holds limbs [xg*K, xg*K + K); both sit in the low half
   uint32_t X[K], Y[K], nf[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) {
@@ -476,7 +476,7 @@ __device__ __forceinline__ void pair_exit_store(uint32_t (&own)[K], const Hensel
     const uint32_t down = dpp_from_above<H>(bc);
     X[j] = halfB ? 0u : own[j];
     Y[j] = halfB ? 0u : down;
-    nf[j] = F.n[x4 * K + j];
+    nf[j] = F.n[xg * K + j];
   }
   wave_lds_sync();
   uint32_t t[K];
@@ -488,7 +488,7 @@ __device__ __forceinline__ void pair_exit_store(uint32_t (&own)[K], const Hensel
   } else {
     add_normalise<FG>(t, X);
   }
-  store_canonical<FG>(t, nf, F.mod_words, bl, io, out, out_stride, first_inst, count, lane, q4, x4);
+  store_canonical<FG>(t, nf, F.mod_words, bl, io, out, out_stride, first_inst, count, lane, grp, xg);
 }
 
 // Fixed-base table of pairs for the DJN obfuscator hs^r (kernels.hpp: fb_build_kernel is the full-width twin):
@@ -500,18 +500,18 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : 1) void hensel_fb_build_k
   __shared__ uint64_t io_[kWavesPerWG][IPW][W64 + 1];
   const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
   auto& io = io_[wv];
-  const int q4 = lane / GS, x4 = lane % GS, x = x4 % H;
-  const uint32_t halfB = (uint32_t)(x4 / H);
-  uint32_t selB = x4 == H ? 1u : 0u;
+  const int grp = lane / GS, xg = lane % GS, x = xg % H;
+  const uint32_t halfB = (uint32_t)(xg / H);
+  uint32_t selB = xg == H ? 1u : 0u;
   asm("" : "+v"(selB));
   const size_t first_inst = ((size_t)blockIdx.x * kWavesPerWG + wv) * IPW;
-  size_t inst = first_inst + q4;
+  size_t inst = first_inst + grp;
   const bool live = inst < (size_t)A.nwin;
   if (!live) inst = (size_t)A.nwin - 1;
   uint32_t n[K], own[K], mreg[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) n[j] = A.ctx.nhat[x * K + j];
-  pair_from_words<H, K>(own, A.base, A.base_words, A.chunk_words, A.nchunks, A.ctx.conv, io[q4], n, halfB, selB, x4);
+  pair_from_words<H, K>(own, A.base, A.base_words, A.chunk_words, A.nchunks, A.ctx.conv, io[grp], n, halfB, selB, xg);
   const int tsize = 1 << A.w;
   // every group runs the squaring count of the LAST live row of its wavefront (uniform control flow); a group stops
   // updating once its own count is reached
@@ -528,11 +528,11 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : 1) void hensel_fb_build_k
       for (int j = 0; j < K; ++j) own[j] = r[j];
     }
   }
-  uint32_t* row = A.table + inst * (size_t)tsize * LQ + x4 * K;
+  uint32_t* row = A.table + inst * (size_t)tsize * LQ + xg * K;
   if (live) {
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      row[j] = A.ctx.one[x4 * K + j];
+      row[j] = A.ctx.one[xg * K + j];
       row[LQ + j] = own[j];
     }
   }
@@ -565,12 +565,12 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : 1) void hensel_fb_encrypt
   auto& bl = bl_[wv];
   auto& io = io_[wv];
   auto& rows = rows_[wv];
-  const int q4 = lane / GS, x4 = lane % GS, x = x4 % H;
-  const uint32_t halfB = (uint32_t)(x4 / H);
-  uint32_t selB = x4 == H ? 1u : 0u;
+  const int grp = lane / GS, xg = lane % GS, x = xg % H;
+  const uint32_t halfB = (uint32_t)(xg / H);
+  uint32_t selB = xg == H ? 1u : 0u;
   asm("" : "+v"(selB));
   const size_t first_inst = ((size_t)blockIdx.x * kWavesPerWG + wv) * IPW;
-  size_t inst = first_inst + q4;
+  size_t inst = first_inst + grp;
   if (inst >= A.count) inst = A.count - 1;
   uint32_t n[K], own[K], mreg[K], nxt[K];
 #pragma unroll
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : 1) void hensel_fb_encrypt
     return (int)(v & (uint64_t)(tsize - 1));
   };
   auto load_entry = [&](uint32_t (&dst)[K], int i) {
-    const uint32_t* e = A.table + ((size_t)i * tsize + digit(i)) * LQ + x4 * K;
+    const uint32_t* e = A.table + ((size_t)i * tsize + digit(i)) * LQ + xg * K;
 #pragma unroll
     for (int j = 0; j < K; ++j) dst[j] = e[j];
   };
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : 1) void hensel_fb_encrypt
     for (int j = 0; j < K; ++j) mreg[j] = nxt[j];
   }
   pair_exit_store<H, K>(own, A.ctx, A.full, true, A.fm_words, A.fm_stride, A.fm_nwords, A.out, A.out_stride, first_inst,
-                        A.count, bl, io, rows, lane, q4, x4, halfB, selB);
+                        A.count, bl, io, rows, lane, grp, xg, halfB, selB);
 }
 
 // base[i]^exp[i] modulo n^2 in split form -- CT x PT (ciphertext.cpp:143-162: per-element exponents, fixed window) and
@@ -624,13 +624,13 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : PGPU_HM_WAVES18) void hen
   auto& bl = bl_[wv];
   auto& io = io_[wv];
   auto& rows = rows_[wv];
-  const int q4 = lane / GS, x4 = lane % GS, x = x4 % H;
-  const uint32_t halfB = (uint32_t)(x4 / H);
-  uint32_t selB = x4 == H ? 1u : 0u;
+  const int grp = lane / GS, xg = lane % GS, x = xg % H;
+  const uint32_t halfB = (uint32_t)(xg / H);
+  uint32_t selB = xg == H ? 1u : 0u;
   asm("" : "+v"(selB));
   const size_t wave_id = (size_t)blockIdx.x * kWavesPerWG + wv;
   const size_t first_inst = wave_id * IPW;
-  size_t inst = first_inst + q4;
+  size_t inst = first_inst + grp;
   if (inst >= A.count) inst = A.count - 1;
   uint32_t n[K], own[K], mreg[K];
 #pragma unroll
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : PGPU_HM_WAVES18) void hen
   const int nsteps = A.sched_len;
   const int w = A.window;
   const int tsize = sched_mode ? 1 << (w - 1) : 1 << w;
-  uint32_t* tbl = A.table + (wave_id * IPW + q4) * (size_t)tsize * LQ + x4 * K;
+  uint32_t* tbl = A.table + (wave_id * IPW + grp) * (size_t)tsize * LQ + xg * K;
   const uint64_t* ep = A.exp + inst * A.exp_stride;
   const int nwin = (A.exp_bits + w - 1) / w;
   auto digit = [&](int i) -> int {
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : PGPU_HM_WAVES18) void hen
 
   // (the FG-sized row of io holds more than the W64+1 words of a half-width chunk)
   pair_from_words<H, K>(own, A.base + inst * A.base_stride, A.base_words, A.chunk_words, A.nchunks, A.ctx.conv,
-                        io[q4], n, halfB, selB, x4);
+                        io[grp], n, halfB, selB, xg);
   // ---- window table (fixed window: all powers; schedule: the odd powers, built with base^2) ----
   {
     int e;
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : PGPU_HM_WAVES18) void hen
 #pragma unroll
       for (int j = 0; j < K; ++j) {
         tbl[LQ + j] = own[j];
-        tbl[j] = A.ctx.one[x4 * K + j];
+        tbl[j] = A.ctx.one[xg * K + j];
         mreg[j] = own[j];
       }
       e = 2;
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : PGPU_HM_WAVES18) void hen
     for (int j = 0; j < K; ++j) own[j] = tbl[(size_t)d0 * LQ + j];
   } else {
 #pragma unroll
-    for (int j = 0; j < K; ++j) own[j] = A.ctx.one[x4 * K + j];
+    for (int j = 0; j < K; ++j) own[j] = A.ctx.one[xg * K + j];
   }
 #pragma unroll 1
   for (;;) {
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : PGPU_HM_WAVES18) void hen
     if (mul) pairmul<H, K, false, true>(own, own, mreg, n, 0, halfB, selB);
   }
   pair_exit_store<H, K>(own, A.ctx, A.full, A.final_mul == FM_PAILLIER_G, A.fm_words, A.fm_stride, A.fm_nwords, A.out,
-                        A.out_stride, first_inst, A.count, bl, io, rows, lane, q4, x4, halfB, selB);
+                        A.out_stride, first_inst, A.count, bl, io, rows, lane, grp, xg, halfB, selB);
 }
 
 }  // namespace pgpu
