@@ -106,7 +106,7 @@ int pgpu_shard_plan(size_t count, int pool_size, int* n_shards, size_t* bounds);
  * batch (the reference computes the same maximum, mod_exp.cpp:484); exponent words above
  * exp_bits must be zero.  The modulus is shared and odd; bases may be any value that fits
  * mod_words words (they are reduced).  out has stride mod_words.
- * A modulus that is the square of an odd root of up to 2048 bits -- every modulus of the Paillier path: n^2, p^2,
+ * A modulus that is the square of an odd root of up to 3072 bits -- every modulus of the Paillier path: n^2, p^2,
  * q^2 -- is recognised (once per modulus) and runs the split form (PGPU_HENSEL=0: never). */
 int pgpu_modexp(const uint64_t* base, size_t base_stride, const uint64_t* exp, size_t exp_stride,
                 int exp_words, int exp_bits, const uint64_t* mod, int mod_words, uint64_t* out,

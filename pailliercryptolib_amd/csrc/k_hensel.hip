@@ -1,11 +1,11 @@
 // pailliercryptolib_amd -- instantiations of the split-form CRT-decrypt exponentiation (hensel.hpp), split over
-// PGPU_PART = 0..8 so that they compile in parallel (3, 4: the fixed-base DJN encrypt; 5, 6, 8: the generic modexp; 7:
+// PGPU_PART = 0..9 so that they compile in parallel (3, 4: the fixed-base DJN encrypt; 5, 6, 8, 9: the generic modexp; 7:
 // the two-wavefronts-per-SIMD build of the (2,19) decrypt form).
 #include "hensel.hpp"
 #include "launch.hpp"
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..8"
+#error "compile with -DPGPU_PART=0..9"
 #endif
 
 namespace pgpu {
@@ -62,6 +62,14 @@ bool launch_hensel_modexp_part8(int H, int K, const HenselModexpArgs& a, unsigne
   }
   if (H == 4 && K == 10) {
     hipLaunchKernelGGL((hensel_modexp_kernel<4, 10>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  return false;
+}
+#elif PGPU_PART == 9
+bool launch_hensel_modexp_part9(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
+  if (H == 8 && K == 14) {
+    hipLaunchKernelGGL((hensel_modexp_kernel<8, 14>), dim3(blocks), dim3(kWGThreads), 0, s, a);
     return true;
   }
   return false;

@@ -64,17 +64,18 @@ inline bool launch_hensel_fb_encrypt(int H, int K, const HenselFbArgs& a, unsign
   return launch_hensel_fb_encrypt_part3(H, K, a, blocks, s) || launch_hensel_fb_encrypt_part4(H, K, a, blocks, s);
 }
 
-// split-form generic modexp modulo a square (hensel.hpp: hensel_modexp_kernel; k_hensel.hip parts 5, 6, 8): roots of up
-// to 2048 bits -- (4,18) / (8,9) -- and of up to 1024 bits -- (2,19) / (4,10) / (8,5) (fewest to most lanes)
+// split-form generic modexp modulo a square (hensel.hpp: hensel_modexp_kernel; k_hensel.hip parts 5, 6, 8, 9): roots of
+// up to 1024 bits -- (2,19) / (4,10) / (8,5), fewest to most lanes --, 2048 bits -- (4,18) / (8,9) --, 3072 bits -- (8,14)
 inline bool hensel_modexp_has(int H, int K) {
-  return (H == 4 && (K == 18 || K == 10)) || (H == 8 && (K == 9 || K == 5)) || (H == 2 && K == 19);
+  return (H == 4 && (K == 18 || K == 10)) || (H == 8 && (K == 9 || K == 5 || K == 14)) || (H == 2 && K == 19);
 }
 bool launch_hensel_modexp_part5(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_modexp_part6(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_modexp_part8(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
+bool launch_hensel_modexp_part9(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
 inline bool launch_hensel_modexp(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
   return launch_hensel_modexp_part5(H, K, a, blocks, s) || launch_hensel_modexp_part6(H, K, a, blocks, s) ||
-         launch_hensel_modexp_part8(H, K, a, blocks, s);
+         launch_hensel_modexp_part8(H, K, a, blocks, s) || launch_hensel_modexp_part9(H, K, a, blocks, s);
 }
 
 bool launch_modmul(int G, int K, const ModmulArgs& a, unsigned blocks, hipStream_t s);
