@@ -15,8 +15,12 @@ have_ossl = c_oracle.openssl_lib() is not None
 t0, cases, elems = time.time(), 0, 0
 while time.time() - t0 < budget:
     bits = rng.choice([rng.randrange(65, 8192), rng.choice([512, 1024, 2048, 3072, 4096, 6144, 8192])])
-    style = rng.randrange(4)
-    if style == 0:
+    style = rng.randrange(6)
+    if style >= 4:                                                      # perfect squares: the split form of the seam
+        root = rng.getrandbits(bits // 2) | (1 << (bits // 2 - 1)) | 1
+        mod = root * root
+        bits = mod.bit_length()
+    elif style == 0:
         mod = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
     elif style == 1:
         mod = (1 << bits) - rng.randrange(1, 1 << 20, 2)            # all-ones limbs
