@@ -235,7 +235,8 @@ int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, i
  * modexp_kernel<Geo<*lanes, *limbs>>.  Host-side query. */
 int pgpu_decrypt_kernel_form(const pgpu_privkey* key, size_t count, int* split, int* lanes, int* limbs);
 /* The same for an encrypt of `count` plaintext rows of m_words words: *split = 1: hensel_fb_encrypt_kernel<*lanes / 2,
- * *limbs> (DJN keys with a fixed-base window, 2048-bit keys, plaintext rows no wider than n); *split = 0:
+ * *limbs> (DJN keys with a fixed-base window, 1024- to 3072-bit keys, plaintext rows no wider than n, batches that
+ * fill the chip); *split = 0:
  * fb_encrypt_kernel / modexp_kernel <Geo<*lanes, *limbs>>. */
 int pgpu_encrypt_kernel_form(const pgpu_pubkey* key, int m_words, size_t count, int* split, int* lanes, int* limbs);
 /* The same for the exponentiations modulo n^2 with per-element bases (CT x PT of a resident batch, the non-DJN

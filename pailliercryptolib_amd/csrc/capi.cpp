@@ -489,11 +489,16 @@ struct pgpu_pubkey {
   mutable std::mutex mu;
   mutable std::vector<std::deque<FbTable>> fb;   // [device]; entries never move once handed out
   mutable size_t fb_elems = 0;  // elements encrypted with this key so far (window policy)
-  // split form of n^2 = (n)^2 (hensel.hpp) for the fixed-base DJN encrypt; hH == 0: not available for this key
-  int hH = 0, hK = 0, h_chunk_words = 0, h_nchunks = 0;
-  rt::Replicated d_hpub;        // P | n | k*R mod n (L2 limbs each) | pair one | pairs conv
-  uint32_t h_n0inv = 0;
-  mutable std::vector<std::deque<FbTable>> fbh;   // [device]: fixed-base tables of pairs
+  // split forms of n^2 = (n)^2 (hensel.hpp) compiled for this key size, most lanes per element first; empty: none
+  struct PubForm {
+    int H = 0, K = 0, chunk_words = 0, nchunks = 0;
+    rt::Replicated pub;      // P | n | k*R mod n (L2 limbs each) | pair one | pairs conv | pairs conv (Montgomery input)
+    rt::Replicated full;     // the way back in Geo<2H,K>, R' = 2^(29*2*L2): n^2 | n*R' | n*R'*Rs | R'*Rs  (2*L2 limbs
+                             // each; Rs = the radix of the n^2 context, which Montgomery-form batches carry)
+    uint32_t n0inv = 0, n0inv_full = 0;
+  };
+  std::vector<std::unique_ptr<PubForm>> hforms;
+  mutable std::vector<std::deque<FbTable>> fbh;   // [device]: fixed-base tables of pairs (form hforms.back())
   ~pgpu_pubkey() {
     for (auto* lists : {&fb, &fbh})
       for (size_t d = 0; d < lists->size(); ++d) {
@@ -857,69 +862,73 @@ int fb_table_for(const pgpu_pubkey* key, rt::Device& d, int w, int nwin, hipStre
 // DJN encrypt in split form (hensel.hpp): needs m < 2n to form the pair of 1 + n*m, i.e. plaintext rows no wider
 // than n; pays once the batch fills the chip in 2H-lane groups -- smaller batches run the full-width kernel in its
 // 16-lane split, whose serial chain per product is shorter (Encrypt(16): 1.4 vs 1.8 ms)
-bool use_split_encrypt(const pgpu_pubkey* key, int m_words, size_t count) {
-  if (!key->hH || !hensel_enabled() || 64 * m_words > key->n.BitSize()) return false;
-  if (g_hensel.load() >= 2) return true;   // tests: whatever the batch size
+const pgpu_pubkey::PubForm* use_split_encrypt(const pgpu_pubkey* key, int m_words, size_t count) {
+  if (key->hforms.empty() || !hensel_enabled() || 64 * m_words > key->n.BitSize()) return nullptr;
+  const pgpu_pubkey::PubForm* f = key->hforms.back().get();   // the form of fewest lanes per element
+  if (!pgpu::hensel_fb_has(f->H, f->K)) return nullptr;
+  if (g_hensel.load() >= 2) return f;   // tests: whatever the batch size
   const GeoInfo g = launch_geo(key->nsq->geo, count);
-  return g.G == 2 * key->hH && g.K == key->hK;
+  const size_t ipw = 64 / (2 * (size_t)f->H);
+  return (g.G <= 2 * f->H || (count + ipw - 1) / ipw >= kSimds) ? f : nullptr;
 }
-pgpu::HenselPubDev hensel_pub_view(const pgpu_pubkey* key, int dev, bool base_mont = false) {
-  const int L2 = key->hH * key->hK;
-  const uint32_t* b = (const uint32_t*)key->d_hpub.d[(size_t)dev];
+pgpu::HenselPubDev hensel_pub_view(const pgpu_pubkey::PubForm* f, int dev, bool base_mont = false) {
+  const int L2 = f->H * f->K;
+  const uint32_t* b = (const uint32_t*)f->pub.d[(size_t)dev];
   pgpu::HenselPubDev v{};
   v.nhat = b;
   v.n = b + L2;
   v.kr = b + 2 * L2;
   v.one = b + 3 * L2;
-  v.conv = b + 5 * L2 + (base_mont ? (size_t)key->h_nchunks * 2 * L2 : 0);
-  v.n0inv = key->h_n0inv;
+  v.conv = b + 5 * L2 + (base_mont ? (size_t)f->nchunks * 2 * L2 : 0);
+  v.n0inv = f->n0inv;
   return v;
 }
-pgpu::HenselFullDev hensel_full_view(const pgpu_pubkey* key, int dev, bool out_mont) {
-  const pgpu::ModCtxDev full = key->nsq->view(dev, out_mont ? VF_GM_MONT : VF_NONE);
-  pgpu::HenselFullDev f{};
-  f.n = full.n;
-  f.nr = full.nr;                         // n*R' (plain result) or n*R'^2 (Montgomery-form result)
-  f.r2 = out_mont ? full.r2 : nullptr;
-  f.n0inv = full.n0inv;
-  f.mod_words = 2 * key->n_words;
-  return f;
+pgpu::HenselFullDev hensel_full_view(const pgpu_pubkey* key, const pgpu_pubkey::PubForm* f, int dev, bool out_mont) {
+  const size_t LF = (size_t)2 * f->H * f->K;
+  const uint32_t* b = (const uint32_t*)f->full.d[(size_t)dev];
+  pgpu::HenselFullDev v{};
+  v.n = b;
+  v.nr = out_mont ? b + 2 * LF : b + LF;     // n*R'*Rs (Montgomery-form result) or n*R'
+  v.r2 = out_mont ? b + 3 * LF : nullptr;
+  v.n0inv = f->n0inv_full;
+  v.mod_words = 2 * key->n_words;
+  return v;
 }
 
-// base^exp modulo n^2 in split form (hensel.hpp: hensel_modexp_kernel): the form with 8 lanes per half (4 elements per
-// wavefront) while it fills no more than the chip, else the key's throughput form.  Returns false when the key has no
-// split form.  (PGPU_SPLIT_MODEXP_MAX_WAVES: larger launches take the full-width kernel -- A/B measurements; a
-// 1 M-element CT x PT batch: 60.0 ms full width, 48.4 ms split.)
-bool split_modexp_form(const pgpu_pubkey* key, size_t count, int* H, int* K) {
-  if (!key->hH || !hensel_enabled()) return false;
-  const int L2 = key->hH * key->hK;
+// base^exp modulo n^2 in split form (hensel.hpp: hensel_modexp_kernel): the form with the most lanes per element that
+// still leaves at most one wavefront per SIMD, else the one of fewest lanes.  Null when the key has no split form.
+// (PGPU_SPLIT_MODEXP_MAX_WAVES: larger launches take the full-width kernel -- A/B measurements; a 1 M-element CT x PT
+// batch: 60.0 ms full width, 48.4 ms split.)
+const pgpu_pubkey::PubForm* split_modexp_form(const pgpu_pubkey* key, size_t count) {
+  if (key->hforms.empty() || !hensel_enabled()) return nullptr;
   static const size_t max_waves = [] {
     const char* e = std::getenv("PGPU_SPLIT_MODEXP_MAX_WAVES");
     return e && std::atol(e) > 0 ? (size_t)std::atol(e) : ~(size_t)0;
   }();
-  if (L2 % 8 == 0 && pgpu::hensel_modexp_has(8, L2 / 8) && (count + 3) / 4 <= kSimds) {
-    *H = 8;
-    *K = L2 / 8;
-    return true;
+  const pgpu_pubkey::PubForm* last = nullptr;
+  for (const auto& f : key->hforms) {
+    if (!pgpu::hensel_modexp_has(f->H, f->K)) continue;
+    last = f.get();
+    const size_t ipw = 64 / (2 * (size_t)f->H);
+    if ((count + ipw - 1) / ipw <= kSimds) return last;
   }
-  const size_t ipw = 64 / (2 * (size_t)key->hH);
-  if (!pgpu::hensel_modexp_has(key->hH, key->hK) || (count + ipw - 1) / ipw > max_waves) return false;
-  *H = key->hH;
-  *K = key->hK;
-  return true;
+  if (!last) return nullptr;
+  const size_t ipw = 64 / (2 * (size_t)last->H);
+  return (count + ipw - 1) / ipw > max_waves ? nullptr : last;
 }
-int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, int H, int K, const uint64_t* d_base, size_t base_stride,
+int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::PubForm* form, const uint64_t* d_base, size_t base_stride,
                     int base_words, bool base_mont, const uint64_t* d_exp, size_t exp_stride, int exp_words,
                     int exp_bits, const SchedRef* sched, int final_mul, const uint64_t* d_m, size_t m_stride,
                     int m_words, uint64_t* d_out, bool out_mont, size_t count, hipStream_t s) {
+  const int H = form->H, K = form->K;
   pgpu::HenselModexpArgs a{};
-  a.ctx = hensel_pub_view(key, d.index, base_mont);
-  a.full = hensel_full_view(key, d.index, out_mont);
+  a.ctx = hensel_pub_view(form, d.index, base_mont);
+  a.full = hensel_full_view(key, form, d.index, out_mont);
   a.base = d_base;
   a.base_stride = base_stride;
   a.base_words = base_words;
-  a.chunk_words = key->h_chunk_words;
-  a.nchunks = (base_words + key->h_chunk_words - 1) / key->h_chunk_words;
+  a.chunk_words = form->chunk_words;
+  a.nchunks = (base_words + form->chunk_words - 1) / form->chunk_words;
   a.exp = d_exp;
   a.exp_stride = exp_stride;
   a.exp_words = exp_words;
@@ -955,7 +964,8 @@ int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, int H, int K, const u
   return PGPU_OK;
 }
 // the fixed-base table of pairs (hensel.hpp: hensel_fb_build_kernel); same size as the full-width one
-int fb_table_for_split(const pgpu_pubkey* key, rt::Device& d, int w, int nwin, hipStream_t s, const FbTable** out) {
+int fb_table_for_split(const pgpu_pubkey* key, const pgpu_pubkey::PubForm* form, rt::Device& d, int w, int nwin,
+                       hipStream_t s, const FbTable** out) {
   std::lock_guard<std::mutex> lk(key->mu);
   if (key->fbh.size() < (size_t)rt::pool_size()) key->fbh.resize((size_t)rt::pool_size());
   auto& list = key->fbh[(size_t)d.index];
@@ -965,18 +975,18 @@ int fb_table_for_split(const pgpu_pubkey* key, rt::Device& d, int w, int nwin, h
       *out = &t;
       return PGPU_OK;
     }
-  const int H = key->hH, K = key->hK;
+  const int H = form->H, K = form->K;
   FbTable t;
   t.w = w;
   t.nwin = nwin;
   HIP_TRY(hipMalloc(&t.p, (size_t)nwin * ((size_t)1 << w) * 2 * H * K * sizeof(uint32_t)));
   HIP_TRY(hipEventCreateWithFlags(&t.ready, hipEventDisableTiming));
   pgpu::HenselFbBuildArgs b{};
-  b.ctx = hensel_pub_view(key, d.index);
+  b.ctx = hensel_pub_view(form, d.index);
   b.base = (const uint64_t*)key->d_hs.d[(size_t)d.index];
   b.base_words = 2 * key->n_words;
-  b.chunk_words = key->h_chunk_words;
-  b.nchunks = key->h_nchunks;
+  b.chunk_words = form->chunk_words;
+  b.nchunks = form->nchunks;
   b.table = (uint32_t*)t.p;
   b.nwin = nwin;
   b.w = w;
@@ -1014,11 +1024,11 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
     const FbTable* tab = nullptr;
     // split form (hensel.hpp): pairs modulo (n*k)^2; needs m < 2n to form the pair of 1 + n*m, i.e. plaintext rows
     // no wider than n, and a batch that fills the chip in 8-lane groups no worse than the full-width kernel does
-    if (use_split_encrypt(key, m_words, count)) {
-      RC_TRY(fb_table_for_split(key, d, fbw, nwin, s, &tab));
+    if (const pgpu_pubkey::PubForm* form = use_split_encrypt(key, m_words, count)) {
+      RC_TRY(fb_table_for_split(key, form, d, fbw, nwin, s, &tab));
       pgpu::HenselFbArgs f{};
-      f.ctx = hensel_pub_view(key, d.index);
-      f.full = hensel_full_view(key, d.index, out_mont);
+      f.ctx = hensel_pub_view(form, d.index);
+      f.full = hensel_full_view(key, form, d.index, out_mont);
       f.table = (const uint32_t*)tab->p;
       f.nwin = nwin;
       f.w = fbw;
@@ -1032,9 +1042,9 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
       f.out_stride = (size_t)W;
       f.count = count;
       TimerScope t(d, s, PGPU_KERNEL_FB_ENCRYPT);
-      const int ipw = 64 / (2 * key->hH);
+      const int ipw = 64 / (2 * form->H);
       const unsigned blocks = (unsigned)(((count + ipw - 1) / ipw + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
-      if (!pgpu::launch_hensel_fb_encrypt(key->hH, key->hK, f, blocks, s))
+      if (!pgpu::launch_hensel_fb_encrypt(form->H, form->K, f, blocks, s))
         return fail(PGPU_ERR_UNSUPPORTED, "split-form fixed-base kernel not compiled");
       HIP_TRY(hipGetLastError());
       t.stop();
@@ -1076,15 +1086,15 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
     a.exp_bits = r_bits;
   } else {         // r^n: per-element base, shared exponent n (pub_key.cpp:66-80)
     if (r_words > W) return fail(PGPU_ERR_INVALID_PARAM, "random wider than n^2");
-    int sh = 0, sk = 0;
-    if (64 * m_words <= key->n.BitSize() && split_modexp_form(key, count, &sh, &sk)) {
+    const pgpu_pubkey::PubForm* form = 64 * m_words <= key->n.BitSize() ? split_modexp_form(key, count) : nullptr;
+    if (form) {
       SchedRef srn;
       if (key->sched_n.dev.bytes) {
         srn.p[0] = (const uint16_t*)key->sched_n.dev.d[(size_t)d.index];
         srn.len[0] = key->sched_n.len;
         srn.w = key->sched_n.w;
       }
-      return modexp_split_on(d, key, sh, sk, d_r, r_stride, r_words, false,
+      return modexp_split_on(d, key, form, d_r, r_stride, r_words, false,
                              (const uint64_t*)key->d_n.d[(size_t)d.index], 0, key->n_words, key->n.BitSize(),
                              srn.p[0] ? &srn : nullptr, pgpu::FM_PAILLIER_G, d_m, m_stride, m_words, d_c, out_mont,
                              count, s);
@@ -1367,10 +1377,11 @@ int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, i
 
 int pgpu_encrypt_kernel_form(const pgpu_pubkey* key, int m_words, size_t count, int* split, int* lanes, int* limbs) {
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_encrypt_kernel_form: bad argument");
-  if (key->djn && fixed_base_window() > 0 && use_split_encrypt(key, m_words, count)) {
+  const pgpu_pubkey::PubForm* ef = key->djn && fixed_base_window() > 0 ? use_split_encrypt(key, m_words, count) : nullptr;
+  if (ef) {
     *split = 1;
-    *lanes = 2 * key->hH;
-    *limbs = key->hK;
+    *lanes = 2 * ef->H;
+    *limbs = ef->K;
     return PGPU_OK;
   }
   const GeoInfo g = launch_geo(key->nsq->geo, count);
@@ -1382,11 +1393,10 @@ int pgpu_encrypt_kernel_form(const pgpu_pubkey* key, int m_words, size_t count, 
 
 int pgpu_modexp_n2_kernel_form(const pgpu_pubkey* key, size_t count, int* split, int* lanes, int* limbs) {
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_modexp_n2_kernel_form: bad argument");
-  int H = 0, K = 0;
-  if (split_modexp_form(key, count, &H, &K)) {
+  if (const pgpu_pubkey::PubForm* mf = split_modexp_form(key, count)) {
     *split = 1;
-    *lanes = 2 * H;
-    *limbs = K;
+    *lanes = 2 * mf->H;
+    *limbs = mf->K;
     return PGPU_OK;
   }
   const GeoInfo lat = latency_geo(key->nsq->geo);
@@ -1624,49 +1634,74 @@ int pgpu_modmul(const uint64_t* a, const uint64_t* b, size_t b_stride, const uin
 
 // ===================== Paillier public key / encrypt =====================
 namespace {
-// Constants of the split form of n^2 (hensel.hpp) for the fixed-base DJN encrypt.  Available when a fixed-base form
-// (H, K) is compiled whose full-width twin Geo<2H, K> is the geometry of the key's n^2 context (the way back to a
-// full-width residue reuses that context's constants): 2048-bit keys, (4,18) <-> Geo<8,18>.
-int build_hensel_pub(pgpu_pubkey* k) {
-  GeoInfo fg = k->nsq->geo;
-  if (fg.K == 9 && fg.G >= 4) fg = GeoInfo{fg.G / 2, 18};   // the wide split of the same context (launch_geo)
-  const int H = fg.G / 2, K = fg.K, L2 = H * K;
-  if (fg.G < 4 || !pgpu::hensel_fb_has(H, K) || !k->nsq->unit) return PGPU_OK;
-  if (pgpu::kLimbBits * L2 < k->n.BitSize() + 29 + 8) return PGPU_OK;
-  const int cw = std::min(k->n_words, k->n.BitSize() / 64);
+// Constants of the split forms of n^2 (hensel.hpp) for DJN encrypt, r^n and CT x PT: per lane count the smallest
+// compiled form (fixed-base or generic kernel) with enough limbs for n*k and a full-width twin Geo<2H,K> wide enough
+// for n^2.  The way back to a full-width residue has constants of its own, so the forms need not match the geometry
+// of the key's n^2 context; Montgomery-form results carry that context's radix Rs (they mix with the full-width
+// kernels of resident batches).
+int build_hensel_pub_form(pgpu_pubkey* k, int H, int K) {
+  const int L2 = H * K;
+  const BigNumber& n = k->n;
+  const BigNumber N = n * n;
+  const int cw = std::min(k->n_words, n.BitSize() / 64);
   if (cw <= 0) return PGPU_OK;
   const int nch = (2 * k->n_words + cw - 1) / cw;
-  const BigNumber& n = k->n;
-  uint32_t n0 = (uint32_t)(n.limbs64()[0] & pgpu::kLimbMask), inv = n0;
-  for (int i = 0; i < 5; ++i) inv *= 2u - n0 * inv;
-  const uint32_t n0inv = (0u - inv) & pgpu::kLimbMask;
-  const BigNumber P = n * BigNumber((Ipp32u)n0inv), P2 = P * P;
+  std::unique_ptr<pgpu_pubkey::PubForm> f(new pgpu_pubkey::PubForm);
+  f->H = H;
+  f->K = K;
+  f->chunk_words = cw;
+  f->nchunks = nch;
+  auto n0inv_of = [](const BigNumber& v) {
+    uint32_t n0 = (uint32_t)(v.limbs64()[0] & pgpu::kLimbMask), inv = n0;
+    for (int i = 0; i < 5; ++i) inv *= 2u - n0 * inv;
+    return (0u - inv) & pgpu::kLimbMask;
+  };
+  f->n0inv = n0inv_of(n);
+  f->n0inv_full = n0inv_of(N);
+  const BigNumber P = n * BigNumber((Ipp32u)f->n0inv), P2 = P * P;
   const BigNumber R = pow2(L2 * pgpu::kLimbBits);
   std::vector<uint32_t> h((size_t)L2 * (5 + 4 * (size_t)nch), 0);
   auto put_pair = [&](uint32_t* dst, const BigNumber& z) {
     const BigNumber zr = z % P2;
-    const BigNumber f = zr / P;
+    const BigNumber q = zr / P;
     to_limbs29(zr % P, L2, dst);
-    to_limbs29(f.isZero() ? f : P - f, L2, dst + L2);
+    to_limbs29(q.isZero() ? q : P - q, L2, dst + L2);
   };
   to_limbs29(P, L2, h.data());
   to_limbs29(n, L2, h.data() + L2);
-  to_limbs29((R % n) * BigNumber((Ipp32u)n0inv) % n, L2, h.data() + 2 * L2);
+  to_limbs29((R % n) * BigNumber((Ipp32u)f->n0inv) % n, L2, h.data() + 2 * L2);
   const BigNumber Rm = R % P2, R2 = (Rm * Rm) % P2;
   put_pair(h.data() + 3 * L2, Rm);
-  // (second set: bases that arrive as c*R' mod n^2, R' the radix of the n^2 context -- resident ciphertexts)
-  const BigNumber R2m = (R2 * P2.InverseMul(pow2(k->nsq->geo.rbits()) % P2)) % P2;
+  // (second set: bases that arrive as c*Rs mod n^2 -- resident ciphertexts)
+  const BigNumber Rs = pow2(k->nsq->geo.rbits());
+  const BigNumber R2m = (R2 * P2.InverseMul(Rs % P2)) % P2;
   for (int i = 0; i < nch; ++i) {
     const BigNumber sh = pow2(64 * cw * i) % P2;
     put_pair(h.data() + 5 * L2 + (size_t)i * 2 * L2, (R2 * sh) % P2);
     put_pair(h.data() + 5 * L2 + (size_t)(nch + i) * 2 * L2, (R2m * sh) % P2);
   }
-  RC_TRY(k->d_hpub.upload(h.data(), h.size() * sizeof(uint32_t), false));
-  k->hH = H;
-  k->hK = K;
-  k->h_chunk_words = cw;
-  k->h_nchunks = nch;
-  k->h_n0inv = n0inv;
+  RC_TRY(f->pub.upload(h.data(), h.size() * sizeof(uint32_t), false));
+  const int LF = 2 * L2;
+  const BigNumber Rf = pow2(LF * pgpu::kLimbBits) % N, Rsn = Rs % N;
+  std::vector<uint32_t> g((size_t)4 * LF, 0);
+  to_limbs29(N, LF, g.data());
+  to_limbs29((n * Rf) % N, LF, g.data() + LF);
+  to_limbs29((((n * Rf) % N) * Rsn) % N, LF, g.data() + 2 * LF);
+  to_limbs29((Rf * Rsn) % N, LF, g.data() + 3 * LF);
+  RC_TRY(f->full.upload(g.data(), g.size() * sizeof(uint32_t), false));
+  k->hforms.push_back(std::move(f));
+  return PGPU_OK;
+}
+int build_hensel_pub(pgpu_pubkey* k) {
+  const int need = k->n.BitSize() + 29 + 8;
+  const int nsq_bits = 2 * k->n.BitSize();
+  for (int H : {8, 4, 2})
+    for (int K = 1; K <= 19; ++K)
+      if ((pgpu::hensel_modexp_has(H, K) || pgpu::hensel_fb_has(H, K)) && pgpu::kLimbBits * H * K >= need &&
+          2 * pgpu::kLimbBits * H * K >= nsq_bits + 8) {
+        RC_TRY(build_hensel_pub_form(k, H, K));
+        break;
+      }
   return PGPU_OK;
 }
 }  // namespace
@@ -2181,9 +2216,8 @@ int pgpu_batch_ct_mul(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_ba
     o->bounds(d, &lo, &hi);
     rt::Device& dev = rt::device(d);
     rt::DeviceGuard g(dev.ordinal);
-    int sh = 0, sk = 0;
-    if (split_modexp_form(key, hi - lo, &sh, &sk)) {
-      RC_TRY(modexp_split_on(dev, key, sh, sk, a->ptr(d), (size_t)W, W, a->mont != nullptr,
+    if (const pgpu_pubkey::PubForm* form = split_modexp_form(key, hi - lo)) {
+      RC_TRY(modexp_split_on(dev, key, form, a->ptr(d), (size_t)W, W, a->mont != nullptr,
                              e->ptr(e->replicated ? d : (bcast ? 0 : d)), bcast ? 0 : (size_t)e->words, e->words, e_bits,
                              nullptr, pgpu::FM_UNIT, nullptr, 0, 0, o->ptr(d), true, hi - lo, dev.bstream));
       continue;

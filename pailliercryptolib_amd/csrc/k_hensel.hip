@@ -1,11 +1,11 @@
 // pailliercryptolib_amd -- instantiations of the split-form CRT-decrypt exponentiation (hensel.hpp), split over
-// PGPU_PART = 0..9 so that they compile in parallel (3, 4: the fixed-base DJN encrypt; 5, 6, 8, 9: the generic modexp; 7:
+// PGPU_PART = 0..10 so that they compile in parallel (3, 4, 10: the fixed-base DJN encrypt; 5, 6, 8, 9: the generic modexp; 7:
 // the two-wavefronts-per-SIMD build of the (2,19) decrypt form).
 #include "hensel.hpp"
 #include "launch.hpp"
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..9"
+#error "compile with -DPGPU_PART=0..10"
 #endif
 
 namespace pgpu {
@@ -26,15 +26,19 @@ bool launch_hensel_part1(int H, int K, const HenselArgs& a, unsigned blocks, hip
   PGPU_HENSEL_ONE(4, 18) PGPU_HENSEL_ONE(4, 14) PGPU_HENSEL_ONE(4, 10)
   return false;
 }
-#elif PGPU_PART == 3 || PGPU_PART == 4
+#elif PGPU_PART == 3 || PGPU_PART == 4 || PGPU_PART == 10
 #if PGPU_PART == 3
 #define PGPU_FB_H 4
 #define PGPU_FB_K 18
 #define PGPU_FB_NAME(f) f##_part3
-#else
+#elif PGPU_PART == 4
 #define PGPU_FB_H 8
 #define PGPU_FB_K 14
 #define PGPU_FB_NAME(f) f##_part4
+#else
+#define PGPU_FB_H 2
+#define PGPU_FB_K 19
+#define PGPU_FB_NAME(f) f##_part10
 #endif
 bool PGPU_FB_NAME(launch_hensel_fb_build)(int H, int K, const HenselFbBuildArgs& a, unsigned blocks, hipStream_t s) {
   if (H == PGPU_FB_H && K == PGPU_FB_K) {

@@ -50,18 +50,21 @@ inline bool launch_hensel(int H, int K, bool packed, const HenselArgs& a, unsign
 }
 
 // split-form fixed-base DJN encrypt (hensel.hpp: hensel_fb_build_kernel / hensel_fb_encrypt_kernel; k_hensel.hip part 3)
-// (4,18): 2048-bit keys, (8,14): 3072-bit keys -- the forms whose full-width twin Geo<2H,K> is the geometry of the
-// key's n^2 context
-inline bool hensel_fb_has(int H, int K) { return (H == 4 && K == 18) || (H == 8 && K == 14); }
+// (2,19): 1024-bit keys, (4,18): 2048, (8,14): 3072 (k_hensel.hip parts 10, 3, 4)
+inline bool hensel_fb_has(int H, int K) { return (H == 2 && K == 19) || (H == 4 && K == 18) || (H == 8 && K == 14); }
 bool launch_hensel_fb_build_part3(int H, int K, const HenselFbBuildArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_fb_build_part4(int H, int K, const HenselFbBuildArgs& a, unsigned blocks, hipStream_t s);
+bool launch_hensel_fb_build_part10(int H, int K, const HenselFbBuildArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_fb_encrypt_part3(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_fb_encrypt_part4(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
+bool launch_hensel_fb_encrypt_part10(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
 inline bool launch_hensel_fb_build(int H, int K, const HenselFbBuildArgs& a, unsigned blocks, hipStream_t s) {
-  return launch_hensel_fb_build_part3(H, K, a, blocks, s) || launch_hensel_fb_build_part4(H, K, a, blocks, s);
+  return launch_hensel_fb_build_part3(H, K, a, blocks, s) || launch_hensel_fb_build_part4(H, K, a, blocks, s) ||
+         launch_hensel_fb_build_part10(H, K, a, blocks, s);
 }
 inline bool launch_hensel_fb_encrypt(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
-  return launch_hensel_fb_encrypt_part3(H, K, a, blocks, s) || launch_hensel_fb_encrypt_part4(H, K, a, blocks, s);
+  return launch_hensel_fb_encrypt_part3(H, K, a, blocks, s) || launch_hensel_fb_encrypt_part4(H, K, a, blocks, s) ||
+         launch_hensel_fb_encrypt_part10(H, K, a, blocks, s);
 }
 
 // split-form generic modexp modulo a square (hensel.hpp: hensel_modexp_kernel; k_hensel.hip parts 5, 6, 8, 9): roots of

@@ -1,0 +1,70 @@
+"""Resident encrypt / CT x PT / decrypt per key class, split form on and off (library HIP-event timers summed per
+operation; tools/, diagnostics only).  usage: python tools/bench_keysizes.py [count]"""
+import ctypes, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import pailliercryptolib_amd as pa
+from pailliercryptolib_amd import _capi
+pa.initialize(0)
+L = _capi.lib()
+L.pgpu_debug_set_hensel.argtypes = [ctypes.c_int]
+count = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+G = os.path.join(os.path.dirname(__file__), "..", "tests", "golden")
+cases = {c["bits"]: c for c in json.load(open(os.path.join(G, "seeded_vectors.json")))["cases"] if c["djn"]}
+rng = np.random.default_rng(2)
+
+
+def ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def timed(fn):
+    fn()
+    _capi.check(L.pgpu_synchronize())
+    t0 = time.perf_counter()
+    h = fn()
+    _capi.check(L.pgpu_synchronize())
+    return (time.perf_counter() - t0) * 1e3, h
+
+
+for bits in (1024, 2048, 3072):
+    c = cases[bits]
+    p, q, hs = int(c["p"], 16), int(c["q"], 16), int(c["hs"], 16)
+    n = p * q
+    nw = bits // 64
+    m = np.zeros((count, nw), dtype=np.uint64)
+    m[:, 0] = rng.integers(0, 1 << 62, size=count, dtype=np.uint64)
+    r = np.frombuffer(rng.bytes(count * nw * 4), dtype=np.uint64).reshape(count, nw // 2).copy()
+    e = rng.integers(0, 1 << 32, size=(count, 1), dtype=np.uint64)
+    for mode in (0, 1):
+        L.pgpu_debug_set_hensel(mode)
+        pk, sk = pa.PublicKey(n, bits, hs=hs), pa.PrivateKey(p, q)
+        hm, hr, he = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        _capi.check(L.pgpu_batch_upload(ptr(m), count, nw, nw, ctypes.byref(hm)))
+        _capi.check(L.pgpu_batch_upload(ptr(r), count, nw // 2, nw // 2, ctypes.byref(hr)))
+        _capi.check(L.pgpu_batch_upload(ptr(e), count, 1, 1, ctypes.byref(he)))
+
+        def enc():
+            h = ctypes.c_void_p()
+            _capi.check(L.pgpu_batch_encrypt(pk._h, hm, hr, bits // 2, ctypes.byref(h)))
+            return h
+        t_enc, ct = timed(enc)
+
+        def mul():
+            h = ctypes.c_void_p()
+            _capi.check(L.pgpu_batch_ct_mul(pk._h, ct, he, 32, ctypes.byref(h)))
+            return h
+        t_mul, cm = timed(mul)
+
+        def dec():
+            h = ctypes.c_void_p()
+            _capi.check(L.pgpu_batch_decrypt_crt(sk._h, ct, ctypes.byref(h)))
+            return h
+        t_dec, dm = timed(dec)
+        out = np.empty((count, nw), dtype=np.uint64)
+        _capi.check(L.pgpu_batch_download(dm, ptr(out)))
+        assert np.array_equal(out, m)
+        print(f"{bits}-bit key, {count} elements, split form {'on ' if mode else 'off'}: encrypt {t_enc:8.2f} ms   "
+              f"CT x PT (u32) {t_mul:8.2f} ms   decrypt {t_dec:8.2f} ms", flush=True)
+        del pk, sk
+pa.terminate()
