@@ -332,3 +332,47 @@ def test_perfect_square_moduli_through_the_generic_seam(engine, hensel, count):
         assert engine.mod_exp(base, [65537] * count, mod) == ref_s, bits
         for i in idx:
             assert ref[i] == pow(base[i], exp[i], mod) and ref_s[i] == pow(base[i], 65537, mod), (bits, i)
+
+
+@pytest.mark.parametrize("m_words", [1, 3])
+def test_split_form_encrypt_narrow_plaintext_rows(engine, hensel, m_words):
+    """Plaintext rows narrower than n (the ipcl:: layer packs u32 / u64 plaintexts into one word) at a batch that takes
+    the split-form fixed-base kernel by size: three ciphertexts against the oracle, all through the round trip."""
+    import numpy as np
+    from pailliercryptolib_amd import _capi
+    from pailliercryptolib_amd.limbs import ints_to_limbs, limbs_to_ints
+    L = _capi.lib()
+    kat = _kat()
+    p, q = kat["p"], kat["q"]
+    n = p * q
+    pk, sk = engine.PublicKey(n, 2048, hs=kat["bench_hs"]), engine.PrivateKey(p, q)
+    opk = orc.PublicKey(n, 2048)
+    opk.set_djn(kat["bench_hs"])
+    rng = random.Random(m_words)
+    count = 8200
+    m = [rng.getrandbits(64 * m_words - 1) for _ in range(count)]
+    r = [rng.getrandbits(1024) for _ in range(count)]
+    hensel(1)
+    split, lanes, limbs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _capi.check(L.pgpu_encrypt_kernel_form(pk._h, m_words, count, ctypes.byref(split), ctypes.byref(lanes),
+                                           ctypes.byref(limbs)))
+    assert split.value == 1
+
+    def ptr(a):
+        return a.ctypes.data_as(ctypes.c_void_p)
+    hm, hr, c, d = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    am, ar = ints_to_limbs(m, m_words), ints_to_limbs(r, 16)
+    _capi.check(L.pgpu_batch_upload(ptr(am), count, m_words, m_words, ctypes.byref(hm)))
+    _capi.check(L.pgpu_batch_upload(ptr(ar), count, 16, 16, ctypes.byref(hr)))
+    _capi.check(L.pgpu_batch_encrypt(pk._h, hm, hr, 1024, ctypes.byref(c)))
+    out = np.empty((count, 64), dtype=np.uint64)
+    _capi.check(L.pgpu_batch_download(c, ptr(out)))
+    ct = limbs_to_ints(out)
+    for i in (0, 1, count - 1):
+        assert ct[i] == opk.encrypt([m[i]], [r[i]])[0]
+    _capi.check(L.pgpu_batch_decrypt_crt(sk._h, c, ctypes.byref(d)))
+    dm = np.empty((count, 32), dtype=np.uint64)
+    _capi.check(L.pgpu_batch_download(d, ptr(dm)))
+    assert limbs_to_ints(dm) == m
+    for h in (hm, hr, c, d):
+        L.pgpu_batch_destroy(h)
