@@ -31,6 +31,9 @@ while time.time() - t0 < budget:
     W = (bits + 63) // 64
     count = rng.choice([1, 2, 7, 8, 9, 16, 17, 33, 64, 100, 257, rng.randrange(1, 600)])
     ebits = rng.choice([1, 5, 32, 64, 100, 300, 1024, min(2048, bits), rng.randrange(1, 1500)])
+    if rng.random() < 0.08 and bits <= 4096:                            # batches that take the throughput kernel forms
+        count = rng.choice([4097, 5000, 8193, 9000, 17000])
+        ebits = rng.choice([1, 17, 40])
     shared = rng.random() < 0.4
     base = [rng.choice([mod - 1, 0, 1, rng.randrange(mod), (1 << (bits - 1)) - 1]) if rng.random() < 0.1
             else rng.randrange(mod) for _ in range(count)]
