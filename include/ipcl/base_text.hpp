@@ -56,7 +56,10 @@ class BaseText {
   std::vector<uint32_t> getElementVec(const std::size_t& idx) const;
   std::string getElementHex(const std::size_t& idx) const;
   std::vector<BigNumber> getChunk(const std::size_t& start, const std::size_t& size) const;
-  std::vector<BigNumber> getTexts() const;
+  // (reference base_text.hpp: "std::vector<BigNumber> getTexts() const".  On a temporary -- the usual
+  // `pk.encrypt(pt).getTexts()` -- the values are moved out instead of copied a second time.)
+  std::vector<BigNumber> getTexts() const&;
+  std::vector<BigNumber> getTexts() &&;
   std::size_t getSize() const;
 
   // reference base_text.hpp:108-114: "size", "texts"

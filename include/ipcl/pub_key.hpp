@@ -62,7 +62,9 @@ class PublicKey {
   BigNumber m_hs;
   int m_randbits = 0;
   bool m_enable_DJN = false;
-  std::vector<BigNumber> m_r;
+  // injected randomness (setRandom); shared between copies of the key -- every CipherText holds a copy of its
+  // PublicKey, as in the reference (ciphertext.cpp:12-22), and must not drag a batch of BigNumbers along
+  std::shared_ptr<const std::vector<BigNumber>> m_r;
   bool m_testv = false;
   // device-side key (n^2 Montgomery context, hs; one copy per pool GPU): rebuilt by every mutator, read-only
   // in between, shared by copies of the key
@@ -72,6 +74,7 @@ class PublicKey {
   std::vector<BigNumber> raw_encrypt(const std::vector<BigNumber>& pt, bool make_secure = true) const;
   std::vector<BigNumber> drawRandom(std::size_t sz) const;
   std::shared_ptr<detail::PubKeyDevice> device() const;
+  void setFields(const BigNumber& n, int bits);
   void rebuildDevice();
 };
 

@@ -89,6 +89,13 @@ int pgpu_get_device(void);
 /* "rccl" | "memcpy" | "single": how key images reached the pool devices (xGMI broadcast, per-device
  * copies, or a pool of one) */
 const char* pgpu_pool_transport(void);
+/* why RCCL is (not) in use ("ok", "pool entries share a physical device", the failing call, ...) */
+const char* pgpu_rccl_note(void);
+/* Replicated key images are read back from every GPU once per upload and compared with the host bytes; a copy
+ * that differs is rewritten over PCIe, counted here, and RCCL is retired if it delivered it. */
+int pgpu_replication_stats(uint64_t* images_verified, uint64_t* copies_repaired);
+/* test hook: flips one byte of the NEXT replicated image on pool entry `pool_index` right after the broadcast */
+int pgpu_debug_corrupt_next_replica(int pool_index);
 /* batches smaller than min_shard * k elements are spread over at most k GPUs (default 256; env
  * PGPU_MIN_SHARD) */
 int pgpu_set_min_shard(size_t min_elements_per_device);
@@ -150,6 +157,14 @@ int pgpu_paillier_encrypt_dev(const pgpu_pubkey* key, const uint64_t* d_m, size_
  * bench batch: 1.19 ms vs 1.41 ms).  Unless a window was set explicitly, a key starts with w = 8 (13 MB,
  * built in ~2 ms) and switches to the default after its first 4096 elements.  Results are identical. */
 int pgpu_set_fixed_base_window(int w);
+/* Table memory is bounded (round 3): per key and GPU by max_bytes_per_key (default 256 MiB, env
+ * PGPU_FB_KEY_MAX_BYTES: the window narrows until the table fits), per GPU over ALL keys by max_bytes_per_device
+ * (default 2 GiB, env PGPU_FB_MAX_BYTES: a new table first evicts the least recently used tables of other keys;
+ * an evicted key rebuilds its table on its next encrypt).  0 leaves a limit unchanged.  Results never change. */
+int pgpu_set_fixed_base_budget(size_t max_bytes_per_device, size_t max_bytes_per_key);
+int pgpu_fixed_base_stats(int pool_index, size_t* live_bytes, uint64_t* evictions);
+/* the table a key currently holds on a pool entry: window, bytes, build time in ms (0: none / still building) */
+int pgpu_pubkey_fixed_base_info(const pgpu_pubkey* key, int pool_index, int* window, size_t* bytes, double* build_ms);
 
 /* ---- Paillier private key: fused CRT decrypt ----
  * Replaces PrivateKey::decryptCRT + computeLfun + computeCRT (pri_key.cpp:114-157): per

@@ -28,6 +28,8 @@ SYMBOLS = [
     "pgpu_batch_create", "pgpu_batch_upload", "pgpu_batch_download", "pgpu_batch_destroy", "pgpu_batch_count",
     "pgpu_batch_words", "pgpu_batch_is_montgomery", "pgpu_batch_encrypt", "pgpu_batch_decrypt_crt",
     "pgpu_batch_ct_add", "pgpu_batch_ct_add_plain", "pgpu_batch_ct_mul",
+    "pgpu_rccl_note", "pgpu_replication_stats", "pgpu_debug_corrupt_next_replica",
+    "pgpu_set_fixed_base_budget", "pgpu_fixed_base_stats", "pgpu_pubkey_fixed_base_info",
 ]
 
 _lib = None
@@ -127,6 +129,13 @@ def lib():
     L.pgpu_batch_ct_add_plain.restype = c_int
     L.pgpu_batch_ct_mul.argtypes = [c_void_p, c_void_p, c_void_p, c_int, POINTER(c_void_p)]
     L.pgpu_batch_ct_mul.restype = c_int
+    L.pgpu_rccl_note.argtypes = []; L.pgpu_rccl_note.restype = c_char_p
+    L.pgpu_replication_stats.argtypes = [POINTER(c_uint64), POINTER(c_uint64)]; L.pgpu_replication_stats.restype = c_int
+    L.pgpu_debug_corrupt_next_replica.argtypes = [c_int]; L.pgpu_debug_corrupt_next_replica.restype = c_int
+    L.pgpu_set_fixed_base_budget.argtypes = [c_size_t, c_size_t]; L.pgpu_set_fixed_base_budget.restype = c_int
+    L.pgpu_fixed_base_stats.argtypes = [c_int, POINTER(c_size_t), POINTER(c_uint64)]; L.pgpu_fixed_base_stats.restype = c_int
+    L.pgpu_pubkey_fixed_base_info.argtypes = [c_void_p, c_int, POINTER(c_int), POINTER(c_size_t), POINTER(c_double)]
+    L.pgpu_pubkey_fixed_base_info.restype = c_int
     _lib = L
     return L
 

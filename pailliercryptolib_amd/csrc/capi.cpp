@@ -11,7 +11,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <list>
 #include <map>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -26,6 +28,13 @@ namespace rt = pgpu::rt;
 using rt::fail;
 
 namespace {
+
+// forget a host buffer that held key material (p-1, q-1, hp, hq, private Montgomery constants): volatile stores,
+// which the compiler may not elide the way it may a std::fill on a buffer that is about to die
+void secure_wipe(void* p, size_t bytes) {
+  volatile unsigned char* w = static_cast<volatile unsigned char*>(p);
+  for (size_t i = 0; i < bytes; ++i) w[i] = 0;
+}
 
 // ---------- geometry table ----------
 struct GeoInfo {
@@ -196,15 +205,77 @@ int build_modctx(const BigNumber& N, int mod_words, const GeoInfo& geo, const Ct
   std::memcpy(host.data() + ctx->off64, n64.data(), n64.size() * 8);
   RC_TRY(ctx->blob.upload(host.data(), host.size(), ex.secret));
   if (ex.secret) {
-    std::fill(host.begin(), host.end(), 0);
-    std::fill(h.begin(), h.end(), 0u);
+    secure_wipe(host.data(), host.size());
+    secure_wipe(h.data(), h.size() * sizeof(uint32_t));
   }
   *out = ctx;
   return PGPU_OK;
 }
 
+// Caches of per-modulus device constants (the key-less seams).  Least-recently-used entries are evicted ONE at a
+// time; an evicted entry is not destroyed on the spot -- a `_dev` call only enqueues its kernel, so the device image
+// may still be read -- but parked: parked entries are destroyed by pgpu_synchronize / pgpu_shutdown (after the
+// devices have drained), or, when more than kParkMax have piled up, oldest first by the evicting call itself
+// (hipFree then waits for the device: correct, merely slow, and only for workloads that cycle through more than
+// kCacheCap + kParkMax moduli without ever synchronising).
+constexpr size_t kCacheCap = 64, kParkMax = 64;
+std::mutex g_park_mu;
+std::deque<std::shared_ptr<void>> g_parked;
+void park(std::shared_ptr<void> victim) {
+  if (!victim) return;
+  std::shared_ptr<void> overflow;
+  {
+    std::lock_guard<std::mutex> lk(g_park_mu);
+    g_parked.push_back(std::move(victim));
+    if (g_parked.size() > kParkMax) {
+      overflow = std::move(g_parked.front());
+      g_parked.pop_front();
+    }
+  }
+  // `overflow` dies here, outside the lock (its hipFree synchronises the device)
+}
+void drain_parked() {
+  std::deque<std::shared_ptr<void>> dead;
+  {
+    std::lock_guard<std::mutex> lk(g_park_mu);
+    dead.swap(g_parked);
+  }
+}
+template <class V>
+struct LruCache {
+  struct Slot {
+    std::shared_ptr<V> value;
+    bool known = false;   // a null value may be a cached verdict ("not a square")
+    uint64_t tick = 0;
+  };
+  std::map<std::vector<uint64_t>, Slot> slots;
+  uint64_t clock = 0;
+  bool find(const std::vector<uint64_t>& key, std::shared_ptr<V>* out) {
+    auto it = slots.find(key);
+    if (it == slots.end()) return false;
+    it->second.tick = ++clock;
+    *out = it->second.value;
+    return true;
+  }
+  void insert(const std::vector<uint64_t>& key, std::shared_ptr<V> value) {
+    if (slots.size() >= kCacheCap) {
+      auto victim = slots.begin();
+      for (auto it = slots.begin(); it != slots.end(); ++it)
+        if (it->second.tick < victim->second.tick) victim = it;
+      park(std::move(victim->second.value));
+      slots.erase(victim);
+    }
+    Slot s;
+    s.value = std::move(value);
+    s.known = true;
+    s.tick = ++clock;
+    slots[key] = std::move(s);
+  }
+  void clear() { slots.clear(); }
+};
+
 std::mutex g_ctx_mu;
-std::map<std::vector<uint64_t>, std::shared_ptr<ModCtx>> g_ctx_cache;
+LruCache<ModCtx> g_ctx_cache;
 
 GeoInfo latency_geo(const GeoInfo& geo);
 // cached plain context for the generic seam: unit_q = true for pgpu_modexp (loop modulo Nhat),
@@ -217,11 +288,7 @@ int get_modctx(const uint64_t* mod, int mod_words, bool unit_q, std::shared_ptr<
   std::vector<uint64_t> key(mod, mod + mod_words);
   key.push_back((unit_q ? 1 : 0) | (latency ? 2 : 0));
   std::lock_guard<std::mutex> lk(g_ctx_mu);
-  auto it = g_ctx_cache.find(key);
-  if (it != g_ctx_cache.end()) {
-    *out = it->second;
-    return PGPU_OK;
-  }
+  if (g_ctx_cache.find(key, out)) return PGPU_OK;
   BigNumber N = BigNumber::fromLimbs64(mod, (size_t)mod_words);
   if (N.isZero() || N == BigNumber::One())
     return fail(PGPU_ERR_INVALID_PARAM, "modulus must be > 1");
@@ -230,8 +297,7 @@ int get_modctx(const uint64_t* mod, int mod_words, bool unit_q, std::shared_ptr<
   CtxExtras ex;
   ex.unit_q = unit_q;
   RC_TRY(build_modctx(N, mod_words, latency ? latency_geo(*geo) : *geo, ex, out));
-  if (g_ctx_cache.size() > 64) g_ctx_cache.clear();   // (contexts in use stay alive through their shared_ptr)
-  g_ctx_cache[key] = *out;
+  g_ctx_cache.insert(key, *out);
   return PGPU_OK;
 }
 
@@ -256,6 +322,13 @@ int secret_policy() {
 // fixed-window width: the w in 1..5 that minimises (2^w - 2) table multiplications +
 // ceil(e/w) window multiplications (w = 5 for e >= ~240 bits).
 int pick_window(int exp_bits) {
+  // PGPU_FIXED_WINDOW=w: A/B measurements of the window width (what an LDS-resident table, which
+  // holds 8 entries per exponentiation at most, would have to beat)
+  static const int forced = [] {
+    const char* e = std::getenv("PGPU_FIXED_WINDOW");
+    return e ? std::max(1, std::min(5, std::atoi(e))) : 0;
+  }();
+  if (forced) return forced;
   int best = 1;
   long best_cost = 1L << 60;
   for (int w = 1; w <= 5; ++w) {
@@ -417,6 +490,13 @@ uint64_t* g_wave_clocks = nullptr;   // diagnostics (tools/wave_spread.py)
 
 // CRT decrypt: exponentiation modulo p^2 / q^2 in split form (hensel.hpp) where it is compiled for the key size;
 // PGPU_HENSEL=0 keeps the full-width modexp_kernel (A/B measurements, parity tests of both paths).
+// two batches in flight (callers that keep two streams busy): take the 256-register build of the (2,19) decrypt kernel
+// also for launches of one wavefront per SIMD, so that the launches of two streams can share a SIMD (the full-budget
+// build holds 291 registers: nothing else fits beside it).  pgpu_debug_set_packed_decrypt / PGPU_PACKED_DECRYPT=1.
+std::atomic<bool> g_packed_decrypt{[] {
+  const char* e = std::getenv("PGPU_PACKED_DECRYPT");
+  return e && std::atoi(e) != 0;
+}()};
 std::atomic<int> g_hensel{-2};
 bool hensel_enabled() {
   int mode = g_hensel.load();
@@ -457,7 +537,7 @@ int run_modexp(rt::Device& d, pgpu::ModexpArgs& a, const GeoInfo& ctx_geo, hipSt
   rt::StreamWork& w = held ? *held : d.work_for(s);
   std::unique_lock<std::mutex> lk(w.mu, std::defer_lock);
   if (!held) lk.lock();
-  RC_TRY(w.table.ensure(padded * (entries + 1) * geo.L() * sizeof(uint32_t)));   // + the parking slot
+  RC_TRY(w.table.ensure(padded * (entries + 1) * geo.L() * sizeof(uint32_t), s));   // + the parking slot
   a.table = (uint32_t*)w.table.p;
   a.wave_clocks = g_wave_clocks;
   TimerScope t(d, s, PGPU_KERNEL_MODEXP);
@@ -476,6 +556,11 @@ struct FbTable {   // immutable once built: hs^(d * 2^(w*i)) * R, [nwin][2^w][L]
   void* p = nullptr;
   int w = 0, nwin = 0;
   hipEvent_t ready = nullptr;   // recorded behind the build; launches on other streams wait for it
+  size_t bytes = 0;
+  uint64_t tick = 0;            // last use (LRU over all keys of a device)
+  int pins = 0;                 // lookups whose launch has not been queued yet: never evicted
+  double build_ms = 0;          // filled in lazily from the events below (bench / diagnostics)
+  hipEvent_t t0 = nullptr;
 };
 struct pgpu_pubkey {
   int n_words = 0;
@@ -487,7 +572,9 @@ struct pgpu_pubkey {
   ExpSchedule sched_n;          // plain: sliding-window schedule of n (r^n mod n^2; n is public)
   // fixed-base tables for hs^r, per pool device; built lazily, kept until the key dies
   mutable std::mutex mu;
-  mutable std::vector<std::deque<FbTable>> fb;   // [device]; entries never move once handed out
+  // [device]; entries never move once handed out (std::list).  Guarded by the process-wide g_fb_mu, not by `mu`:
+  // a table may be evicted to make room for ANOTHER key's table (fb_budget)
+  mutable std::vector<std::list<FbTable>> fb;
   mutable size_t fb_elems = 0;  // elements encrypted with this key so far (window policy)
   // split forms of n^2 = (n)^2 (hensel.hpp) compiled for this key size, most lanes per element first; empty: none
   struct PubForm {
@@ -498,21 +585,13 @@ struct pgpu_pubkey {
     uint32_t n0inv = 0, n0inv_full = 0;
   };
   std::vector<std::unique_ptr<PubForm>> hforms;
-  mutable std::vector<std::deque<FbTable>> fbh;   // [device]: fixed-base tables of pairs (form hforms.back())
-  ~pgpu_pubkey() {
-    for (auto* lists : {&fb, &fbh})
-      for (size_t d = 0; d < lists->size(); ++d) {
-        if ((*lists)[d].empty() || (int)d >= rt::pool_size()) continue;
-        rt::DeviceGuard g(rt::device((int)d).ordinal);
-        for (FbTable& t : (*lists)[d]) {
-          if (t.ready) (void)hipEventDestroy(t.ready);
-          if (t.p) (void)hipFree(t.p);
-        }
-      }
-  }
+  mutable std::vector<std::list<FbTable>> fbh;   // [device]: fixed-base tables of pairs (form hforms.back())
+  uint64_t gen = 0;             // pool generation the device images belong to
+  ~pgpu_pubkey();
 };
 
 struct pgpu_privkey {
+  uint64_t gen = 0;             // pool generation the device images belong to
   int n_words = 0;              // words of n (= words of p^2, q^2 rows)
   int pq_words = 0;
   GeoInfo geo_exp{};            // geometry of the two half-width exponentiations
@@ -547,6 +626,7 @@ struct pgpu_batch {
   bool replicated = false;
   std::vector<rt::DevMem> shard;
   std::shared_ptr<ModCtx> mont;        // non-null: values are x*R mod N (canonical) for this context
+  uint64_t gen = 0;                    // pool generation of the shards
   uint64_t* ptr(int d) const { return (uint64_t*)shard[(size_t)d].p; }
   void bounds(int d, size_t* lo, size_t* hi) const {
     if (replicated) { *lo = 0; *hi = count; }
@@ -561,6 +641,7 @@ int new_batch(size_t count, int words, std::unique_ptr<pgpu_batch>* out) {
   std::unique_ptr<pgpu_batch> b(new pgpu_batch);
   b->count = count;
   b->words = words;
+  b->gen = rt::pool_generation();
   b->replicated = count == 1 && rt::pool_size() > 1;
   b->ndev = b->replicated ? rt::pool_size() : rt::shard_devices(count);
   b->shard.resize((size_t)b->ndev);
@@ -629,7 +710,7 @@ struct SquareCtx {
   std::vector<std::unique_ptr<SquareForm>> forms;   // most lanes per element (shortest serial chain) first
 };
 std::mutex g_sq_mu;
-std::map<std::vector<uint64_t>, std::shared_ptr<SquareCtx>> g_sq_cache;   // null entry: not a (supported) square
+LruCache<SquareCtx> g_sq_cache;   // null entry: not a (supported) square
 
 // floor(sqrt(N)) by Newton's iteration from above
 BigNumber isqrt(const BigNumber& N) {
@@ -675,11 +756,16 @@ int build_square_form(const BigNumber& N, const BigNumber& root, int mod_words, 
   const BigNumber Rm = R % P2, R2 = (Rm * Rm) % P2;
   put_pair(h.data() + 3 * L2, Rm);
   for (int i = 0; i < nch; ++i) put_pair(h.data() + 5 * L2 + (size_t)i * 2 * L2, (R2 * (pow2(64 * cw * i) % P2)) % P2);
-  RC_TRY(f->pub.upload(h.data(), h.size() * sizeof(uint32_t), false));
+  // The caller of the key-less seam may be the reference's own decryptCRT (pri_key.cpp:128-134: moduli p^2, q^2): the
+  // root is then a private prime.  The images are therefore treated as key material: zeroed on the devices before
+  // they are freed, the host staging copies wiped, and the cache entry dropped at pgpu_shutdown.
+  RC_TRY(f->pub.upload(h.data(), h.size() * sizeof(uint32_t), true));
+  secure_wipe(h.data(), h.size() * sizeof(uint32_t));
   std::vector<uint32_t> g((size_t)4 * L2, 0);
   to_limbs29(N, 2 * L2, g.data());
   to_limbs29((root * (pow2(2 * L2 * pgpu::kLimbBits) % N)) % N, 2 * L2, g.data() + 2 * L2);
-  RC_TRY(f->full.upload(g.data(), g.size() * sizeof(uint32_t), false));
+  RC_TRY(f->full.upload(g.data(), g.size() * sizeof(uint32_t), true));
+  secure_wipe(g.data(), g.size() * sizeof(uint32_t));
   *out = std::move(f);
   return PGPU_OK;
 }
@@ -690,11 +776,7 @@ int get_square_ctx(const uint64_t* mod, int mod_words, std::shared_ptr<SquareCtx
   if (!hensel_enabled() || !(mod[0] & 1)) return PGPU_OK;
   std::vector<uint64_t> key(mod, mod + mod_words);
   std::lock_guard<std::mutex> lk(g_sq_mu);
-  auto it = g_sq_cache.find(key);
-  if (it != g_sq_cache.end()) {
-    *out = it->second;
-    return PGPU_OK;
-  }
+  if (g_sq_cache.find(key, out)) return PGPU_OK;
   std::shared_ptr<SquareCtx> ctx;
   const BigNumber N = BigNumber::fromLimbs64(mod, (size_t)mod_words);
   // (a square is 0, 1, 4 or 9 mod 16 -- an odd one is 1 or 9: cheap rejection of almost every other modulus)
@@ -717,8 +799,7 @@ int get_square_ctx(const uint64_t* mod, int mod_words, std::shared_ptr<SquareCtx
       if (ctx->forms.empty()) ctx.reset();
     }
   }
-  if (g_sq_cache.size() > 64) g_sq_cache.clear();
-  g_sq_cache[key] = ctx;
+  g_sq_cache.insert(key, ctx);
   *out = ctx;
   return PGPU_OK;
 }
@@ -775,7 +856,7 @@ int modexp_square_on(rt::Device& d, const SquareCtx& sq, const uint64_t* d_base,
   const unsigned blocks = (unsigned)((waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
   rt::StreamWork& w = d.work_for(s);
   std::lock_guard<std::mutex> lk(w.mu);
-  RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * ipw * entries * 2 * L2 * sizeof(uint32_t)));
+  RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * ipw * entries * 2 * L2 * sizeof(uint32_t), s));
   a.table = (uint32_t*)w.table.p;
   TimerScope t(d, s, PGPU_KERNEL_MODEXP);
   if (!pgpu::launch_hensel_modexp(f->H, f->K, a, blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "split-form modexp kernel not compiled");
@@ -826,36 +907,163 @@ int modexp_on(rt::Device& d, const uint64_t* d_base, size_t base_stride, const u
   return run_modexp(d, a, run_geo, s, sched);
 }
 
-// fixed-base table of (key, device) for window w covering nwin windows: built on first use
-int fb_table_for(const pgpu_pubkey* key, rt::Device& d, int w, int nwin, hipStream_t s, const FbTable** out) {
-  std::lock_guard<std::mutex> lk(key->mu);
-  if (key->fb.size() < (size_t)rt::pool_size()) key->fb.resize((size_t)rt::pool_size());
-  auto& list = key->fb[(size_t)d.index];
-  for (const FbTable& t : list)
+// ---------- fixed-base tables: budget and LRU ----------
+// A table is 13 MB (w = 8) to 203 MB (w = 12) per 2048-bit key and GPU.  Two limits keep a server with thousands of
+// keys inside its memory (pgpu_set_fixed_base_budget / PGPU_FB_MAX_BYTES, PGPU_FB_KEY_MAX_BYTES):
+//   * per key and GPU: the widest window <= the configured one whose table fits kFbKeyMax (default 256 MiB);
+//   * per GPU, over all keys: kFbDevMax (default 2 GiB).  A new table that would exceed it evicts the least
+//     recently used tables of any key on that GPU first (never one whose launch is still being queued); if the
+//     budget cannot hold the table at all, the window shrinks until it does.
+// An evicted table is freed on the spot (hipFree waits for the kernels that still read it): making room costs a
+// device synchronisation, staying inside the budget costs nothing.
+std::mutex g_fb_mu;                       // all FbTable lists, the registry, the counters
+std::set<const pgpu_pubkey*> g_fb_keys;   // keys that own tables
+std::vector<size_t> g_fb_dev_bytes;       // [device] bytes of live tables
+std::atomic<size_t> g_fb_dev_max{0}, g_fb_key_max{0};
+std::atomic<uint64_t> g_fb_tick{0}, g_fb_evictions{0};
+size_t fb_dev_max() {
+  size_t v = g_fb_dev_max.load();
+  if (v == 0) {
+    const char* e = std::getenv("PGPU_FB_MAX_BYTES");
+    v = e && std::atoll(e) > 0 ? (size_t)std::atoll(e) : (size_t)2 << 30;
+    g_fb_dev_max.store(v);
+  }
+  return v;
+}
+size_t fb_key_max() {
+  size_t v = g_fb_key_max.load();
+  if (v == 0) {
+    const char* e = std::getenv("PGPU_FB_KEY_MAX_BYTES");
+    v = e && std::atoll(e) > 0 ? (size_t)std::atoll(e) : (size_t)256 << 20;
+    g_fb_key_max.store(v);
+  }
+  return v;
+}
+size_t fb_table_bytes(int r_bits, int w, size_t entry_bytes) {
+  return (size_t)std::max(1, (r_bits + w - 1) / w) * ((size_t)1 << w) * entry_bytes;
+}
+// the window a table of this key may use on a GPU: <= w_cfg, fits the per-key limit and the per-GPU budget
+int fb_fit_window(int w_cfg, int r_bits, size_t entry_bytes) {
+  int w = w_cfg;
+  const size_t cap = std::min(fb_key_max(), fb_dev_max());
+  while (w > 1 && fb_table_bytes(r_bits, w, entry_bytes) > cap) --w;
+  return w;
+}
+void fb_free_table(FbTable& t) {
+  if (t.ready) (void)hipEventDestroy(t.ready);
+  if (t.t0) (void)hipEventDestroy(t.t0);
+  if (t.p) (void)hipFree(t.p);   // (synchronises the device: kernels that read the table have finished)
+  t.p = nullptr;
+}
+// g_fb_mu held.  Frees least-recently-used, unpinned tables on device `dev` until `need` more bytes fit.
+void fb_make_room(int dev, size_t need) {
+  if (g_fb_dev_bytes.size() <= (size_t)dev) g_fb_dev_bytes.resize((size_t)dev + 1, 0);
+  while (g_fb_dev_bytes[(size_t)dev] + need > fb_dev_max()) {
+    std::list<FbTable>* vlist = nullptr;
+    std::list<FbTable>::iterator victim;
+    for (const pgpu_pubkey* k : g_fb_keys)
+      for (auto* lists : {&k->fb, &k->fbh}) {
+        if (lists->size() <= (size_t)dev) continue;
+        auto& l = (*lists)[(size_t)dev];
+        for (auto it = l.begin(); it != l.end(); ++it)
+          if (it->pins == 0 && (!vlist || it->tick < victim->tick)) {
+            vlist = &l;
+            victim = it;
+          }
+      }
+    if (!vlist) return;   // everything left is pinned: the caller allocates beyond the budget rather than fail
+    g_fb_dev_bytes[(size_t)dev] -= victim->bytes;
+    fb_free_table(*victim);
+    vlist->erase(victim);
+    g_fb_evictions.fetch_add(1);
+  }
+}
+// RAII pin: the table cannot be evicted between the lookup and the moment its consumer kernel is queued
+struct FbPin {
+  FbTable* t = nullptr;
+  FbPin() = default;
+  FbPin(const FbPin&) = delete;
+  FbPin& operator=(const FbPin&) = delete;
+  ~FbPin() { release(); }
+  void release() {
+    if (!t) return;
+    std::lock_guard<std::mutex> lk(g_fb_mu);
+    --t->pins;
+    t = nullptr;
+  }
+  const FbTable* operator->() const { return t; }
+};
+
+// Looks up / builds the table of (key, device) for window w covering nwin windows.  `build` queues the build kernel
+// on s for a freshly allocated table; entry_bytes: bytes per table entry.
+template <class Build>
+int fb_table_get(const pgpu_pubkey* key, std::vector<std::list<FbTable>>& lists, rt::Device& d, int w, int nwin,
+                 size_t entry_bytes, hipStream_t s, FbPin* out, Build build) {
+  std::lock_guard<std::mutex> lk(g_fb_mu);
+  if (lists.size() < (size_t)rt::pool_size()) lists.resize((size_t)rt::pool_size());
+  auto& list = lists[(size_t)d.index];
+  for (FbTable& t : list)
     if (t.w == w && t.nwin >= nwin) {
       HIP_TRY(hipStreamWaitEvent(s, t.ready, 0));
-      *out = &t;
+      t.tick = g_fb_tick.fetch_add(1) + 1;
+      ++t.pins;
+      out->t = &t;
       return PGPU_OK;
     }
-  const GeoInfo& geo = key->nsq->geo;
+  // a key keeps ONE table per device: a wider window replaces the young key's narrow one
+  for (auto it = list.begin(); it != list.end();) {
+    if (it->pins == 0) {
+      g_fb_dev_bytes.resize(std::max(g_fb_dev_bytes.size(), (size_t)d.index + 1), 0);
+      g_fb_dev_bytes[(size_t)d.index] -= it->bytes;
+      fb_free_table(*it);
+      it = list.erase(it);
+    } else {
+      ++it;
+    }
+  }
   FbTable t;
   t.w = w;
   t.nwin = nwin;
-  HIP_TRY(hipMalloc(&t.p, (size_t)nwin * ((size_t)1 << w) * geo.L() * sizeof(uint32_t)));
-  HIP_TRY(hipEventCreateWithFlags(&t.ready, hipEventDisableTiming));
-  pgpu::FixedBaseBuildArgs b{};
-  b.ctx = key->nsq->view(d.index);
-  b.base = (const uint64_t*)key->d_hs.d[(size_t)d.index];
-  b.table = (uint32_t*)t.p;
-  b.nwin = nwin;
-  b.w = w;
-  if (!pgpu::launch_fb_build(geo.G, geo.K, b, blocks_for((size_t)nwin, geo), s))
-    return fail(PGPU_ERR_UNSUPPORTED, "fixed-base build kernel geometry not compiled");
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(t.ready, s));
+  t.bytes = (size_t)nwin * ((size_t)1 << w) * entry_bytes;
+  fb_make_room(d.index, t.bytes);
+  hipError_t e = hipMalloc(&t.p, t.bytes);
+  if (e != hipSuccess) return fail(PGPU_ERR_HIP, std::string("fixed-base table: ") + hipGetErrorString(e));
+  if (hipEventCreateWithFlags(&t.ready, hipEventDefault) != hipSuccess || hipEventCreateWithFlags(&t.t0, hipEventDefault) != hipSuccess) {
+    fb_free_table(t);
+    return fail(PGPU_ERR_HIP, "fixed-base table: event creation failed");
+  }
+  (void)hipEventRecord(t.t0, s);
+  int rc = build(t);
+  if (rc == PGPU_OK && hipGetLastError() != hipSuccess) rc = fail(PGPU_ERR_HIP, "fixed-base build launch failed");
+  if (rc == PGPU_OK && hipEventRecord(t.ready, s) != hipSuccess) rc = fail(PGPU_ERR_HIP, "fixed-base table: event record failed");
+  if (rc != PGPU_OK) {
+    fb_free_table(t);   // (round-2 advisor: the error paths leaked the table and its event)
+    return rc;
+  }
+  t.tick = g_fb_tick.fetch_add(1) + 1;
+  t.pins = 1;
+  g_fb_dev_bytes.resize(std::max(g_fb_dev_bytes.size(), (size_t)d.index + 1), 0);
+  g_fb_dev_bytes[(size_t)d.index] += t.bytes;
+  g_fb_keys.insert(key);
   list.push_back(t);
-  *out = &list.back();
+  out->t = &list.back();
   return PGPU_OK;
+}
+
+// fixed-base table of (key, device) for window w covering nwin windows: built on first use
+int fb_table_for(const pgpu_pubkey* key, rt::Device& d, int w, int nwin, hipStream_t s, FbPin* out) {
+  const GeoInfo& geo = key->nsq->geo;
+  return fb_table_get(key, key->fb, d, w, nwin, (size_t)geo.L() * sizeof(uint32_t), s, out, [&](FbTable& t) -> int {
+    pgpu::FixedBaseBuildArgs b{};
+    b.ctx = key->nsq->view(d.index);
+    b.base = (const uint64_t*)key->d_hs.d[(size_t)d.index];
+    b.table = (uint32_t*)t.p;
+    b.nwin = nwin;
+    b.w = w;
+    if (!pgpu::launch_fb_build(geo.G, geo.K, b, blocks_for((size_t)nwin, geo), s))
+      return fail(PGPU_ERR_UNSUPPORTED, "fixed-base build kernel geometry not compiled");
+    return PGPU_OK;
+  });
 }
 
 // fused encrypt on one device; out_mont: ciphertexts leave in the Montgomery domain of n^2
@@ -955,7 +1163,7 @@ int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::Pu
   const unsigned blocks = (unsigned)((waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
   rt::StreamWork& w = d.work_for(s);
   std::lock_guard<std::mutex> lk(w.mu);
-  RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * ipw * entries * 2 * H * K * sizeof(uint32_t)));
+  RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * ipw * entries * 2 * H * K * sizeof(uint32_t), s));
   a.table = (uint32_t*)w.table.p;
   TimerScope t(d, s, PGPU_KERNEL_MODEXP);
   if (!pgpu::launch_hensel_modexp(H, K, a, blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "split-form modexp kernel not compiled");
@@ -965,40 +1173,24 @@ int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::Pu
 }
 // the fixed-base table of pairs (hensel.hpp: hensel_fb_build_kernel); same size as the full-width one
 int fb_table_for_split(const pgpu_pubkey* key, const pgpu_pubkey::PubForm* form, rt::Device& d, int w, int nwin,
-                       hipStream_t s, const FbTable** out) {
-  std::lock_guard<std::mutex> lk(key->mu);
-  if (key->fbh.size() < (size_t)rt::pool_size()) key->fbh.resize((size_t)rt::pool_size());
-  auto& list = key->fbh[(size_t)d.index];
-  for (const FbTable& t : list)
-    if (t.w == w && t.nwin >= nwin) {
-      HIP_TRY(hipStreamWaitEvent(s, t.ready, 0));
-      *out = &t;
-      return PGPU_OK;
-    }
+                       hipStream_t s, FbPin* out) {
   const int H = form->H, K = form->K;
-  FbTable t;
-  t.w = w;
-  t.nwin = nwin;
-  HIP_TRY(hipMalloc(&t.p, (size_t)nwin * ((size_t)1 << w) * 2 * H * K * sizeof(uint32_t)));
-  HIP_TRY(hipEventCreateWithFlags(&t.ready, hipEventDisableTiming));
-  pgpu::HenselFbBuildArgs b{};
-  b.ctx = hensel_pub_view(form, d.index);
-  b.base = (const uint64_t*)key->d_hs.d[(size_t)d.index];
-  b.base_words = 2 * key->n_words;
-  b.chunk_words = form->chunk_words;
-  b.nchunks = form->nchunks;
-  b.table = (uint32_t*)t.p;
-  b.nwin = nwin;
-  b.w = w;
-  const int ipw = 64 / (2 * H);
-  const unsigned blocks = (unsigned)((((size_t)nwin + ipw - 1) / ipw + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
-  if (!pgpu::launch_hensel_fb_build(H, K, b, blocks, s))
-    return fail(PGPU_ERR_UNSUPPORTED, "split-form fixed-base build kernel not compiled");
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(t.ready, s));
-  list.push_back(t);
-  *out = &list.back();
-  return PGPU_OK;
+  return fb_table_get(key, key->fbh, d, w, nwin, (size_t)2 * H * K * sizeof(uint32_t), s, out, [&](FbTable& t) -> int {
+    pgpu::HenselFbBuildArgs b{};
+    b.ctx = hensel_pub_view(form, d.index);
+    b.base = (const uint64_t*)key->d_hs.d[(size_t)d.index];
+    b.base_words = 2 * key->n_words;
+    b.chunk_words = form->chunk_words;
+    b.nchunks = form->nchunks;
+    b.table = (uint32_t*)t.p;
+    b.nwin = nwin;
+    b.w = w;
+    const int ipw = 64 / (2 * H);
+    const unsigned blocks = (unsigned)((((size_t)nwin + ipw - 1) / ipw + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
+    if (!pgpu::launch_hensel_fb_build(H, K, b, blocks, s))
+      return fail(PGPU_ERR_UNSUPPORTED, "split-form fixed-base build kernel not compiled");
+    return PGPU_OK;
+  });
 }
 
 int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_t m_stride, int m_words,
@@ -1020,11 +1212,14 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
     }
     // hs is a key constant: fixed-base windowing, no squarings (kernels.hpp: fb_encrypt_kernel)
     const GeoInfo& geo = key->nsq->geo;
+    const pgpu_pubkey::PubForm* sform = use_split_encrypt(key, m_words, count);
+    // the per-key / per-GPU table limits may narrow the window (fb_fit_window)
+    fbw = fb_fit_window(fbw, r_bits, sform ? (size_t)2 * sform->H * sform->K * sizeof(uint32_t) : (size_t)geo.L() * sizeof(uint32_t));
     const int nwin = std::max(1, (r_bits + fbw - 1) / fbw);
-    const FbTable* tab = nullptr;
+    FbPin tab;
     // split form (hensel.hpp): pairs modulo (n*k)^2; needs m < 2n to form the pair of 1 + n*m, i.e. plaintext rows
     // no wider than n, and a batch that fills the chip in 8-lane groups no worse than the full-width kernel does
-    if (const pgpu_pubkey::PubForm* form = use_split_encrypt(key, m_words, count)) {
+    if (const pgpu_pubkey::PubForm* form = sform) {
       RC_TRY(fb_table_for_split(key, form, d, fbw, nwin, s, &tab));
       pgpu::HenselFbArgs f{};
       f.ctx = hensel_pub_view(form, d.index);
@@ -1144,7 +1339,7 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
   const int nw = key->n_words;
   rt::StreamWork& w = d.work_for(s);
   std::lock_guard<std::mutex> lk(w.mu);   // the hand-over buffer is ours until both stages are queued
-  RC_TRY(w.vbuf.ensure(2 * count * (size_t)nw * 8));
+  RC_TRY(w.vbuf.ensure(2 * count * (size_t)nw * 8, s));
   const bool lat = use_latency_geo(key->geo_lat, key->geo_exp, 2 * count);
   const bool sliding = secret_policy() == PGPU_EXP_SLIDING && key->sched[0].dev.bytes;
   bool have_m = false;
@@ -1192,10 +1387,10 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
     h.count = count;
     const size_t waves = 2 * ((count + ipw - 1) / ipw);
     const unsigned blocks = (unsigned)((waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
-    RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * ipw * entries * 2 * L2 * sizeof(uint32_t)));
+    RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * ipw * entries * 2 * L2 * sizeof(uint32_t), s));
     h.table = (uint32_t*)w.table.p;
     TimerScope t(d, s, PGPU_KERNEL_MODEXP);
-    if (!pgpu::launch_hensel(hset->H, hset->K, waves > kSimds, h, blocks, s))
+    if (!pgpu::launch_hensel(hset->H, hset->K, waves > kSimds || g_packed_decrypt.load(), h, blocks, s))
       return fail(PGPU_ERR_UNSUPPORTED, "split-form kernel not compiled");
     HIP_TRY(hipGetLastError());
     t.stop();
@@ -1284,7 +1479,36 @@ int run_sharded(size_t count, size_t sub_min, F fn) {
 // the copies are < 5 % of the time); products and short exponents are copy-bound and pipeline in pieces
 constexpr size_t kSubMinHeavy = (size_t)1 << 17, kSubMinLight = (size_t)1 << 14;
 
+// objects of a pool that has been shut down are refused (their device images went with it)
+int check_gen(uint64_t gen, const char* what) {
+  if (gen != rt::pool_generation())
+    return fail(PGPU_ERR_INVALID_PARAM, std::string(what) + " was created under a device pool that has been shut down");
+  return PGPU_OK;
+}
+
 }  // namespace
+
+pgpu_pubkey::~pgpu_pubkey() {
+  std::lock_guard<std::mutex> lk(g_fb_mu);
+  g_fb_keys.erase(this);
+  const bool live = gen == rt::pool_generation();
+  for (auto* lists : {&fb, &fbh})
+    for (size_t d = 0; d < lists->size(); ++d) {
+      if ((*lists)[d].empty()) continue;
+      if (live && (int)d < rt::pool_size()) {
+        rt::DeviceGuard g(rt::device((int)d).ordinal);
+        for (FbTable& t : (*lists)[d]) {
+          if (d < g_fb_dev_bytes.size()) g_fb_dev_bytes[d] -= std::min(g_fb_dev_bytes[d], t.bytes);
+          fb_free_table(t);
+        }
+      } else {
+        for (FbTable& t : (*lists)[d]) {
+          fb_free_table(t);
+          (void)hipGetLastError();
+        }
+      }
+    }
+}
 
 extern "C" {
 
@@ -1320,10 +1544,18 @@ int pgpu_init_all(int n_devices) {
 
 void pgpu_shutdown(void) {
   if (!rt::initialized()) return;
+  // every cached device image was sized and placed for THIS pool: none may survive it (a later pgpu_init with
+  // another device set would index past its copies or read another GPU's memory)
+  (void)pgpu_synchronize();
   {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     g_ctx_cache.clear();
   }
+  {
+    std::lock_guard<std::mutex> lk(g_sq_mu);
+    g_sq_cache.clear();
+  }
+  drain_parked();
   rt::pool_shutdown();
 }
 
@@ -1347,6 +1579,7 @@ int pgpu_synchronize(void) {
     HIP_TRY(hipStreamSynchronize(d.bstream));
     for (auto& lane : d.lanes) HIP_TRY(hipStreamSynchronize(lane->stream));
   }
+  drain_parked();   // evicted per-modulus contexts (their hipFree waits for whatever still reads them)
   return PGPU_OK;
 }
 
@@ -1377,6 +1610,7 @@ int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, i
 
 int pgpu_encrypt_kernel_form(const pgpu_pubkey* key, int m_words, size_t count, int* split, int* lanes, int* limbs) {
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_encrypt_kernel_form: bad argument");
+  RC_TRY(check_gen(key->gen, "key"));
   const pgpu_pubkey::PubForm* ef = key->djn && fixed_base_window() > 0 ? use_split_encrypt(key, m_words, count) : nullptr;
   if (ef) {
     *split = 1;
@@ -1393,6 +1627,7 @@ int pgpu_encrypt_kernel_form(const pgpu_pubkey* key, int m_words, size_t count, 
 
 int pgpu_modexp_n2_kernel_form(const pgpu_pubkey* key, size_t count, int* split, int* lanes, int* limbs) {
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_modexp_n2_kernel_form: bad argument");
+  RC_TRY(check_gen(key->gen, "key"));
   if (const pgpu_pubkey::PubForm* mf = split_modexp_form(key, count)) {
     *split = 1;
     *lanes = 2 * mf->H;
@@ -1409,6 +1644,7 @@ int pgpu_modexp_n2_kernel_form(const pgpu_pubkey* key, size_t count, int* split,
 
 int pgpu_decrypt_kernel_form(const pgpu_privkey* key, size_t count, int* split, int* lanes, int* limbs) {
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_decrypt_kernel_form: bad argument");
+  RC_TRY(check_gen(key->gen, "key"));
   if (const pgpu_privkey::HenselSet* f = pick_hensel(key, count)) {
     *split = 1;
     *lanes = 2 * f->H;
@@ -1447,6 +1683,9 @@ void pgpu_debug_set_row_source(int mode) { g_row_source.store(mode < 0 ? -1 : (m
 // tests / A-B measurements: 0 = CRT decrypt through the full-width modexp_kernel, 1 = split form where compiled
 // (throughput or latency form by batch size), 2 / 3 = always its throughput / latency form
 void pgpu_debug_set_hensel(int mode) { g_hensel.store(mode < 0 ? 0 : (mode > 3 ? 3 : mode)); }
+// A/B measurements (bench.py two_streams): 1 = the two-wavefronts-per-SIMD build of the (2,19) decrypt kernel for
+// every launch.  Not part of the public header.
+void pgpu_debug_set_packed_decrypt(int on) { g_packed_decrypt.store(on != 0); }
 
 int pgpu_set_timing(int enabled) {
   g_timing.store(enabled != 0);
@@ -1711,6 +1950,7 @@ int pgpu_pubkey_create(const uint64_t* n, int n_words, const uint64_t* hs_or_nul
   RC_TRY(rt::check_ready());
   if (!n || n_words <= 0 || !out) return fail(PGPU_ERR_INVALID_PARAM, "null key material");
   std::unique_ptr<pgpu_pubkey> k(new pgpu_pubkey);
+  k->gen = rt::pool_generation();
   k->n_words = n_words;
   k->n = BigNumber::fromLimbs64(n, (size_t)n_words);
   if (!k->n.IsOdd()) return fail(PGPU_ERR_EVEN_MODULUS, "n must be odd");
@@ -1741,6 +1981,7 @@ int pgpu_paillier_encrypt_dev(const pgpu_pubkey* key, const uint64_t* d_m, size_
                               int r_bits, uint64_t* d_c, size_t count, void* hip_stream) {
   RC_TRY(rt::check_ready());
   if (!key) return fail(PGPU_ERR_INVALID_PARAM, "null key");
+  RC_TRY(check_gen(key->gen, "key"));
   if (count == 0) return PGPU_OK;
   if (!d_m || !d_r || !d_c) return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer");
   rt::Device& d = rt::current();
@@ -1759,6 +2000,7 @@ int pgpu_paillier_encrypt(const pgpu_pubkey* key, const uint64_t* m, size_t m_st
                           uint64_t* c, size_t count) {
   RC_TRY(rt::check_ready());
   if (!key) return fail(PGPU_ERR_INVALID_PARAM, "null key");
+  RC_TRY(check_gen(key->gen, "key"));
   if (count == 0) return PGPU_OK;
   if (!m || !r || !c) return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer");
   const int W = 2 * key->n_words;
@@ -1837,7 +2079,7 @@ int build_hensel_set(pgpu_privkey* k, pgpu_privkey::HenselSet* hs, int H, int K,
     hs->n0inv[sd] = n0inv;
   }
   const int rc = hs->blob.upload(h.data(), h.size() * sizeof(uint32_t), true);
-  std::fill(h.begin(), h.end(), 0u);
+  secure_wipe(h.data(), h.size() * sizeof(h[0]));
   return rc;
 }
 int build_hensel(pgpu_privkey* k, const BigNumber& p, const BigNumber& q, const BigNumber& hp, const BigNumber& hq) {
@@ -1867,6 +2109,7 @@ int pgpu_privkey_create(const uint64_t* p_in, const uint64_t* q_in, int pq_words
   if (!p.IsOdd() || !q.IsOdd() || p <= BigNumber::Two())
     return fail(PGPU_ERR_EVEN_MODULUS, "p and q must be odd primes");
   std::unique_ptr<pgpu_privkey> k(new pgpu_privkey);
+  k->gen = rt::pool_generation();
   const BigNumber n = p * q;
   const int nw = (n.BitSize() + 63) / 64;  // words of n; p^2, q^2 rows use the same width
   k->n_words = nw;
@@ -1921,7 +2164,7 @@ int pgpu_privkey_create(const uint64_t* p_in, const uint64_t* q_in, int pq_words
   pm1.toLimbs64(exps.data(), pq_words);
   qm1.toLimbs64(exps.data() + pq_words, pq_words);
   RC_TRY(k->d_exps.upload(exps.data(), exps.size() * 8, true));
-  std::fill(exps.begin(), exps.end(), 0);
+  secure_wipe(exps.data(), exps.size() * sizeof(exps[0]));
   k->exp_bits = std::max(pm1.BitSize(), qm1.BitSize());
   {
     const int sw = pick_sliding_window(k->exp_bits);
@@ -1957,7 +2200,7 @@ int pgpu_privkey_create(const uint64_t* p_in, const uint64_t* q_in, int pq_words
   to_limbs29((pinv_q * Rc) % q, Lc, c32.data() + 2 * Lc);
   to_limbs29((p * Rc) % M, Lc, c32.data() + 3 * Lc);
   RC_TRY(k->d_crt32.upload(c32.data(), c32.size() * 4, true));
-  std::fill(c32.begin(), c32.end(), 0u);
+  secure_wipe(c32.data(), c32.size() * sizeof(c32[0]));
   const int pad = gc->w64() + 1;  // rows padded so word helpers can run over W64 words
   std::vector<uint64_t> c64((size_t)5 * pad, 0);
   hp.toLimbs64(c64.data(), pad);
@@ -1966,7 +2209,7 @@ int pgpu_privkey_create(const uint64_t* p_in, const uint64_t* q_in, int pq_words
   qsq.toLimbs64(c64.data() + 3 * pad, pad);
   q.toLimbs64(c64.data() + 4 * pad, pad);
   RC_TRY(k->d_crt64.upload(c64.data(), c64.size() * 8, true));
-  std::fill(c64.begin(), c64.end(), 0);
+  secure_wipe(c64.data(), c64.size() * sizeof(c64[0]));
   *out = k.release();
   return PGPU_OK;
 }
@@ -1977,6 +2220,7 @@ int pgpu_paillier_decrypt_crt_dev(const pgpu_privkey* key, const uint64_t* d_c, 
                                   size_t count, void* hip_stream) {
   RC_TRY(rt::check_ready());
   if (!key) return fail(PGPU_ERR_INVALID_PARAM, "null key");
+  RC_TRY(check_gen(key->gen, "key"));
   if (count == 0) return PGPU_OK;
   if (!d_c || !d_m) return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer");
   rt::Device& d = rt::current();
@@ -1988,6 +2232,7 @@ int pgpu_paillier_decrypt_crt(const pgpu_privkey* key, const uint64_t* c, uint64
                               size_t count) {
   RC_TRY(rt::check_ready());
   if (!key) return fail(PGPU_ERR_INVALID_PARAM, "null key");
+  RC_TRY(check_gen(key->gen, "key"));
   if (count == 0) return PGPU_OK;
   if (!c || !m) return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer");
   const int nw = key->n_words;
@@ -2054,6 +2299,7 @@ int pgpu_batch_upload(const uint64_t* host, size_t count, int words, size_t stri
 int pgpu_batch_download(const pgpu_batch* b, uint64_t* host) {
   RC_TRY(rt::check_ready());
   if (!b || !host) return fail(PGPU_ERR_INVALID_PARAM, "null pointer");
+  RC_TRY(check_gen(b->gen, "batch"));
   rt::TaskGroup tg;
   const int nd = b->replicated ? 1 : b->ndev;
   for (int d = 0; d < nd; ++d) {
@@ -2077,6 +2323,9 @@ int pgpu_batch_encrypt(const pgpu_pubkey* key, const pgpu_batch* m, const pgpu_b
                        pgpu_batch** c) {
   RC_TRY(rt::check_ready());
   if (!key || !m || !r || !c) return fail(PGPU_ERR_INVALID_PARAM, "null argument");
+  RC_TRY(check_gen(key->gen, "key"));
+  RC_TRY(check_gen(m->gen, "batch"));
+  RC_TRY(check_gen(r->gen, "batch"));
   if (m->count != r->count) return fail(PGPU_ERR_INVALID_PARAM, "modExp: input vector size error");
   if (m->mont || r->mont) return fail(PGPU_ERR_INVALID_PARAM, "encrypt: operands must be plain batches");
   RC_TRY(same_layout(m, r));
@@ -2102,6 +2351,8 @@ int pgpu_batch_encrypt(const pgpu_pubkey* key, const pgpu_batch* m, const pgpu_b
 int pgpu_batch_decrypt_crt(const pgpu_privkey* key, const pgpu_batch* c, pgpu_batch** m) {
   RC_TRY(rt::check_ready());
   if (!key || !c || !m) return fail(PGPU_ERR_INVALID_PARAM, "null argument");
+  RC_TRY(check_gen(key->gen, "key"));
+  RC_TRY(check_gen(c->gen, "batch"));
   if (c->words != 2 * key->n_words) return fail(PGPU_ERR_INVALID_PARAM, "decrypt: ciphertext width mismatch");
   if (c->mont && c->mont->geo.rbits() != key->nsq_rbits)
     return fail(PGPU_ERR_INVALID_PARAM, "decrypt: ciphertext batch belongs to a different key size");
@@ -2137,6 +2388,9 @@ static int to_montgomery(const pgpu_pubkey* key, const pgpu_batch* a, std::uniqu
 int pgpu_batch_ct_add(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_batch* b, pgpu_batch** out) {
   RC_TRY(rt::check_ready());
   if (!key || !a || !b || !out) return fail(PGPU_ERR_INVALID_PARAM, "null argument");
+  RC_TRY(check_gen(key->gen, "key"));
+  RC_TRY(check_gen(a->gen, "batch"));
+  RC_TRY(check_gen(b->gen, "batch"));
   const int W = 2 * key->n_words;
   if (a->words != W || b->words != W) return fail(PGPU_ERR_INVALID_PARAM, "CT + CT error: width mismatch");
   if (b->count != a->count && b->count != 1) return fail(PGPU_ERR_INVALID_PARAM, "CT + CT error: Size mismatch!");
@@ -2172,6 +2426,9 @@ int pgpu_batch_ct_add(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_ba
 int pgpu_batch_ct_add_plain(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_batch* m, pgpu_batch** out) {
   RC_TRY(rt::check_ready());
   if (!key || !a || !m || !out) return fail(PGPU_ERR_INVALID_PARAM, "null argument");
+  RC_TRY(check_gen(key->gen, "key"));
+  RC_TRY(check_gen(a->gen, "batch"));
+  RC_TRY(check_gen(m->gen, "batch"));
   const int W = 2 * key->n_words;
   if (a->words != W || m->words > W) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: width mismatch");
   if (m->count != a->count && m->count != 1) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: Size mismatch!");
@@ -2198,6 +2455,9 @@ int pgpu_batch_ct_mul(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_ba
                       pgpu_batch** out) {
   RC_TRY(rt::check_ready());
   if (!key || !a || !e || !out) return fail(PGPU_ERR_INVALID_PARAM, "null argument");
+  RC_TRY(check_gen(key->gen, "key"));
+  RC_TRY(check_gen(a->gen, "batch"));
+  RC_TRY(check_gen(e->gen, "batch"));
   const int W = 2 * key->n_words;
   if (a->words != W) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: width mismatch");
   if (e->count != a->count && e->count != 1) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: Size mismatch!");
@@ -2227,6 +2487,58 @@ int pgpu_batch_ct_mul(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_ba
                      nullptr, a->mont != nullptr, true, key->nsq));
   }
   *out = o.release();
+  return PGPU_OK;
+}
+
+// ---- diagnostics of the pool's self-checks and table budget ----
+int pgpu_replication_stats(uint64_t* images_verified, uint64_t* copies_repaired) {
+  rt::replication_stats(images_verified, copies_repaired);
+  return PGPU_OK;
+}
+const char* pgpu_rccl_note(void) {
+  static thread_local std::string note;
+  note = rt::rccl_note();
+  return note.c_str();
+}
+int pgpu_debug_corrupt_next_replica(int pool_index) {
+  RC_TRY(rt::check_ready());
+  if (pool_index < 0 || pool_index >= rt::pool_size()) return fail(PGPU_ERR_INVALID_PARAM, "pool index out of range");
+  rt::debug_corrupt_next_replica(pool_index);
+  return PGPU_OK;
+}
+int pgpu_set_fixed_base_budget(size_t max_bytes_per_device, size_t max_bytes_per_key) {
+  if (max_bytes_per_device) g_fb_dev_max.store(max_bytes_per_device);
+  if (max_bytes_per_key) g_fb_key_max.store(max_bytes_per_key);
+  return PGPU_OK;
+}
+int pgpu_fixed_base_stats(int pool_index, size_t* live_bytes, uint64_t* evictions) {
+  std::lock_guard<std::mutex> lk(g_fb_mu);
+  if (live_bytes) *live_bytes = (pool_index >= 0 && (size_t)pool_index < g_fb_dev_bytes.size()) ? g_fb_dev_bytes[(size_t)pool_index] : 0;
+  if (evictions) *evictions = g_fb_evictions.load();
+  return PGPU_OK;
+}
+int pgpu_pubkey_fixed_base_info(const pgpu_pubkey* key, int pool_index, int* window, size_t* bytes, double* build_ms) {
+  if (!key) return fail(PGPU_ERR_INVALID_PARAM, "null key");
+  std::lock_guard<std::mutex> lk(g_fb_mu);
+  int w = 0;
+  size_t b = 0;
+  double ms = 0;
+  for (auto* lists : {&key->fb, &key->fbh}) {
+    if (pool_index < 0 || (size_t)pool_index >= lists->size()) continue;
+    for (FbTable& t : (*lists)[(size_t)pool_index])
+      if (t.w >= w) {
+        w = t.w;
+        b = t.bytes;
+        if (t.build_ms == 0 && t.t0 && t.ready && hipEventQuery(t.ready) == hipSuccess) {
+          float f = 0;
+          if (hipEventElapsedTime(&f, t.t0, t.ready) == hipSuccess) t.build_ms = f;
+        }
+        ms = t.build_ms;
+      }
+  }
+  if (window) *window = w;
+  if (bytes) *bytes = b;
+  if (build_ms) *build_ms = ms;
   return PGPU_OK;
 }
 

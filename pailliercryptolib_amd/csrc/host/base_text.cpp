@@ -22,7 +22,7 @@ BaseText::BaseText(std::shared_ptr<detail::DeviceBatch> dev)
 // a text may be copied while another thread materialises its host values (const accessors download lazily)
 BaseText::BaseText(const BaseText& o) {
   std::lock_guard<std::mutex> lk(g_materialise_mu);
-  m_texts = o.m_texts;
+  m_texts = detail::copy_texts(o.m_texts);
   m_size = o.m_size;
   m_dev = o.m_dev;
   m_host_valid = (bool)o.m_host_valid;
@@ -31,7 +31,7 @@ BaseText::BaseText(const BaseText& o) {
 BaseText& BaseText::operator=(const BaseText& o) {
   if (this == &o) return *this;
   std::lock_guard<std::mutex> lk(g_materialise_mu);
-  m_texts = o.m_texts;
+  m_texts = detail::copy_texts(o.m_texts);
   m_size = o.m_size;
   m_dev = o.m_dev;
   m_host_valid = (bool)o.m_host_valid;
@@ -62,20 +62,23 @@ std::shared_ptr<detail::DeviceBatch> BaseText::deviceBatch(int words, const BigN
     if (m_dev && m_dev->words == words) return m_dev;
   }
   ensureHost();
-  bool fits = true;
-  for (const auto& x : m_texts)
-    if (x.isNegative() || x.limbs64().size() > (size_t)words) { fits = false; break; }
-  if (fits) {
+  if (detail::all_fit(m_texts, words)) {
     auto b = detail::DeviceBatch::upload(detail::pack(m_texts, words), m_size, words);
     std::lock_guard<std::mutex> lk(g_materialise_mu);
     m_dev = b;   // the device copy mirrors m_texts exactly: cache it
     return b;
   }
   ERROR_CHECK(reduce_mod != nullptr, "BaseText: value does not fit the device batch width");
-  std::vector<BigNumber> red(m_texts);
-  for (auto& x : red)
-    if (x.isNegative() || x.limbs64().size() > (size_t)words) x = x % *reduce_mod;
-  return detail::DeviceBatch::upload(detail::pack(red, words), m_size, words);  // not cached
+  // a reduced value (negative: the non-negative residue, as IPP's mod gives the reference) may be as wide as the
+  // modulus, whatever width the caller derived from the magnitudes: widen the batch rather than fail in pack()
+  const int rw = std::max(words, detail::words_for_bits(reduce_mod->BitSize()));
+  std::vector<BigNumber> red = detail::copy_texts(m_texts);
+  const BigNumber& mod = *reduce_mod;
+  detail::parallel_for(red.size(), 64, [&](std::size_t i) {
+    BigNumber& x = red[i];
+    if (x.isNegative() || x.limbs64().size() > (size_t)words) x = x % mod;
+  });
+  return detail::DeviceBatch::upload(detail::pack(red, rw), m_size, rw);  // not cached
 }
 
 BaseText::BaseText(const uint32_t& n) : m_texts(1, BigNumber((Ipp32u)n)), m_size(1) {}
@@ -88,7 +91,7 @@ BaseText::BaseText(const std::vector<uint32_t>& n_v) {
 
 BaseText::BaseText(const BigNumber& bn) : m_texts(1, bn), m_size(1) {}
 
-BaseText::BaseText(const std::vector<BigNumber>& bn_v) : m_texts(bn_v), m_size(bn_v.size()) {}
+BaseText::BaseText(const std::vector<BigNumber>& bn_v) : m_texts(detail::copy_texts(bn_v)), m_size(bn_v.size()) {}
 
 BigNumber& BaseText::operator[](const std::size_t idx) {
   ERROR_CHECK(idx < m_size, "BaseText:operator[] index is out of range");
@@ -178,9 +181,19 @@ void PlainText::load(serializer::InputArchive& ar) {
   BaseText::load(ar);
 }
 
-std::vector<BigNumber> BaseText::getTexts() const {
+std::vector<BigNumber> BaseText::getTexts() const& {
   ensureHost();
-  return m_texts;
+  return detail::copy_texts(m_texts);
+}
+// on a temporary (`pk.encrypt(pt).getTexts()`): hand the values over instead of copying them a second time
+std::vector<BigNumber> BaseText::getTexts() && {
+  ensureHost();
+  std::lock_guard<std::mutex> lk(g_materialise_mu);
+  std::vector<BigNumber> out = std::move(m_texts);
+  m_texts.clear();
+  if (m_dev) m_host_valid = false;   // the device copy is still there: a later accessor downloads again
+  else m_size = 0;
+  return out;
 }
 std::size_t BaseText::getSize() const { return m_size; }
 

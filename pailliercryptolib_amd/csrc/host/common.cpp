@@ -2,13 +2,20 @@
 // the RDSEED / RDRAND / IPP-PRNG chain.  Randomness never reaches the GPU path except as data.
 #include "ipcl/utils/common.hpp"
 
+#include <sched.h>
 #include <sys/random.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
+#include <condition_variable>
 #include <cstddef>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <random>
+#include <thread>
 
 #include "chacha20.hpp"
 #include "detail.hpp"
@@ -53,8 +60,7 @@ void fill_random(void* dst, std::size_t n) {
   unsigned char seed[44];
   os_random(seed, sizeof(seed));
   chacha20_stream(seed, seed + 32, 0, static_cast<unsigned char*>(dst), n);
-  volatile unsigned char* w = seed;
-  for (std::size_t i = 0; i < sizeof(seed); ++i) w[i] = 0;
+  wipe(seed, sizeof(seed));
 }
 }  // namespace detail
 
@@ -70,32 +76,200 @@ BigNumber getRandomBN(int bits) {
 
 namespace detail {
 
-// BigNumber <-> flat limb arrays.  Deliberately serial: an OpenMP team was measured SLOWER here (fork/join of a
-// sleeping team costs more than the ~0.3 ms a conversion of 8192 elements takes, and OpenMP's default team of one
-// thread per visible CPU turns each region into hundreds of milliseconds on a 256-thread host under a 16-core quota).
+// ---- host thread budget (detail.hpp) ----
+namespace {
+int compute_thread_budget() {
+  int n = 1;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::max(1, CPU_COUNT(&set));
+  // cgroup v2 / v1 CPU quota: a container that sees 256 CPUs may own 16 of them
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char quota[32] = {0};
+    long period = 0;
+    if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && period > 0 && std::strcmp(quota, "max") != 0) {
+      const long q = std::atol(quota);
+      if (q > 0) n = std::min<long>(n, std::max<long>(1, (q + period - 1) / period));
+    }
+    std::fclose(f);
+  } else {
+    long q = -1, period = -1;
+    if (FILE* fq = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+      if (std::fscanf(fq, "%ld", &q) != 1) q = -1;
+      std::fclose(fq);
+    }
+    if (FILE* fp = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (std::fscanf(fp, "%ld", &period) != 1) period = -1;
+      std::fclose(fp);
+    }
+    if (q > 0 && period > 0) n = std::min<long>(n, std::max<long>(1, (q + period - 1) / period));
+  }
+  n = std::min(n, 16);
+  for (const char* var : {"IPCL_NUM_THREADS", "OMP_NUM_THREADS"}) {
+    const char* e = std::getenv(var);
+    if (e && std::atoi(e) > 0) {
+      n = std::min(n, std::atoi(e));
+      break;
+    }
+  }
+  return std::max(1, n);
+}
+}  // namespace
+
+int max_host_threads() {
+  static const int budget = compute_thread_budget();
+  return budget;
+}
+
+int threads_for(std::size_t n, std::size_t grain) {
+  const std::size_t by_work = n / std::max<std::size_t>(grain, 1);
+  return (int)std::max<std::size_t>(1, std::min<std::size_t>((std::size_t)max_host_threads(), by_work));
+}
+
+namespace {
+// The sleeping team: max_host_threads() - 1 workers, started on first use, parked on a condition variable.
+// One loop at a time owns the team (try_lock: a second concurrent loop runs serially on its caller).
+class Team {
+ public:
+  static Team& get() {
+    static Team* t = new Team;   // intentionally leaked: workers may outlive static destruction order
+    return *t;
+  }
+  bool run(std::size_t n, std::size_t chunk, int threads, const std::function<void(std::size_t, std::size_t)>& body) {
+    std::unique_lock<std::mutex> owner(owner_mu_, std::try_to_lock);
+    if (!owner.owns_lock()) return false;
+    ensure_workers(threads - 1);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      body_ = &body;
+      n_ = n;
+      chunk_ = chunk;
+      next_.store(0, std::memory_order_relaxed);
+      active_ = std::min<int>(threads - 1, (int)workers_.size());
+      pending_ = active_;
+      ++generation_;
+    }
+    cv_.notify_all();
+    work();   // the caller is a member of the team
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [this] { return pending_ == 0; });
+    body_ = nullptr;
+    return true;
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      const std::size_t lo = next_.fetch_add(chunk_, std::memory_order_relaxed);
+      if (lo >= n_) return;
+      (*body_)(lo, std::min(n_, lo + chunk_));
+    }
+  }
+  void ensure_workers(int want) {
+    // (called by the owner of the team before it publishes a new generation: a new worker starts out having
+    // "seen" the current one, so it neither replays a finished loop nor misses the next)
+    uint64_t now;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      now = generation_;
+    }
+    while ((int)workers_.size() < want) {
+      const int id = (int)workers_.size();
+      workers_.emplace_back([this, id, now] { loop(id, now); });
+      workers_.back().detach();
+    }
+  }
+  void loop(int id, uint64_t seen) {
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (id >= active_) continue;   // not part of this loop's team
+      }
+      work();
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--pending_ == 0) done_cv_.notify_one();
+    }
+  }
+  std::mutex owner_mu_, mu_;
+  std::condition_variable cv_, done_cv_;
+  std::vector<std::thread> workers_;
+  const std::function<void(std::size_t, std::size_t)>* body_ = nullptr;
+  std::size_t n_ = 0, chunk_ = 1;
+  std::atomic<std::size_t> next_{0};
+  int active_ = 0, pending_ = 0;
+  uint64_t generation_ = 0;
+};
+thread_local bool t_in_team_loop = false;
+}  // namespace
+
+void parallel_chunks(std::size_t n, std::size_t grain, const std::function<void(std::size_t, std::size_t)>& body) {
+  const int t = threads_for(n, grain);
+  if (t > 1 && !t_in_team_loop) {
+    // chunks of at least `grain` elements, about four per thread (dynamic hand-out evens out uneven elements)
+    const std::size_t chunk = std::max<std::size_t>(grain, (n + 4 * (std::size_t)t - 1) / (4 * (std::size_t)t));
+    t_in_team_loop = true;
+    const bool ran = Team::get().run(n, chunk, t, body);
+    t_in_team_loop = false;
+    if (ran) return;
+  }
+  body(0, n);
+}
+
+void wipe(void* p, std::size_t bytes) {
+  volatile unsigned char* w = static_cast<volatile unsigned char*>(p);
+  for (std::size_t i = 0; i < bytes; ++i) w[i] = 0;
+}
+
+// BigNumber <-> flat limb arrays: per-element loops on the sleeping team (detail.hpp).
+constexpr std::size_t kGrain = 512;   // elements per thread below which a team is not worth waking
 
 int max_bits(const std::vector<BigNumber>& v) {
-  int b = 0;
-  const std::ptrdiff_t n = (std::ptrdiff_t)v.size();
-  for (std::ptrdiff_t i = 0; i < n; ++i) b = std::max(b, v[(size_t)i].isZero() ? 0 : v[(size_t)i].BitSize());
-  return b;
+  std::atomic<int> best{0};
+  parallel_chunks(v.size(), 8 * kGrain, [&](std::size_t lo, std::size_t hi) {
+    int b = 0;
+    for (std::size_t i = lo; i < hi; ++i) b = std::max(b, v[i].isZero() ? 0 : v[i].BitSize());
+    int cur = best.load(std::memory_order_relaxed);
+    while (b > cur && !best.compare_exchange_weak(cur, b, std::memory_order_relaxed)) {}
+  });
+  return best.load();
+}
+
+bool all_fit(const std::vector<BigNumber>& v, int words) {
+  std::atomic<bool> bad{false};
+  parallel_chunks(v.size(), 8 * kGrain, [&](std::size_t lo, std::size_t hi) {
+    for (std::size_t i = lo; i < hi; ++i)
+      if (v[i].isNegative() || v[i].limbs64().size() > (size_t)words) {
+        bad.store(true, std::memory_order_relaxed);
+        return;
+      }
+  });
+  return !bad.load();
+}
+
+std::vector<BigNumber> copy_texts(const std::vector<BigNumber>& v) {
+  if (threads_for(v.size(), kGrain) <= 1) return v;
+  std::vector<BigNumber> out(v.size());
+  parallel_for(v.size(), kGrain, [&](std::size_t i) { out[i] = v[i]; });
+  return out;
 }
 
 std::vector<uint64_t> pack(const std::vector<BigNumber>& v, int words) {
   std::vector<uint64_t> flat(v.size() * (size_t)words);
-  const std::ptrdiff_t n = (std::ptrdiff_t)v.size();
-  bool fits = true;
-  for (std::ptrdiff_t i = 0; i < n; ++i)
-    fits = fits && v[(size_t)i].toLimbs64(flat.data() + (size_t)i * (size_t)words, (size_t)words);
-  ERROR_CHECK(fits, "pack: value wider than the batch stride");
+  std::atomic<bool> fits{true};
+  parallel_for(v.size(), kGrain, [&](std::size_t i) {
+    if (!v[i].toLimbs64(flat.data() + i * (size_t)words, (size_t)words)) fits.store(false, std::memory_order_relaxed);
+  });
+  ERROR_CHECK(fits.load(), "pack: value wider than the batch stride");
   return flat;
 }
 
 std::vector<BigNumber> unpack(const std::vector<uint64_t>& flat, std::size_t count, int words) {
   std::vector<BigNumber> v(count);
-  const std::ptrdiff_t n = (std::ptrdiff_t)count;
-  for (std::ptrdiff_t i = 0; i < n; ++i)
-    v[(size_t)i] = BigNumber::fromLimbs64(flat.data() + (size_t)i * (size_t)words, (size_t)words);
+  parallel_for(count, kGrain, [&](std::size_t i) {
+    v[i] = BigNumber::fromLimbs64(flat.data() + i * (size_t)words, (size_t)words);
+  });
   return v;
 }
 

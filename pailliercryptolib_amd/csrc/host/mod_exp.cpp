@@ -35,27 +35,31 @@ void modexp_shared_mod(const std::vector<BigNumber>& base, const std::vector<Big
   ERROR_CHECK(!mod.isNegative() && !mod.isZero(), "modExp: modulus must be positive");
   const int mw = detail::words_for_bits(mod.BitSize());
   int ebits = 0;
+  bool neg_exp = false;
   for (size_t i : idx) {
-    ERROR_CHECK(!exp[i].isNegative(), "modExp: negative exponent");
+    neg_exp = neg_exp || exp[i].isNegative();
     ebits = std::max(ebits, exp[i].isZero() ? 0 : exp[i].BitSize());
   }
+  ERROR_CHECK(!neg_exp, "modExp: negative exponent");
   const int ew = detail::words_for_bits(ebits);
   std::vector<uint64_t> fb(idx.size() * (size_t)mw), fe(idx.size() * (size_t)ew), fm((size_t)mw),
       fo(idx.size() * (size_t)mw);
   mod.toLimbs64(fm.data(), (size_t)mw);
-  for (size_t k = 0; k < idx.size(); ++k) {
+  // per-element marshalling on the host team (the reference's chunk loop runs under OpenMP: mod_exp.cpp:607-612)
+  detail::parallel_for(idx.size(), 512, [&](size_t k) {
     const BigNumber& b = base[idx[k]];
     // the engine reduces any base that fits the modulus width; wider / negative ones first go
     // through the host (callers of the reference guarantee base < mod)
     if (b.isNegative() || b.limbs64().size() > (size_t)mw) (b % mod).toLimbs64(fb.data() + k * (size_t)mw, (size_t)mw);
     else b.toLimbs64(fb.data() + k * (size_t)mw, (size_t)mw);
     exp[idx[k]].toLimbs64(fe.data() + k * (size_t)ew, (size_t)ew);
-  }
+  });
   IPCL_GPU_CHECK(pgpu_modexp(fb.data(), (size_t)mw, fe.data(), (size_t)ew, ew, ebits, fm.data(), mw,
                              fo.data(), idx.size()),
                  "modExp");
-  for (size_t k = 0; k < idx.size(); ++k)
+  detail::parallel_for(idx.size(), 512, [&](size_t k) {
     out[idx[k]] = BigNumber::fromLimbs64(fo.data() + k * (size_t)mw, (size_t)mw);
+  });
 }
 
 }  // namespace
@@ -107,10 +111,10 @@ std::vector<BigNumber> modMul(const std::vector<BigNumber>& a, const std::vector
   const int mw = detail::words_for_bits(mod.BitSize());
   auto reduce_fit = [&](const std::vector<BigNumber>& v) {
     std::vector<uint64_t> flat(v.size() * (size_t)mw);
-    for (size_t i = 0; i < v.size(); ++i) {
+    detail::parallel_for(v.size(), 512, [&](size_t i) {   // (reference ciphertext.cpp:53-68: OpenMP per element)
       if (v[i].isNegative() || v[i].limbs64().size() > (size_t)mw) (v[i] % mod).toLimbs64(flat.data() + i * (size_t)mw, (size_t)mw);
       else v[i].toLimbs64(flat.data() + i * (size_t)mw, (size_t)mw);
-    }
+    });
     return flat;
   };
   std::vector<uint64_t> fa = reduce_fit(a), fb = reduce_fit(b), fm((size_t)mw), fo(a.size() * (size_t)mw);

@@ -113,7 +113,8 @@ void PrivateKey::decryptRAW(std::vector<BigNumber>& plaintext, const std::vector
   const std::size_t sz = ciphertext.size();
   std::vector<BigNumber> res = modExp(ciphertext, std::vector<BigNumber>(sz, m_lambda),
                                       std::vector<BigNumber>(sz, *m_nsquare));
-  for (std::size_t i = 0; i < sz; ++i) plaintext[i] = (computeLfun(res[i], *m_n) * m_x) % *m_n;
+  // L function and * x on the host team (reference pri_key.cpp:104-110, under OpenMP there as well)
+  detail::parallel_for(sz, 32, [&](std::size_t i) { plaintext[i] = (computeLfun(res[i], *m_n) * m_x) % *m_n; });
 }
 
 // host-vector variant of the CRT path (kept for the private interface of the reference class)

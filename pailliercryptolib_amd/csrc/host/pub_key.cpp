@@ -16,7 +16,7 @@ namespace ipcl {
 
 PublicKey::PublicKey(const BigNumber& n, int bits, bool enableDJN_) { create(n, bits, enableDJN_); }
 
-void PublicKey::create(const BigNumber& n, int bits, bool enableDJN_) {
+void PublicKey::setFields(const BigNumber& n, int bits) {
   m_n = std::make_shared<BigNumber>(n);
   m_g = std::make_shared<BigNumber>(n + 1);
   m_nsquare = std::make_shared<BigNumber>(n * n);
@@ -26,19 +26,25 @@ void PublicKey::create(const BigNumber& n, int bits, bool enableDJN_) {
   m_hs = BigNumber::Zero();
   m_randbits = 0;
   m_testv = false;
-  m_r.clear();
+  m_r.reset();
   m_dev.reset();
-  if (enableDJN_) enableDJN();
+}
+
+void PublicKey::create(const BigNumber& n, int bits, bool enableDJN_) {
+  setFields(n, bits);
+  if (enableDJN_) enableDJN();   // (draws hs, then builds the device key)
   else rebuildDevice();
   m_isInitialized = true;
 }
 
+// (the path PublicKey::load takes for DJN keys: fields first, ONE device-key build)
 void PublicKey::create(const BigNumber& n, int bits, const BigNumber& hs, int randbits) {
-  create(n, bits, false);
+  setFields(n, bits);
   m_enable_DJN = true;
   m_hs = hs;
   m_randbits = randbits;
   rebuildDevice();
+  m_isInitialized = true;
 }
 
 // hs = (-x^2 mod n)^n mod n^2 for a random x coprime to n (reference pub_key.cpp:29-49)
@@ -65,7 +71,10 @@ void PublicKey::setDJN(const BigNumber& hs, int randbit) {
 }
 
 void PublicKey::setRandom(const std::vector<BigNumber>& r) {
-  m_r.insert(m_r.end(), r.begin(), r.end());
+  auto all = std::make_shared<std::vector<BigNumber>>();
+  if (m_r) *all = *m_r;
+  all->insert(all->end(), r.begin(), r.end());   // appends, like pub_key.cpp:92-95
+  m_r = std::move(all);
   m_testv = true;
 }
 
@@ -101,7 +110,7 @@ std::shared_ptr<detail::PubKeyDevice> PublicKey::device() const {
 // the per-element randomness: injected (setRandom) or drawn on the host like the reference
 // (DJN: randbits random bits, pub_key.cpp:59-61; otherwise uniform in [1, n-1], pub_key.cpp:74-76)
 std::vector<BigNumber> PublicKey::drawRandom(std::size_t sz) const {
-  if (m_testv) return m_r;  // used as is: size is checked by the caller like ippMBModExp does
+  if (m_testv) return m_r ? *m_r : std::vector<BigNumber>();  // used as is: size is checked by the caller like ippMBModExp does
   std::vector<BigNumber> r(sz);
   // one bulk read of the kernel CSPRNG for the whole batch
   const int bits = m_enable_DJN ? m_randbits : m_bits;
@@ -111,14 +120,13 @@ std::vector<BigNumber> PublicKey::drawRandom(std::size_t sz) const {
   detail::fill_random(pool.data(), pool.size() * sizeof(Ipp32u));
   const BigNumber nm1 = *m_n - 1;
   const bool djn = m_enable_DJN;
-  const std::ptrdiff_t n = (std::ptrdiff_t)sz;
-  for (std::ptrdiff_t i = 0; i < n; ++i) {
-    Ipp32u* w = pool.data() + (std::size_t)i * w32;
+  detail::parallel_for(sz, 256, [&](std::size_t i) {
+    Ipp32u* w = pool.data() + i * w32;
     if (bits % 32) w[w32 - 1] &= (1u << (bits % 32)) - 1;
     BigNumber x(w, (int)w32);
-    r[(std::size_t)i] = djn ? x : x % nm1 + 1;
-  }
-  std::fill(pool.begin(), pool.end(), 0u);
+    r[i] = djn ? x : x % nm1 + 1;
+  });
+  detail::wipe(pool.data(), pool.size() * sizeof(Ipp32u));
   return r;
 }
 
@@ -128,7 +136,7 @@ std::vector<BigNumber> PublicKey::raw_encrypt(const std::vector<BigNumber>& pt, 
   const BigNumber& n = *m_n;
   const BigNumber& nsq = *m_nsquare;
   std::vector<BigNumber> ct(pt.size());
-  for (std::size_t i = 0; i < pt.size(); ++i) ct[i] = (n * pt[i] + 1) % nsq;
+  detail::parallel_for(pt.size(), 64, [&](std::size_t i) { ct[i] = (n * pt[i] + 1) % nsq; });   // pub_key.cpp:105
   return ct;
 }
 
@@ -192,23 +200,38 @@ CipherText PublicKey::encrypt(const PlainText& pt, bool make_secure) const {
       for (std::size_t i = 0; i < sz; ++i) flat[i * (std::size_t)rw + (std::size_t)rw - 1] &= top;
     }
     auto dr = detail::DeviceBatch::upload(flat, sz, rw);
-    volatile uint64_t* wipe = flat.data();
-    for (std::size_t i = 0; i < flat.size(); ++i) wipe[i] = 0;
+    detail::wipe(flat.data(), flat.size() * sizeof(uint64_t));
     pgpu_batch* c = nullptr;
     IPCL_GPU_CHECK(pgpu_batch_encrypt(dev->h, dm->h, dr->h, m_randbits, &c), "encrypt");
     return CipherText(*this, detail::DeviceBatch::adopt(c));
   }
-  std::vector<BigNumber> r = drawRandom(sz);
-  ERROR_CHECK(r.size() == sz, "ippMBModExp: input vector size error");  // reference mod_exp.cpp:452-454
-  for (auto& x : r) ERROR_CHECK(!x.isNegative(), "encrypt: negative random value");
-  auto dev = device();
+  // injected randomness (setRandom) is read in place, without a copy of the batch
+  std::vector<BigNumber> drawn;
+  if (!m_testv) drawn = drawRandom(sz);
+  static const std::vector<BigNumber> kNone;
+  const std::vector<BigNumber>* rp = m_testv ? (m_r ? m_r.get() : &kNone) : &drawn;
+  ERROR_CHECK(rp->size() == sz, "ippMBModExp: input vector size error");  // reference mod_exp.cpp:452-454
+  std::vector<BigNumber> reduced;   // non-DJN bases wider than n^2, reduced copies
   const int nw = detail::words_for_bits(m_n->BitSize());
+  {
+    bool neg = false, wide = false;
+    for (const auto& x : *rp) {
+      neg = neg || x.isNegative();
+      wide = wide || (!m_enable_DJN && x.BitSize() > 64 * 2 * nw);
+    }
+    ERROR_CHECK(!neg, "encrypt: negative random value");
+    if (wide) {
+      reduced = *rp;
+      for (auto& x : reduced)
+        if (x.BitSize() > 64 * 2 * nw) x = x % *m_nsquare;  // base wider than n^2
+      rp = &reduced;
+    }
+  }
+  const std::vector<BigNumber>& r = *rp;
+  auto dev = device();
   // (n*m+1) % n^2 only depends on m mod n: reduce plaintexts that are negative or wider than n^2
   const int mw = pt.isDeviceResident() ? 0 : std::min(2 * nw, detail::words_for_bits(pt.maxBitsHint()));
   std::shared_ptr<detail::DeviceBatch> dm = pt.isDeviceResident() ? pt.m_dev : pt.deviceBatch(mw, m_n.get());
-  if (!m_enable_DJN)
-    for (auto& x : r)
-      if (x.BitSize() > 64 * 2 * nw) x = x % *m_nsquare;  // base wider than n^2
   const int rbits = detail::max_bits(r);
   const int rw = detail::words_for_bits(rbits);
   auto dr = detail::DeviceBatch::upload(detail::pack(r, rw), sz, rw);

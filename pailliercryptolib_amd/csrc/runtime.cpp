@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>   // types only: the library is dlopen'ed (replicate over xGMI), never linked
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <set>
@@ -27,6 +28,9 @@ std::vector<std::unique_ptr<Device>>& g_pool = *new std::vector<std::unique_ptr<
 // after terminateContext); the (small) Device records they point to are parked here instead of being deleted.
 std::vector<std::unique_ptr<Device>>& g_retired = *new std::vector<std::unique_ptr<Device>>();
 bool g_init = false;
+std::atomic<uint64_t> g_generation{0};
+std::atomic<uint64_t> g_repl_verified{0}, g_repl_repaired{0};
+std::atomic<int> g_corrupt_next{-1};
 thread_local int t_current = 0;
 size_t g_min_shard = 0;
 const char* g_transport = "single";
@@ -123,22 +127,47 @@ void lane_main(Device* d, Lane* lane) {
 }  // namespace
 
 // ---------------- Workspace ----------------
-int Workspace::ensure(size_t need) {
+int Workspace::ensure(size_t need, hipStream_t s) {
   if (need <= bytes) return PGPU_OK;
-  if (p) {
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipFree(p));
-    p = nullptr;
-    bytes = 0;
+  // Stream-ordered growth (hipMallocAsync / hipFreeAsync on the owning stream): the launches already queued on `s`
+  // keep the old block until they have run, later ones see the new block; no other stream of the device waits.
+  // Grow by half at least, so that a slowly growing batch does not reallocate on every call.
+  const size_t want = std::max(need, bytes + bytes / 2);
+  void* np = nullptr;
+  hipError_t e = hipMallocAsync(&np, want, s);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    // no stream-ordered pool (or it is exhausted): the synchronous path, as before round 3
+    if (p) {
+      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(hipFree(p));
+      p = nullptr;
+      bytes = 0;
+      async_ = false;
+    }
+    HIP_TRY(hipMalloc(&np, need));
+    p = np;
+    bytes = need;
+    async_ = false;
+    return PGPU_OK;
   }
-  HIP_TRY(hipMalloc(&p, need));
-  bytes = need;
+  if (p) {
+    if (async_) HIP_TRY(hipFreeAsync(p, s));
+    else {
+      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(hipFree(p));
+    }
+  }
+  p = np;
+  bytes = want;
+  async_ = true;
   return PGPU_OK;
 }
 void Workspace::release() {
-  if (p) (void)hipFree(p);
+  if (p) (void)hipFree(p);   // (hipFree accepts stream-ordered allocations too; it synchronises the device)
   p = nullptr;
   bytes = 0;
+  async_ = false;
 }
 
 // ---------------- Device ----------------
@@ -395,6 +424,12 @@ int check_ready() {
 }
 
 int pool_size() { return (int)g_pool.size(); }
+uint64_t pool_generation() { return g_generation.load(std::memory_order_acquire); }
+void replication_stats(uint64_t* verified, uint64_t* repaired) {
+  if (verified) *verified = g_repl_verified.load();
+  if (repaired) *repaired = g_repl_repaired.load();
+}
+void debug_corrupt_next_replica(int index) { g_corrupt_next.store(index); }
 Device& device(int i) { return *g_pool[(size_t)i]; }
 Device& current() {
   int i = t_current;
@@ -482,6 +517,9 @@ int pool_init(const std::vector<int>& ordinals) {
   rccl_init(ordinals);
   g_transport = g_pool.size() == 1 && !g_rccl.ready ? "single" : (g_rccl.ready ? "rccl" : "memcpy");
   t_current = 0;
+  g_generation.fetch_add(1, std::memory_order_acq_rel);
+  g_repl_verified.store(0);
+  g_repl_repaired.store(0);
   g_init = true;
   return PGPU_OK;
 }
@@ -548,17 +586,32 @@ Replicated::~Replicated() { scrub_and_free(); }
 void Replicated::scrub_and_free() {
   for (size_t i = 0; i < d.size(); ++i) {
     if (!d[i]) continue;
-    if (i < g_pool.size()) {
+    if (gen == pool_generation() && i < g_pool.size()) {
       DeviceGuard g(g_pool[i]->ordinal);
       if (secret_) (void)hipMemset(d[i], 0, bytes);   // key material does not outlive the key object
       (void)hipFree(d[i]);
     } else {
+      // the pool this copy was made for is gone (its devices were reset or re-enumerated): the address identifies
+      // its device to the driver; a failure here means the memory went with the old context
+      if (secret_) (void)hipMemset(d[i], 0, bytes);
       (void)hipFree(d[i]);
+      (void)hipGetLastError();
     }
   }
   d.clear();
   bytes = 0;
 }
+
+namespace {
+uint64_t fnv1a64(const unsigned char* p, size_t n) {
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < n; ++i) {
+    h ^= p[i];
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+}  // namespace
 
 int Replicated::upload(const void* host, size_t nbytes, bool secret) {
   static std::mutex collective_mu;   // one collective at a time on the pool's communicators
@@ -566,6 +619,7 @@ int Replicated::upload(const void* host, size_t nbytes, bool secret) {
   scrub_and_free();
   secret_ = secret;
   bytes = nbytes;
+  gen = pool_generation();
   const int D = pool_size();
   d.assign((size_t)D, nullptr);
   for (int i = 0; i < D; ++i) {
@@ -577,6 +631,7 @@ int Replicated::upload(const void* host, size_t nbytes, bool secret) {
     HIP_TRY(hipMemcpy(d[0], host, nbytes, hipMemcpyHostToDevice));
   }
   if (D == 1 && !g_rccl.ready) return PGPU_OK;
+  bool by_rccl = false;
   if (g_rccl.ready) {
     // ONE broadcast from device 0 over xGMI (single process: a group call over all communicators)
     ncclResult_t r = g_rccl.GroupStart();
@@ -591,16 +646,54 @@ int Replicated::upload(const void* host, size_t nbytes, bool secret) {
         DeviceGuard g(device(i).ordinal);
         HIP_TRY(hipStreamSynchronize(device(i).bstream));
       }
-      return PGPU_OK;
+      by_rccl = true;
+    } else {
+      // a failed collective leaves RCCL unusable: remember it and copy per device from here on
+      g_rccl.note = std::string("ncclBroadcast: ") + g_rccl.GetErrorString(r);
+      g_rccl.ready = false;
+      g_transport = "memcpy";
     }
-    // a failed collective leaves RCCL unusable: remember it and copy per device from here on
-    g_rccl.note = std::string("ncclBroadcast: ") + g_rccl.GetErrorString(r);
-    g_rccl.ready = false;
-    g_transport = "memcpy";
   }
-  for (int i = 1; i < D; ++i) {
+  if (!by_rccl) {
+    for (int i = 1; i < D; ++i) {
+      DeviceGuard g(device(i).ordinal);
+      HIP_TRY(hipMemcpy(d[(size_t)i], host, nbytes, hipMemcpyHostToDevice));
+    }
+  }
+  const int hit = g_corrupt_next.exchange(-1);   // test hook: what a wrong-but-successful collective leaves behind
+  if (hit >= 0 && hit < D && nbytes > 0) {
+    DeviceGuard g(device(hit).ordinal);
+    const size_t off = nbytes / 2;
+    unsigned char x = (unsigned char)(((const unsigned char*)host)[off] ^ 0x5a);
+    HIP_TRY(hipMemcpy((char*)d[(size_t)hit] + off, &x, 1, hipMemcpyHostToDevice));
+  }
+  // ---- self-check: every copy is read back once and compared with the host image ----
+  // (key images are a few KB to a few hundred KB and are uploaded once per key: the read-back is noise next to the
+  // hipMallocs above.  The first run on real multi-GPU hardware diagnoses itself: a copy that differs is rewritten
+  // from the host, counted, and RCCL is retired for the rest of the process if it produced it.)
+  const uint64_t want = fnv1a64((const unsigned char*)host, nbytes);
+  std::vector<unsigned char> back(nbytes);
+  for (int i = 0; i < D; ++i) {
     DeviceGuard g(device(i).ordinal);
-    HIP_TRY(hipMemcpy(d[(size_t)i], host, nbytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(back.data(), d[(size_t)i], nbytes, hipMemcpyDeviceToHost));
+    const bool ok = fnv1a64(back.data(), nbytes) == want;
+    g_repl_verified.fetch_add(1);
+    if (!ok) {
+      g_repl_repaired.fetch_add(1);
+      HIP_TRY(hipMemcpy(d[(size_t)i], host, nbytes, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(back.data(), d[(size_t)i], nbytes, hipMemcpyDeviceToHost));
+      if (fnv1a64(back.data(), nbytes) != want)
+        return fail(PGPU_ERR_HIP, "replicated key image does not read back correctly on pool entry " + std::to_string(i));
+      if (by_rccl) {
+        g_rccl.note = "ncclBroadcast delivered a wrong image to pool entry " + std::to_string(i) + ": retired, copying per device";
+        g_rccl.ready = false;
+        g_transport = "memcpy";
+      }
+    }
+  }
+  if (secret) {
+    volatile unsigned char* w = back.data();
+    for (size_t i = 0; i < nbytes; ++i) w[i] = 0;
   }
   return PGPU_OK;
 }

@@ -68,12 +68,15 @@ struct DeviceGuard {
   }
 };
 
-// grow-only device buffer owned by one (device, stream) pair
+// grow-only device buffer owned by one (device, stream) pair.  Growth is stream-ordered: the old block is handed
+// to the runtime's free-async queue behind the work already queued on the stream and the new one is allocated in
+// stream order too, so a busy pool never sees a device-wide synchronisation because one stream's batch grew.
 struct Workspace {
   void* p = nullptr;
   size_t bytes = 0;
-  int ensure(size_t need);   // may synchronise the device when it has to grow
+  int ensure(size_t need, hipStream_t s);
   void release();
+  bool async_ = false;   // p came from hipMallocAsync
 };
 
 // launch scratch of one stream: `mu` is held from sizing the workspace until the launch is queued
@@ -165,12 +168,20 @@ int check_ready();
 int pool_init(const std::vector<int>& ordinals);   // one pool entry per listed HIP ordinal
 void pool_shutdown();
 int pool_size();
+// bumped by every successful pool_init: device-side objects (key images, batches) remember the generation they
+// were created in and are refused once the pool they belong to has been shut down
+uint64_t pool_generation();
 Device& device(int i);
 Device& current();              // pool entry the calling thread addresses with the `_dev` entry points
 int set_current(int index);
 int current_index();
 const char* replicate_transport();   // "rccl" | "memcpy" | "single"
 std::string rccl_note();             // why RCCL is (not) in use
+// replication self-check (Replicated::upload): images verified / copies found wrong and rewritten since pool_init
+void replication_stats(uint64_t* verified, uint64_t* repaired);
+// test hook: corrupt the copy on pool entry `index` of the NEXT replicated upload right after the broadcast
+// (before verification), as a wrong-but-successful collective would
+void debug_corrupt_next_replica(int index);
 
 // ---- tasks ----
 // runs fn(lane) for every item on a lane of items[i].first; returns the first non-zero status
@@ -188,6 +199,14 @@ struct TaskGroup {
 struct Replicated {
   std::vector<void*> d;   // one copy per pool device
   size_t bytes = 0;
+  uint64_t gen = 0;       // pool generation of the upload
+  // usable by the pool as it is now (same generation, one copy per device)?
+  bool current() const { return !d.empty() && gen == pool_generation() && (int)d.size() == pool_size(); }
+  const void* at(int index) const { return (index >= 0 && (size_t)index < d.size() && gen == pool_generation()) ? d[(size_t)index] : nullptr; }
+  // What the copies looked like after replication: the image is read back from EVERY device once per upload and
+  // compared with the host bytes (64-bit FNV-1a); a mismatching copy is rewritten by a plain host-to-device copy
+  // and counted (replication_repairs()).  A collective that "succeeds" with wrong bytes on some rank would
+  // otherwise decrypt garbage on that GPU only.
   Replicated() = default;
   Replicated(const Replicated&) = delete;
   Replicated& operator=(const Replicated&) = delete;

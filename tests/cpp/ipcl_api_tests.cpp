@@ -202,6 +202,46 @@ TEST(ct_times_zero_pt) {
   }
 }
 
+// Negative plaintexts: the reference accepts them -- (n*m + 1) % n^2 with IPP's non-negative remainder
+// (pub_key.cpp:105) -- and so must the device path, whatever batch width the magnitudes suggest: -5 is one word wide
+// but n - 5 is not.  Encrypt (DJN fast path and injected randomness), CT + PT, and values wider than n.
+TEST(negative_and_wide_plaintexts) {
+  ipcl::KeyPair& key = shared_key();
+  const BigNumber& n = *key.pub_key.getN();
+  std::vector<BigNumber> vals = {BigNumber(5) - BigNumber(10), BigNumber(7), BigNumber::Zero() - n - BigNumber(3),
+                                 n + BigNumber(11), BigNumber::Zero() - (n * n) - BigNumber(1), BigNumber(0u)};
+  std::vector<BigNumber> want;
+  for (const auto& v : vals) want.push_back(v % n);
+  ipcl::PlainText pt(vals);
+  ipcl::CipherText ct = key.pub_key.encrypt(pt);
+  std::vector<BigNumber> got = key.priv_key.decrypt(ct).getTexts();
+  EXPECT_EQ(got.size(), want.size());
+  for (size_t i = 0; i < want.size() && i < got.size(); ++i) EXPECT_EQ(got[i], want[i]);
+  // a single small negative value (batch width 1 by magnitude)
+  ipcl::PlainText one(std::vector<BigNumber>{BigNumber(5) - BigNumber(10)});
+  EXPECT_EQ(key.priv_key.decrypt(key.pub_key.encrypt(one)).getElement(0), n - BigNumber(5));
+  // CT + PT with negative plaintexts: Enc(a) + (-b) decrypts to (a - b) mod n
+  std::vector<BigNumber> a = {BigNumber(100), BigNumber(3), BigNumber(0u), n - BigNumber(1), BigNumber(42), BigNumber(9)};
+  ipcl::CipherText ca = key.pub_key.encrypt(ipcl::PlainText(a));
+  std::vector<BigNumber> sum = key.priv_key.decrypt(ca + pt).getTexts();
+  for (size_t i = 0; i < a.size() && i < sum.size(); ++i) EXPECT_EQ(sum[i], (a[i] + vals[i]) % n);
+  std::vector<BigNumber> sum1 = key.priv_key.decrypt(ca + one).getTexts();
+  for (size_t i = 0; i < a.size() && i < sum1.size(); ++i) EXPECT_EQ(sum1[i], (a[i] + n - BigNumber(5)) % n);
+  // non-DJN key with injected randomness
+  BigNumber P(KAT_P), Q(KAT_Q);
+  ipcl::PublicKey pk(P * Q, 2048, false);
+  ipcl::PrivateKey sk(pk, P, Q);
+  pk.setRandom(std::vector<BigNumber>(vals.size(), BigNumber(KAT_R0)));
+  std::vector<BigNumber> got2 = sk.decrypt(pk.encrypt(pt)).getTexts();
+  for (size_t i = 0; i < vals.size() && i < got2.size(); ++i) EXPECT_EQ(got2[i], vals[i] % (P * Q));
+  // getTexts() on a temporary moves the values out; on an lvalue it copies and the text stays usable
+  ipcl::PlainText keep(a);
+  std::vector<BigNumber> c1 = keep.getTexts(), c2 = keep.getTexts();
+  EXPECT_EQ(c1.size(), a.size());
+  EXPECT_TRUE(c1 == c2);
+  EXPECT_EQ(keep.getElement(1), a[1]);
+}
+
 TEST(add_sub_expression) {  // a + b*2 + b
   ipcl::KeyPair& key = shared_key();
   auto a = random_u32(14, 10), b = random_u32(14, 11);

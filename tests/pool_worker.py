@@ -159,6 +159,78 @@ def main():
             ok[f"enc{bits}"] = ct == orc.PublicKey(n2, bits).encrypt(m, r)
             ok[f"dec{bits}"] = pa.PrivateKey(p2, q2).decrypt(ct) == m
         res["ok"] = ok
+    elif scenario == "corrupt_replica":
+        # A collective that "succeeds" with wrong bytes on one rank: the debug hook flips a byte of
+        # the NEXT replicated key image on the last pool entry right after the broadcast.  The read-back check must see
+        # it, rewrite the copy and count it -- and every shard must still decrypt correctly.
+        ver0, rep0 = ctypes.c_uint64(), ctypes.c_uint64()
+        L.pgpu_replication_stats(ctypes.byref(ver0), ctypes.byref(rep0))
+        _capi.check(L.pgpu_debug_corrupt_next_replica(ndev - 1))
+        sk = pa.PrivateKey(p, q)                 # its first image (mod p^2 context) is the one that gets hit
+        _capi.check(L.pgpu_debug_corrupt_next_replica(ndev - 1))
+        pk = pa.PublicKey(n, 2048, hs=hs)
+        ver, rep = ctypes.c_uint64(), ctypes.c_uint64()
+        L.pgpu_replication_stats(ctypes.byref(ver), ctypes.byref(rep))
+        count = 40 * ndev
+        m = [rng.randrange(n) for _ in range(count)]
+        r = [rng.getrandbits(1024) for _ in range(count)]
+        opk = orc.PublicKey(n, 2048)
+        opk.set_djn(hs)
+        ct = pk.encrypt(m, r)
+        res["ok"] = {"detected": rep.value - rep0.value == 2, "verified": ver.value - ver0.value >= 2 * ndev,
+                     "enc": ct == opk.encrypt(m, r), "dec": sk.decrypt(ct) == m}
+        res["repaired"] = rep.value - rep0.value
+    elif scenario == "reinit":
+        # objects of a pool that was shut down are refused (stale Replicated images were indexed blindly);
+        # the per-modulus caches of the key-less seam do not survive the pool either
+        ok = {}
+        pk, sk = pa.PublicKey(n, 2048, hs=hs), pa.PrivateKey(p, q)
+        m = [rng.randrange(n) for _ in range(9)]
+        r = [rng.getrandbits(1024) for _ in range(9)]
+        ct = pk.encrypt(m, r)
+        ok["before"] = sk.decrypt(ct) == m
+        psq = p * p
+        ok["seam_before"] = pa.mod_exp(ct, [p - 1] * 9, psq) == [pow(c, p - 1, psq) for c in ct]
+        L.pgpu_shutdown()
+        _capi.check(L.pgpu_init_all(ndev + 1))          # a DIFFERENT device set
+        out = np.zeros((9, 64), dtype=np.uint64)
+        a_m, a_r = ints_to_limbs(m, 32), ints_to_limbs(r, 16)
+        rc = L.pgpu_paillier_encrypt(pk._h, ptr(a_m), 32, 32, ptr(a_r), 16, 16, 1024, ptr(out), 9)
+        ok["stale_key_refused"] = rc != 0 and b"shut down" in L.pgpu_last_error()
+        pk2, sk2 = pa.PublicKey(n, 2048, hs=hs), pa.PrivateKey(p, q)
+        ct2 = pk2.encrypt(m, r)
+        ok["after"] = ct2 == ct and sk2.decrypt(ct2) == m
+        ok["seam_after"] = pa.mod_exp(ct, [p - 1] * 9, psq) == [pow(c, p - 1, psq) for c in ct]   # same modulus, new pool
+        res["ok"] = ok
+        res["pool"] = L.pgpu_pool_size()
+    elif scenario == "fb_budget":
+        # 64 DJN keys on one GPU under a 64 MiB fixed-base budget: every key's table is built,
+        # used and evicted in turn; live table bytes never exceed the budget; ciphertexts are what the oracle says
+        budget = 64 << 20
+        _capi.check(L.pgpu_set_fixed_base_budget(budget, budget))
+        live, ev = ctypes.c_size_t(), ctypes.c_uint64()
+        ok, worst = {}, 0
+        keys = []
+        for i in range(64):
+            hs_i = pow(hs, 2 * i + 3, nsq)                # 64 distinct valid hs values (powers of an n-th residue)
+            keys.append((pa.PublicKey(n, 2048, hs=hs_i), hs_i))
+        m = [rng.randrange(n) for _ in range(24)]
+        r = [rng.getrandbits(1024) for _ in range(24)]
+        good = True
+        for rnd in range(2):
+            for pk_i, hs_i in keys:
+                opk = orc.PublicKey(n, 2048)
+                opk.set_djn(hs_i)
+                good = good and pk_i.encrypt(m, r) == opk.encrypt(m, r)
+                for d in range(ndev):
+                    L.pgpu_fixed_base_stats(d, ctypes.byref(live), ctypes.byref(ev))
+                    worst = max(worst, live.value)
+        ok["ciphertexts"] = good
+        ok["within_budget"] = worst <= budget
+        ok["evicted"] = ev.value > 0
+        res["ok"] = ok
+        res["worst_live_bytes"] = worst
+        res["evictions"] = ev.value
     print(json.dumps(res), flush=True)
     if scenario != "no_terminate":
         pa.terminate()

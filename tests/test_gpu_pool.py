@@ -65,3 +65,31 @@ def test_process_exits_without_shutdown(engine):
     atexit hook); a hang here would burn the whole gpurun limit."""
     res = run_worker("no_terminate", 2, timeout=120)
     assert res["ok"]["enc"]
+
+
+@pytest.mark.gpu
+def test_corrupted_replica_is_detected_and_repaired(engine):
+    """A wrong-but-successful replication (debug hook: one byte of a key image flipped on the last pool entry) is seen by
+    the read-back check of rt::Replicated::upload, rewritten from the host and counted; results stay correct."""
+    res = run_worker("corrupt_replica", 3)
+    bad = [k for k, v in res["ok"].items() if not v]
+    assert not bad, (bad, res)
+
+
+@pytest.mark.gpu
+def test_objects_of_a_previous_pool_are_refused(engine):
+    """pgpu_shutdown + pgpu_init_all with a different device set: stale keys fail with a clear error, the caches of the
+    key-less seam (perfect-square moduli included) are rebuilt for the new pool."""
+    res = run_worker("reinit", 2)
+    assert res["pool"] == 3
+    bad = [k for k, v in res["ok"].items() if not v]
+    assert not bad, (bad, res)
+
+
+@pytest.mark.gpu
+def test_fixed_base_tables_stay_within_budget(engine):
+    """64 DJN keys take turns on one GPU under a 64 MiB table budget: LRU eviction keeps the live bytes under the cap and
+    every ciphertext identical to the oracle's."""
+    res = run_worker("fb_budget", 1, timeout=900)
+    bad = [k for k, v in res["ok"].items() if not v]
+    assert not bad, (bad, res)

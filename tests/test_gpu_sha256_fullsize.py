@@ -99,3 +99,116 @@ def test_config5_full_output_hash(engine, cpu):
     d_a = T.to_device(a)
     assert sha(T.to_host(T.mod_mul(d_a, T.to_device(b), nsq))) == sha(c_oracle.modmul_batch(a, b, mod))
     assert sha(T.to_host(T.mod_exp(d_a, T.to_device(e), nsq, exp_bits=32))) == sha(modexp_cpu(a, e, mod))
+
+
+class _Batches:
+    """pgpu_batch handles through the C-ABI (the resident, sharded form of a batch)"""
+
+    def __init__(self):
+        import ctypes
+        from pailliercryptolib_amd import _capi
+        self.ct, self.L, self.check = ctypes, _capi.lib(), _capi.check
+
+    def up(self, a):
+        h = self.ct.c_void_p()
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        self.check(self.L.pgpu_batch_upload(a.ctypes.data_as(self.ct.c_void_p), a.shape[0], a.shape[1], a.shape[1],
+                                            self.ct.byref(h)))
+        return h
+
+    def down(self, h):
+        out = np.empty((self.L.pgpu_batch_count(h), self.L.pgpu_batch_words(h)), dtype=np.uint64)
+        self.check(self.L.pgpu_batch_download(h, out.ctypes.data_as(self.ct.c_void_p)))
+        return out
+
+    def op(self, fn, *a):
+        h = self.ct.c_void_p()
+        self.check(fn(*a, self.ct.byref(h)))
+        return h
+
+    def free(self, *hs):
+        for h in hs:
+            self.L.pgpu_batch_destroy(h)
+
+
+def test_config4_full_batch_hash_through_the_pool(engine, cpu):
+    """configs[3] at its FULL size on one GPU: 65536 x 3072-bit DJN encrypt + CRT decrypt, every ciphertext and every
+    plaintext hashed against the C oracle -- once through the host-pointer entry points (pgpu_paillier_encrypt /
+    pgpu_paillier_decrypt_crt: sharding, staging, sub-batches) and once as resident pgpu_batch objects."""
+    import ctypes
+    from pailliercryptolib_amd import _capi
+    enc_cpu, dec_cpu, _, _ = cpu
+    bits, count = 3072, 65536
+    case = [c for c in json.load(open(os.path.join(GOLD, "seeded_vectors.json")))["cases"]
+            if c["bits"] == bits and c["djn"]][0]
+    p, q, hs = int(case["p"], 16), int(case["q"], 16), int(case["hs"], 16)
+    n = p * q
+    nw, pw = bits // 64, bits // 128
+    rng = np.random.default_rng(4004)
+    m = rand_rows(rng, count, nw, (1 << 62) - 1)
+    r = rand_rows(rng, count, pw)
+    n_l, hs_l, sk_l = key_limbs(p, q, hs, bits)
+    c_cpu = enc_cpu(n_l, hs_l, m, r)
+    want_c, want_m = sha(c_cpu), sha(m)
+    assert sha(dec_cpu(*sk_l, c_cpu)) == want_m
+    pk, sk = engine.PublicKey(n, bits, hs=hs), engine.PrivateKey(p, q)
+    L = _capi.lib()
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    c_gpu = np.empty((count, 2 * nw), dtype=np.uint64)
+    m_gpu = np.empty((count, nw), dtype=np.uint64)
+    _capi.check(L.pgpu_paillier_encrypt(pk._h, vp(m), nw, nw, vp(r), pw, pw, 64 * pw, vp(c_gpu), count))
+    assert sha(c_gpu) == want_c, "host-pointer encrypt differs from the C oracle"
+    _capi.check(L.pgpu_paillier_decrypt_crt(sk._h, vp(c_gpu), vp(m_gpu), count))
+    assert sha(m_gpu) == want_m, "host-pointer decrypt differs from the C oracle"
+    B = _Batches()
+    bm, br = B.up(m), B.up(r)
+    bc = B.op(L.pgpu_batch_encrypt, pk._h, bm, br, 64 * pw)
+    bo = B.op(L.pgpu_batch_decrypt_crt, sk._h, bc)
+    assert sha(B.down(bc)) == want_c, "resident encrypt differs from the C oracle"
+    assert sha(B.down(bo)) == want_m, "resident decrypt differs from the C oracle"
+    B.free(bm, br, bc, bo)
+
+
+def test_config5_full_batch_hash_through_the_pool(engine, cpu):
+    """configs[4] at its FULL size on one GPU: 1 M x 2048-bit CT+CT and CT x PT (32-bit plaintexts), all results hashed
+    against the C oracle -- through pgpu_modmul / pgpu_modexp on host arrays and through resident pgpu_batch chains
+    (Montgomery-domain operands: the form config 5 is benchmarked in)."""
+    import ctypes
+    from pailliercryptolib_amd import _capi
+    from pailliercryptolib_amd.limbs import ints_to_limbs
+    _, _, modexp_cpu, c_oracle = cpu
+    k = json.load(open(os.path.join(GOLD, "iso_kat.json")))
+    p, q, hs = int(k["p"], 16), int(k["q"], 16), int(k["bench_hs"], 16)
+    n = p * q
+    nsq = n * n
+    N, W = 1 << 20, 64
+    rng = np.random.default_rng(5005)
+    a = rand_rows(rng, N, W, (1 << 60) - 1)
+    b = rand_rows(rng, N, W, (1 << 60) - 1)
+    e = rand_rows(rng, N, 1, (1 << 32) - 1)
+    mod = ints_to_limbs([nsq], W)[0]
+    want_add = sha(c_oracle.modmul_batch(a, b, mod))
+    want_mul = sha(modexp_cpu(a, e, mod))
+    L = _capi.lib()
+    vp = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    out = np.empty_like(a)
+    _capi.check(L.pgpu_modmul(vp(a), vp(b), W, vp(mod), W, vp(out), N))
+    assert sha(out) == want_add, "pgpu_modmul differs from the C oracle"
+    _capi.check(L.pgpu_modexp(vp(a), W, vp(e), 1, 1, 32, vp(mod), W, vp(out), N))
+    assert sha(out) == want_mul, "pgpu_modexp differs from the C oracle"
+    del out
+    pk = engine.PublicKey(n, 2048, hs=hs)
+    B = _Batches()
+    ba, bb, be = B.up(a), B.up(b), B.up(e)
+    s1 = B.op(L.pgpu_batch_ct_add, pk._h, ba, bb)                 # plain operands: converted on the way in
+    assert sha(B.down(s1)) == want_add, "resident CT+CT differs from the C oracle"
+    t1 = B.op(L.pgpu_batch_ct_mul, pk._h, ba, be, 32)
+    assert sha(B.down(t1)) == want_mul, "resident CT x PT differs from the C oracle"
+    # the same on device-produced (Montgomery-domain) operands: (a*1) and (b*1) are resident products of the key
+    one = B.up(np.array([[1] + [0] * (W - 1)], dtype=np.uint64))
+    am, bmm = B.op(L.pgpu_batch_ct_add, pk._h, ba, one), B.op(L.pgpu_batch_ct_add, pk._h, bb, one)
+    s2 = B.op(L.pgpu_batch_ct_add, pk._h, am, bmm)
+    assert sha(B.down(s2)) == want_add, "resident CT+CT on device-produced operands differs from the C oracle"
+    t2 = B.op(L.pgpu_batch_ct_mul, pk._h, am, be, 32)
+    assert sha(B.down(t2)) == want_mul, "resident CT x PT on device-produced operands differs from the C oracle"
+    B.free(ba, bb, be, s1, t1, one, am, bmm, s2, t2)
