@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
                     help="2: BASELINE configs[1]+[2] (default, the headline); 4 / 5: configs[3] / configs[4]")
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+                    help="resident batches in flight per GPU: consecutive steps alternate between the library's two "
+                         "batch lanes (2, default) or all run on one lane (1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the N=1 side measurements (end-to-end, API level, non-DJN variant)")
@@ -170,35 +173,59 @@ def run_pool(args):
     parts = [synth(g, BATCH, nw, pw) for g in range(N)]
     m_host = np.concatenate([a for a, _ in parts])
     r_host = np.concatenate([b for _, b in parts])
-    bm, br = B.up(m_host), B.up(r_host)
-    state = {"c": None, "out": None}
+    # one input set per batch lane (the same values): a step takes the set of its lane, its ciphertexts and plaintexts
+    # inherit the lane, so consecutive steps run on different streams of every GPU and overlap
+    nfl = args.in_flight
+    sets = []
+    for ln in range(nfl):
+        _capi.check(L.pgpu_set_batch_lane(ln))
+        sets.append((B.up(m_host), B.up(r_host)))
+    _capi.check(L.pgpu_set_batch_lane(0))
+    bm, br = sets[0]
+    state = {"c": [None] * nfl, "out": [None] * nfl, "i": 0}
 
     def step():
-        B.free(state["c"], state["out"])
-        state["c"] = B.op(L.pgpu_batch_encrypt, pk._h, bm, br, 64 * pw)
-        state["out"] = B.op(L.pgpu_batch_decrypt_crt, sk._h, state["c"])
+        k = state["i"] % nfl
+        state["i"] += 1
+        B.free(state["c"][k], state["out"][k])
+        state["c"][k] = B.op(L.pgpu_batch_encrypt, pk._h, sets[k][0], sets[k][1], 64 * pw)
+        state["out"][k] = B.op(L.pgpu_batch_decrypt_crt, sk._h, state["c"][k])
 
     def sync_all():
         _capi.check(L.pgpu_synchronize())
         if torch is not None and torch.cuda.is_available():
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, nfl)):
         step()
     sync_all()
     # live per-kernel timing: the library brackets every launch with HIP events on the launch stream (no
-    # synchronisation inside the timed region); collected after the final synchronisation (pool entry 0)
-    _capi.check(L.pgpu_set_timing(1))
+    # synchronisation inside the timed region); collected after the final synchronisation (pool entry 0).  With two
+    # batches in flight the launches of the two lanes overlap, so an event pair then spans BOTH kernels' share of the
+    # SIMDs: the per-kernel numbers of the roofline come from a short single-lane pass behind the timed region.
+    _capi.check(L.pgpu_set_timing(1 if nfl == 1 else 0))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    per_kind = collect_timing(L, 4 * args.steps + 8)
+    if nfl == 1:
+        per_kind = collect_timing(L, 4 * args.steps + 8)
+    else:
+        _capi.check(L.pgpu_set_timing(1))
+        t1 = time.perf_counter()
+        for _ in range(10):
+            state["i"] = 0          # lane 0 only
+            step()
+        sync_all()
+        single_ms = (time.perf_counter() - t1) / 10 * 1e3
+        per_kind = collect_timing(L, 64)
     _capi.check(L.pgpu_set_timing(0))
 
     # ---- correctness of what was timed: full-size round trip + oracle spot checks ----
-    ok = bool(np.array_equal(B.down(state["out"]), m_host))
+    ok = all(bool(np.array_equal(B.down(o), m_host)) for o in state["out"])
+    all_c, all_out = state["c"], state["out"]
+    state["c"], state["out"] = all_c[0], all_out[0]
     from oracle import paillier_oracle as orc
     opk = orc.PublicKey(n, KEY_BITS)
     opk.set_djn(hs)
@@ -221,12 +248,27 @@ def run_pool(args):
                       decrypt_kernel(sk, BATCH, nw, KEY_BITS),
                       encrypt_kernel(pk, BATCH, nw, KEY_BITS, fb["window"] or int(os.environ.get("PGPU_FB_WINDOW", "12"))), fb)
     result["config"]["secret_exponent_policy"] = ["fixed-window", "sliding"][L.pgpu_get_secret_exponent_policy()]
+    result["config"]["batches_in_flight_per_gpu"] = nfl
+    result["config"]["resident_ciphertext_form"] = ("pair rows (%d limbs)" % L.pgpu_batch_row_limbs(state["c"])
+                                                    if L.pgpu_batch_row_limbs(state["c"]) else "Montgomery-form words")
+    if nfl == 2:
+        result["config"]["workload"] += ("; TWO batches in flight per GPU: consecutive steps alternate between the "
+                                         "library's two batch lanes (streams), exactly K steps timed")
+        result["one_batch_in_flight"] = {"ms_per_step": round(single_ms, 4), "modexps_per_s": round(3 * BATCH * N / (single_ms * 1e-3), 1),
+                                         "what": "the same steps on ONE lane, 10 steps behind the timed region; roofline.kernel_ms and "
+                                                 "the other per-kernel times are from this pass (launches do not overlap in it)"}
+        r = result["roofline"]
+        share = r["kernel_ms"] / single_ms
+        r["kernel_ms_effective_two_in_flight"] = round(result["ms_per_step"] * share, 3)
+        r["frac_two_in_flight"] = sig(r["executed_mac32_per_launch"] / (result["ms_per_step"] * share * 1e-3) / 1e12 / PEAK_TMAC32)
+        r["frac_two_in_flight_note"] = ("derived: the kernel's share of a single-lane step applied to the two-in-flight "
+                                        "ms_per_step (the launches of the two lanes share the SIMDs, two wavefronts each)")
     result["pool"] = per_gpu
     if N == 1 and not args.no_extras:
         result.update(extras(pa, L, B, pk, sk, n, p, q, hs, m_host, r_host, per_kind))
     if N == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(n, p, q, hs, m_host, r_host)
-    B.free(state["c"], state["out"], bm, br)
+    B.free(*[h for pair in sets for h in pair], *all_c, *all_out)
     del pk, sk
     pa.terminate()
     ctypes.CDLL(None).fflush(None)

@@ -157,7 +157,7 @@ int pgpu_paillier_encrypt_dev(const pgpu_pubkey* key, const uint64_t* d_m, size_
  * bench batch: 1.19 ms vs 1.41 ms).  Unless a window was set explicitly, a key starts with w = 8 (13 MB,
  * built in ~2 ms) and switches to the default after its first 4096 elements.  Results are identical. */
 int pgpu_set_fixed_base_window(int w);
-/* Table memory is bounded (round 3): per key and GPU by max_bytes_per_key (default 256 MiB, env
+/* Table memory is bounded (round 3): per key and GPU by max_bytes_per_key (default 512 MiB, env
  * PGPU_FB_KEY_MAX_BYTES: the window narrows until the table fits), per GPU over ALL keys by max_bytes_per_device
  * (default 2 GiB, env PGPU_FB_MAX_BYTES: a new table first evicts the least recently used tables of other keys;
  * an evicted key rebuilds its table on its next encrypt).  0 leaves a limit unchanged.  Results never change. */
@@ -211,7 +211,18 @@ int pgpu_batch_download(const pgpu_batch* b, uint64_t* host /* [count][words] */
 void pgpu_batch_destroy(pgpu_batch* b);
 size_t pgpu_batch_count(const pgpu_batch* b);
 int pgpu_batch_words(const pgpu_batch* b);
-int pgpu_batch_is_montgomery(const pgpu_batch* b);
+int pgpu_batch_is_montgomery(const pgpu_batch* b);   /* 1: a device-side domain (Montgomery words or pair rows), 0: plain */
+/* limbs per row when the batch is stored as PAIR ROWS (round 3; csrc/kargs.hpp), else 0.  Ciphertext batches produced
+ * on the device for keys of 1024 / 2048 / 3072 bits are pairs (a, b) of 29-bit limbs with c*R == a - (n*k)*b mod n^2 --
+ * the register image of the split-form kernels: CT+CT is ONE pair product, CT+PT two half-width products, encrypt /
+ * CT*PT / CRT decrypt read and write the rows without any conversion.  PGPU_PAIR_ROWS=0 keeps Montgomery words. */
+int pgpu_batch_row_limbs(const pgpu_batch* b);
+/* Batch lanes: every GPU of the pool has TWO batch streams, so two independent chains of resident batches can be in
+ * flight at once (their kernels share the SIMDs: a wavefront that is alone on a SIMD issues ~8 % slower than two).
+ * Uploads and pgpu_batch_create take the calling thread's lane (default 0); every result inherits the lane of the
+ * operation's first operand; operands of the other lane are ordered in by events. */
+int pgpu_set_batch_lane(int lane /* 0 | 1 */);
+int pgpu_batch_lane(const pgpu_batch* b);
 /* c = Enc(m; r): m, r batches of `count` elements (PublicKey::encrypt, pub_key.cpp:112-129) */
 int pgpu_batch_encrypt(const pgpu_pubkey* key, const pgpu_batch* m, const pgpu_batch* r, int r_bits,
                        pgpu_batch** c);

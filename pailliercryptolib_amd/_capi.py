@@ -30,6 +30,7 @@ SYMBOLS = [
     "pgpu_batch_ct_add", "pgpu_batch_ct_add_plain", "pgpu_batch_ct_mul",
     "pgpu_rccl_note", "pgpu_replication_stats", "pgpu_debug_corrupt_next_replica",
     "pgpu_set_fixed_base_budget", "pgpu_fixed_base_stats", "pgpu_pubkey_fixed_base_info",
+    "pgpu_batch_row_limbs", "pgpu_set_batch_lane", "pgpu_batch_lane",
 ]
 
 _lib = None
@@ -136,6 +137,9 @@ def lib():
     L.pgpu_fixed_base_stats.argtypes = [c_int, POINTER(c_size_t), POINTER(c_uint64)]; L.pgpu_fixed_base_stats.restype = c_int
     L.pgpu_pubkey_fixed_base_info.argtypes = [c_void_p, c_int, POINTER(c_int), POINTER(c_size_t), POINTER(c_double)]
     L.pgpu_pubkey_fixed_base_info.restype = c_int
+    L.pgpu_batch_row_limbs.argtypes = [c_void_p]; L.pgpu_batch_row_limbs.restype = c_int
+    L.pgpu_set_batch_lane.argtypes = [c_int]; L.pgpu_set_batch_lane.restype = c_int
+    L.pgpu_batch_lane.argtypes = [c_void_p]; L.pgpu_batch_lane.restype = c_int
     _lib = L
     return L
 

@@ -53,7 +53,7 @@ def _objects():
         out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src] + kdeps))
     src = os.path.join(CSRC, "k_misc.hip")
     out.append((os.path.join(obj, "k_misc.o"), hip + ["-c", src, "-o", os.path.join(obj, "k_misc.o")], [src] + kdeps))
-    for part in range(11):
+    for part in range(14):
         src = os.path.join(CSRC, "k_hensel.hip")
         o = os.path.join(obj, f"k_hensel_{part}.o")
         out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src, os.path.join(CSRC, "hensel.hpp")] + kdeps))
@@ -64,15 +64,49 @@ def _objects():
     return out
 
 
+def align8_enabled():
+    """PGPU_ALIGN8=0 builds the device code exactly as hipcc emits it (A/B of the alignment pass, align8.py)"""
+    return os.environ.get("PGPU_ALIGN8", "1") != "0"
+
+
+def compile_one(obj, cmd, extra_flags=()):
+    """One translation unit.  Device code (.hip) goes through the instruction-alignment pass (align8.py) unless
+    PGPU_ALIGN8=0; host code is a plain compiler call."""
+    cmd = list(cmd)
+    src = cmd[cmd.index("-c") + 1]
+    if src.endswith(".hip") and align8_enabled():
+        try:
+            from . import align8
+        except ImportError:      # imported as a top-level module (cwd = the package directory)
+            import align8
+        flags = [c for c in cmd[1:] if c not in ("-c", src, "-o", cmd[cmd.index("-o") + 1])] + list(extra_flags)
+        print("[build] (aligned)", " ".join([cmd[0]] + flags + ["-c", src, "-o", obj]), file=sys.stderr, flush=True)
+        align8.compile_hip_aligned(cmd[0], flags, src, obj, os.path.join(os.path.dirname(obj), "align8"))
+        return
+    cmd[cmd.index("-o") + 1] = obj
+    _run(cmd + list(extra_flags))
+
+
 def build_pgpu(force=False):
     from concurrent.futures import ThreadPoolExecutor
     out = os.path.join(HERE, "libpgpu.so")
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     objs = _objects()
-    todo = [(o, cmd) for o, cmd, deps in objs if force or _newer(o, deps)]
+    stamp = os.path.join(HERE, "build", "align8.on" if align8_enabled() else "align8.off")
+    if not os.path.exists(stamp):      # the pass was switched: every device object is stale
+        for f in ("align8.on", "align8.off"):
+            if os.path.exists(os.path.join(HERE, "build", f)):
+                os.remove(os.path.join(HERE, "build", f))
+        force_dev = True
+    else:
+        force_dev = False
+    kdep = os.path.join(HERE, "align8.py")
+    todo = [(o, cmd) for o, cmd, deps in objs
+            if force or _newer(o, deps + ([kdep] if cmd[-3].endswith(".hip") else [])) or (force_dev and cmd[-3].endswith(".hip"))]
     if todo:
         with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
-            list(ex.map(lambda oc: _run(oc[1]), todo))
+            list(ex.map(lambda oc: compile_one(oc[0], oc[1]), todo))
+    open(stamp, "w").close()
     if todo or not os.path.exists(out):
         _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _, _ in objs]
              + ["-ldl", "-lpthread", "-o", out])

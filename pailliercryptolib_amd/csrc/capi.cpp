@@ -490,13 +490,22 @@ uint64_t* g_wave_clocks = nullptr;   // diagnostics (tools/wave_spread.py)
 
 // CRT decrypt: exponentiation modulo p^2 / q^2 in split form (hensel.hpp) where it is compiled for the key size;
 // PGPU_HENSEL=0 keeps the full-width modexp_kernel (A/B measurements, parity tests of both paths).
-// two batches in flight (callers that keep two streams busy): take the 256-register build of the (2,19) decrypt kernel
-// also for launches of one wavefront per SIMD, so that the launches of two streams can share a SIMD (the full-budget
-// build holds 291 registers: nothing else fits beside it).  pgpu_debug_set_packed_decrypt / PGPU_PACKED_DECRYPT=1.
+// two batches in flight (the two batch lanes, callers that keep two streams busy): take the 256-register build of the
+// (2,19) decrypt kernel also for launches of one wavefront per SIMD, so that the launches of two streams can share a
+// SIMD (the full-budget build holds 291 registers: nothing else fits beside it).  pgpu_debug_set_packed_decrypt /
+// PGPU_PACKED_DECRYPT=0 selects the full-budget build again.
 std::atomic<bool> g_packed_decrypt{[] {
   const char* e = std::getenv("PGPU_PACKED_DECRYPT");
-  return e && std::atoi(e) != 0;
+  return !(e && std::atoi(e) == 0);   // default since round 3: with aligned code both builds run a lone launch equally fast
 }()};
+// PGPU_PAIR_ROWS=0: resident ciphertext batches stay Montgomery-form words (the round-2 representation; A/B)
+bool pair_rows_enabled() {
+  static const bool on = [] {
+    const char* e = std::getenv("PGPU_PAIR_ROWS");
+    return !(e && std::atoi(e) == 0);
+  }();
+  return on;
+}
 std::atomic<int> g_hensel{-2};
 bool hensel_enabled() {
   int mode = g_hensel.load();
@@ -577,14 +586,16 @@ struct pgpu_pubkey {
   mutable std::vector<std::list<FbTable>> fb;
   mutable size_t fb_elems = 0;  // elements encrypted with this key so far (window policy)
   // split forms of n^2 = (n)^2 (hensel.hpp) compiled for this key size, most lanes per element first; empty: none
-  struct PubForm {
+  struct PubForm {   // (shared: resident pair-row batches keep the form they were produced under alive)
     int H = 0, K = 0, chunk_words = 0, nchunks = 0;
+    int n_words = 0;
+    BigNumber n;
     rt::Replicated pub;      // P | n | k*R mod n (L2 limbs each) | pair one | pairs conv | pairs conv (Montgomery input)
     rt::Replicated full;     // the way back in Geo<2H,K>, R' = 2^(29*2*L2): n^2 | n*R' | n*R'*Rs | R'*Rs  (2*L2 limbs
                              // each; Rs = the radix of the n^2 context, which Montgomery-form batches carry)
     uint32_t n0inv = 0, n0inv_full = 0;
   };
-  std::vector<std::unique_ptr<PubForm>> hforms;
+  std::vector<std::shared_ptr<PubForm>> hforms;
   mutable std::vector<std::list<FbTable>> fbh;   // [device]: fixed-base tables of pairs (form hforms.back())
   uint64_t gen = 0;             // pool generation the device images belong to
   ~pgpu_pubkey();
@@ -612,8 +623,10 @@ struct pgpu_privkey {
     int H = 0, K = 0;           // 2H lanes per ciphertext side, K limbs per lane; L2 = H*K limbs per half
     int chunk_words = 0, nchunks = 0;
     rt::Replicated blob;        // per side: P | p | h | k*R mod p (L2 limbs each) | pair one | pairs conv | pairs conv (Montgomery input)
+                                //           | pairs pconv[pchunks] | pcb[pchunks] (L2 limbs each): entry from pair rows
     uint32_t n0inv[2] = {0, 0};
-    size_t side_words() const { return (size_t)H * K * (6 + 4 * (size_t)nchunks); }
+    int pair_l2 = 0, pchunk_limbs = 0, pchunks = 0;   // pair rows of this key's n^2 domain (0: none)
+    size_t side_words() const { return (size_t)H * K * (6 + 4 * (size_t)nchunks + 3 * (size_t)pchunks); }
   };
   std::vector<std::unique_ptr<HenselSet>> hs;
 };
@@ -626,7 +639,15 @@ struct pgpu_batch {
   bool replicated = false;
   std::vector<rt::DevMem> shard;
   std::shared_ptr<ModCtx> mont;        // non-null: values are x*R mod N (canonical) for this context
+  // pair rows (kargs.hpp): pair_l2 > 0 -> a row is 2*pair_l2 29-bit limbs (pair_l2 64-bit words of storage), the pair of
+  // c*R modulo pair_form->n squared; `words` stays the logical width of the values (download)
+  int pair_l2 = 0;
+  std::shared_ptr<const pgpu_pubkey::PubForm> pair_form;   // constants of the domain (conversions need no key)
+  const uint32_t* prow(int d) const { return (const uint32_t*)shard[(size_t)d].p; }
+  uint32_t* prow(int d) { return (uint32_t*)shard[(size_t)d].p; }
   uint64_t gen = 0;                    // pool generation of the shards
+  int lane = 0;                        // batch lane (stream) its shards are ordered on: results inherit the lane of
+                                       // their first operand, uploads take the calling thread's lane (pgpu_set_batch_lane)
   uint64_t* ptr(int d) const { return (uint64_t*)shard[(size_t)d].p; }
   void bounds(int d, size_t* lo, size_t* hi) const {
     if (replicated) { *lo = 0; *hi = count; }
@@ -636,12 +657,14 @@ struct pgpu_batch {
 
 namespace {
 
-int new_batch(size_t count, int words, std::unique_ptr<pgpu_batch>* out) {
+thread_local int t_batch_lane = 0;
+int new_batch(size_t count, int words, std::unique_ptr<pgpu_batch>* out, int pair_l2 = 0, int lane = -1) {
   if (count == 0 || words <= 0) return fail(PGPU_ERR_INVALID_PARAM, "batch needs count > 0 and words > 0");
   std::unique_ptr<pgpu_batch> b(new pgpu_batch);
   b->count = count;
   b->words = words;
   b->gen = rt::pool_generation();
+  b->lane = lane < 0 ? t_batch_lane : (lane & 1);
   b->replicated = count == 1 && rt::pool_size() > 1;
   b->ndev = b->replicated ? rt::pool_size() : rt::shard_devices(count);
   b->shard.resize((size_t)b->ndev);
@@ -649,8 +672,9 @@ int new_batch(size_t count, int words, std::unique_ptr<pgpu_batch>* out) {
     size_t lo, hi;
     b->bounds(d, &lo, &hi);
     rt::Device& dev = rt::device(d);
-    RC_TRY(b->shard[(size_t)d].alloc(dev, dev.bstream, (hi - lo) * (size_t)words * 8));
+    RC_TRY(b->shard[(size_t)d].alloc(dev, dev.bs(b->lane), (hi - lo) * (size_t)(pair_l2 ? pair_l2 : words) * 8));
   }
+  b->pair_l2 = pair_l2;
   *out = std::move(b);
   return PGPU_OK;
 }
@@ -667,6 +691,38 @@ int same_layout(const pgpu_batch* a, const pgpu_batch* b) {
   if (b->count == 1 && a->count != 1) return PGPU_OK;   // broadcast operand: a copy everywhere (or on device 0)
   if (a->ndev != b->ndev || a->replicated != b->replicated)
     return fail(PGPU_ERR_INVALID_PARAM, "batches were sharded differently (pgpu_set_min_shard changed in between)");
+  return PGPU_OK;
+}
+
+// ---- batch lanes ----
+// Two independent chains of resident batches may be in flight on a GPU (Device::bs(0/1)): a result lives in the lane of
+// the operation's first operand.  An operand of the OTHER lane is ordered in before the launch (its producer has to be
+// done) and its lane is ordered behind the launch afterwards (its memory may be recycled by that lane's allocator only
+// after this reader is done).
+std::mutex g_xlane_mu;
+int lane_acquire(rt::Device& dev, const pgpu_batch* x, int lane) {
+  if (!x || x->lane == lane) return PGPU_OK;
+  std::lock_guard<std::mutex> lk(g_xlane_mu);
+  HIP_TRY(hipEventRecord(dev.xlane_ev[x->lane], dev.bs(x->lane)));
+  HIP_TRY(hipStreamWaitEvent(dev.bs(lane), dev.xlane_ev[x->lane], 0));
+  return PGPU_OK;
+}
+int lane_release(rt::Device& dev, const pgpu_batch* x, int lane) {
+  if (!x || x->lane == lane) return PGPU_OK;
+  std::lock_guard<std::mutex> lk(g_xlane_mu);
+  HIP_TRY(hipEventRecord(dev.xlane_ev[lane], dev.bs(lane)));
+  HIP_TRY(hipStreamWaitEvent(dev.bs(x->lane), dev.xlane_ev[lane], 0));
+  return PGPU_OK;
+}
+
+// the same for every device an operand lives on (acquire before the launches of an operation, release after them)
+int lanes_order(const pgpu_batch* x, int lane, bool acquire) {
+  if (!x || x->lane == lane) return PGPU_OK;
+  for (int d = 0; d < x->ndev; ++d) {
+    rt::Device& dev = rt::device(d);
+    rt::DeviceGuard g(dev.ordinal);
+    RC_TRY(acquire ? lane_acquire(dev, x, lane) : lane_release(dev, x, lane));
+  }
   return PGPU_OK;
 }
 
@@ -910,7 +966,8 @@ int modexp_on(rt::Device& d, const uint64_t* d_base, size_t base_stride, const u
 // ---------- fixed-base tables: budget and LRU ----------
 // A table is 13 MB (w = 8) to 203 MB (w = 12) per 2048-bit key and GPU.  Two limits keep a server with thousands of
 // keys inside its memory (pgpu_set_fixed_base_budget / PGPU_FB_MAX_BYTES, PGPU_FB_KEY_MAX_BYTES):
-//   * per key and GPU: the widest window <= the configured one whose table fits kFbKeyMax (default 256 MiB);
+//   * per key and GPU: the widest window <= the configured one whose table fits kFbKeyMax (default 512 MiB: w = 12
+//     also for the 2047-bit randomness of the reference's benchmark fixture, 403 MB);
 //   * per GPU, over all keys: kFbDevMax (default 2 GiB).  A new table that would exceed it evicts the least
 //     recently used tables of any key on that GPU first (never one whose launch is still being queued); if the
 //     budget cannot hold the table at all, the window shrinks until it does.
@@ -934,7 +991,7 @@ size_t fb_key_max() {
   size_t v = g_fb_key_max.load();
   if (v == 0) {
     const char* e = std::getenv("PGPU_FB_KEY_MAX_BYTES");
-    v = e && std::atoll(e) > 0 ? (size_t)std::atoll(e) : (size_t)256 << 20;
+    v = e && std::atoll(e) > 0 ? (size_t)std::atoll(e) : (size_t)512 << 20;
     g_fb_key_max.store(v);
   }
   return v;
@@ -1088,10 +1145,25 @@ pgpu::HenselPubDev hensel_pub_view(const pgpu_pubkey::PubForm* f, int dev, bool 
   v.kr = b + 2 * L2;
   v.one = b + 3 * L2;
   v.conv = b + 5 * L2 + (base_mont ? (size_t)f->nchunks * 2 * L2 : 0);
+  v.gm = b + (size_t)L2 * (5 + 4 * (size_t)f->nchunks);
   v.n0inv = f->n0inv;
   return v;
 }
-pgpu::HenselFullDev hensel_full_view(const pgpu_pubkey* key, const pgpu_pubkey::PubForm* f, int dev, bool out_mont) {
+// ---- pair rows (kargs.hpp): the resident form of ciphertext batches of keys that have a split form ----
+// the form whose limb count defines the rows of this key (fewest lanes per element), or null: no pair domain
+const pgpu_pubkey::PubForm* pair_form(const pgpu_pubkey* key) {
+  if (key->hforms.empty() || !hensel_enabled() || !pair_rows_enabled()) return nullptr;
+  const pgpu_pubkey::PubForm* f = key->hforms.back().get();
+  return pgpu::pair_ops_has(f->H, f->K) ? f : nullptr;
+}
+int pair_l2(const pgpu_pubkey* key) {
+  const pgpu_pubkey::PubForm* f = pair_form(key);
+  return f ? f->H * f->K : 0;
+}
+std::shared_ptr<const pgpu_pubkey::PubForm> pair_form_shared(const pgpu_pubkey* key) {
+  return pair_form(key) ? key->hforms.back() : nullptr;
+}
+pgpu::HenselFullDev hensel_full_view(const pgpu_pubkey* /*key*/, const pgpu_pubkey::PubForm* f, int dev, bool out_mont) {
   const size_t LF = (size_t)2 * f->H * f->K;
   const uint32_t* b = (const uint32_t*)f->full.d[(size_t)dev];
   pgpu::HenselFullDev v{};
@@ -1099,7 +1171,7 @@ pgpu::HenselFullDev hensel_full_view(const pgpu_pubkey* key, const pgpu_pubkey::
   v.nr = out_mont ? b + 2 * LF : b + LF;     // n*R'*Rs (Montgomery-form result) or n*R'
   v.r2 = out_mont ? b + 3 * LF : nullptr;
   v.n0inv = f->n0inv_full;
-  v.mod_words = 2 * key->n_words;
+  v.mod_words = 2 * f->n_words;
   return v;
 }
 
@@ -1127,9 +1199,13 @@ const pgpu_pubkey::PubForm* split_modexp_form(const pgpu_pubkey* key, size_t cou
 int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::PubForm* form, const uint64_t* d_base, size_t base_stride,
                     int base_words, bool base_mont, const uint64_t* d_exp, size_t exp_stride, int exp_words,
                     int exp_bits, const SchedRef* sched, int final_mul, const uint64_t* d_m, size_t m_stride,
-                    int m_words, uint64_t* d_out, bool out_mont, size_t count, hipStream_t s) {
+                    int m_words, uint64_t* d_out, bool out_mont, size_t count, hipStream_t s,
+                    const uint32_t* base_pair = nullptr, size_t base_pair_stride = 0, uint32_t* out_pair = nullptr) {
   const int H = form->H, K = form->K;
   pgpu::HenselModexpArgs a{};
+  a.base_pair = base_pair;
+  a.base_pair_stride = base_pair_stride;
+  a.out_pair = out_pair;
   a.ctx = hensel_pub_view(form, d.index, base_mont);
   a.full = hensel_full_view(key, form, d.index, out_mont);
   a.base = d_base;
@@ -1195,7 +1271,9 @@ int fb_table_for_split(const pgpu_pubkey* key, const pgpu_pubkey::PubForm* form,
 
 int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_t m_stride, int m_words,
                const uint64_t* d_r, size_t r_stride, int r_words, int r_bits, uint64_t* d_c, size_t count,
-               hipStream_t s, bool out_mont, size_t total_count) {
+               hipStream_t s, bool out_mont, size_t total_count, uint32_t* d_pair = nullptr) {
+  // d_pair: the ciphertexts leave as pair rows (resident batches; the caller has checked that the key has a pair form,
+  // that the plaintext rows are no wider than n and that the obfuscator runs through a split-form kernel)
   const int W = 2 * key->n_words;
   if (m_words <= 0 || m_words > W || m_stride < (size_t)m_words)
     return fail(PGPU_ERR_INVALID_PARAM, "plaintext width/stride invalid");
@@ -1212,7 +1290,7 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
     }
     // hs is a key constant: fixed-base windowing, no squarings (kernels.hpp: fb_encrypt_kernel)
     const GeoInfo& geo = key->nsq->geo;
-    const pgpu_pubkey::PubForm* sform = use_split_encrypt(key, m_words, count);
+    const pgpu_pubkey::PubForm* sform = d_pair ? pair_form(key) : use_split_encrypt(key, m_words, count);
     // the per-key / per-GPU table limits may narrow the window (fb_fit_window)
     fbw = fb_fit_window(fbw, r_bits, sform ? (size_t)2 * sform->H * sform->K * sizeof(uint32_t) : (size_t)geo.L() * sizeof(uint32_t));
     const int nwin = std::max(1, (r_bits + fbw - 1) / fbw);
@@ -1236,6 +1314,7 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
       f.out = d_c;
       f.out_stride = (size_t)W;
       f.count = count;
+      f.out_pair = d_pair;
       TimerScope t(d, s, PGPU_KERNEL_FB_ENCRYPT);
       const int ipw = 64 / (2 * form->H);
       const unsigned blocks = (unsigned)(((count + ipw - 1) / ipw + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
@@ -1281,7 +1360,8 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
     a.exp_bits = r_bits;
   } else {         // r^n: per-element base, shared exponent n (pub_key.cpp:66-80)
     if (r_words > W) return fail(PGPU_ERR_INVALID_PARAM, "random wider than n^2");
-    const pgpu_pubkey::PubForm* form = 64 * m_words <= key->n.BitSize() ? split_modexp_form(key, count) : nullptr;
+    const pgpu_pubkey::PubForm* form = d_pair ? pair_form(key)
+                                       : (64 * m_words <= key->n.BitSize() ? split_modexp_form(key, count) : nullptr);
     if (form) {
       SchedRef srn;
       if (key->sched_n.dev.bytes) {
@@ -1292,7 +1372,7 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
       return modexp_split_on(d, key, form, d_r, r_stride, r_words, false,
                              (const uint64_t*)key->d_n.d[(size_t)d.index], 0, key->n_words, key->n.BitSize(),
                              srn.p[0] ? &srn : nullptr, pgpu::FM_PAILLIER_G, d_m, m_stride, m_words, d_c, out_mont,
-                             count, s);
+                             count, s, nullptr, 0, d_pair);
     }
     a.base = d_r;
     a.base_stride = r_stride;
@@ -1302,6 +1382,7 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
     a.exp_words = key->n_words;
     a.exp_bits = key->n.BitSize();
   }
+  if (d_pair) return fail(PGPU_ERR_UNSUPPORTED, "pair-row output needs a split-form encrypt kernel");
   a.exp_per_ctx = 0;
   a.final_mul = pgpu::FM_PAILLIER_G;
   a.fm_words = d_m;
@@ -1335,7 +1416,8 @@ const pgpu_privkey::HenselSet* pick_hensel(const pgpu_privkey* key, size_t count
 
 // fused CRT decrypt on one device; in_mont: ciphertexts arrive in the Montgomery domain of n^2
 int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m, size_t count,
-               hipStream_t s, bool in_mont) {
+               hipStream_t s, bool in_mont, const uint32_t* d_pair = nullptr, int in_pair_l2 = 0) {
+  // d_pair: the ciphertexts are pair rows of 2*in_pair_l2 limbs (d_c unused); needs a split form of the key
   const int nw = key->n_words;
   rt::StreamWork& w = d.work_for(s);
   std::lock_guard<std::mutex> lk(w.mu);   // the hand-over buffer is ours until both stages are queued
@@ -1344,6 +1426,8 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
   const bool sliding = secret_policy() == PGPU_EXP_SLIDING && key->sched[0].dev.bytes;
   bool have_m = false;
   const pgpu_privkey::HenselSet* hset = pick_hensel(key, count);
+  if (d_pair && (!hset || hset->pair_l2 != in_pair_l2))
+    return fail(PGPU_ERR_UNSUPPORTED, "decrypt: pair-row ciphertexts need the split-form kernel of this key size");
   if (hset) {
     // stage 1, split form: M[2i] = mp, M[2i+1] = mq  (hensel.hpp)
     const int L2 = hset->H * hset->K, nch = hset->nchunks, ipw = 64 / (2 * hset->H);
@@ -1363,6 +1447,18 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
     h.ct = d_c;
     h.ct_stride = (size_t)2 * nw;
     h.ct_words = 2 * nw;
+    if (d_pair) {
+      h.ct_pair = d_pair;
+      h.ct_pair_stride = (size_t)2 * in_pair_l2;
+      h.pair_l2 = in_pair_l2;
+      h.pchunk_limbs = hset->pchunk_limbs;
+      h.pchunks = hset->pchunks;
+      for (int sd = 0; sd < 2; ++sd) {
+        const uint32_t* pc = blob + sd * side_words + (size_t)L2 * (6 + 4 * (size_t)nch);
+        h.ctx[sd].pconv = pc;
+        h.ctx[sd].pcb = pc + (size_t)hset->pchunks * 2 * L2;
+      }
+    }
     h.chunk_words = hset->chunk_words;
     h.nchunks = nch;
     h.exp = (const uint64_t*)key->d_exps.d[(size_t)d.index];
@@ -1450,6 +1546,90 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
     return fail(PGPU_ERR_UNSUPPORTED, "crt kernel geometry not compiled");
   HIP_TRY(hipGetLastError());
   tc.stop();
+  return PGPU_OK;
+}
+
+// ---------- pair rows: launches and conversions ----------
+int pair_op_launch(rt::Device& d, const pgpu_pubkey::PubForm* f, pgpu::PairOpsArgs& a, hipStream_t s, int kind) {
+  const size_t ipw = 64 / (2 * (size_t)f->H);
+  const size_t waves = (a.count + ipw - 1) / ipw;
+  const unsigned blocks = (unsigned)((waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
+  TimerScope t(d, s, kind);
+  if (!pgpu::launch_pair_ops(f->H, f->K, a, blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "pair-row kernel not compiled");
+  HIP_TRY(hipGetLastError());
+  t.stop();
+  return PGPU_OK;
+}
+// one shard: 64-bit words (plain, or c*Rs mod n^2 when src_mont) -> pair rows
+int words_to_pair_on(rt::Device& d, const pgpu_pubkey::PubForm* f, const uint64_t* words, size_t stride, int nwords,
+                     bool src_mont, uint32_t* out, size_t count, hipStream_t s) {
+  pgpu::PairOpsArgs a{};
+  a.ctx = hensel_pub_view(f, d.index, src_mont);
+  a.op = pgpu::PO_FROM_WORDS;
+  a.words = words;
+  a.words_stride = stride;
+  a.nwords = nwords;
+  a.chunk_words = f->chunk_words;
+  a.nchunks = (nwords + f->chunk_words - 1) / f->chunk_words;
+  a.out = out;
+  a.count = count;
+  return pair_op_launch(d, f, a, s, PGPU_KERNEL_MODMUL);
+}
+// one shard: pair rows -> canonical plain words
+int pair_to_words_on(rt::Device& d, const pgpu_pubkey::PubForm* f, const uint32_t* rows, uint64_t* out, size_t count,
+                     hipStream_t s) {
+  pgpu::PairOpsArgs a{};
+  a.ctx = hensel_pub_view(f, d.index);
+  a.full = hensel_full_view(nullptr, f, d.index, false);
+  a.op = pgpu::PO_TO_WORDS;
+  a.a = rows;
+  a.out_words = out;
+  a.out_stride = (size_t)2 * f->n_words;
+  a.count = count;
+  return pair_op_launch(d, f, a, s, PGPU_KERNEL_MODMUL);
+}
+// a ciphertext batch of the key in pair rows: `a` itself when it already is one, else a converted copy held by *tmp
+int as_pair_batch(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_batch** out, std::unique_ptr<pgpu_batch>* tmp) {
+  const pgpu_pubkey::PubForm* f = pair_form(key);
+  if (!f) return fail(PGPU_ERR_UNSUPPORTED, "key has no pair form");
+  const int l2 = f->H * f->K;
+  if (a->pair_l2) {
+    if (a->pair_l2 != l2 || !(a->pair_form->n == key->n))
+      return fail(PGPU_ERR_INVALID_PARAM, "ciphertext batch belongs to a different key");
+    *out = a;
+    return PGPU_OK;
+  }
+  std::unique_ptr<pgpu_batch> t;
+  RC_TRY(new_batch(a->count, a->words, &t, l2, a->lane));
+  t->pair_form = pair_form_shared(key);
+  for (int d = 0; d < t->ndev; ++d) {
+    size_t lo, hi;
+    t->bounds(d, &lo, &hi);
+    rt::Device& dev = rt::device(d);
+    rt::DeviceGuard g(dev.ordinal);
+    RC_TRY(words_to_pair_on(dev, f, a->ptr(d), (size_t)a->words, a->words, a->mont != nullptr, t->prow(d), hi - lo, dev.bs(a->lane)));
+  }
+  *tmp = std::move(t);
+  *out = tmp->get();
+  return PGPU_OK;
+}
+// a ciphertext batch as 64-bit words (plain): `a` itself unless it is in pair rows
+int as_word_batch(const pgpu_batch* a, const pgpu_batch** out, std::unique_ptr<pgpu_batch>* tmp) {
+  if (!a->pair_l2) {
+    *out = a;
+    return PGPU_OK;
+  }
+  std::unique_ptr<pgpu_batch> t;
+  RC_TRY(new_batch(a->count, a->words, &t, 0, a->lane));
+  for (int d = 0; d < t->ndev; ++d) {
+    size_t lo, hi;
+    t->bounds(d, &lo, &hi);
+    rt::Device& dev = rt::device(d);
+    rt::DeviceGuard g(dev.ordinal);
+    RC_TRY(pair_to_words_on(dev, a->pair_form.get(), a->prow(d), t->ptr(d), hi - lo, dev.bs(a->lane)));
+  }
+  *tmp = std::move(t);
+  *out = tmp->get();
   return PGPU_OK;
 }
 
@@ -1577,6 +1757,7 @@ int pgpu_synchronize(void) {
     rt::Device& d = rt::device(i);
     rt::DeviceGuard g(d.ordinal);
     HIP_TRY(hipStreamSynchronize(d.bstream));
+    HIP_TRY(hipStreamSynchronize(d.bstream1));
     for (auto& lane : d.lanes) HIP_TRY(hipStreamSynchronize(lane->stream));
   }
   drain_parked();   // evicted per-modulus contexts (their hipFree waits for whatever still reads them)
@@ -1885,11 +2066,13 @@ int build_hensel_pub_form(pgpu_pubkey* k, int H, int K) {
   const int cw = std::min(k->n_words, n.BitSize() / 64);
   if (cw <= 0) return PGPU_OK;
   const int nch = (2 * k->n_words + cw - 1) / cw;
-  std::unique_ptr<pgpu_pubkey::PubForm> f(new pgpu_pubkey::PubForm);
+  std::shared_ptr<pgpu_pubkey::PubForm> f(new pgpu_pubkey::PubForm);
   f->H = H;
   f->K = K;
   f->chunk_words = cw;
   f->nchunks = nch;
+  f->n_words = k->n_words;
+  f->n = n;
   auto n0inv_of = [](const BigNumber& v) {
     uint32_t n0 = (uint32_t)(v.limbs64()[0] & pgpu::kLimbMask), inv = n0;
     for (int i = 0; i < 5; ++i) inv *= 2u - n0 * inv;
@@ -1899,7 +2082,7 @@ int build_hensel_pub_form(pgpu_pubkey* k, int H, int K) {
   f->n0inv_full = n0inv_of(N);
   const BigNumber P = n * BigNumber((Ipp32u)f->n0inv), P2 = P * P;
   const BigNumber R = pow2(L2 * pgpu::kLimbBits);
-  std::vector<uint32_t> h((size_t)L2 * (5 + 4 * (size_t)nch), 0);
+  std::vector<uint32_t> h((size_t)L2 * (6 + 4 * (size_t)nch), 0);
   auto put_pair = [&](uint32_t* dst, const BigNumber& z) {
     const BigNumber zr = z % P2;
     const BigNumber q = zr / P;
@@ -1908,6 +2091,12 @@ int build_hensel_pub_form(pgpu_pubkey* k, int H, int K) {
   };
   to_limbs29(P, L2, h.data());
   to_limbs29(n, L2, h.data() + L2);
+  {
+    // gm = (-k^-1 mod n) * R^2 mod n  (kargs.hpp HenselPubDev::gm; hensel.hpp pair_times_gm)
+    const BigNumber kinv = n.InverseMul(BigNumber((Ipp32u)f->n0inv) % n);
+    const BigNumber Rn = R % n;
+    to_limbs29((((n - kinv) % n) * ((Rn * Rn) % n)) % n, L2, h.data() + (size_t)L2 * (5 + 4 * (size_t)nch));
+  }
   to_limbs29((R % n) * BigNumber((Ipp32u)f->n0inv) % n, L2, h.data() + 2 * L2);
   const BigNumber Rm = R % P2, R2 = (Rm * Rm) % P2;
   put_pair(h.data() + 3 * L2, Rm);
@@ -2034,6 +2223,20 @@ int pgpu_paillier_encrypt(const pgpu_pubkey* key, const uint64_t* m, size_t m_st
 namespace {
 // Constants of the split-form exponentiation (hensel.hpp) for both sides of the key.  A residue z modulo P^2 is
 // the pair (a, b) with z == a - P*b: a = z mod P, b = (P - z div P) mod P.
+// limbs per half of the pair rows a PUBLIC key over n would use (build_hensel_pub: its form of fewest lanes), 0: none
+int pair_l2_for_modulus(const BigNumber& n) {
+  const int need = n.BitSize() + 29 + 8, nsq_bits = 2 * n.BitSize();
+  int l2 = 0;
+  for (int H : {8, 4, 2})
+    for (int K = 1; K <= 19; ++K)
+      if ((pgpu::hensel_modexp_has(H, K) || pgpu::hensel_fb_has(H, K)) && pgpu::kLimbBits * H * K >= need &&
+          2 * pgpu::kLimbBits * H * K >= nsq_bits + 8) {
+        l2 = pgpu::pair_ops_has(H, K) ? H * K : 0;
+        break;
+      }
+  return l2;
+}
+
 int build_hensel_set(pgpu_privkey* k, pgpu_privkey::HenselSet* hs, int H, int K, const BigNumber& p,
                      const BigNumber& q, const BigNumber& hp, const BigNumber& hq) {
   const int L2 = H * K;
@@ -2048,6 +2251,20 @@ int build_hensel_set(pgpu_privkey* k, pgpu_privkey::HenselSet* hs, int H, int K,
   hs->K = K;
   hs->chunk_words = cw;
   hs->nchunks = nch;
+  // entry from pair rows of the n^2 domain: the a part in chunks of at most L2 limbs (so that a chunk fits the lanes of
+  // one half), evenly sized
+  const BigNumber nmod = p * q;
+  hs->pair_l2 = pair_l2_for_modulus(nmod);
+  if (hs->pair_l2) {
+    hs->pchunks = (hs->pair_l2 + L2 - 1) / L2;
+    hs->pchunk_limbs = (hs->pair_l2 + hs->pchunks - 1) / hs->pchunks;
+  }
+  uint32_t kn = 0;   // Pn = n * kn == -1 mod 2^29
+  {
+    uint32_t n0 = (uint32_t)(nmod.limbs64()[0] & pgpu::kLimbMask), inv = n0;
+    for (int i = 0; i < 5; ++i) inv *= 2u - n0 * inv;
+    kn = (0u - inv) & pgpu::kLimbMask;
+  }
   const size_t side_words = hs->side_words();
   std::vector<uint32_t> h(2 * side_words, 0);
   for (int sd = 0; sd < 2; ++sd) {
@@ -2075,6 +2292,24 @@ int build_hensel_set(pgpu_privkey* k, pgpu_privkey::HenselSet* hs, int H, int K,
       const BigNumber sh = pow2(64 * cw * i) % P2;
       put_pair(b + 6 * L2 + (size_t)i * 2 * L2, (R2 * sh) % P2);
       put_pair(b + 6 * L2 + (size_t)(nch + i) * 2 * L2, (R2m * sh) % P2);
+    }
+    if (hs->pair_l2) {
+      // c*Rn == a - Pn*b (mod n^2), Pn = n*kn = pr * (n/pr) * kn.  Modulo pr^2:  c*Rn == a - P*(kappa*b) with
+      // kappa = (n/pr) * kn * k^-1 mod pr  (P = pr*k; P*y only depends on y mod pr).  The pair of c*R is that times R/Rn.
+      const BigNumber Rn = pow2(hs->pair_l2 * pgpu::kLimbBits);
+      const BigNumber R2n = (R2 * P2.InverseMul(Rn % P2)) % P2;            // R^2 * Rn^-1 mod P^2
+      const BigNumber other = sd ? p : q;
+      const BigNumber kinv = pr.InverseMul(BigNumber((Ipp32u)n0inv) % pr);   // k^-1 mod pr
+      const BigNumber kappa = (((other % pr) * (BigNumber((Ipp32u)kn) % pr)) % pr * kinv) % pr;
+      const BigNumber Rp = R % pr;
+      const BigNumber r2n_p = (((Rp * Rp) % pr) * pr.InverseMul(Rn % pr)) % pr;   // R^2 * Rn^-1 mod pr
+      uint32_t* pc = b + (size_t)L2 * (6 + 4 * (size_t)nch);
+      uint32_t* pb = pc + (size_t)hs->pchunks * 2 * L2;
+      for (int i = 0; i < hs->pchunks; ++i) {
+        const BigNumber sh = pow2(pgpu::kLimbBits * hs->pchunk_limbs * i);
+        put_pair(pc + (size_t)i * 2 * L2, (R2n * (sh % P2)) % P2);
+        to_limbs29((((kappa * (sh % pr)) % pr) * r2n_p) % pr, L2, pb + (size_t)i * L2);
+      }
     }
     hs->n0inv[sd] = n0inv;
   }
@@ -2262,7 +2497,7 @@ int pgpu_batch_create(size_t count, int words, pgpu_batch** out) {
 void pgpu_batch_destroy(pgpu_batch* b) { delete b; }
 size_t pgpu_batch_count(const pgpu_batch* b) { return b ? b->count : 0; }
 int pgpu_batch_words(const pgpu_batch* b) { return b ? b->words : 0; }
-int pgpu_batch_is_montgomery(const pgpu_batch* b) { return b && b->mont ? 1 : 0; }
+int pgpu_batch_is_montgomery(const pgpu_batch* b) { return b && (b->mont || b->pair_l2) ? 1 : 0; }   // any device-side domain
 
 int pgpu_batch_upload(const uint64_t* host, size_t count, int words, size_t stride, pgpu_batch** out) {
   RC_TRY(rt::check_ready());
@@ -2276,7 +2511,7 @@ int pgpu_batch_upload(const uint64_t* host, size_t count, int words, size_t stri
     tg.run(rt::device(d), [=](rt::Lane& lane) -> int {
       size_t lo, hi;
       bp->bounds(d, &lo, &hi);
-      hipStream_t s = lane.dev->bstream;
+      hipStream_t s = lane.dev->bs(bp->lane);
       if (stride == (size_t)words) {
         RC_TRY(lane.h2d(bp->ptr(d), host + lo * (size_t)words, (hi - lo) * (size_t)words * 8, s));
       } else {   // rows padded to a wider stride on the host: the device batch is dense
@@ -2307,8 +2542,15 @@ int pgpu_batch_download(const pgpu_batch* b, uint64_t* host) {
       size_t lo, hi;
       b->bounds(d, &lo, &hi);
       rt::Device& dev = *lane.dev;
-      hipStream_t s = dev.bstream;
+      hipStream_t s = dev.bs(b->lane);
       const size_t bytes = (hi - lo) * (size_t)b->words * 8;
+      if (b->pair_l2) {   // pair rows: the plain value materialises here
+        rt::DevMem plain;
+        RC_TRY(plain.alloc(dev, s, bytes));
+        rt::DeviceGuard g(dev.ordinal);
+        RC_TRY(pair_to_words_on(dev, b->pair_form.get(), b->prow(d), (uint64_t*)plain.p, hi - lo, s));
+        return lane.d2h(host + lo * (size_t)b->words, plain.p, bytes, s);
+      }
       if (!b->mont) return lane.d2h(host + lo * (size_t)b->words, b->ptr(d), bytes, s);
       rt::DevMem plain;   // leave the Montgomery domain on the way out
       RC_TRY(plain.alloc(dev, s, bytes));
@@ -2328,17 +2570,27 @@ int pgpu_batch_encrypt(const pgpu_pubkey* key, const pgpu_batch* m, const pgpu_b
   RC_TRY(check_gen(r->gen, "batch"));
   if (m->count != r->count) return fail(PGPU_ERR_INVALID_PARAM, "modExp: input vector size error");
   if (m->mont || r->mont) return fail(PGPU_ERR_INVALID_PARAM, "encrypt: operands must be plain batches");
+  if (m->pair_l2 || r->pair_l2) return fail(PGPU_ERR_INVALID_PARAM, "encrypt: operands must be plain batches");
   RC_TRY(same_layout(m, r));
+  // Keys with a split form keep their resident ciphertexts as PAIR ROWS (kargs.hpp) whenever the obfuscator runs
+  // through a split-form kernel: DJN with a fixed-base table, or r^n.  Plaintext rows wider than n take the full-width
+  // kernels and leave Montgomery-form words, as in round 2; consumers convert on the way in.
+  const int l2 = (pair_form(key) && 64 * m->words <= key->n.BitSize() && (!key->djn || fixed_base_window() > 0) &&
+                  (key->djn || r->words <= 2 * key->n_words))
+                     ? pair_l2(key) : 0;
   std::unique_ptr<pgpu_batch> out;
-  RC_TRY(new_batch(m->count, 2 * key->n_words, &out));
-  out->mont = key->nsq;
+  RC_TRY(new_batch(m->count, 2 * key->n_words, &out, l2, m->lane));
+  if (l2) out->pair_form = pair_form_shared(key);
+  else out->mont = key->nsq;
   for (int d = 0; d < out->ndev; ++d) {
     size_t lo, hi;
     out->bounds(d, &lo, &hi);
     rt::Device& dev = rt::device(d);
     rt::DeviceGuard g(dev.ordinal);
+    RC_TRY(lane_acquire(dev, r, m->lane));
     RC_TRY(encrypt_on(dev, key, m->ptr(d), (size_t)m->words, m->words, r->ptr(d), (size_t)r->words, r->words, r_bits,
-                      out->ptr(d), hi - lo, dev.bstream, true, m->count));
+                      l2 ? nullptr : out->ptr(d), hi - lo, dev.bs(m->lane), true, m->count, l2 ? out->prow(d) : nullptr));
+    RC_TRY(lane_release(dev, r, m->lane));
   }
   if (key->djn) {
     std::lock_guard<std::mutex> lk(key->mu);
@@ -2356,14 +2608,30 @@ int pgpu_batch_decrypt_crt(const pgpu_privkey* key, const pgpu_batch* c, pgpu_ba
   if (c->words != 2 * key->n_words) return fail(PGPU_ERR_INVALID_PARAM, "decrypt: ciphertext width mismatch");
   if (c->mont && c->mont->geo.rbits() != key->nsq_rbits)
     return fail(PGPU_ERR_INVALID_PARAM, "decrypt: ciphertext batch belongs to a different key size");
+  // pair rows enter the split-form kernel as they are; when this launch would not take it (PGPU_HENSEL=0, a key class
+  // without the form) they become plain words first
+  std::unique_ptr<pgpu_batch> tmp;
+  if (c->pair_l2) {
+    size_t lo0, hi0;
+    c->bounds(0, &lo0, &hi0);
+    const pgpu_privkey::HenselSet* hset = pick_hensel(key, hi0 - lo0);
+    if (!hset || hset->pair_l2 != c->pair_l2) {
+      const pgpu_batch* cw = nullptr;
+      RC_TRY(as_word_batch(c, &cw, &tmp));
+      c = cw;
+    }
+  }
   std::unique_ptr<pgpu_batch> out;
-  RC_TRY(new_batch(c->count, key->n_words, &out));
+  RC_TRY(new_batch(c->count, key->n_words, &out, 0, c->lane));
   for (int d = 0; d < out->ndev; ++d) {
     size_t lo, hi;
     out->bounds(d, &lo, &hi);
     rt::Device& dev = rt::device(d);
     rt::DeviceGuard g(dev.ordinal);
-    RC_TRY(decrypt_on(dev, key, c->ptr(d), out->ptr(d), hi - lo, dev.bstream, c->mont != nullptr));
+    if (c->pair_l2)
+      RC_TRY(decrypt_on(dev, key, nullptr, out->ptr(d), hi - lo, dev.bs(c->lane), false, c->prow(d), c->pair_l2));
+    else
+      RC_TRY(decrypt_on(dev, key, c->ptr(d), out->ptr(d), hi - lo, dev.bs(c->lane), c->mont != nullptr));
   }
   *m = out.release();
   return PGPU_OK;
@@ -2372,14 +2640,14 @@ int pgpu_batch_decrypt_crt(const pgpu_privkey* key, const pgpu_batch* c, pgpu_ba
 // brings a plain ciphertext batch into the key's Montgomery domain (fresh batch), shard by shard
 static int to_montgomery(const pgpu_pubkey* key, const pgpu_batch* a, std::unique_ptr<pgpu_batch>* out) {
   std::unique_ptr<pgpu_batch> t;
-  RC_TRY(new_batch(a->count, a->words, &t));
+  RC_TRY(new_batch(a->count, a->words, &t, 0, a->lane));
   t->mont = key->nsq;
   for (int d = 0; d < t->ndev; ++d) {
     size_t lo, hi;
     t->bounds(d, &lo, &hi);
     rt::Device& dev = rt::device(d);
     rt::DeviceGuard g(dev.ordinal);
-    RC_TRY(modmul_on(dev, *key->nsq, pgpu::MM_BY_R2, a->ptr(d), nullptr, 0, 0, t->ptr(d), hi - lo, dev.bstream));
+    RC_TRY(modmul_on(dev, *key->nsq, pgpu::MM_BY_R2, a->ptr(d), nullptr, 0, 0, t->ptr(d), hi - lo, dev.bs(a->lane)));
   }
   *out = std::move(t);
   return PGPU_OK;
@@ -2396,9 +2664,39 @@ int pgpu_batch_ct_add(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_ba
   if (b->count != a->count && b->count != 1) return fail(PGPU_ERR_INVALID_PARAM, "CT + CT error: Size mismatch!");
   if (!same_domain(a->mont, key->nsq) || !same_domain(b->mont, key->nsq))
     return fail(PGPU_ERR_INVALID_PARAM, "CT + CT error: 2 different public keys detected!");
-  // both operands in the Montgomery domain -> ONE product per element, result stays there
   RC_TRY(same_layout(a, b));
   std::unique_ptr<pgpu_batch> ta, tb;
+  if (const pgpu_pubkey::PubForm* f = pair_form(key)) {
+    // pair rows: ONE pair product per element (5 instead of 8 s^2 limb products, no word <-> limb conversion)
+    RC_TRY(as_pair_batch(key, a, &a, &ta));
+    RC_TRY(as_pair_batch(key, b, &b, &tb));
+    const int l2 = f->H * f->K;
+    std::unique_ptr<pgpu_batch> o;
+    RC_TRY(new_batch(a->count, W, &o, l2, a->lane));
+    o->pair_form = pair_form_shared(key);
+    RC_TRY(lanes_order(b, a->lane, true));
+  const bool bcast = b->count == 1 && a->count != 1;
+    for (int d = 0; d < o->ndev; ++d) {
+      size_t lo, hi;
+      o->bounds(d, &lo, &hi);
+      rt::Device& dev = rt::device(d);
+      rt::DeviceGuard g(dev.ordinal);
+      pgpu::PairOpsArgs pa{};
+      pa.ctx = hensel_pub_view(f, dev.index);
+      pa.op = pgpu::PO_MUL;
+      pa.a = a->prow(d);
+      pa.b = b->prow(b->replicated ? d : (bcast ? 0 : d));
+      pa.b_stride = bcast ? 0 : (size_t)2 * l2;
+      pa.out = o->prow(d);
+      pa.count = hi - lo;
+      RC_TRY(pair_op_launch(dev, f, pa, dev.bs(a->lane), PGPU_KERNEL_MODMUL));
+    }
+    RC_TRY(lanes_order(b, a->lane, false));
+    *out = o.release();
+    return PGPU_OK;
+  }
+  if (a->pair_l2 || b->pair_l2) return fail(PGPU_ERR_INVALID_PARAM, "CT + CT error: 2 different public keys detected!");
+  // both operands in the Montgomery domain -> ONE product per element, result stays there
   if (!a->mont) {
     RC_TRY(to_montgomery(key, a, &ta));
     a = ta.get();
@@ -2408,8 +2706,9 @@ int pgpu_batch_ct_add(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_ba
     b = tb.get();
   }
   std::unique_ptr<pgpu_batch> o;
-  RC_TRY(new_batch(a->count, W, &o));
+  RC_TRY(new_batch(a->count, W, &o, 0, a->lane));
   o->mont = key->nsq;
+  RC_TRY(lanes_order(b, a->lane, true));
   const bool bcast = b->count == 1 && a->count != 1;
   for (int d = 0; d < o->ndev; ++d) {
     size_t lo, hi;
@@ -2417,8 +2716,9 @@ int pgpu_batch_ct_add(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_ba
     rt::Device& dev = rt::device(d);
     rt::DeviceGuard g(dev.ordinal);
     RC_TRY(modmul_on(dev, *key->nsq, pgpu::MM_SINGLE, a->ptr(d), b->ptr(b->replicated ? d : (bcast ? 0 : d)),
-                     bcast ? 0 : (size_t)W, 0, o->ptr(d), hi - lo, dev.bstream));
+                     bcast ? 0 : (size_t)W, 0, o->ptr(d), hi - lo, dev.bs(a->lane)));
   }
+  RC_TRY(lanes_order(b, a->lane, false));
   *out = o.release();
   return PGPU_OK;
 }
@@ -2433,11 +2733,48 @@ int pgpu_batch_ct_add_plain(const pgpu_pubkey* key, const pgpu_batch* a, const p
   if (a->words != W || m->words > W) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: width mismatch");
   if (m->count != a->count && m->count != 1) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: Size mismatch!");
   if (!same_domain(a->mont, key->nsq)) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: batch belongs to a different key");
-  if (m->mont) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: plaintext batch in Montgomery form");
+  if (m->mont || m->pair_l2) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: plaintext batch in Montgomery form");
   RC_TRY(same_layout(a, m));
+  std::unique_ptr<pgpu_batch> ta;
+  const pgpu_pubkey::PubForm* pf = pair_form(key);
+  if (pf && 64 * m->words <= key->n.BitSize()) {
+    // pair rows: c * (1 + n*m) only changes the b half -- two half-width products (hensel.hpp: pair_times_gm)
+    RC_TRY(as_pair_batch(key, a, &a, &ta));
+    const int l2 = pf->H * pf->K;
+    std::unique_ptr<pgpu_batch> o;
+    RC_TRY(new_batch(a->count, W, &o, l2, a->lane));
+    o->pair_form = pair_form_shared(key);
+    RC_TRY(lanes_order(m, a->lane, true));
+  const bool bcast = m->count == 1 && a->count != 1;
+    for (int d = 0; d < o->ndev; ++d) {
+      size_t lo, hi;
+      o->bounds(d, &lo, &hi);
+      rt::Device& dev = rt::device(d);
+      rt::DeviceGuard g(dev.ordinal);
+      pgpu::PairOpsArgs pa{};
+      pa.ctx = hensel_pub_view(pf, dev.index);
+      pa.op = pgpu::PO_TIMES_GM;
+      pa.a = a->prow(d);
+      pa.words = m->ptr(m->replicated ? d : (bcast ? 0 : d));
+      pa.words_stride = bcast ? 0 : (size_t)m->words;
+      pa.nwords = m->words;
+      pa.out = o->prow(d);
+      pa.count = hi - lo;
+      RC_TRY(pair_op_launch(dev, pf, pa, dev.bs(a->lane), PGPU_KERNEL_MODMUL));
+    }
+    RC_TRY(lanes_order(m, a->lane, false));
+    *out = o.release();
+    return PGPU_OK;
+  }
+  if (a->pair_l2) {   // plaintext rows wider than n: the full-width kernel, on plain words
+    const pgpu_batch* aw = nullptr;
+    RC_TRY(as_word_batch(a, &aw, &ta));
+    a = aw;
+  }
   std::unique_ptr<pgpu_batch> o;
-  RC_TRY(new_batch(a->count, W, &o));
+  RC_TRY(new_batch(a->count, W, &o, 0, a->lane));
   o->mont = a->mont ? key->nsq : nullptr;   // the product keeps the form of the ciphertext
+  RC_TRY(lanes_order(m, a->lane, true));
   const bool bcast = m->count == 1 && a->count != 1;
   for (int d = 0; d < o->ndev; ++d) {
     size_t lo, hi;
@@ -2445,8 +2782,9 @@ int pgpu_batch_ct_add_plain(const pgpu_pubkey* key, const pgpu_batch* a, const p
     rt::Device& dev = rt::device(d);
     rt::DeviceGuard g(dev.ordinal);
     RC_TRY(modmul_on(dev, *key->nsq, pgpu::MM_GM, a->ptr(d), m->ptr(m->replicated ? d : (bcast ? 0 : d)),
-                     bcast ? 0 : (size_t)m->words, m->words, o->ptr(d), hi - lo, dev.bstream, VF_GM_MONT));
+                     bcast ? 0 : (size_t)m->words, m->words, o->ptr(d), hi - lo, dev.bs(a->lane), VF_GM_MONT));
   }
+  RC_TRY(lanes_order(m, a->lane, false));
   *out = o.release();
   return PGPU_OK;
 }
@@ -2464,11 +2802,39 @@ int pgpu_batch_ct_mul(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_ba
   if (e->mont) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: exponent batch in Montgomery form");
   if (!same_domain(a->mont, key->nsq)) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: batch belongs to a different key");
   if (e_bits < 0 || e_bits > 64 * e->words) return fail(PGPU_ERR_INVALID_PARAM, "exp_bits/exp_words inconsistent");
+  if (e->pair_l2) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: exponent batch in Montgomery form");
   RC_TRY(same_layout(a, e));
-  std::unique_ptr<pgpu_batch> o;
-  RC_TRY(new_batch(a->count, W, &o));
-  o->mont = key->nsq;
+  RC_TRY(lanes_order(e, a->lane, true));
   const bool bcast = e->count == 1 && a->count != 1;
+  std::unique_ptr<pgpu_batch> ta;
+  if (const pgpu_pubkey::PubForm* pf = pair_form(key)) {
+    // pair rows in, pair rows out: the split-form kernel starts from the row as it is and stores its result as it is.
+    // Forms of the same limb count share the rows (2048-bit keys: (8,9) for small batches, (4,18) beyond).
+    const int l2 = pf->H * pf->K;
+    RC_TRY(as_pair_batch(key, a, &a, &ta));
+    std::unique_ptr<pgpu_batch> o;
+    RC_TRY(new_batch(a->count, W, &o, l2, a->lane));
+    o->pair_form = pair_form_shared(key);
+    for (int d = 0; d < o->ndev; ++d) {
+      size_t lo, hi;
+      o->bounds(d, &lo, &hi);
+      rt::Device& dev = rt::device(d);
+      rt::DeviceGuard g(dev.ordinal);
+      const pgpu_pubkey::PubForm* form = split_modexp_form(key, hi - lo);
+      if (!form || form->H * form->K != l2) form = pf;
+      if (!pgpu::hensel_modexp_has(form->H, form->K)) return fail(PGPU_ERR_UNSUPPORTED, "split-form modexp kernel not compiled");
+      RC_TRY(modexp_split_on(dev, key, form, nullptr, 0, W, false, e->ptr(e->replicated ? d : (bcast ? 0 : d)),
+                             bcast ? 0 : (size_t)e->words, e->words, e_bits, nullptr, pgpu::FM_UNIT, nullptr, 0, 0, nullptr,
+                             false, hi - lo, dev.bs(a->lane), a->prow(d), (size_t)2 * l2, o->prow(d)));
+    }
+    RC_TRY(lanes_order(e, a->lane, false));
+    *out = o.release();
+    return PGPU_OK;
+  }
+  if (a->pair_l2) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: batch belongs to a different key");
+  std::unique_ptr<pgpu_batch> o;
+  RC_TRY(new_batch(a->count, W, &o, 0, a->lane));
+  o->mont = key->nsq;
   std::vector<uint64_t> mod((size_t)W);
   key->nsq->N.toLimbs64(mod.data(), mod.size());
   for (int d = 0; d < o->ndev; ++d) {
@@ -2479,16 +2845,25 @@ int pgpu_batch_ct_mul(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_ba
     if (const pgpu_pubkey::PubForm* form = split_modexp_form(key, hi - lo)) {
       RC_TRY(modexp_split_on(dev, key, form, a->ptr(d), (size_t)W, W, a->mont != nullptr,
                              e->ptr(e->replicated ? d : (bcast ? 0 : d)), bcast ? 0 : (size_t)e->words, e->words, e_bits,
-                             nullptr, pgpu::FM_UNIT, nullptr, 0, 0, o->ptr(d), true, hi - lo, dev.bstream));
+                             nullptr, pgpu::FM_UNIT, nullptr, 0, 0, o->ptr(d), true, hi - lo, dev.bs(a->lane)));
       continue;
     }
     RC_TRY(modexp_on(dev, a->ptr(d), (size_t)W, e->ptr(e->replicated ? d : (bcast ? 0 : d)),
-                     bcast ? 0 : (size_t)e->words, e->words, e_bits, mod.data(), W, o->ptr(d), hi - lo, dev.bstream,
+                     bcast ? 0 : (size_t)e->words, e->words, e_bits, mod.data(), W, o->ptr(d), hi - lo, dev.bs(a->lane),
                      nullptr, a->mont != nullptr, true, key->nsq));
   }
+  RC_TRY(lanes_order(e, a->lane, false));
   *out = o.release();
   return PGPU_OK;
 }
+
+int pgpu_set_batch_lane(int lane) {
+  if (lane < 0 || lane > 1) return fail(PGPU_ERR_INVALID_PARAM, "batch lane must be 0 or 1");
+  t_batch_lane = lane;
+  return PGPU_OK;
+}
+int pgpu_batch_lane(const pgpu_batch* b) { return b ? b->lane : 0; }
+int pgpu_batch_row_limbs(const pgpu_batch* b) { return b ? 2 * b->pair_l2 : 0; }
 
 // ---- diagnostics of the pool's self-checks and table budget ----
 int pgpu_replication_stats(uint64_t* images_verified, uint64_t* copies_repaired) {

@@ -217,7 +217,40 @@ __global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_kernel(Hensel
   uint32_t acc[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) acc[j] = 0;
-  {
+  if (A.ct_pair) {
+    // the ciphertext is a pair row of the n^2 domain: c*Rn == a - Pn*b.  Modulo p^2 (Pn = p * (n/p) * kn):
+    //   c*Rn == a - P*(kappa*b),  kappa = (n/p)*kn*k^-1 mod p   -- the a part enters in pchunks chunks z_i like the words of
+    // a plain ciphertext do, (z_i, 0) (x) pconv[i]; the b part only matters modulo p: b_i (x) pcb[i], half-width,
+    // added to half B.  Limbs are read in place: no word -> limb conversion, no LDS.
+    const uint32_t* row = A.ct_pair + elem * A.ct_pair_stride + (size_t)halfB * A.pair_l2;
+    const uint32_t* pconv = HCTX(pconv);
+    const uint32_t* pcb = HCTX(pcb);
+    const int trips = A.pchunks + ((sched_mode && tsize > 1) ? 1 : 0);
+#pragma unroll 1
+    for (int i = 0; i < trips; ++i) {
+      if (i < A.pchunks) {
+        const int first = i * A.pchunk_limbs;
+        uint32_t z[K], cb[K], tb[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const int li = x * K + j;
+          z[j] = (li < A.pchunk_limbs && first + li < A.pair_l2) ? row[first + li] : 0u;   // half A: a_i, half B: b_i
+          cb[j] = pcb[(size_t)i * L2 + x * K + j];
+          mreg[j] = pconv[(size_t)i * LQ + xg * K + j];
+          own[j] = halfB ? 0u : z[j];
+        }
+        montmul_reg<HG, false, true>(tb, z, cb, n, 0);   // (half A's result is not used)
+        pairmul<H, K, false, true>(own, own, mreg, n, n0inv, halfB, selB);
+#pragma unroll
+        for (int j = 0; j < K; ++j) own[j] += halfB ? tb[j] : 0u;
+        add_normalise<HG>(acc, own);
+      } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) own[j] = mreg[j] = acc[j];
+        pairmul<H, K, false, true>(own, own, mreg, n, n0inv, halfB, selB);
+      }
+    }
+  } else {
     const uint64_t* row = A.ct + elem * A.ct_stride;
     const uint32_t* conv = HCTX(conv);
     const int trips = A.nchunks + ((sched_mode && tsize > 1) ? 1 : 0);
@@ -292,6 +325,14 @@ __global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_kernel(Hensel
 #pragma unroll
     for (int j = 0; j < K; ++j) own[j] = HCTX(one)[xg * K + j];
   }
+  // Placement of the main loop in the instruction stream (A/B: tools/build_variant.py -DPGPU_PHASE_PAD=n): bit 0 shifts
+  // it by one 4-byte instruction, bit 1 starts it on a 64-byte line.  A lone wavefront's issue cadence depends on where
+  // its 8-byte instructions sit relative to the fetch granules (profiles/r03_ubench_phase.txt).
+#ifndef PGPU_PHASE_PAD
+#define PGPU_PHASE_PAD 0
+#endif
+  if constexpr ((PGPU_PHASE_PAD & 2) != 0) asm volatile(".p2align 6");
+  if constexpr ((PGPU_PHASE_PAD & 1) != 0) asm volatile("s_nop 0");
 #pragma unroll 1
   for (;;) {
     int nsq, idx;
@@ -369,6 +410,66 @@ __global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_kernel(Hensel
 template <int D>
 __device__ __forceinline__ uint32_t dpp_from_above(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + D /*row_shl:D*/, 0xf, 0xf, true);
+}
+
+// ---- pair rows (kargs.hpp): the HBM image of a resident ciphertext IS the register image of these kernels ----
+// lane xg of the group holds limbs [xg*K, xg*K + K) of the row's 2*H*K limbs
+template <int K>
+__device__ __forceinline__ void load_pair_row(uint32_t (&v)[K], const uint32_t* __restrict__ row, int xg) {
+  const uint32_t* p = row + xg * K;
+  if constexpr (K % 2 == 0) {   // rows are 8-byte aligned (2*H*K*4 bytes per row, K even): 64-bit loads
+    const uint2* q = reinterpret_cast<const uint2*>(p);
+#pragma unroll
+    for (int j = 0; j < K / 2; ++j) {
+      const uint2 t = q[j];
+      v[2 * j] = t.x;
+      v[2 * j + 1] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j) v[j] = p[j];
+  }
+}
+template <int K>
+__device__ __forceinline__ void store_pair_row(uint32_t* __restrict__ row, const uint32_t (&v)[K], int xg) {
+  uint32_t* p = row + xg * K;
+  if constexpr (K % 2 == 0) {
+    uint2* q = reinterpret_cast<uint2*>(p);
+#pragma unroll
+    for (int j = 0; j < K / 2; ++j) q[j] = make_uint2(v[2 * j], v[2 * j + 1]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j) p[j] = v[j];
+  }
+}
+
+// own (pair of x*R, loop modulus P = n*k) times g^m = 1 + n*m, the result again a pair of the same domain:
+//   (a - P*b)(1 + n*m) == a - P*b + n*m*a == a - P*(b - k^-1*m*a)   (mod n^2)     [n*m*P*b == 0; n = P/k]
+// so only b changes: b += (-k^-1 * m * a) mod n -- two half-width Montgomery products under the TRUE modulus n
+// (montmul(m, gm) = -k^-1*m*R, then times a), instead of the pair product by the pair of g^m (CT + PT:
+// ciphertext.cpp:75-80; the g^m factor of encrypt: pub_key.cpp:88-105).  mwords: the group's plaintext words in LDS
+// (zero padded to W64+1 of the half width); both halves run the same instruction stream.
+template <int H, int K>
+__device__ __forceinline__ void pair_times_gm(uint32_t (&own)[K], const HenselPubDev& C, const uint64_t* mwords, int x,
+                                              uint32_t halfB) {
+  using HG = Geo<H, K>;
+  uint32_t n[K], mv[K], cg[K], u[K], av[K], v[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    n[j] = C.n[x * K + j];
+    cg[j] = C.gm[x * K + j];
+    mv[j] = limb_from_words(mwords, x * K + j);
+  }
+  montmul_reg<HG, false, false>(u, mv, cg, n, C.n0inv);
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const uint32_t below = dpp_from_below<H>(own[j]);   // half B takes a copy of a
+    av[j] = halfB ? below : own[j];
+  }
+  montmul_reg<HG, false, false>(v, u, av, n, C.n0inv);
+#pragma unroll
+  for (int j = 0; j < K; ++j) v[j] = halfB ? v[j] : 0u;
+  add_normalise<HG>(own, v);
 }
 
 // own = words * R as a pair: sum over the chunks z_i of (z_i, 0) (x) pair(2^(64*cw*i) * R^2).  iorow: the group's
@@ -599,6 +700,14 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : 1) void hensel_fb_encrypt
 #pragma unroll
     for (int j = 0; j < K; ++j) mreg[j] = nxt[j];
   }
+  if (A.out_pair) {
+    // resident result: stay a pair.  hs^r * (1 + n*m): two half-width products (pair_times_gm), no way back to words.
+    stage_words<FG>(io, A.fm_words, A.fm_stride, 0, A.fm_nwords, first_inst, A.count, 1, lane);
+    wave_lds_sync();
+    pair_times_gm<H, K>(own, A.ctx, io[grp], x, halfB);
+    if (first_inst + grp < A.count) store_pair_row<K>(A.out_pair + inst * (size_t)LQ, own, xg);
+    return;
+  }
   pair_exit_store<H, K>(own, A.ctx, A.full, true, A.fm_words, A.fm_stride, A.fm_nwords, A.out, A.out_stride, first_inst,
                         A.count, bl, io, rows, lane, grp, xg, halfB, selB);
 }
@@ -653,8 +762,9 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : PGPU_HM_WAVES18) void hen
   };
 
   // (the FG-sized row of io holds more than the W64+1 words of a half-width chunk)
-  pair_from_words<H, K>(own, A.base + inst * A.base_stride, A.base_words, A.chunk_words, A.nchunks, A.ctx.conv,
-                        io[grp], n, halfB, selB, xg);
+  if (A.base_pair) load_pair_row<K>(own, A.base_pair + inst * A.base_pair_stride, xg);   // resident base: already c*R as a pair
+  else pair_from_words<H, K>(own, A.base + inst * A.base_stride, A.base_words, A.chunk_words, A.nchunks, A.ctx.conv,
+                             io[grp], n, halfB, selB, xg);
   // ---- window table (fixed window: all powers; schedule: the odd powers, built with base^2) ----
   {
     int e;
@@ -719,8 +829,70 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : PGPU_HM_WAVES18) void hen
     for (int i = 0; i < nsq; ++i) pairmul<H, K, true, true>(own, own, own, n, 0, halfB, selB);
     if (mul) pairmul<H, K, false, true>(own, own, mreg, n, 0, halfB, selB);
   }
+  if (A.out_pair) {
+    if (A.final_mul == FM_PAILLIER_G) {
+      wave_lds_sync();
+      stage_words<FG>(io, A.fm_words, A.fm_stride, 0, A.fm_nwords, first_inst, A.count, 1, lane);
+      wave_lds_sync();
+      pair_times_gm<H, K>(own, A.ctx, io[grp], xg % H, halfB);
+    }
+    if (first_inst + grp < A.count) store_pair_row<K>(A.out_pair + inst * (size_t)LQ, own, xg);
+    return;
+  }
   pair_exit_store<H, K>(own, A.ctx, A.full, A.final_mul == FM_PAILLIER_G, A.fm_words, A.fm_stride, A.fm_nwords, A.out,
                         A.out_stride, first_inst, A.count, bl, io, rows, lane, grp, xg, halfB, selB);
+}
+
+// Element-wise operations on pair rows (kargs.hpp: PairOp): CT + CT as ONE pair product, CT + PT as two half-width
+// products, and the conversions between pair rows and 64-bit words (upload of caller data, pgpu_batch_download).
+template <int H, int K>
+__global__ __launch_bounds__(kWGThreads, 2) void pair_ops_kernel(PairOpsArgs A) {
+  using HG = Geo<H, K>;
+  using FG = Geo<2 * H, K>;
+  constexpr int GS = 2 * H, IPW = kWave / GS, LQ = 2 * H * K;
+  raise_wave_priority();
+  __shared__ uint32_t bl_[kWavesPerWG][IPW][FG::L];
+  __shared__ uint64_t io_[kWavesPerWG][IPW][FG::W64 + 1];
+  __shared__ uint32_t rows_[kWavesPerWG][2][FG::L];
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  auto& bl = bl_[wv];
+  auto& io = io_[wv];
+  auto& rows = rows_[wv];
+  const int grp = lane / GS, xg = lane % GS, x = xg % H;
+  const uint32_t halfB = (uint32_t)(xg / H);
+  uint32_t selB = xg == H ? 1u : 0u;
+  asm("" : "+v"(selB));
+  const size_t first_inst = ((size_t)blockIdx.x * kWavesPerWG + wv) * IPW;
+  size_t inst = first_inst + grp;
+  const bool live = inst < A.count;
+  if (!live) inst = A.count - 1;
+  uint32_t own[K];
+  if (A.op == PO_MUL) {
+    uint32_t n[K], mreg[K];
+    load_pair_row<K>(own, A.a + inst * (size_t)LQ, xg);
+    load_pair_row<K>(mreg, A.b + inst * A.b_stride, xg);
+#pragma unroll
+    for (int j = 0; j < K; ++j) n[j] = A.ctx.nhat[x * K + j];
+    pairmul<H, K, false, true>(own, own, mreg, n, 0, halfB, selB);
+    if (live) store_pair_row<K>(A.out + inst * (size_t)LQ, own, xg);
+  } else if (A.op == PO_TIMES_GM) {
+    load_pair_row<K>(own, A.a + inst * (size_t)LQ, xg);
+    stage_words<FG>(io, A.words, A.words_stride, 0, A.nwords, first_inst, A.count, 1, lane);
+    wave_lds_sync();
+    pair_times_gm<H, K>(own, A.ctx, io[grp], x, halfB);
+    if (live) store_pair_row<K>(A.out + inst * (size_t)LQ, own, xg);
+  } else if (A.op == PO_FROM_WORDS) {
+    uint32_t n[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) n[j] = A.ctx.nhat[x * K + j];
+    pair_from_words<H, K>(own, A.words + inst * A.words_stride, A.nwords, A.chunk_words, A.nchunks, A.ctx.conv, io[grp], n,
+                          halfB, selB, xg);
+    if (live) store_pair_row<K>(A.out + inst * (size_t)LQ, own, xg);
+  } else {
+    load_pair_row<K>(own, A.a + inst * (size_t)LQ, xg);
+    pair_exit_store<H, K>(own, A.ctx, A.full, false, nullptr, 0, 0, A.out_words, A.out_stride, first_inst, A.count, bl, io,
+                          rows, lane, grp, xg, halfB, selB);
+  }
 }
 
 }  // namespace pgpu

@@ -1,11 +1,11 @@
 // pailliercryptolib_amd -- instantiations of the split-form CRT-decrypt exponentiation (hensel.hpp), split over
-// PGPU_PART = 0..10 so that they compile in parallel (3, 4, 10: the fixed-base DJN encrypt; 5, 6, 8, 9: the generic modexp; 7:
-// the two-wavefronts-per-SIMD build of the (2,19) decrypt form).
+// PGPU_PART = 0..13 so that they compile in parallel (3, 4, 10: the fixed-base DJN encrypt; 5, 6, 8, 9: the generic modexp; 7:
+// the two-wavefronts-per-SIMD build of the (2,19) decrypt form; 11-13: element-wise operations on pair rows).
 #include "hensel.hpp"
 #include "launch.hpp"
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..10"
+#error "compile with -DPGPU_PART=0..13"
 #endif
 
 namespace pgpu {
@@ -50,6 +50,27 @@ bool PGPU_FB_NAME(launch_hensel_fb_build)(int H, int K, const HenselFbBuildArgs&
 bool PGPU_FB_NAME(launch_hensel_fb_encrypt)(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
   if (H == PGPU_FB_H && K == PGPU_FB_K) {
     hipLaunchKernelGGL((hensel_fb_encrypt_kernel<PGPU_FB_H, PGPU_FB_K>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  return false;
+}
+#elif PGPU_PART == 11 || PGPU_PART == 12 || PGPU_PART == 13
+#if PGPU_PART == 11
+#define PGPU_PO_H 4
+#define PGPU_PO_K 18
+#define PGPU_PO_NAME launch_pair_ops_part11
+#elif PGPU_PART == 12
+#define PGPU_PO_H 2
+#define PGPU_PO_K 19
+#define PGPU_PO_NAME launch_pair_ops_part12
+#else
+#define PGPU_PO_H 8
+#define PGPU_PO_K 14
+#define PGPU_PO_NAME launch_pair_ops_part13
+#endif
+bool PGPU_PO_NAME(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s) {
+  if (H == PGPU_PO_H && K == PGPU_PO_K) {
+    hipLaunchKernelGGL((pair_ops_kernel<PGPU_PO_H, PGPU_PO_K>), dim3(blocks), dim3(kWGThreads), 0, s, a);
     return true;
   }
   return false;

@@ -126,6 +126,13 @@ struct CrtArgs {
 // CRT-decrypt exponentiation in split form (hensel.hpp): one side (p or q) of the key.  L2 = H*K limbs per half;
 // "pair" arrays hold 2*L2 limbs in group-lane order: the L2 limbs of a, then the L2 limbs of b, for
 // x == a - P*b (mod P^2).
+// Resident ciphertext batches of keys that have a split form live in HBM as PAIRS of limbs ("pair rows", round 3):
+// row i = 2*L2n 29-bit limbs (one uint32_t each) in group-lane order -- the L2n limbs of a, then the L2n limbs of b --
+// with  c*R == a - P*b  (mod n^2),  P = n*k == -1 (mod 2^29),  R = 2^(29*L2n),  0 <= a, b < 4P (lazy, relaxed limbs as
+// the products leave them).  That IS the register image of the split-form kernels: no word <-> limb conversion, no
+// canonical reduction and no full-width product on the way in or out; CT+CT is one pair product (5 instead of 8 s^2
+// limb products), CT+PT two half-width products, encrypt / CT x PT / decrypt enter and leave without their
+// conversion products.  Only pgpu_batch_download materialises the plain value.
 struct HenselCtxDev {
   const uint32_t* nhat;  // [L2]  P = p * k == -1 mod 2^29: the loop modulus
   const uint32_t* n;     // [L2]  p
@@ -135,6 +142,10 @@ struct HenselCtxDev {
   const uint32_t* h;     // [L2]  hp (hq): the constant multiplier of pri_key.cpp:153-154
   const uint32_t* kr;    // [L2]  (P / p) * R mod p
   uint32_t n0inv;        // -p^-1 mod 2^29
+  // entry from a pair row of the n^2 domain (HenselArgs::ct_pair): the a part enters as pchunks chunks of pchunk_limbs
+  // limbs, (z_i, 0) (x) pconv[i]; the b part only matters modulo p and enters as b_i (x) pcb[i], half-width
+  const uint32_t* pconv; // [pchunks] pairs  2^(29*pchunk_limbs*i) * R^2 * Rn^-1 mod P^2       (Rn: the radix of the rows)
+  const uint32_t* pcb;   // [pchunks][L2]    (n/p) * kn * k^-1 * 2^(29*pchunk_limbs*i) * R^2 * Rn^-1 mod P
 };
 
 struct HenselArgs {
@@ -156,6 +167,10 @@ struct HenselArgs {
   int out_words;
   uint32_t* table;       // [wavefronts * 64/(2H)][entries][2*L2] workspace
   size_t count;          // ciphertexts
+  const uint32_t* ct_pair;   // non-null: ciphertexts as pair rows [count][ct_pair_stride] (ct unused)
+  size_t ct_pair_stride;     // limbs per row = 2 * pair_l2
+  int pair_l2;               // L2n of the rows
+  int pchunk_limbs, pchunks;
 };
 
 // Split form (hensel.hpp) of the public modulus n^2 = (n)^2: DJN encrypt with fixed-base tables of pairs.
@@ -165,6 +180,8 @@ struct HenselPubDev {
   const uint32_t* kr;    // [L2]  k * R mod n          (R = 2^(29*L2))
   const uint32_t* one;   // pair  R mod P^2
   const uint32_t* conv;  // [nchunks] pairs  2^(64*chunk_words*i) * R^2 mod P^2
+  const uint32_t* gm;    // [L2]  (-k^-1 mod n) * R^2 mod n: multiplying a resident pair by g^m = 1 + n*m is
+                         //       b += montmul(montmul(m, gm), a) under the true modulus n (hensel.hpp: pair_times_gm)
   uint32_t n0inv;        // -n^-1 mod 2^29
 };
 
@@ -205,6 +222,7 @@ struct HenselFbArgs {
   uint64_t* out;             // [count][out_stride]
   size_t out_stride;
   size_t count;
+  uint32_t* out_pair;        // non-null: ciphertexts leave as pair rows [count][2*L2] (out unused)
 };
 
 // base[i]^exp[i] modulo n^2 in split form (hensel.hpp: hensel_modexp_kernel): CT x PT and the non-DJN obfuscator r^n.
@@ -230,6 +248,33 @@ struct HenselModexpArgs {
   uint64_t* out;             // [count][out_stride]
   size_t out_stride;
   uint32_t* table;           // [wavefronts * 64/(2H)][entries][2*L2] workspace
+  size_t count;
+  const uint32_t* base_pair; // non-null: bases as pair rows [count][2*L2] (base unused; base_pair_stride 0: one shared row)
+  size_t base_pair_stride;
+  uint32_t* out_pair;        // non-null: results leave as pair rows [count][2*L2] (out unused)
+};
+
+// Element-wise operations on pair rows (hensel.hpp: pair_ops_kernel).
+enum PairOp : int {
+  PO_MUL = 0,         // out = a (x) b                 CT + CT (ciphertext.cpp:135-141): ONE pair product
+  PO_TIMES_GM = 1,    // out = a * (1 + n*m)           CT + PT (ciphertext.cpp:75-80): two half-width products
+  PO_FROM_WORDS = 2,  // words (plain, or c*Rs mod n^2 with the chunk constants of that form) -> pair row
+  PO_TO_WORDS = 3     // pair row -> canonical words (plain)
+};
+struct PairOpsArgs {
+  HenselPubDev ctx;
+  HenselFullDev full;        // PO_TO_WORDS
+  int op;
+  const uint32_t* a;         // [count][2*L2] pair rows (PO_MUL, PO_TIMES_GM, PO_TO_WORDS)
+  const uint32_t* b;         // PO_MUL: [count][2*L2] pair rows (b_stride 0: one shared row)
+  size_t b_stride;           // in limbs
+  const uint64_t* words;     // PO_FROM_WORDS: [count][words_stride]; PO_TIMES_GM: plaintexts (words_stride 0: one shared)
+  size_t words_stride;
+  int nwords;                // valid words per row of `words`
+  int chunk_words, nchunks;  // PO_FROM_WORDS
+  uint32_t* out;             // pair rows (PO_TO_WORDS: unused)
+  uint64_t* out_words;       // PO_TO_WORDS: [count][out_stride]
+  size_t out_stride;
   size_t count;
 };
 

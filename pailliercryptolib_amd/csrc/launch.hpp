@@ -81,6 +81,17 @@ inline bool launch_hensel_modexp(int H, int K, const HenselModexpArgs& a, unsign
          launch_hensel_modexp_part8(H, K, a, blocks, s) || launch_hensel_modexp_part9(H, K, a, blocks, s);
 }
 
+// element-wise operations on pair rows (hensel.hpp: pair_ops_kernel; k_hensel.hip parts 11-13): the throughput form of
+// each key class -- (2,19): 1024-bit keys, (4,18): 2048, (8,14): 3072
+inline bool pair_ops_has(int H, int K) { return (H == 2 && K == 19) || (H == 4 && K == 18) || (H == 8 && K == 14); }
+bool launch_pair_ops_part11(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s);
+bool launch_pair_ops_part12(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s);
+bool launch_pair_ops_part13(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s);
+inline bool launch_pair_ops(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s) {
+  return launch_pair_ops_part11(H, K, a, blocks, s) || launch_pair_ops_part12(H, K, a, blocks, s) ||
+         launch_pair_ops_part13(H, K, a, blocks, s);
+}
+
 bool launch_modmul(int G, int K, const ModmulArgs& a, unsigned blocks, hipStream_t s);
 bool launch_crt(int G, int K, const CrtArgs& a, unsigned blocks, hipStream_t s);
 bool launch_fb_build(int G, int K, const FixedBaseBuildArgs& a, unsigned blocks, hipStream_t s);

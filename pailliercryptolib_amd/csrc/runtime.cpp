@@ -501,6 +501,8 @@ int pool_init(const std::vector<int>& ordinals) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
       return fail(PGPU_ERR_NO_DEVICE, "device is not gfx950: " + d->name);
     HIP_TRY(hipStreamCreateWithFlags(&d->bstream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&d->bstream1, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreateWithFlags(&d->xlane_ev[k], hipEventDisableTiming));
     for (int l = 0; l < 2; ++l) {
       std::unique_ptr<Lane> lane(new Lane);
       lane->dev = d.get();
@@ -568,11 +570,16 @@ void pool_shutdown() {
       if (lane->stream) (void)hipStreamDestroy(lane->stream);
     }
     if (d->bstream) (void)hipStreamDestroy(d->bstream);
+    if (d->bstream1) (void)hipStreamDestroy(d->bstream1);
+    for (int k = 0; k < 2; ++k)
+      if (d->xlane_ev[k]) (void)hipEventDestroy(d->xlane_ev[k]);
   }
   if (!g_pool.empty()) (void)hipSetDevice(g_pool[0]->ordinal);
   for (auto& d : g_pool) {
     d->alive = false;
     d->bstream = nullptr;
+    d->bstream1 = nullptr;
+    d->xlane_ev[0] = d->xlane_ev[1] = nullptr;
     d->lanes.clear();
     g_retired.push_back(std::move(d));
   }

@@ -110,7 +110,11 @@ struct Device {
   int ordinal = 0;   // HIP device ordinal (several pool entries may share one when oversubscribed)
   std::string name;
   bool alive = true;               // false once its pool has been shut down (objects may still point here)
-  hipStream_t bstream = nullptr;   // resident-batch operations
+  hipStream_t bstream = nullptr;   // resident-batch operations: batch lane 0 (also key replication)
+  hipStream_t bstream1 = nullptr;  // batch lane 1: a second, independent chain of resident batches in flight
+  hipStream_t bs(int lane) const { return lane ? bstream1 : bstream; }
+  // cross-lane ordering (a batch of one lane consumed by an operation on the other): one event per direction
+  hipEvent_t xlane_ev[2] = {nullptr, nullptr};
   std::mutex mu;                   // allocator, work map, timing, queue
 
   // ---- caching allocator (sizes rounded to 64 KiB; free lists per stream tag) ----

@@ -1,0 +1,137 @@
+"""Resident ciphertext batches as PAIR ROWS (csrc/kargs.hpp, round 3): keys with a split form keep c*R as the pair
+(a, b), c*R == a - (n*k)*b mod n^2, in HBM -- the register image of the split-form kernels.  Every operation on
+resident batches (encrypt DJN / r^n, CT+CT, CT+PT, CT x PT, CRT decrypt, download, mixing with uploaded plain
+ciphertexts, one-element broadcast operands) is held bit-identical to the oracle for the 1024-, 2048- and 3072-bit key
+classes, at batch sizes on both sides of the kernels' form thresholds, with edge plaintexts and exponents."""
+import ctypes
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+class Res:
+    def __init__(self):
+        from pailliercryptolib_amd import _capi
+        from pailliercryptolib_amd.limbs import ints_to_limbs, limbs_to_ints
+        self.L, self.check, self.i2l, self.l2i = _capi.lib(), _capi.check, ints_to_limbs, limbs_to_ints
+        self.live = []
+
+    def up(self, vals, words):
+        h = ctypes.c_void_p()
+        a = self.i2l(vals, words)
+        self.check(self.L.pgpu_batch_upload(a.ctypes.data_as(ctypes.c_void_p), len(vals), words, words, ctypes.byref(h)))
+        self.live.append(h)
+        return h
+
+    def down(self, h):
+        out = np.empty((self.L.pgpu_batch_count(h), self.L.pgpu_batch_words(h)), dtype=np.uint64)
+        self.check(self.L.pgpu_batch_download(h, out.ctypes.data_as(ctypes.c_void_p)))
+        return self.l2i(out)
+
+    def op(self, fn, *a):
+        h = ctypes.c_void_p()
+        self.check(fn(*a, ctypes.byref(h)))
+        self.live.append(h)
+        return h
+
+    def close(self):
+        for h in self.live:
+            self.L.pgpu_batch_destroy(h)
+        self.live = []
+
+
+def key_case(bits, djn):
+    if bits == 2048:
+        k = json.load(open(os.path.join(GOLD, "iso_kat.json")))
+        return int(k["p"], 16), int(k["q"], 16), int(k["bench_hs"], 16) if djn else None
+    c = [c for c in json.load(open(os.path.join(GOLD, "seeded_vectors.json")))["cases"] if c["bits"] == bits and c["djn"]][0]
+    return int(c["p"], 16), int(c["q"], 16), int(c["hs"], 16) if djn else None
+
+
+@pytest.mark.parametrize("bits,djn,count", [(2048, True, 203), (2048, False, 37), (2048, True, 2500), (1024, True, 131),
+                                            (1024, False, 19), (3072, True, 70), (3072, False, 9), (2048, True, 1)])
+def test_resident_chain_in_pair_rows(engine, bits, djn, count):
+    from oracle import paillier_oracle as orc
+    p, q, hs = key_case(bits, djn)
+    n = p * q
+    nsq = n * n
+    nw, pw = bits // 64, bits // 128
+    rng = random.Random(bits * 7 + count)
+    edge_m = [0, 1, n - 1, n, (1 << (64 * nw)) - 1]           # (rows no wider than n may still hold values >= n)
+    m1 = (edge_m + [rng.randrange(n) for _ in range(count)])[:count]
+    m2 = [rng.randrange(n) for _ in range(count)]
+    if djn:
+        r1 = ([0, 1, (1 << (bits // 2)) - 1] + [rng.getrandbits(bits // 2) for _ in range(count)])[:count]
+        r2 = [rng.getrandbits(bits // 2) for _ in range(count)]
+    else:
+        r1 = ([1, n - 1] + [rng.randrange(1, n) for _ in range(count)])[:count]
+        r2 = [rng.randrange(1, n) for _ in range(count)]
+    e = ([0, 1, 2, (1 << 40) - 1] + [rng.getrandbits(40) for _ in range(count)])[:count]
+    pk, sk = engine.PublicKey(n, bits, hs=hs), engine.PrivateKey(p, q)
+    opk = orc.PublicKey(n, bits)
+    if djn:
+        opk.set_djn(hs)
+    R = Res()
+    L = R.L
+    try:
+        rw = pw if djn else nw
+        rb = 64 * rw
+        bm1, bm2, br1, br2, be = R.up(m1, nw), R.up(m2, nw), R.up(r1, rw), R.up(r2, rw), R.up(e, 1)
+        c1 = R.op(L.pgpu_batch_encrypt, pk._h, bm1, br1, rb)
+        c2 = R.op(L.pgpu_batch_encrypt, pk._h, bm2, br2, rb)
+        oc1, oc2 = opk.encrypt(m1, r1), opk.encrypt(m2, r2)
+        assert L.pgpu_batch_is_montgomery(c1) == 1                      # a device-side domain, not plain words
+        assert R.down(c1) == oc1 and R.down(c2) == oc2
+        s = R.op(L.pgpu_batch_ct_add, pk._h, c1, c2)
+        osum = [a * b % nsq for a, b in zip(oc1, oc2)]
+        assert R.down(s) == osum
+        t = R.op(L.pgpu_batch_ct_mul, pk._h, s, be, 40)
+        omul = [pow(a, b, nsq) for a, b in zip(osum, e)]
+        assert R.down(t) == omul
+        u = R.op(L.pgpu_batch_ct_add_plain, pk._h, t, bm1)             # plaintexts with the edge values
+        oadd = [a * ((1 + n * b) % nsq) % nsq for a, b in zip(omul, m1)]
+        assert R.down(u) == oadd
+        d = R.op(L.pgpu_batch_decrypt_crt, sk._h, u)
+        assert R.down(d) == [((a + b) * x + a) % n for a, b, x in zip(m1, m2, e)]
+        assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, c1)) == [v % n for v in m1]
+        # an uploaded (plain) ciphertext batch joins; one-element operands broadcast
+        pc2 = R.up(oc2, 2 * nw)
+        assert R.down(R.op(L.pgpu_batch_ct_add, pk._h, c1, pc2)) == osum
+        assert R.down(R.op(L.pgpu_batch_ct_add, pk._h, pc2, c1)) == osum
+        if count > 1:
+            one = R.up([oc2[0]], 2 * nw)
+            assert R.down(R.op(L.pgpu_batch_ct_add, pk._h, c1, one)) == [a * oc2[0] % nsq for a in oc1]
+            e1 = R.up([e[-1]], 1)
+            assert R.down(R.op(L.pgpu_batch_ct_mul, pk._h, c2, e1, 40)) == [pow(a, e[-1], nsq) for a in oc2]
+            m0 = R.up([m2[0]], nw)
+            assert R.down(R.op(L.pgpu_batch_ct_add_plain, pk._h, c1, m0)) == [a * ((1 + n * m2[0]) % nsq) % nsq for a in oc1]
+        assert R.down(R.op(L.pgpu_batch_ct_mul, pk._h, pc2, be, 40)) == [pow(a, b, nsq) for a, b in zip(oc2, e)]
+        assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, pc2)) == m2
+        # plaintext rows WIDER than n take the full-width kernels (round-2 path) and still mix with pair rows
+        wide = [v + n * (i % 3) for i, v in enumerate(m2)]
+        bw = R.up(wide, 2 * nw)
+        cw = R.op(L.pgpu_batch_encrypt, pk._h, bw, br2, rb)
+        assert R.down(cw) == oc2
+        assert R.down(R.op(L.pgpu_batch_ct_add, pk._h, c1, cw)) == osum
+        assert R.down(R.op(L.pgpu_batch_ct_add_plain, pk._h, c1, bw)) == [a * ((1 + n * b) % nsq) % nsq for a, b in zip(oc1, wide)]
+    finally:
+        R.close()
+
+
+def test_pair_rows_can_be_switched_off(engine):
+    """PGPU_PAIR_ROWS=0 keeps the round-2 representation (Montgomery-form words): same results (own process: the switch is
+    read once)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "pool_worker.py"), "batch_chain", "1"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, PGPU_PAIR_ROWS="0", PGPU_MIN_SHARD="8"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert all(res["ok"].values()), res
