@@ -565,6 +565,31 @@ def extras(pa, L, B, pk, sk, n, p, q, hs, m_host, r_host, per_kind):
                                         "decrypt_kernel_ms": round(dec_ms, 4),
                                         "decrypt_kernel_canonical_frac": sig(mac_dec / (dec_ms * 1e-3) / 1e12 / PEAK_TMAC32)}
         B.free(st.get("c"), st.get("o"), bm2, br)
+    # (4b) the opt-in masked table gather (include/pgpu.h, SIDE CHANNELS): every window-table entry is read and the wanted
+    # one selected -- what the reference's mbx_exp_mb8 does; cost of the decrypt launch with it
+    try:
+        _capi.check(L.pgpu_set_table_gather_policy(1))
+        bm3, br3 = B.up(m_host), B.up(r_host)
+        c3 = B.op(L.pgpu_batch_encrypt, pk._h, bm3, br3, 64 * pw)
+        hold3 = {}
+
+        def dec_masked():
+            B.free(hold3.get("o"))
+            hold3["o"] = B.op(L.pgpu_batch_decrypt_crt, sk._h, c3)
+            _capi.check(L.pgpu_synchronize())
+        dec_masked()
+        tm = best_of(dec_masked, 5)
+        assert np.array_equal(B.down(hold3["o"]), m_host)
+        _capi.check(L.pgpu_set_table_gather_policy(0))
+        dec_masked()
+        ti = best_of(dec_masked, 5)
+        out["masked_table_gather"] = {"what": "pgpu_set_table_gather_policy(1): CRT decrypt of the batch with every window-table "
+                                              "entry read and selected (address stream independent of p-1 / q-1) vs indexed",
+                                      "decrypt_ms_masked": round(tm * 1e3, 3), "decrypt_ms_indexed": round(ti * 1e3, 3)}
+        B.free(hold3.get("o"), c3, bm3, br3)
+    except Exception as e:                                  # noqa: BLE001
+        _capi.check(L.pgpu_set_table_gather_policy(0))
+        out["masked_table_gather"] = {"error": str(e)[:300]}
     # (5) two batches in flight: consecutive steps alternate between two HIP streams (`_dev` entry points), so that the
     # encrypt launch of step i+1 and the decrypt launches of steps i / i+1 share the SIMDs -- how a pool entry with its
     # two worker lanes actually runs under load.  A lone wavefront on a SIMD issues every ~4.6 cycles, two every ~4.3

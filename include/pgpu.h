@@ -42,7 +42,9 @@
  * multiplications with a key-dependent schedule.  Table ADDRESSES are not hidden: the window table
  * of a wavefront is indexed by exponent digits (per-key constant pattern for p-1/q-1, per-element
  * for the randomness r of the DJN fixed-base product and for CT*PT exponents), i.e. the engine
- * is not hardened against a co-resident observer of the memory system.  Device copies of
+ * is not hardened against a co-resident observer of the memory system -- unless
+ * pgpu_set_table_gather_policy(1) is chosen, which makes the split-form kernels read every entry of
+ * a window table and select (the fixed-base table of DJN encrypt stays digit-addressed).  Device copies of
  * private-key constants are zeroed before they are freed.
  *
  * ERRORS.  Every function returns PGPU_OK (0) or a negative pgpu_status; nothing calls
@@ -194,6 +196,14 @@ typedef enum pgpu_exp_policy {
 } pgpu_exp_policy;
 int pgpu_set_secret_exponent_policy(int policy);
 int pgpu_get_secret_exponent_policy(void);
+/* Window-table ACCESS of the split-form kernels (CRT decrypt, CT*PT and the key-less seam for 1024- to 3072-bit keys):
+ * 0 (default) the entry is addressed by the exponent digit; 1 every entry of the table is read and the wanted one
+ * selected, so that the address stream does not depend on the exponent -- what the reference's mbx_exp_mb8 does
+ * (SURVEY Appendix B).  Costs 2^w x the table loads plus as many selects per multiplication (bench.py reports it).
+ * The fixed-base table of DJN encrypt (2^12 entries per window) is always addressed by the digits of r.  Env
+ * PGPU_CT_GATHER=1. */
+int pgpu_set_table_gather_policy(int masked);
+int pgpu_get_table_gather_policy(void);
 
 /* ---- sharded device-resident batches (SURVEY 8(f) N1 across the pool) ----
  * A pgpu_batch is [count][words] little-endian limbs living in GPU memory, cut into contiguous shards

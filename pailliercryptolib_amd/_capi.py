@@ -31,6 +31,7 @@ SYMBOLS = [
     "pgpu_rccl_note", "pgpu_replication_stats", "pgpu_debug_corrupt_next_replica",
     "pgpu_set_fixed_base_budget", "pgpu_fixed_base_stats", "pgpu_pubkey_fixed_base_info",
     "pgpu_batch_row_limbs", "pgpu_set_batch_lane", "pgpu_batch_lane",
+    "pgpu_set_table_gather_policy", "pgpu_get_table_gather_policy",
 ]
 
 _lib = None
@@ -140,6 +141,8 @@ def lib():
     L.pgpu_batch_row_limbs.argtypes = [c_void_p]; L.pgpu_batch_row_limbs.restype = c_int
     L.pgpu_set_batch_lane.argtypes = [c_int]; L.pgpu_set_batch_lane.restype = c_int
     L.pgpu_batch_lane.argtypes = [c_void_p]; L.pgpu_batch_lane.restype = c_int
+    L.pgpu_set_table_gather_policy.argtypes = [c_int]; L.pgpu_set_table_gather_policy.restype = c_int
+    L.pgpu_get_table_gather_policy.argtypes = []; L.pgpu_get_table_gather_policy.restype = c_int
     _lib = L
     return L
 

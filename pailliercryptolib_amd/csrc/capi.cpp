@@ -498,6 +498,12 @@ std::atomic<bool> g_packed_decrypt{[] {
   const char* e = std::getenv("PGPU_PACKED_DECRYPT");
   return !(e && std::atoi(e) == 0);   // default since round 3: with aligned code both builds run a lone launch equally fast
 }()};
+// Window-table access of the split-form kernels (include/pgpu.h, SIDE CHANNELS): 0 = indexed by the exponent digit
+// (default), 1 = every entry is read and the wanted one selected (pgpu_set_table_gather_policy / PGPU_CT_GATHER=1)
+std::atomic<int> g_ct_gather{[] {
+  const char* e = std::getenv("PGPU_CT_GATHER");
+  return e && std::atoi(e) != 0 ? 1 : 0;
+}()};
 // PGPU_PAIR_ROWS=0: resident ciphertext batches stay Montgomery-form words (the round-2 representation; A/B)
 bool pair_rows_enabled() {
   static const bool on = [] {
@@ -904,6 +910,7 @@ int modexp_square_on(rt::Device& d, const SquareCtx& sq, const uint64_t* d_base,
     entries = (size_t)1 << a.window;
   }
   a.final_mul = pgpu::FM_UNIT;
+  a.ct_gather = (sched && sched->p[0]) ? 0 : g_ct_gather.load();
   a.out = d_out;
   a.out_stride = (size_t)sq.mod_words;
   a.count = count;
@@ -1228,6 +1235,7 @@ int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::Pu
     entries = (size_t)1 << a.window;
   }
   a.final_mul = final_mul;
+  a.ct_gather = (sched && sched->p[0]) ? 0 : g_ct_gather.load();   // (a host-built schedule belongs to a PUBLIC exponent)
   a.fm_words = d_m;
   a.fm_stride = m_stride;
   a.fm_nwords = m_words;
@@ -1299,6 +1307,18 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
     // no wider than n, and a batch that fills the chip in 8-lane groups no worse than the full-width kernel does
     if (const pgpu_pubkey::PubForm* form = sform) {
       RC_TRY(fb_table_for_split(key, form, d, fbw, nwin, s, &tab));
+      // pair-row output of a batch that leaves SIMDs idle: the encrypt kernel of a form with more lanes per element and
+      // the SAME limbs per half (2048-bit keys: (8,9) beside (4,18)) -- same table, same rows, shorter serial chain
+      if (d_pair) {
+        for (const auto& alt : key->hforms) {
+          const size_t ipw_alt = 64 / (2 * (size_t)alt->H);
+          if (alt->H * alt->K == form->H * form->K && alt->H > form->H && pgpu::hensel_fb_encrypt_has(alt->H, alt->K) &&
+              (total_count + ipw_alt - 1) / ipw_alt <= kSimds) {
+            form = alt.get();
+            break;
+          }
+        }
+      }
       pgpu::HenselFbArgs f{};
       f.ctx = hensel_pub_view(form, d.index);
       f.full = hensel_full_view(key, form, d.index, out_mont);
@@ -1477,6 +1497,7 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
       h.window = pick_window(h.exp_bits);
       entries = (size_t)1 << h.window;
     }
+    h.ct_gather = g_ct_gather.load();
     h.out = (uint64_t*)w.vbuf.p;
     h.out_stride = (size_t)key->pq_words;
     h.out_words = key->pq_words;
@@ -1854,6 +1875,11 @@ int pgpu_set_secret_exponent_policy(int policy) {
   return PGPU_OK;
 }
 int pgpu_get_secret_exponent_policy(void) { return secret_policy(); }
+int pgpu_set_table_gather_policy(int masked) {
+  g_ct_gather.store(masked ? 1 : 0);
+  return PGPU_OK;
+}
+int pgpu_get_table_gather_policy(void) { return g_ct_gather.load(); }
 
 // diagnostics (tools/wave_spread.py): device buffer that receives per-wave start/end clocks of the
 // next modexp_kernel launches; null switches it off.  Not part of the public header.

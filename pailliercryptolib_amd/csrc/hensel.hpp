@@ -161,6 +161,36 @@ __device__ __forceinline__ uint32_t sub_limbs(uint32_t (&d)[GEO::K], const uint3
   return (uint32_t)__shfl((int)top_borrow, top_lane);
 }
 
+// Window-table entry `idx` of this lane's slice (entries are LQ limbs apart).  gather: read EVERY entry and keep the one
+// wanted -- the address stream is then the same for every exponent, as in the reference's mbx_exp_mb8, which gathers its
+// table in constant time; costs tsize*K loads and selects per multiplication instead of K loads.
+template <int K>
+__device__ __forceinline__ void load_table_entry(uint32_t (&dst)[K], const uint32_t* tbl, int idx, int tsize, size_t stride,
+                                                 bool gather) {
+  if (!gather) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) dst[j] = tbl[(size_t)idx * stride + j];
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) dst[j] = 0;
+  // two entries per trip: their loads are in flight together (a trip is latency-bound otherwise: 2^w round trips to
+  // L2 per multiplication); tsize is a power of two >= 2 whenever a table is used
+#pragma unroll 1
+  for (int e = 0; e < tsize; e += 2) {
+    uint32_t t0[K], t1[K];
+    const int e1 = e + 1 < tsize ? e + 1 : e;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      t0[j] = tbl[(size_t)e * stride + j];
+      t1[j] = tbl[(size_t)e1 * stride + j];
+    }
+    const uint32_t k0 = 0u - (uint32_t)(e == idx), k1 = 0u - (uint32_t)(e1 == idx);
+#pragma unroll
+    for (int j = 0; j < K; ++j) dst[j] |= (t0[j] & k0) | (t1[j] & k1);
+  }
+}
+
 // One wavefront = 64/(2H) groups = that many ciphertexts of ONE side (wave parity: even = p, odd = q), so context,
 // exponent and schedule are wave-uniform.  Output: row 2i = mp, row 2i+1 = mq (canonical words) for crt_kernel
 // (have_m).  H = 2: the throughput form (16 ciphertexts per wavefront); H = 8: the latency form for small batches
@@ -319,8 +349,7 @@ __global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_kernel(Hensel
   }
   if (any) {
     const int d0 = sched_mode ? (__builtin_amdgcn_readfirstlane((int)sch[0]) & 63) - 1 : digit(nwin - 1);
-#pragma unroll
-    for (int j = 0; j < K; ++j) own[j] = tbl[(size_t)d0 * LQ + j];   // (this lane's own earlier stores)
+    load_table_entry<K>(own, tbl, d0, tsize, LQ, A.ct_gather != 0);   // (this lane's own earlier stores)
   } else {
 #pragma unroll
     for (int j = 0; j < K; ++j) own[j] = HCTX(one)[xg * K + j];
@@ -347,10 +376,7 @@ __global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_kernel(Hensel
       idx = digit(win--);
     }
     const bool mul = !sched_mode || idx >= 0;
-    if (mul) {   // the entry travels while the squarings run
-#pragma unroll
-      for (int j = 0; j < K; ++j) mreg[j] = tbl[(size_t)idx * LQ + j];
-    }
+    if (mul) load_table_entry<K>(mreg, tbl, idx, tsize, LQ, A.ct_gather != 0);   // the entry travels while the squarings run
 #pragma unroll 1
     for (int i = 0; i < nsq; ++i) pairmul<H, K, true, true>(own, own, own, n, n0inv, halfB, selB);
     if (mul) pairmul<H, K, false, true>(own, own, mreg, n, n0inv, halfB, selB);
@@ -801,8 +827,7 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : PGPU_HM_WAVES18) void hen
   }
   if (any) {
     const int d0 = sched_mode ? (__builtin_amdgcn_readfirstlane((int)sch[0]) & 63) - 1 : digit(nwin - 1);
-#pragma unroll
-    for (int j = 0; j < K; ++j) own[j] = tbl[(size_t)d0 * LQ + j];
+    load_table_entry<K>(own, tbl, d0, tsize, LQ, A.ct_gather != 0);
   } else {
 #pragma unroll
     for (int j = 0; j < K; ++j) own[j] = A.ctx.one[xg * K + j];
@@ -821,10 +846,7 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : PGPU_HM_WAVES18) void hen
       idx = digit(win--);
     }
     const bool mul = !sched_mode || idx >= 0;
-    if (mul) {
-#pragma unroll
-      for (int j = 0; j < K; ++j) mreg[j] = tbl[(size_t)idx * LQ + j];
-    }
+    if (mul) load_table_entry<K>(mreg, tbl, idx, tsize, LQ, A.ct_gather != 0);
 #pragma unroll 1
     for (int i = 0; i < nsq; ++i) pairmul<H, K, true, true>(own, own, own, n, 0, halfB, selB);
     if (mul) pairmul<H, K, false, true>(own, own, mreg, n, 0, halfB, selB);

@@ -5,7 +5,7 @@
 #include "launch.hpp"
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..13"
+#error "compile with -DPGPU_PART=0..14"
 #endif
 
 namespace pgpu {
@@ -71,6 +71,14 @@ bool PGPU_FB_NAME(launch_hensel_fb_encrypt)(int H, int K, const HenselFbArgs& a,
 bool PGPU_PO_NAME(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s) {
   if (H == PGPU_PO_H && K == PGPU_PO_K) {
     hipLaunchKernelGGL((pair_ops_kernel<PGPU_PO_H, PGPU_PO_K>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  return false;
+}
+#elif PGPU_PART == 14
+bool launch_hensel_fb_encrypt_part14(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
+  if (H == 8 && K == 9) {
+    hipLaunchKernelGGL((hensel_fb_encrypt_kernel<8, 9>), dim3(blocks), dim3(kWGThreads), 0, s, a);
     return true;
   }
   return false;

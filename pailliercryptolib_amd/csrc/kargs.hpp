@@ -167,6 +167,8 @@ struct HenselArgs {
   int out_words;
   uint32_t* table;       // [wavefronts * 64/(2H)][entries][2*L2] workspace
   size_t count;          // ciphertexts
+  int ct_gather;             // 1: window-table entries are fetched by reading ALL entries and selecting (addresses do
+                             //    not depend on exponent digits; pgpu_set_table_gather_policy)
   const uint32_t* ct_pair;   // non-null: ciphertexts as pair rows [count][ct_pair_stride] (ct unused)
   size_t ct_pair_stride;     // limbs per row = 2 * pair_l2
   int pair_l2;               // L2n of the rows
@@ -249,6 +251,7 @@ struct HenselModexpArgs {
   size_t out_stride;
   uint32_t* table;           // [wavefronts * 64/(2H)][entries][2*L2] workspace
   size_t count;
+  int ct_gather;             // as HenselArgs::ct_gather
   const uint32_t* base_pair; // non-null: bases as pair rows [count][2*L2] (base unused; base_pair_stride 0: one shared row)
   size_t base_pair_stride;
   uint32_t* out_pair;        // non-null: results leave as pair rows [count][2*L2] (out unused)

@@ -62,9 +62,13 @@ inline bool launch_hensel_fb_build(int H, int K, const HenselFbBuildArgs& a, uns
   return launch_hensel_fb_build_part3(H, K, a, blocks, s) || launch_hensel_fb_build_part4(H, K, a, blocks, s) ||
          launch_hensel_fb_build_part10(H, K, a, blocks, s);
 }
+// (8,9): the ENCRYPT kernel only, for batches that leave SIMDs idle under a 2048-bit key -- 16 lanes per element, the
+// same 72 limbs per half as (4,18): it reads the table the (4,18) build kernel wrote and writes the same pair rows
+bool launch_hensel_fb_encrypt_part14(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
+inline bool hensel_fb_encrypt_has(int H, int K) { return hensel_fb_has(H, K) || (H == 8 && K == 9); }
 inline bool launch_hensel_fb_encrypt(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
   return launch_hensel_fb_encrypt_part3(H, K, a, blocks, s) || launch_hensel_fb_encrypt_part4(H, K, a, blocks, s) ||
-         launch_hensel_fb_encrypt_part10(H, K, a, blocks, s);
+         launch_hensel_fb_encrypt_part10(H, K, a, blocks, s) || launch_hensel_fb_encrypt_part14(H, K, a, blocks, s);
 }
 
 // split-form generic modexp modulo a square (hensel.hpp: hensel_modexp_kernel; k_hensel.hip parts 5, 6, 8, 9): roots of

@@ -135,3 +135,88 @@ def test_pair_rows_can_be_switched_off(engine):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert all(res["ok"].values()), res
+
+
+def test_masked_table_gather_is_bit_identical(engine):
+    """pgpu_set_table_gather_policy(1): the split-form kernels read every window-table entry and select (the address stream
+    no longer depends on exponent digits).  CRT decrypt (both exponent policies), CT x PT with per-element exponents and
+    the key-less seam modulo p^2 give the same bits as with indexed access."""
+    from oracle import paillier_oracle as orc
+    from pailliercryptolib_amd import _capi
+    p, q, hs = key_case(2048, True)
+    n = p * q
+    nsq = n * n
+    rng = random.Random(991)
+    count = 150
+    m = [rng.randrange(n) for _ in range(count)]
+    r = [rng.getrandbits(1024) for _ in range(count)]
+    e = [rng.getrandbits(64) for _ in range(count)]
+    opk = orc.PublicKey(n, 2048)
+    opk.set_djn(hs)
+    oc = opk.encrypt(m, r)
+    L = _capi.lib()
+    pk, sk = engine.PublicKey(n, 2048, hs=hs), engine.PrivateKey(p, q)
+    R = Res()
+    assert L.pgpu_get_table_gather_policy() == 0
+    _capi.check(L.pgpu_set_table_gather_policy(1))
+    try:
+        assert sk.decrypt(oc) == m
+        bc, be = R.up(oc, 64), R.up(e, 1)
+        assert R.down(R.op(L.pgpu_batch_ct_mul, pk._h, bc, be, 64)) == [pow(a, b, nsq) for a, b in zip(oc, e)]
+        assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, bc)) == m
+        psq = p * p
+        base = [c % psq for c in oc[:40]]
+        assert engine.mod_exp(base, [p - 1] * 40, psq) == [pow(c, p - 1, psq) for c in base]
+        old = L.pgpu_get_secret_exponent_policy()
+        _capi.check(L.pgpu_set_secret_exponent_policy(1))
+        try:
+            assert sk.decrypt(oc) == m
+        finally:
+            _capi.check(L.pgpu_set_secret_exponent_policy(old))
+    finally:
+        _capi.check(L.pgpu_set_table_gather_policy(0))
+        R.close()
+
+
+def test_two_batch_lanes(engine):
+    """Two chains of resident batches on the two batch lanes of the GPU, issued interleaved; a result inherits the lane of
+    its first operand; an operation whose operands live on different lanes is ordered by events and still correct."""
+    from oracle import paillier_oracle as orc
+    from pailliercryptolib_amd import _capi
+    p, q, hs = key_case(2048, True)
+    n = p * q
+    nsq = n * n
+    rng = random.Random(4242)
+    count = 300
+    L = _capi.lib()
+    pk, sk = engine.PublicKey(n, 2048, hs=hs), engine.PrivateKey(p, q)
+    opk = orc.PublicKey(n, 2048)
+    opk.set_djn(hs)
+    R = Res()
+    try:
+        data, h = [], []
+        for lane in (0, 1):
+            m = [rng.randrange(n) for _ in range(count)]
+            r = [rng.getrandbits(1024) for _ in range(count)]
+            _capi.check(L.pgpu_set_batch_lane(lane))
+            h.append((R.up(m, 32), R.up(r, 16)))
+            data.append((m, r))
+        _capi.check(L.pgpu_set_batch_lane(0))
+        cs, ds = [None, None], [None, None]
+        for rep in range(3):                      # interleaved issue: lane 0, lane 1, lane 0, ...
+            for lane in (0, 1):
+                cs[lane] = R.op(L.pgpu_batch_encrypt, pk._h, h[lane][0], h[lane][1], 1024)
+                ds[lane] = R.op(L.pgpu_batch_decrypt_crt, sk._h, cs[lane])
+        for lane in (0, 1):
+            assert L.pgpu_batch_lane(cs[lane]) == lane and L.pgpu_batch_lane(ds[lane]) == lane
+            assert R.down(ds[lane]) == data[lane][0]
+            assert R.down(cs[lane]) == opk.encrypt(*data[lane])
+        x = R.op(L.pgpu_batch_ct_add, pk._h, cs[0], cs[1])          # operands of both lanes
+        assert L.pgpu_batch_lane(x) == 0
+        assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, x)) == [(a + b) % n for a, b in zip(data[0][0], data[1][0])]
+        y = R.op(L.pgpu_batch_ct_add_plain, pk._h, cs[1], h[0][0])   # ciphertext of lane 1, plaintext of lane 0
+        assert L.pgpu_batch_lane(y) == 1
+        assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, y)) == [(a + b) % n for a, b in zip(data[1][0], data[0][0])]
+    finally:
+        _capi.check(L.pgpu_set_batch_lane(0))
+        R.close()

@@ -5,7 +5,7 @@ src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 
 def short(name):
-    for k in ("modexp_kernel", "hensel_decrypt_kernel", "crt_kernel", "modmul_kernel", "fixedbase", "fb_"):
+    for k in ("modexp_kernel", "hensel_decrypt_kernel", "crt_kernel", "modmul_kernel", "fixedbase", "fb_", "pair_ops_kernel"):
         if k in name:
             return name.split("(")[0].replace("void pgpu::", "")
     return None
@@ -67,6 +67,18 @@ fb = next((v for k, v in out.items() if k.startswith("fb_encrypt_kernel<")), Non
 if fb and "hbm_bytes_fetch_x2_corrected" in fb:
     summary["fb_encrypt_hbm_bytes_per_launch"] = fb["hbm_bytes_fetch_x2_corrected"]
     summary["fb_encrypt_hbm_bytes_per_launch_raw"] = fb["hbm_bytes_raw"]
+fb = next((v for k, v in out.items() if k.startswith("hensel_fb_encrypt_kernel<")), None) or fb
+if fb and "hbm_bytes_fetch_x2_corrected" in fb:
+    summary["fb_encrypt_hbm_bytes_per_launch"] = fb["hbm_bytes_fetch_x2_corrected"]
+# keys of other profile tags (config 5: the CT+CT launch) survive a re-run of the headline tag and vice versa
+old = {}
+if os.path.exists("profiles/pmc_summary.json"):
+    old = json.load(open("profiles/pmc_summary.json"))
+po = next((v for k, v in out.items() if k.startswith("pair_ops_kernel<")), None)
+if po and "hbm_bytes_fetch_x2_corrected" in po and float(po["dispatch"]["Grid_Size"]) >= 8e6:
+    summary = {"ct_add_pair_mul_hbm_bytes_per_launch": po["hbm_bytes_fetch_x2_corrected"],
+               "ct_add_source": f"profiles/{tag}_pmc_counters.json"}
 if len(summary) > 1:
-    json.dump(summary, open("profiles/pmc_summary.json", "w"), indent=1)
+    old.update(summary)
+    json.dump(old, open("profiles/pmc_summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
