@@ -792,30 +792,50 @@ def run_config45(args, pa, L, B, N):
     t_e2e = best_of(e2e_add, 2)
     shard = total // N
     mm_ms = float(np.mean(per_add[K_MODMUL]))
-    # SURVEY 8(d) / BASELINE.md: "CT add = 65 792 MAC32" = TWO canonical Montgomery products mod n^2 per element
-    # (into the domain and the product); a resident chain executes ONE, so the executed fraction is half of `frac`
+    # SURVEY 8(d) / BASELINE.md: "CT add = 65 792 MAC32" = TWO canonical Montgomery products mod n^2 per element (into the
+    # domain and the product).  A resident chain executes ONE product: on pair rows (round 3) one PAIR product, three
+    # half-width products and two half-width reductions = 6 L2^2 limb products; on Montgomery-form words (round 2,
+    # PGPU_PAIR_ROWS=0) one full-width product of 144 limbs, 2 * 144^2.
     mac_add = 2 * (2 * 128 * 128 + 128) * shard
+    row_limbs = L.pgpu_batch_row_limbs(st["s"])
+    if row_limbs:
+        l2 = row_limbs // 2
+        add_kernel = f"pair_ops_kernel<{8 if l2 == 112 else 4 if l2 == 72 else 2},{l2 // (8 if l2 == 112 else 4 if l2 == 72 else 2)}> (PO_MUL: CT+CT as one pair product on pair rows)"
+        exec_add = 6 * l2 * l2 * shard
+        row_bytes = 4 * row_limbs
+    else:
+        add_kernel = f"modmul_kernel<{geo_name(W, 2 * KEY_BITS, shard)}> (CT+CT on Montgomery-form words)"
+        exec_add = 2 * 144 * 144 * shard
+        row_bytes = W * 8
     mac_mul = algorithmic_mac32(2 * KEY_BITS, 32) * shard
     me_ms = float(np.mean(per_mul[K_MODEXP]))
+    pmc = {}
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
     return {
         "metric": "2048-bit CipherText add (modmul mod n^2) elements/sec, batch=1M sharded over the GPUs",
         "value": round(total / t_add, 1), "unit": "modmuls/s", "n_gpus": N, "steps": args.steps, "warmup": 1,
         "ms_per_step": round(t_add * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[4]: k=2048, batch=1M: (i) CT+CT on resident Montgomery-domain ciphertexts "
+        "config": {"workload": "BASELINE configs[4]: k=2048, batch=1M: (i) CT+CT on resident ciphertexts "
                                "(one product each), (ii) CT x PT with 32-bit plaintexts; sharded contiguously over "
                                f"{N} GPU(s) ({shard} elements each)",
+                   "resident_ciphertext_form": ("pair rows (%d limbs)" % row_limbs) if row_limbs else "Montgomery-form words",
                    "parallelism": f"in-process device pool x{N} (key images: {L.pgpu_pool_transport().decode()})"},
-        "roofline": {"bound": "int-alu", "kernel": f"modmul_kernel<{geo_name(W, 2 * KEY_BITS, shard)}> (CT+CT, {shard} per GPU)",
-                     "achieved": round(mac_add / (mm_ms * 1e-3) / 1e12, 3), "peak": PEAK_TMAC32, "unit": "TMAC32/s",
-                     "frac": round(mac_add / (mm_ms * 1e-3) / 1e12 / PEAK_TMAC32, 4), "traffic": None,
-                     "kernel_ms": round(mm_ms, 4), "executed_frac": round(mac_add / 2 / (mm_ms * 1e-3) / 1e12 / PEAK_TMAC32, 4),
-                     "algorithmic_bytes_per_launch": 3 * W * 8 * shard,
-                     "hbm_achieved_GBs": round(3 * W * 8 * shard / (mm_ms * 1e-3) / 1e9, 1), "hbm_peak_GBs": HBM_PEAK_GBS,
-                     "hbm_frac": round(3 * W * 8 * shard / (mm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "roofline": {"bound": "int-alu", "kernel": f"{add_kernel}, {shard} per GPU",
+                     "achieved": sig(exec_add / (mm_ms * 1e-3) / 1e12, 3), "peak": PEAK_TMAC32, "unit": "TMAC32/s",
+                     "frac": sig(exec_add / (mm_ms * 1e-3) / 1e12 / PEAK_TMAC32),
+                     "frac_basis": "executed multiply-accumulates per launch / kernel time / peak",
+                     "canonical_frac": sig(mac_add / (mm_ms * 1e-3) / 1e12 / PEAK_TMAC32),
+                     "traffic": pmc.get("ct_add_pair_mul_hbm_bytes_per_launch") if row_limbs else None,
+                     "kernel_ms": round(mm_ms, 4), "executed_mac32_per_launch": exec_add,
+                     "algorithmic_bytes_per_launch": 3 * row_bytes * shard,
+                     "hbm_achieved_GBs": round(3 * row_bytes * shard / (mm_ms * 1e-3) / 1e9, 1), "hbm_peak_GBs": HBM_PEAK_GBS,
+                     "hbm_frac": sig(3 * row_bytes * shard / (mm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)},
         "config5_mul_ctpt_u32": {"ms_per_step": round(t_mul * 1e3, 3), "modexps_per_s": round(total / t_mul, 1),
                                  "kernel": modexp_n2_kernel(pk, shard), "kernel_ms": round(me_ms, 3),
-                                 "frac": round(mac_mul / (me_ms * 1e-3) / 1e12 / PEAK_TMAC32, 4)},
+                                 "canonical_frac": sig(mac_mul / (me_ms * 1e-3) / 1e12 / PEAK_TMAC32)},
         "end_to_end": {"what": "CT+CT through pgpu_modmul on caller-owned host arrays (plain operands: two products, "
                                "H2D + kernel + D2H pipelined in sub-batches over the worker lanes)",
                        "ms_per_step": round(t_e2e * 1e3, 3), "modmuls_per_s": round(total / t_e2e, 1),
