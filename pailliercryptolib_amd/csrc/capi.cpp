@@ -1757,6 +1757,11 @@ void pgpu_shutdown(void) {
     g_sq_cache.clear();
   }
   drain_parked();
+  {
+    // fixed-base tables of keys that outlive the pool are freed with their keys; the budget of the next pool starts empty
+    std::lock_guard<std::mutex> lk(g_fb_mu);
+    g_fb_dev_bytes.assign(g_fb_dev_bytes.size(), 0);
+  }
   rt::pool_shutdown();
 }
 
