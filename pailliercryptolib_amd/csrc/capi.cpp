@@ -1435,8 +1435,18 @@ const pgpu_privkey::HenselSet* pick_hensel(const pgpu_privkey* key, size_t count
 }
 
 // fused CRT decrypt on one device; in_mont: ciphertexts arrive in the Montgomery domain of n^2
+// PGPU_AB_DECRYPT: 0 (default) = never, 1 = whenever it applies, 2 = when the GPU's other batch lane is busy at launch time.
+// hensel_ab.hpp: the two halves of a residue in different wavefronts -- 12.5 % fewer VALU instructions per launch (PMC),
+// but measured (profiles/r03_ab_decrypt.txt): alone its longer half sets the pace (5.41 vs 4.59 ms), and with two batches
+// in flight the gain depends on which wavefronts the dispatcher pairs on a SIMD (A+B: good, B+B: none) -- +1.6 % on
+// average.  Kept as an experiment, bit-identical, off by default.
+std::atomic<int> g_ab_policy{[] {
+  const char* e = std::getenv("PGPU_AB_DECRYPT");
+  return e ? std::max(0, std::min(2, std::atoi(e))) : 0;
+}()};
+int ab_policy() { return g_ab_policy.load(); }
 int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m, size_t count,
-               hipStream_t s, bool in_mont, const uint32_t* d_pair = nullptr, int in_pair_l2 = 0) {
+               hipStream_t s, bool in_mont, const uint32_t* d_pair = nullptr, int in_pair_l2 = 0, bool other_lane_busy = false) {
   // d_pair: the ciphertexts are pair rows of 2*in_pair_l2 limbs (d_c unused); needs a split form of the key
   const int nw = key->n_words;
   rt::StreamWork& w = d.work_for(s);
@@ -1507,7 +1517,15 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
     RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * ipw * entries * 2 * L2 * sizeof(uint32_t), s));
     h.table = (uint32_t*)w.table.p;
     TimerScope t(d, s, PGPU_KERNEL_MODEXP);
-    if (!pgpu::launch_hensel(hset->H, hset->K, waves > kSimds || g_packed_decrypt.load(), h, blocks, s))
+    const bool ab = d_pair && !sliding && hset->H == 2 && pgpu::hensel_ab_has(hset->K) && count >= 2048 &&
+                    (ab_policy() == 1 || (ab_policy() == 2 && other_lane_busy));
+    if (ab) {
+      // one A/B pair per 32 ciphertexts and side; a workgroup = the p pair and the q pair of the same 32 ciphertexts
+      const unsigned ab_blocks = (unsigned)((count + 31) / 32);
+      RC_TRY(w.table.ensure((size_t)ab_blocks * 2 * 32 * entries * 2 * L2 * sizeof(uint32_t), s));
+      h.table = (uint32_t*)w.table.p;
+      if (!pgpu::launch_hensel_ab(hset->K, h, ab_blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "A/B decrypt kernel not compiled");
+    } else if (!pgpu::launch_hensel(hset->H, hset->K, waves > kSimds || g_packed_decrypt.load(), h, blocks, s))
       return fail(PGPU_ERR_UNSUPPORTED, "split-form kernel not compiled");
     HIP_TRY(hipGetLastError());
     t.stop();
@@ -1898,6 +1916,9 @@ void pgpu_debug_set_hensel(int mode) { g_hensel.store(mode < 0 ? 0 : (mode > 3 ?
 // A/B measurements (bench.py two_streams): 1 = the two-wavefronts-per-SIMD build of the (2,19) decrypt kernel for
 // every launch.  Not part of the public header.
 void pgpu_debug_set_packed_decrypt(int on) { g_packed_decrypt.store(on != 0); }
+// tests / A-B measurements: the A/B-wavefront decrypt kernel (hensel_ab.hpp): 0 never, 1 whenever it applies, 2 when the
+// other batch lane is busy.  Not part of the public header.
+void pgpu_debug_set_ab_decrypt(int policy) { g_ab_policy.store(policy < 0 ? 0 : (policy > 2 ? 2 : policy)); }
 
 int pgpu_set_timing(int enabled) {
   g_timing.store(enabled != 0);
@@ -2659,8 +2680,12 @@ int pgpu_batch_decrypt_crt(const pgpu_privkey* key, const pgpu_batch* c, pgpu_ba
     out->bounds(d, &lo, &hi);
     rt::Device& dev = rt::device(d);
     rt::DeviceGuard g(dev.ordinal);
-    if (c->pair_l2)
-      RC_TRY(decrypt_on(dev, key, nullptr, out->ptr(d), hi - lo, dev.bs(c->lane), false, c->prow(d), c->pair_l2));
+    if (c->pair_l2) {
+      // is the GPU's other batch lane busy right now?  Then this launch will share the SIMDs with another one
+      const bool busy = hipStreamQuery(dev.bs(c->lane ^ 1)) == hipErrorNotReady;
+      (void)hipGetLastError();
+      RC_TRY(decrypt_on(dev, key, nullptr, out->ptr(d), hi - lo, dev.bs(c->lane), false, c->prow(d), c->pair_l2, busy));
+    }
     else
       RC_TRY(decrypt_on(dev, key, c->ptr(d), out->ptr(d), hi - lo, dev.bs(c->lane), c->mont != nullptr));
   }
