@@ -105,14 +105,20 @@ int compute_thread_budget() {
     if (q > 0 && period > 0) n = std::min<long>(n, std::max<long>(1, (q + period - 1) / period));
   }
   n = std::min(n, 16);
+  // Default: ONE thread.  Measured on the GPU hosts of this pool (EPYC 9575F, 16 cores under the quota;
+  // profiles/r03_host_glue_threads.txt): the loops the team would split -- pack, unpack, copy of 8192 BigNumbers -- take
+  // 60-260 us on one core and get SLOWER with more (pack 93 -> 144 us, unpack 190 -> 227 us at 16 threads; only the plain
+  // copy gains, 103 -> 70 us): they are bound by the allocator and by first touches of fresh pages, not by arithmetic.
+  // IPCL_NUM_THREADS=k (or OMP_NUM_THREADS) opts into the team, up to the budget above.
+  int want = 1;
   for (const char* var : {"IPCL_NUM_THREADS", "OMP_NUM_THREADS"}) {
     const char* e = std::getenv(var);
     if (e && std::atoi(e) > 0) {
-      n = std::min(n, std::atoi(e));
+      want = std::atoi(e);
       break;
     }
   }
-  return std::max(1, n);
+  return std::max(1, std::min(n, want));
 }
 }  // namespace
 

@@ -26,9 +26,10 @@ inline int words_for_bits(int bits) { return bits <= 0 ? 1 : (bits + 63) / 64; }
 // threads that SLEEP between loops (condition variable) does the same job: an OpenMP team spins at its barriers,
 // which under a CPU quota (16 cores of a 256-thread host on this pool's GPU boxes, fewer in CI sandboxes) turns a
 // 0.5 ms loop into tens of milliseconds -- measured, round 2 and again round 3 with a bounded team (pack of 8192
-// values: 0.57 ms serial, 36 ms on 8 spinning threads, 0.2-0.3 ms on the sleeping team).  The budget is what the
-// process may actually run on -- the CPU affinity mask cut by the cgroup quota, capped at 16 and by
-// IPCL_NUM_THREADS / OMP_NUM_THREADS.  A loop that finds the team busy (another application thread is inside a
+// values in a CI sandbox: 0.57 ms serial, 36 ms on 8 spinning threads).  The team is OPT-IN (IPCL_NUM_THREADS /
+// OMP_NUM_THREADS > 1): on the GPU hosts of this pool the loops it would split take 60-260 us on one core and do not
+// get faster on more (common.cpp: compute_thread_budget); the budget is capped by what the process may actually run
+// on -- the CPU affinity mask cut by the cgroup quota -- and at 16.  A loop that finds the team busy (another application thread is inside a
 // loop: the reference's application-level OpenMP pattern) runs on the calling thread alone -- the "remaining
 // threads" rule of assignOMPThreads.
 int max_host_threads();

@@ -242,6 +242,30 @@ TEST(negative_and_wide_plaintexts) {
   EXPECT_EQ(keep.getElement(1), a[1]);
 }
 
+// the host layer's per-element loops on a batch large enough for the thread team (IPCL_NUM_THREADS > 1 in the pool run of
+// tests/test_gpu_cpp_api.py; one thread otherwise): 4096 elements through every marshalling loop
+TEST(large_batch_marshalling) {
+  ipcl::KeyPair& key = shared_key();
+  const size_t N = 4096;
+  std::vector<uint32_t> v = random_u32(N, 77);
+  std::vector<BigNumber> m(N);
+  for (size_t i = 0; i < N; ++i) m[i] = BigNumber(v[i]) * BigNumber(v[(i + 1) % N]) + BigNumber(v[i]);
+  ipcl::PlainText pt(m);
+  ipcl::CipherText ct = key.pub_key.encrypt(pt);
+  std::vector<BigNumber> c = ct.getTexts();
+  EXPECT_EQ(c.size(), N);
+  std::vector<BigNumber> d = key.priv_key.decrypt(ipcl::CipherText(key.pub_key, c)).getTexts();
+  EXPECT_EQ(d.size(), N);
+  bool same = d.size() == N;
+  for (size_t i = 0; same && i < N; ++i) same = d[i] == m[i];
+  EXPECT_TRUE(same);
+  std::vector<BigNumber> sq = ipcl::modExp(c, std::vector<BigNumber>(N, BigNumber(2)), std::vector<BigNumber>(N, *key.pub_key.getNSQ()));
+  std::vector<BigNumber> d2 = key.priv_key.decrypt(ipcl::CipherText(key.pub_key, sq)).getTexts();
+  same = d2.size() == N;
+  for (size_t i = 0; same && i < N; ++i) same = d2[i] == (m[i] + m[i]) % *key.pub_key.getN();
+  EXPECT_TRUE(same);
+}
+
 TEST(add_sub_expression) {  // a + b*2 + b
   ipcl::KeyPair& key = shared_key();
   auto a = random_u32(14, 10), b = random_u32(14, 11);

@@ -59,7 +59,9 @@ def test_cpp_api_suite_on_oversubscribed_pool():
     b.build_pgpu()
     b.build_ipcl()
     exe = build_test_binary()
-    env = dict(os.environ, PGPU_POOL_OVERSUBSCRIBE="1", IPCL_GPU_DEVICES="3", PGPU_MIN_SHARD="4", IPCL_EXPECT_POOL="3")
+    # (and with the host layer's thread team switched on: IPCL_NUM_THREADS -- off by default, csrc/host/common.cpp)
+    env = dict(os.environ, PGPU_POOL_OVERSUBSCRIBE="1", IPCL_GPU_DEVICES="3", PGPU_MIN_SHARD="4", IPCL_EXPECT_POOL="3",
+               IPCL_NUM_THREADS="4")
     env.pop("LOCAL_RANK", None)
     env.pop("IPCL_GPU_DEVICE", None)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
