@@ -158,4 +158,10 @@ def compile_hip_aligned(hipcc, flags, src, obj, workdir):
          "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", "-input=" + dev_out,
          "-output=" + fatbin])
     run([hipcc] + flags + ["--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fatbin, "-c", src, "-o", obj])
+    if os.environ.get("PGPU_ALIGN8_KEEP", "0") == "0":      # the intermediates are ~6 MB per translation unit
+        for f in (raw_s, fix_s, dev_o, dev_out, fatbin):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
     return kept
