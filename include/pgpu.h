@@ -210,10 +210,14 @@ int pgpu_get_table_gather_policy(void);
  * over the pool (count == 1: one copy on every GPU, the reference's "vector (+) scalar" operand,
  * ciphertext.cpp:51-58).  Operations enqueue one launch per shard on the GPUs' batch streams and
  * return at once; pgpu_batch_download waits.  Batches are immutable once produced.
- * Ciphertext batches produced on the device stay in the MONTGOMERY DOMAIN of n^2 (value*R mod n^2):
- * CT+CT is then ONE Montgomery product (ciphertext.cpp:135-141 does a multiply and a divide),
- * encrypt emits that form for free and CRT decrypt absorbs it into its load constants; the plain
- * value only materialises in pgpu_batch_download.  Callers never see the difference. */
+ * Ciphertext batches produced on the device stay in a device-side DOMAIN; the plain value only materialises in
+ * pgpu_batch_download and callers never see the difference:
+ *   - keys of 1024 / 2048 / 3072 bits (those with a split form): PAIR ROWS, c*R == a - (n*k)*b mod n^2 as 29-bit limbs
+ *     (pgpu_batch_row_limbs) -- CT+CT is ONE pair product, CT+PT two half-width products, encrypt / CT*PT / CRT decrypt
+ *     read and write the rows without conversion (ciphertext.cpp:135-141 does a multiply and a divide per CT+CT);
+ *   - other keys, plaintext rows wider than n, PGPU_PAIR_ROWS=0: Montgomery-form words c*R mod n^2 -- CT+CT one
+ *     full-width Montgomery product, encrypt emits the form for free, CRT decrypt absorbs it into its load constants.
+ * Operations accept any mix (plain uploaded batches included) and convert on the way in. */
 typedef struct pgpu_batch pgpu_batch;
 int pgpu_batch_create(size_t count, int words, pgpu_batch** out);            /* uninitialised */
 int pgpu_batch_upload(const uint64_t* host, size_t count, int words, size_t stride, pgpu_batch** out);
