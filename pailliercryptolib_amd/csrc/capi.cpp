@@ -1442,7 +1442,7 @@ const pgpu_privkey::HenselSet* pick_hensel(const pgpu_privkey* key, size_t count
 // average.  Kept as an experiment, bit-identical, off by default.
 std::atomic<int> g_ab_policy{[] {
   const char* e = std::getenv("PGPU_AB_DECRYPT");
-  return e ? std::max(0, std::min(2, std::atoi(e))) : 0;
+  return e ? std::max(0, std::min(3, std::atoi(e))) : 0;
 }()};
 int ab_policy() { return g_ab_policy.load(); }
 int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m, size_t count,
@@ -1518,13 +1518,17 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
     h.table = (uint32_t*)w.table.p;
     TimerScope t(d, s, PGPU_KERNEL_MODEXP);
     const bool ab = d_pair && !sliding && hset->H == 2 && pgpu::hensel_ab_has(hset->K) && count >= 2048 &&
-                    (ab_policy() == 1 || (ab_policy() == 2 && other_lane_busy));
+                    (ab_policy() == 1 || ab_policy() == 3 || (ab_policy() == 2 && other_lane_busy));   // 3: always, four pairs per workgroup
     if (ab) {
-      // one A/B pair per 32 ciphertexts and side; a workgroup = the p pair and the q pair of the same 32 ciphertexts
-      const unsigned ab_blocks = (unsigned)((count + 31) / 32);
-      RC_TRY(w.table.ensure((size_t)ab_blocks * 2 * 32 * entries * 2 * L2 * sizeof(uint32_t), s));
+      // one A/B pair per 32 ciphertexts and side.  Workgroups of two pairs (one wavefront per SIMD) when the launch has
+      // the GPU to itself; of four pairs (two wavefronts per SIMD, an A and a B by construction) when it shares the GPU
+      // with a second batch or is large enough to put two wavefronts on every SIMD anyway
+      const int ppw = (other_lane_busy || count >= 16384 || ab_policy() == 3) ? 4 : 2;
+      const size_t pairs = 2 * ((count + 31) / 32);
+      const unsigned ab_blocks = (unsigned)((pairs + ppw - 1) / ppw);
+      RC_TRY(w.table.ensure((size_t)ab_blocks * ppw * 32 * entries * 2 * L2 * sizeof(uint32_t), s));
       h.table = (uint32_t*)w.table.p;
-      if (!pgpu::launch_hensel_ab(hset->K, h, ab_blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "A/B decrypt kernel not compiled");
+      if (!pgpu::launch_hensel_ab(hset->K, ppw, h, ab_blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "A/B decrypt kernel not compiled");
     } else if (!pgpu::launch_hensel(hset->H, hset->K, waves > kSimds || g_packed_decrypt.load(), h, blocks, s))
       return fail(PGPU_ERR_UNSUPPORTED, "split-form kernel not compiled");
     HIP_TRY(hipGetLastError());
@@ -1918,7 +1922,7 @@ void pgpu_debug_set_hensel(int mode) { g_hensel.store(mode < 0 ? 0 : (mode > 3 ?
 void pgpu_debug_set_packed_decrypt(int on) { g_packed_decrypt.store(on != 0); }
 // tests / A-B measurements: the A/B-wavefront decrypt kernel (hensel_ab.hpp): 0 never, 1 whenever it applies, 2 when the
 // other batch lane is busy.  Not part of the public header.
-void pgpu_debug_set_ab_decrypt(int policy) { g_ab_policy.store(policy < 0 ? 0 : (policy > 2 ? 2 : policy)); }
+void pgpu_debug_set_ab_decrypt(int policy) { g_ab_policy.store(policy < 0 ? 0 : (policy > 3 ? 3 : policy)); }
 
 int pgpu_set_timing(int enabled) {
   g_timing.store(enabled != 0);

@@ -129,15 +129,30 @@ struct AbShared {
 // (The counters are read and written with explicit ds_ instructions on their LDS offset -- the low half of the generic
 // address: through a volatile generic pointer hipcc emits flat_load + s_waitcnt vmcnt(0) lgkmcnt(0), the very wait this is
 // meant to avoid.)
-__device__ __forceinline__ void ab_wait_ge(const uint32_t* flag, uint32_t want) {
+template <int SLEEP = 1>
+__device__ __forceinline__ uint32_t ab_wait_ge(const uint32_t* flag, uint32_t want) {
   const uint32_t off = (uint32_t)(uintptr_t)flag;
+  uint32_t seen;
   for (;;) {
     uint32_t v;
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(off) : "memory");
-    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)v) >= want) break;
-    __builtin_amdgcn_s_sleep(1);
+    seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    if (seen >= want) break;
+    __builtin_amdgcn_s_sleep(SLEEP);
   }
   asm volatile("" ::: "memory");
+  return seen;
+}
+// the counter read in two halves: issued now, looked at later (its round trip hides behind whatever is in between)
+__device__ __forceinline__ uint32_t ab_peek_issue(const uint32_t* flag) {
+  const uint32_t off = (uint32_t)(uintptr_t)flag;
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(off) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint32_t ab_peek_value(uint32_t v) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) : : "memory");
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 __device__ __forceinline__ void ab_publish(uint32_t* flag, uint32_t value, int lane) {
   const uint32_t off = (uint32_t)(uintptr_t)flag;
@@ -282,26 +297,31 @@ __device__ __forceinline__ void ab_b_mul(uint32_t (&r)[K], const uint32_t (&b)[K
 // One workgroup = two A/B pairs (four wavefronts, one per SIMD of a CU; with a second batch in flight every SIMD hosts
 // one wavefront of each launch).  Pair P serves 32 ciphertexts of ONE side (even pairs p, odd pairs q), like a wavefront
 // of hensel_decrypt_kernel<2,K> serves 16.
-template <int K>
-__global__ __launch_bounds__(kWGThreads, 2) void hensel_decrypt_ab_kernel(HenselArgs A) {
+// PAIRS = 2: four wavefronts, one per SIMD (A, A, B, B) -- the form for a launch that has the chip to itself.
+// PAIRS = 4: eight wavefronts, two per SIMD; wavefronts w and w + 4 share a SIMD (MI355X_MICROARCH.md: a 512-thread
+// workgroup places two waves on each SIMD), so every SIMD hosts the A wavefront of one pair and the B wavefront of
+// another BY CONSTRUCTION -- the form for launches of 16384 ciphertexts and more (two per SIMD anyway) and for a batch
+// that shares the GPU with a second one (each launch then covers half the CUs).
+template <int K, int PAIRS>
+__global__ __launch_bounds__(PAIRS * 2 * kWave, 2) void hensel_decrypt_ab_kernel(HenselArgs A) {
   using HG = Geo<2, K>;
   constexpr int L2 = 2 * K, LQ = 4 * K, IPW = kAbIPW, W64 = HG::W64;
   raise_wave_priority();
-  __shared__ AbShared<K> sh_[2];
+  __shared__ AbShared<K> sh_[PAIRS];
   const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
-  const int pr = wv >> 1;
-  const bool roleB = (wv & 1) != 0;
+  const int pr = wv % PAIRS;
+  const bool roleB = wv >= PAIRS;
   AbShared<K>& sh = sh_[pr];
   const int grp = lane / 2, x = lane % 2;
   uint32_t sel0 = x == 0 ? 1u : 0u;
   asm("" : "+v"(sel0));
-  const size_t pair_id = (size_t)blockIdx.x * 2 + pr;
+  const size_t pair_id = (size_t)blockIdx.x * PAIRS + pr;
   const int side = __builtin_amdgcn_readfirstlane((int)(pair_id & 1));
   const size_t first_elem = (pair_id >> 1) * IPW;
   size_t elem = first_elem + grp;
   if (elem >= A.count) elem = A.count - 1;
 #define HCTX(field) (side ? A.ctx[1].field : A.ctx[0].field)
-  if (threadIdx.x % (2 * kWave) == 0) {
+  if (!roleB && lane == 0) {
     sh.produced = 0;
     sh.consumed = 0;
   }
@@ -335,7 +355,7 @@ __global__ __launch_bounds__(kWGThreads, 2) void hensel_decrypt_ab_kernel(Hensel
     // one multiplication: wait for a free slot, multiply, publish result + digits
 #define AB_A_STEP(SQ, UQ, RES, LHS, RHS, N0, PUBLISH_VALUE)                                    \
   do {                                                                                          \
-    if (m >= (uint32_t)kAbRing) ab_wait_ge(&sh.consumed, m - (uint32_t)kAbRing + 1);            \
+    if (m >= (uint32_t)kAbRing) ab_wait_ge<8>(&sh.consumed, m - (uint32_t)kAbRing + 1);            \
     ab_a_mul<K, SQ, UQ>(RES, LHS, RHS, n, N0, qslot(m), x);                                     \
     ab_store20<K>(aslot(m), PUBLISH_VALUE);                                                     \
     ++m;                                                                                        \
@@ -352,7 +372,7 @@ __global__ __launch_bounds__(kWGThreads, 2) void hensel_decrypt_ab_kernel(Hensel
         own[j] = (li < A.pchunk_limbs && first + li < A.pair_l2) ? row[first + li] : 0u;
         mreg[j] = HCTX(pconv)[(size_t)i * LQ + x * K + j];
       }
-      if (m >= (uint32_t)kAbRing) ab_wait_ge(&sh.consumed, m - (uint32_t)kAbRing + 1);
+      if (m >= (uint32_t)kAbRing) ab_wait_ge<8>(&sh.consumed, m - (uint32_t)kAbRing + 1);
       ab_a_mul<K, false, true>(own, own, mreg, n, 0, qslot(m), x);
       add_normalise<HG>(acc, own);
       ab_store20<K>(aslot(m), acc);        // B's copy of the a part is the running sum
@@ -371,7 +391,7 @@ __global__ __launch_bounds__(kWGThreads, 2) void hensel_decrypt_ab_kernel(Hensel
     // with a release fence in between -- here, and only here, the global stores of this wavefront matter to B)
 #pragma unroll 1
     for (int e = 2; e < tsize; ++e) {
-      if (m >= (uint32_t)kAbRing) ab_wait_ge(&sh.consumed, m - (uint32_t)kAbRing + 1);
+      if (m >= (uint32_t)kAbRing) ab_wait_ge<8>(&sh.consumed, m - (uint32_t)kAbRing + 1);
       ab_a_mul<K, false, true>(own, own, mreg, n, 0, qslot(m), x);
 #pragma unroll
       for (int j = 0; j < K; ++j) tbl[(size_t)e * LQ + j] = own[j];
@@ -403,7 +423,7 @@ __global__ __launch_bounds__(kWGThreads, 2) void hensel_decrypt_ab_kernel(Hensel
     }
     {
       const uint32_t n0 = HCTX(n0inv);
-      if (m >= (uint32_t)kAbRing) ab_wait_ge(&sh.consumed, m - (uint32_t)kAbRing + 1);
+      if (m >= (uint32_t)kAbRing) ab_wait_ge<8>(&sh.consumed, m - (uint32_t)kAbRing + 1);
       // (n[] is the loop modulus; the exit product reduces modulo p)
       uint32_t res[K];
       {
@@ -435,11 +455,19 @@ __global__ __launch_bounds__(kWGThreads, 2) void hensel_decrypt_ab_kernel(Hensel
   // ============================ wavefront B: the b parts ============================
   uint32_t own[K], acur[K], mc_[K], md_[K], acc[K];
   // one multiplication: wait for A's digits, multiply, take over A's result as the new a copy, retire the slot
+  // (A is usually two multiplications ahead: `seen`, the counter as read at the end of the previous step, then already
+  // covers this one and the poll costs nothing; A's result of THIS multiplication is fetched before the product starts
+  // and becomes the a copy of the next one, its LDS round trip hidden behind the product)
+  uint32_t seen = 0;
 #define AB_B_STEP(SQ, UQ, CVAL, DVAL, N, N0)                                                   \
   do {                                                                                          \
-    ab_wait_ge(&sh.produced, m + 1);                                                            \
+    if (seen < m + 1) seen = ab_wait_ge(&sh.produced, m + 1);                                   \
+    uint32_t anext[K];                                                                          \
+    ab_load20<K>(anext, aslot(m));                                                              \
+    const uint32_t peek = ab_peek_issue(&sh.produced);                                          \
     ab_b_mul<K, SQ, UQ>(own, own, DVAL, acur, CVAL, N, N0, qslot(m), sel0);                     \
-    ab_load20<K>(acur, aslot(m));                                                               \
+    _Pragma("unroll") for (int j = 0; j < K; ++j) acur[j] = anext[j];                           \
+    seen = ab_peek_value(peek);                                                                 \
     ++m;                                                                                        \
     ab_publish(&sh.consumed, m, lane);                                                          \
   } while (0)
@@ -463,7 +491,7 @@ __global__ __launch_bounds__(kWGThreads, 2) void hensel_decrypt_ab_kernel(Hensel
         own[j] = 0;                                              // the b part of (z_i, 0)
       }
       montmul_reg<HG, false, true>(tb, zb, cb, n, 0);
-      ab_wait_ge(&sh.produced, m + 1);
+      seen = ab_wait_ge(&sh.produced, m + 1);
       ab_b_mul<K, false, true>(own, own, md_, acur, mc_, n, 0, qslot(m), sel0);
 #pragma unroll
       for (int j = 0; j < K; ++j) own[j] += tb[j];

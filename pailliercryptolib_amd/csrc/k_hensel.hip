@@ -76,9 +76,13 @@ bool PGPU_PO_NAME(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream
   return false;
 }
 #elif PGPU_PART == 15
-bool launch_hensel_ab_part15(int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
-  if (K == 19) {
-    hipLaunchKernelGGL((hensel_decrypt_ab_kernel<19>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+bool launch_hensel_ab_part15(int K, int pairs_per_wg, const HenselArgs& a, unsigned blocks, hipStream_t s) {
+  if (K == 19 && pairs_per_wg == 2) {
+    hipLaunchKernelGGL((hensel_decrypt_ab_kernel<19, 2>), dim3(blocks), dim3(4 * kWave), 0, s, a);
+    return true;
+  }
+  if (K == 19 && pairs_per_wg == 4) {
+    hipLaunchKernelGGL((hensel_decrypt_ab_kernel<19, 4>), dim3(blocks), dim3(8 * kWave), 0, s, a);
     return true;
   }
   return false;

@@ -99,9 +99,9 @@ inline bool launch_pair_ops(int H, int K, const PairOpsArgs& a, unsigned blocks,
 // CRT decrypt with the two halves of a residue in different wavefronts (hensel_ab.hpp; k_hensel.hip part 15): pair-row
 // ciphertexts, fixed-window scan, 2048-bit keys (2 lanes x 19 limbs per half)
 inline bool hensel_ab_has(int K) { return K == 19; }
-bool launch_hensel_ab_part15(int K, const HenselArgs& a, unsigned blocks, hipStream_t s);
-inline bool launch_hensel_ab(int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
-  return launch_hensel_ab_part15(K, a, blocks, s);
+bool launch_hensel_ab_part15(int K, int pairs_per_wg, const HenselArgs& a, unsigned blocks, hipStream_t s);
+inline bool launch_hensel_ab(int K, int pairs_per_wg, const HenselArgs& a, unsigned blocks, hipStream_t s) {
+  return launch_hensel_ab_part15(K, pairs_per_wg, a, blocks, s);
 }
 
 bool launch_modmul(int G, int K, const ModmulArgs& a, unsigned blocks, hipStream_t s);

@@ -243,7 +243,9 @@ def test_ab_wavefront_decrypt_kernel_is_bit_identical(engine):
         assert want == m
         L.pgpu_debug_set_ab_decrypt(1)
         try:
-            assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, c)) == m
+            assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, c)) == m       # workgroups of two A/B pairs
+            L.pgpu_debug_set_ab_decrypt(3)
+            assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, c)) == m       # workgroups of four pairs (two per SIMD)
             _capi.check(L.pgpu_set_table_gather_policy(1))
             assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, c)) == m
         finally:
