@@ -215,8 +215,8 @@ def main():
         for i in range(64):
             hs_i = pow(hs, 2 * i + 3, nsq)                # 64 distinct valid hs values (powers of an n-th residue)
             keys.append((pa.PublicKey(n, 2048, hs=hs_i), hs_i))
-        m = [rng.randrange(n) for _ in range(24)]
-        r = [rng.getrandbits(1024) for _ in range(24)]
+        m = [rng.randrange(n) for _ in range(6)]
+        r = [rng.getrandbits(1024) for _ in range(6)]
         good = True
         for rnd in range(2):
             for pk_i, hs_i in keys:

@@ -2,7 +2,8 @@
 (a, b), c*R == a - (n*k)*b mod n^2, in HBM -- the register image of the split-form kernels.  Every operation on
 resident batches (encrypt DJN / r^n, CT+CT, CT+PT, CT x PT, CRT decrypt, download, mixing with uploaded plain
 ciphertexts, one-element broadcast operands) is held bit-identical to the oracle for the 1024-, 2048- and 3072-bit key
-classes, at batch sizes on both sides of the kernels' form thresholds, with edge plaintexts and exponents."""
+classes, at small and medium batch sizes (the large-batch forms are covered element by element against the C oracle in
+test_gpu_sha256_fullsize.py), with edge plaintexts and exponents."""
 import ctypes
 import json
 import os
@@ -54,7 +55,7 @@ def key_case(bits, djn):
     return int(c["p"], 16), int(c["q"], 16), int(c["hs"], 16) if djn else None
 
 
-@pytest.mark.parametrize("bits,djn,count", [(2048, True, 203), (2048, False, 37), (2048, True, 2500), (1024, True, 131),
+@pytest.mark.parametrize("bits,djn,count", [(2048, True, 203), (2048, False, 37), (2048, True, 700), (1024, True, 131),
                                             (1024, False, 19), (3072, True, 70), (3072, False, 9), (2048, True, 1)])
 def test_resident_chain_in_pair_rows(engine, bits, djn, count):
     from oracle import paillier_oracle as orc
