@@ -40,7 +40,7 @@ def _wanted(mangled):
     return len(nums) >= 2 and int(nums[1]) >= MIN_LIMBS
 
 
-def _rewrite(lines, keep_e32):
+def _rewrite(lines, keep_e32, skip_funcs=()):
     out = []
     in_text = False
     getpc_guard = 0
@@ -52,7 +52,7 @@ def _rewrite(lines, keep_e32):
             in_text = False
         f = _FUNC.match(ln)
         if f:
-            active = _wanted(f.group(1))
+            active = _wanted(f.group(1)) and f.group(1) not in skip_funcs
         if not in_text or not active or not _INSTR.match(ln) or ln.startswith("\t."):
             out.append(ln)
             continue
@@ -80,8 +80,9 @@ def align_assembly(src_s, dst_s, assemble_cmd):
     rejects are restored to `_e32`, then the file is assembled once more."""
     lines = open(src_s).read().split("\n")
     keep = set()
-    for _ in range(6):
-        cand = _rewrite(lines, keep)
+    skip = set()
+    for _ in range(8):
+        cand = _rewrite(lines, keep, skip)
         # map output line numbers back to input lines for error reporting
         open(dst_s, "w").write("\n".join(cand))
         ok, err = assemble_cmd(dst_s)
@@ -90,8 +91,20 @@ def align_assembly(src_s, dst_s, assemble_cmd):
         bad_out = {int(m.group(1)) for m in re.finditer(r":(\d+):\d+: error", err)}
         if not bad_out:
             raise RuntimeError("align8: assembler failed without line information:\n" + err[-2000:])
+        # a short branch the compiler had sized for the ORIGINAL code no longer reaches (the pass grows a kernel by a few
+        # per cent): leave that kernel as hipcc emitted it (they are the largest ones, which run several wavefronts per
+        # SIMD anyway, where placement does not matter)
+        grew = {int(m.group(1)) for m in re.finditer(r":(\d+):\d+: error: branch size exceeds", err)}
+        if grew:
+            for b in grew:
+                for k in range(min(b, len(cand)) - 1, -1, -1):
+                    f = _FUNC.match(cand[k])
+                    if f:
+                        skip.add(f.group(1))
+                        break
+            continue
         # find the input line of each rejected output line: replay the rewrite, tracking indices
-        idx_map = _index_map(lines, keep)
+        idx_map = _index_map(lines, keep, skip)
         new = {idx_map[b - 1] for b in bad_out if b - 1 in idx_map}
         if not new or new <= keep:
             raise RuntimeError("align8: cannot resolve assembler errors:\n" + err[-2000:])
@@ -99,7 +112,7 @@ def align_assembly(src_s, dst_s, assemble_cmd):
     raise RuntimeError("align8: did not converge")
 
 
-def _index_map(lines, keep_e32):
+def _index_map(lines, keep_e32, skip_funcs=()):
     """output line index -> input line index, for lines that were re-encoded"""
     out_idx = 0
     mapping = {}
@@ -113,7 +126,7 @@ def _index_map(lines, keep_e32):
             in_text = False
         f = _FUNC.match(ln)
         if f:
-            active = _wanted(f.group(1))
+            active = _wanted(f.group(1)) and f.group(1) not in skip_funcs
         if not in_text or not active or not _INSTR.match(ln) or ln.startswith("\t."):
             out_idx += 1
             continue

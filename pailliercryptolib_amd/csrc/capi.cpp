@@ -1440,6 +1440,13 @@ const pgpu_privkey::HenselSet* pick_hensel(const pgpu_privkey* key, size_t count
 // but measured (profiles/r03_ab_decrypt.txt): alone its longer half sets the pace (5.41 vs 4.59 ms), and with two batches
 // in flight the gain depends on which wavefronts the dispatcher pairs on a SIMD (A+B: good, B+B: none) -- +1.6 % on
 // average.  Kept as an experiment, bit-identical, off by default.
+// PGPU_SEQ_DECRYPT: 0 = never, 1 (default) = for launches that put at least one wavefront of that form on every SIMD
+// (16384 ciphertexts under a 2048-bit key, 8192 under a 3072-bit key), 2 = whenever it applies.  hensel_seq.hpp: both halves of a residue in the same lanes, one after the other -- 10-13 %
+// fewer instructions per exponentiation on half the lanes.
+std::atomic<int> g_seq_policy{[] {
+  const char* e = std::getenv("PGPU_SEQ_DECRYPT");
+  return e ? std::max(0, std::min(2, std::atoi(e))) : 1;
+}()};
 std::atomic<int> g_ab_policy{[] {
   const char* e = std::getenv("PGPU_AB_DECRYPT");
   return e ? std::max(0, std::min(3, std::atoi(e))) : 0;
@@ -1519,7 +1526,17 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
     TimerScope t(d, s, PGPU_KERNEL_MODEXP);
     const bool ab = d_pair && !sliding && hset->H == 2 && pgpu::hensel_ab_has(hset->K) && count >= 2048 &&
                     (ab_policy() == 1 || ab_policy() == 3 || (ab_policy() == 2 && other_lane_busy));   // 3: always, four pairs per workgroup
-    if (ab) {
+    const size_t seq_ipw = 64 / (size_t)hset->H;
+    const size_t seq_waves = 2 * ((count + seq_ipw - 1) / seq_ipw);
+    const bool seq = !ab && d_pair && !sliding && pgpu::hensel_seq_has(hset->H, hset->K) &&
+                     (g_seq_policy.load() == 2 || (g_seq_policy.load() == 1 && seq_waves >= kSimds));
+    if (seq) {
+      const unsigned sblocks = (unsigned)((seq_waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
+      RC_TRY(w.table.ensure((size_t)sblocks * pgpu::kWavesPerWG * seq_ipw * entries * 2 * L2 * sizeof(uint32_t), s));
+      h.table = (uint32_t*)w.table.p;
+      if (!pgpu::launch_hensel_seq(hset->H, hset->K, h, sblocks, s))
+        return fail(PGPU_ERR_UNSUPPORTED, "sequential-halves decrypt kernel not compiled");
+    } else if (ab) {
       // one A/B pair per 32 ciphertexts and side.  Workgroups of two pairs (one wavefront per SIMD) when the launch has
       // the GPU to itself; of four pairs (two wavefronts per SIMD, an A and a B by construction) when it shares the GPU
       // with a second batch or is large enough to put two wavefronts on every SIMD anyway
@@ -1922,6 +1939,8 @@ void pgpu_debug_set_hensel(int mode) { g_hensel.store(mode < 0 ? 0 : (mode > 3 ?
 void pgpu_debug_set_packed_decrypt(int on) { g_packed_decrypt.store(on != 0); }
 // tests / A-B measurements: the A/B-wavefront decrypt kernel (hensel_ab.hpp): 0 never, 1 whenever it applies, 2 when the
 // other batch lane is busy.  Not part of the public header.
+// tests / A-B measurements: hensel_seq.hpp (0 never, 1 by launch size, 2 whenever it applies).  Not part of the public header.
+void pgpu_debug_set_seq_decrypt(int policy) { g_seq_policy.store(policy < 0 ? 0 : (policy > 2 ? 2 : policy)); }
 void pgpu_debug_set_ab_decrypt(int policy) { g_ab_policy.store(policy < 0 ? 0 : (policy > 3 ? 3 : policy)); }
 
 int pgpu_set_timing(int enabled) {

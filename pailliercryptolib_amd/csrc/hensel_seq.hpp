@@ -1,0 +1,293 @@
+// pailliercryptolib_amd -- CRT-decrypt exponentiation in split form with BOTH halves of a residue in the same lanes
+// (round 3): the form for launches that put two or more wavefronts on every SIMD.
+//
+// hensel_decrypt_kernel (hensel.hpp) gives the a half and the b half of a pair x == a - P*b lanes of their own and runs
+// them through one instruction stream; half A then sits through the K^2 products of half B's 2*a*b although its own
+// squaring needs K(K+1)/2 (the squaring symmetry), and idles through d*a in a general product: 12.5 % of the kernel's
+// VALU instructions (PMC, hensel_ab.hpp).  Here a group of G lanes holds a AND b (K limbs of each per lane) and does
+// the two halves one after the other with the same accumulators:
+//     t = a*c            half-width Montgomery product modulo P, symmetric when it is a squaring; its quotient digits
+//                        are kept in registers (G*K of them)
+//     w = a*d + b*c + q  the digits enter column by column (mont_reduce_rows_q, QMODE 2)
+// -- the arithmetic of hensel_ab.hpp without its hand-over: no LDS, no counters, no second wavefront.  Per
+// exponentiation it issues the instructions of one A and one B stream on HALF the lanes of the paired form (3072-bit keys,
+// per squaring and exponentiation: 4 lanes x 3 758 against 8 lanes x ~2 100, -10 %; general products -8 %; 2048-bit
+// keys: 2 x 3 287 against 4 x 1 851, -11 %, and -17 %).  Half the lanes means half the wavefronts per batch, so the
+// form pays as soon as it still puts a wavefront on every SIMD -- measured (profiles/r03_seq_decrypt.txt): config 4's
+// decrypt leg 117.3 -> 103.1 ms, 2048-bit keys 16384 / 32768 / 65536 ciphertexts 4.49 / 4.34 / 4.35 -> 4.20 / 4.18 / 4.00 ms
+// per 8192 -- and costs where a batch just fills the chip once in the paired form (the bench's 8192 ciphertexts: 512
+// wavefronts, 8.1 ms; stays with hensel_decrypt_kernel).  Ciphertexts as pair rows, fixed-window scan; bit-identical.
+#ifndef PAILLIERCRYPTOLIB_AMD_CSRC_HENSEL_SEQ_HPP_
+#define PAILLIERCRYPTOLIB_AMD_CSRC_HENSEL_SEQ_HPP_
+
+#include "hensel_ab.hpp"
+
+namespace pgpu {
+
+// t = a*m (rows: the limbs of m, lane-distributed like a), digits of block S recorded in qd[S]
+template <int G, int K, bool SQR, bool UNITQ, int S>
+__device__ __forceinline__ void seq_a_blocks(uint64_t (&c0)[K], uint64_t (&c1)[K], const uint32_t (&a)[K],
+                                             const uint32_t (&a2)[K], const uint32_t (&n)[K], uint32_t n0inv,
+                                             const uint32_t (&m)[K], uint32_t (&qd)[G][K]) {
+  using HG = Geo<G, K>;
+  if constexpr (S < G) {
+    uint32_t b[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) b[r] = bcast_lane<G, S>(m[r]);
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        uint64_t p;
+        if constexpr (SQR) {
+          if (j > r) continue;
+          p = (uint64_t)(j < r ? a2[j] : a[j]) * b[r];
+        } else {
+          p = (uint64_t)a[j] * b[r];
+        }
+        if (r + j < K) c0[r + j] += p;
+        else c1[r + j - K] += p;
+      }
+    }
+    mont_reduce_rows_q<HG, UNITQ, 1>(c0, c1, n, n0inv, qd[S], 0u);
+    seq_a_blocks<G, K, SQR, UNITQ, S + 1>(c1, c0, a, a2, n, n0inv, m, qd);
+  }
+}
+
+// w = a*d + b*c + q: mc (= b, or 2b in a squaring) times the rows of c, md (= d) times the rows of a, the digits of A
+template <int G, int K, bool SQR, bool UNITQ, int S>
+__device__ __forceinline__ void seq_b_blocks(uint64_t (&c0)[K], uint64_t (&c1)[K], const uint32_t (&mc)[K],
+                                             const uint32_t (&md)[K], const uint32_t (&a)[K], const uint32_t (&c)[K],
+                                             const uint32_t (&n)[K], uint32_t n0inv, uint32_t (&qd)[G][K], uint32_t sel0) {
+  using HG = Geo<G, K>;
+  if constexpr (S < G) {
+    uint32_t row[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) row[r] = bcast_lane<G, S>(SQR ? a[r] : c[r]);
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const uint64_t p = (uint64_t)mc[j] * row[r];
+        if (r + j < K) c0[r + j] += p;
+        else c1[r + j - K] += p;
+      }
+    }
+    if constexpr (!SQR) {
+#pragma unroll
+      for (int r = 0; r < K; ++r) row[r] = bcast_lane<G, S>(a[r]);
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const uint64_t p = (uint64_t)md[j] * row[r];
+          if (r + j < K) c0[r + j] += p;
+          else c1[r + j - K] += p;
+        }
+      }
+    }
+    mont_reduce_rows_q<HG, UNITQ, 2>(c0, c1, n, n0inv, qd[S], sel0);
+    seq_b_blocks<G, K, SQR, UNITQ, S + 1>(c1, c0, mc, md, a, c, n, n0inv, qd, sel0);
+  }
+}
+
+// (a, b) = (a, b) (x) (c, d): the Montgomery product of two pairs held in the same lanes (lazy: inputs < 8P -> outputs
+// < 2P).  A squaring passes c = a, d = b.
+template <int G, int K, bool SQR, bool UNITQ>
+__device__ __forceinline__ void seq_pairmul(uint32_t (&a)[K], uint32_t (&b)[K], const uint32_t (&c)[K],
+                                            const uint32_t (&d)[K], const uint32_t (&n)[K], uint32_t n0inv, uint32_t sel0) {
+  static_assert(3 * K + 6 < 64, "a column receives 3K products (+ relaxed limbs): must stay below 2^64");
+  static_assert(G % 2 == 0, "blocks alternate between the two accumulator sets and end in the first");
+  using HG = Geo<G, K>;
+  uint32_t qd[G][K];
+  uint32_t t[K];
+  {
+    uint64_t c0[K], c1[K];
+    uint32_t a2[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      c0[j] = 0;
+      c1[j] = 0;
+      a2[j] = SQR ? a[j] << 1 : 0;
+    }
+    seq_a_blocks<G, K, SQR, UNITQ, 0>(c0, c1, a, a2, n, n0inv, c, qd);
+    montmul_finish<HG>(t, c0);
+  }
+  {
+    uint64_t c0[K], c1[K];
+    uint32_t mc[K], md[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      c0[j] = 0;
+      c1[j] = 0;
+      mc[j] = SQR ? b[j] << 1 : b[j];
+      md[j] = SQR ? 0u : d[j];
+    }
+    seq_b_blocks<G, K, SQR, UNITQ, 0>(c0, c1, mc, md, a, c, n, n0inv, qd, sel0);
+    montmul_finish<HG>(b, c0);
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) a[j] = t[j];
+}
+
+// One wavefront = 64/G ciphertexts of ONE side (wave parity: even = p, odd = q).  Output: row 2i = mp, row 2i+1 = mq
+// (canonical words) for crt_kernel, like hensel_decrypt_kernel.
+template <int G, int K>
+__global__ __launch_bounds__(kWGThreads, 2) void hensel_decrypt_seq_kernel(HenselArgs A) {
+  using HG = Geo<G, K>;
+  constexpr int IPW = kWave / G, L2 = G * K, LQ = 2 * L2, W64 = HG::W64;
+  raise_wave_priority();
+  __shared__ uint32_t bl_[kWavesPerWG][IPW][L2];
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  auto& bl = bl_[wv];
+  const int grp = lane / G, x = lane % G;
+  uint32_t sel0 = x == 0 ? 1u : 0u;
+  asm("" : "+v"(sel0));
+  const size_t wave_id = (size_t)blockIdx.x * kWavesPerWG + wv;
+  const int side = __builtin_amdgcn_readfirstlane((int)(wave_id & 1));
+  const size_t first_elem = (wave_id >> 1) * IPW;
+  size_t elem = first_elem + grp;
+  if (elem >= A.count) elem = A.count - 1;
+#define HCTX(field) (side ? A.ctx[1].field : A.ctx[0].field)
+  uint32_t n[K], a[K], b[K], ma[K], mb[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) n[j] = HCTX(nhat)[x * K + j];
+  const int w = A.window, tsize = 1 << w;
+  uint32_t* tbl = A.table + (wave_id * IPW + grp) * (size_t)tsize * LQ + x * K;   // entry e: a part at e*LQ, b part at e*LQ + L2
+  const uint64_t* ep = A.exp + (size_t)side * A.exp_stride;
+  const int nwin = (A.exp_bits + w - 1) / w;
+  auto digit = [&](int i) -> int {
+    int bit = i * w;
+    int word = bit >> 6, sh = bit & 63;
+    uint64_t v = (word < A.exp_words) ? ep[word] >> sh : 0;
+    if (sh + w > 64 && word + 1 < A.exp_words) v |= ep[word + 1] << (64 - sh);
+    return (int)(v & (uint64_t)(tsize - 1));
+  };
+  const bool gather = A.ct_gather != 0;
+
+  // ---- c*R as a pair from the pair row of the n^2 domain (hensel_decrypt_kernel: the ct_pair entry) ----
+  {
+    const uint32_t* row = A.ct_pair + elem * A.ct_pair_stride;
+    uint32_t acc_a[K], acc_b[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc_a[j] = acc_b[j] = 0;
+#pragma unroll 1
+    for (int i = 0; i < A.pchunks; ++i) {
+      const int first = i * A.pchunk_limbs;
+      uint32_t zb[K], cb[K], tb[K];
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const int li = x * K + j;
+        const bool in = li < A.pchunk_limbs && first + li < A.pair_l2;
+        a[j] = in ? row[first + li] : 0u;
+        zb[j] = in ? row[A.pair_l2 + first + li] : 0u;
+        b[j] = 0;
+        cb[j] = HCTX(pcb)[(size_t)i * L2 + x * K + j];
+        ma[j] = HCTX(pconv)[(size_t)i * LQ + x * K + j];
+        mb[j] = HCTX(pconv)[(size_t)i * LQ + L2 + x * K + j];
+      }
+      montmul_reg<HG, false, true>(tb, zb, cb, n, 0);
+      seq_pairmul<G, K, false, true>(a, b, ma, mb, n, 0, sel0);
+#pragma unroll
+      for (int j = 0; j < K; ++j) b[j] += tb[j];
+      add_normalise<HG>(acc_a, a);
+      add_normalise<HG>(acc_b, b);
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      a[j] = ma[j] = acc_a[j];
+      b[j] = mb[j] = acc_b[j];
+    }
+  }
+  // ---- window table: entry 0 = one, entry 1 = base, entry e = entry e-1 times base ----
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    tbl[(size_t)LQ + j] = a[j];
+    tbl[(size_t)LQ + L2 + j] = b[j];
+    tbl[j] = HCTX(one)[x * K + j];
+    tbl[L2 + j] = HCTX(one)[L2 + x * K + j];
+  }
+#pragma unroll 1
+  for (int e = 2; e < tsize; ++e) {
+    seq_pairmul<G, K, false, true>(a, b, ma, mb, n, 0, sel0);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      tbl[(size_t)e * LQ + j] = a[j];
+      tbl[(size_t)e * LQ + L2 + j] = b[j];
+    }
+  }
+  // ---- main loop: w squarings, one multiplication by a table entry (always, also entry 0 = one) ----
+  int win = nwin - 2;
+  if (nwin > 0) {
+    const int d0 = digit(nwin - 1);
+    load_table_entry<K>(a, tbl, d0, tsize, LQ, gather);
+    load_table_entry<K>(b, tbl + L2, d0, tsize, LQ, gather);
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      a[j] = HCTX(one)[x * K + j];
+      b[j] = HCTX(one)[L2 + x * K + j];
+    }
+  }
+#pragma unroll 1
+  for (; nwin > 0 && win >= 0; --win) {
+    const int idx = digit(win);
+    load_table_entry<K>(ma, tbl, idx, tsize, LQ, gather);        // the entry travels while the squarings run
+    load_table_entry<K>(mb, tbl + L2, idx, tsize, LQ, gather);
+#pragma unroll 1
+    for (int i = 0; i < w; ++i) seq_pairmul<G, K, true, true>(a, b, a, b, n, 0, sel0);
+    seq_pairmul<G, K, false, true>(a, b, ma, mb, n, 0, sel0);
+  }
+  // ---- exit under the TRUE prime: (a, k*b mod p) times (hp, 0);  mp = ([a' >= p] - b') mod p ----
+  uint32_t np[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    np[j] = HCTX(n)[x * K + j];
+    ma[j] = HCTX(kr)[x * K + j];
+  }
+  const uint32_t n0 = HCTX(n0inv);
+  {
+    uint32_t kb[K];
+    montmul_reg<HG, false, false>(kb, b, ma, np, n0);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      b[j] = kb[j];
+      ma[j] = HCTX(h)[x * K + j];
+      mb[j] = 0;
+    }
+  }
+  seq_pairmul<G, K, false, false>(a, b, ma, mb, np, n0, sel0);
+  full_normalise<HG>(a, x);
+  uint32_t d[K];
+  const uint32_t below_a = sub_limbs<HG>(d, a, np, x, lane);
+  const uint32_t jflag = below_a ^ 1u;
+  full_normalise<HG>(b, x);
+  const uint32_t below = sub_limbs<HG>(d, b, np, x, lane);
+  if (!below) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) b[j] = d[j];
+  }
+  (void)sub_limbs<HG>(d, np, b, x, lane);
+  if (x == 0) d[0] += jflag;
+  full_normalise<HG>(d, x);
+  const uint32_t small = sub_limbs<HG>(b, d, np, x, lane);
+  if (small) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) b[j] = d[j];
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int j = 0; j < K; ++j) bl[grp][x * K + j] = b[j];
+  wave_lds_sync();
+  const int ow = A.out_words;
+  for (int t = lane; t < IPW * ow; t += kWave) {
+    const int gg = t / ow, ww = t % ow;
+    const size_t oe = first_elem + gg;
+    if (oe < A.count) A.out[(2 * oe + side) * A.out_stride + ww] = ww < W64 ? word_from_limbs(bl[gg], L2, ww) : 0;
+  }
+#undef HCTX
+}
+
+}  // namespace pgpu
+
+#endif  // PAILLIERCRYPTOLIB_AMD_CSRC_HENSEL_SEQ_HPP_

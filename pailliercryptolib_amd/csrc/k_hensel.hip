@@ -1,11 +1,11 @@
 // pailliercryptolib_amd -- instantiations of the split-form CRT-decrypt exponentiation (hensel.hpp), split over
 // PGPU_PART = 0..13 so that they compile in parallel (3, 4, 10: the fixed-base DJN encrypt; 5, 6, 8, 9: the generic modexp; 7:
 // the two-wavefronts-per-SIMD build of the (2,19) decrypt form; 11-13: element-wise operations on pair rows).
-#include "hensel_ab.hpp"
+#include "hensel_seq.hpp"
 #include "launch.hpp"
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..15"
+#error "compile with -DPGPU_PART=0..17"
 #endif
 
 namespace pgpu {
@@ -71,6 +71,22 @@ bool PGPU_FB_NAME(launch_hensel_fb_encrypt)(int H, int K, const HenselFbArgs& a,
 bool PGPU_PO_NAME(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s) {
   if (H == PGPU_PO_H && K == PGPU_PO_K) {
     hipLaunchKernelGGL((pair_ops_kernel<PGPU_PO_H, PGPU_PO_K>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  return false;
+}
+#elif PGPU_PART == 16
+bool launch_hensel_seq_part16(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
+  if (G == 4 && K == 14) {
+    hipLaunchKernelGGL((hensel_decrypt_seq_kernel<4, 14>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  return false;
+}
+#elif PGPU_PART == 17
+bool launch_hensel_seq_part17(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
+  if (G == 2 && K == 19) {
+    hipLaunchKernelGGL((hensel_decrypt_seq_kernel<2, 19>), dim3(blocks), dim3(kWGThreads), 0, s, a);
     return true;
   }
   return false;

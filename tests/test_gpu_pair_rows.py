@@ -254,3 +254,38 @@ def test_ab_wavefront_decrypt_kernel_is_bit_identical(engine):
             L.pgpu_debug_set_ab_decrypt(0)
     finally:
         R.close()
+
+
+@pytest.mark.parametrize("bits,count", [(3072, 300), (2048, 515)])
+def test_sequential_halves_decrypt_kernel_is_bit_identical(engine, bits, count):
+    """csrc/hensel_seq.hpp: both halves of a residue in the same lanes, one after the other (the form large launches take
+    by default; forced here at test sizes).  Same plaintexts as the paired kernel and the oracle, ragged batch, with and
+    without the masked table gather."""
+    from oracle import paillier_oracle as orc
+    from pailliercryptolib_amd import _capi
+    p, q, hs = key_case(bits, True)
+    n = p * q
+    nw = bits // 64
+    rng = random.Random(bits + 5)
+    m = ([0, 1, n - 1] + [rng.randrange(n) for _ in range(count)])[:count]
+    r = [rng.getrandbits(bits // 2) for _ in range(count)]
+    L = _capi.lib()
+    pk, sk = engine.PublicKey(n, bits, hs=hs), engine.PrivateKey(p, q)
+    R = Res()
+    try:
+        c = R.op(L.pgpu_batch_encrypt, pk._h, R.up(m, nw), R.up(r, nw // 2), bits // 2)
+        assert L.pgpu_batch_row_limbs(c) > 0
+        L.pgpu_debug_set_seq_decrypt(0)
+        assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, c)) == m       # the paired kernel
+        L.pgpu_debug_set_seq_decrypt(2)
+        try:
+            assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, c)) == m
+            s2 = R.op(L.pgpu_batch_ct_add, pk._h, c, c)                     # a ciphertext that is not a fresh encryption
+            assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, s2)) == [2 * v % n for v in m]
+            _capi.check(L.pgpu_set_table_gather_policy(1))
+            assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, c)) == m
+        finally:
+            _capi.check(L.pgpu_set_table_gather_policy(0))
+            L.pgpu_debug_set_seq_decrypt(1)
+    finally:
+        R.close()
