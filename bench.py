@@ -323,12 +323,16 @@ def decrypt_kernel(sk, count, nw, key_bits):
     e = key_bits // 2
     if not split.value:
         return f"modexp_kernel<Geo<{lanes.value},{limbs.value}>>", algorithmic_mac32(key_bits, e)
-    l2 = lanes.value // 2 * limbs.value
+    seq = split.value == 2
+    l2 = (lanes.value if seq else lanes.value // 2) * limbs.value
     if _capi.lib().pgpu_get_secret_exponent_policy():          # sliding schedule of p-1: ~e/7 products, 32 odd powers
         nsq, nmul = e, e // 7 + 32
     else:                                                      # 5-bit fixed window
         nsq, nmul = e, (e + 4) // 5 + 30
     nmul += (2 * nw + e // 64 - 1) // (e // 64) + 2            # ciphertext chunks in, exit products
+    if seq:    # both halves in the same lanes: the a*a of a squaring uses its symmetry, L2 (L2 + lanes) / 2 products
+        sq = l2 * (l2 + lanes.value) // 2 + 3 * l2 * l2
+        return f"hensel_decrypt_seq_kernel<{lanes.value},{limbs.value}>", nsq * sq + nmul * 6 * l2 * l2
     return f"hensel_decrypt_kernel<{lanes.value // 2},{limbs.value}>", nsq * 4 * l2 * l2 + nmul * 6 * l2 * l2
 
 

@@ -271,8 +271,10 @@ int pgpu_timing_collect(int* kinds, double* ms, int max_entries);
 int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, int* limbs);
 /* Exponentiation kernel a CRT decrypt of `count` ciphertexts (per device) runs under this key: *split = 1:
  * hensel_decrypt_kernel<*lanes / 2, *limbs> -- residues modulo p^2 / q^2 as pairs of half-width numbers (DESIGN.md
- * section 3; compiled for 1024- to 4096-bit keys; PGPU_HENSEL=0 turns it off); *split = 0: the full-width
- * modexp_kernel<Geo<*lanes, *limbs>>.  Host-side query. */
+ * section 3; compiled for 1024- to 4096-bit keys; PGPU_HENSEL=0 turns it off); *split = 2: for ciphertexts of a
+ * resident batch (pair rows), hensel_decrypt_seq_kernel<*lanes, *limbs> -- both halves of a pair in the same *lanes
+ * lanes, launches that still put a wavefront on every SIMD that way (PGPU_SEQ_DECRYPT=0 turns it off); *split = 0:
+ * the full-width modexp_kernel<Geo<*lanes, *limbs>>.  Host-side query. */
 int pgpu_decrypt_kernel_form(const pgpu_privkey* key, size_t count, int* split, int* lanes, int* limbs);
 /* The same for an encrypt of `count` plaintext rows of m_words words: *split = 1: hensel_fb_encrypt_kernel<*lanes / 2,
  * *limbs> (DJN keys with a fixed-base window, 1024- to 3072-bit keys, plaintext rows no wider than n, batches that

@@ -1452,6 +1452,15 @@ std::atomic<int> g_ab_policy{[] {
   return e ? std::max(0, std::min(3, std::atoi(e))) : 0;
 }()};
 int ab_policy() { return g_ab_policy.load(); }
+
+// the sequential-halves form (csrc/hensel_seq.hpp) for a decrypt of `count` resident ciphertexts in form (H, K)?
+bool seq_form_pays(int H, int K, size_t count) {
+  if (!pgpu::hensel_seq_has(H, K)) return false;
+  const size_t ipw = 64 / (size_t)H;
+  const size_t waves = 2 * ((count + ipw - 1) / ipw);
+  const int pol = g_seq_policy.load();
+  return pol == 2 || (pol == 1 && waves >= kSimds);
+}
 int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m, size_t count,
                hipStream_t s, bool in_mont, const uint32_t* d_pair = nullptr, int in_pair_l2 = 0, bool other_lane_busy = false) {
   // d_pair: the ciphertexts are pair rows of 2*in_pair_l2 limbs (d_c unused); needs a split form of the key
@@ -1528,8 +1537,7 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
                     (ab_policy() == 1 || ab_policy() == 3 || (ab_policy() == 2 && other_lane_busy));   // 3: always, four pairs per workgroup
     const size_t seq_ipw = 64 / (size_t)hset->H;
     const size_t seq_waves = 2 * ((count + seq_ipw - 1) / seq_ipw);
-    const bool seq = !ab && d_pair && !sliding && pgpu::hensel_seq_has(hset->H, hset->K) &&
-                     (g_seq_policy.load() == 2 || (g_seq_policy.load() == 1 && seq_waves >= kSimds));
+    const bool seq = !ab && d_pair && !sliding && seq_form_pays(hset->H, hset->K, count);
     if (seq) {
       const unsigned sblocks = (unsigned)((seq_waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
       RC_TRY(w.table.ensure((size_t)sblocks * pgpu::kWavesPerWG * seq_ipw * entries * 2 * L2 * sizeof(uint32_t), s));
@@ -1892,8 +1900,13 @@ int pgpu_decrypt_kernel_form(const pgpu_privkey* key, size_t count, int* split, 
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_decrypt_kernel_form: bad argument");
   RC_TRY(check_gen(key->gen, "key"));
   if (const pgpu_privkey::HenselSet* f = pick_hensel(key, count)) {
-    *split = 1;
-    *lanes = 2 * f->H;
+    if (pair_rows_enabled() && secret_policy() != PGPU_EXP_SLIDING && ab_policy() == 0 && seq_form_pays(f->H, f->K, count)) {
+      *split = 2;
+      *lanes = f->H;
+    } else {
+      *split = 1;
+      *lanes = 2 * f->H;
+    }
     *limbs = f->K;
     return PGPU_OK;
   }

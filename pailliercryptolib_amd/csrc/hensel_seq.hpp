@@ -1,5 +1,5 @@
 // pailliercryptolib_amd -- CRT-decrypt exponentiation in split form with BOTH halves of a residue in the same lanes
-// (round 3): the form for launches that put two or more wavefronts on every SIMD.
+// (round 3): the form for launches that still put a wavefront on every SIMD with half the lanes per residue.
 //
 // hensel_decrypt_kernel (hensel.hpp) gives the a half and the b half of a pair x == a - P*b lanes of their own and runs
 // them through one instruction stream; half A then sits through the K^2 products of half B's 2*a*b although its own
