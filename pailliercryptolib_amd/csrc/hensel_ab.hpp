@@ -69,7 +69,7 @@ __device__ __forceinline__ void mont_reduce_rows_q(uint64_t (&LOWC)[GEO::K], uin
         __builtin_amdgcn_sched_barrier(kNoValuCross);
       }
     }
-    uint32_t q = and_bcast_lane0<GEO::G>(UNITQ ? (uint32_t)LOWC[r] : (uint32_t)LOWC[r] * n0inv, maskv);
+    uint32_t q = and_bcast_lane0<GEO::G>(quot_digit<UNITQ>(LOWC[r], n0inv), maskv);
     if constexpr (QMODE == 1) qio[r] = q;
     __builtin_amdgcn_sched_barrier(kNoValuCross);
     if (r > 0) {

@@ -136,6 +136,28 @@ __device__ __forceinline__ uint32_t and_bcast_lane0(uint32_t v, uint32_t m) {
   }
 }
 
+// The quotient digit of a reduction row (before the 29-bit mask): the low limb itself under a unit-quotient modulus,
+// else low limb * n0'.  PGPU_QDIGIT_MAD=1 takes the product as the low half of a v_mad_u64_u32 instead of v_mul_lo_u32
+// (the empty asm keeps the 64-bit product alive): measured equal within 1 % (profiles/r03_ubench_pairmul.txt) -- what a
+// multiplied digit costs is the multiplication AND the two wait states between it and the DPP move that reads it, in
+// a pair product 2 x (1 + nop) per row: +9 %, which is what a 36-limb loop modulus (the prime itself instead of
+// P = p*k, 38 limbs) would save.  Unit digits stay.
+#ifndef PGPU_QDIGIT_MAD
+#define PGPU_QDIGIT_MAD 0
+#endif
+template <bool UNITQ>
+__device__ __forceinline__ uint32_t quot_digit(uint64_t col, uint32_t n0inv) {
+  if constexpr (UNITQ) {
+    return (uint32_t)col;
+  } else if constexpr (PGPU_QDIGIT_MAD != 0) {
+    uint64_t t = (uint64_t)(uint32_t)col * n0inv;
+    asm("" : "+v"(t));
+    return (uint32_t)t;
+  } else {
+    return (uint32_t)col * n0inv;
+  }
+}
+
 // One K-row block of the word-serial Montgomery product.
 //   LOWC: the K columns this lane shares with nobody below it (get reduced / passed down)
 //   UPC : the next K columns (become LOWC of the next block; enter as zero)
@@ -190,7 +212,7 @@ __device__ __forceinline__ void mont_reduce_rows(uint64_t (&LOWC)[GEO::K], uint6
     if constexpr (PAIR) {
       static_assert(GEO::G <= 8, "a pair is two G-lane halves of a 2G-lane group inside a DPP row");
       // lane G of the group takes the digit from lane 0, G lanes below it (the other lanes multiply theirs by 0)
-      const uint32_t qa = dpp_from_below<GEO::G>(UNITQ ? (uint32_t)LOWC[r] : (uint32_t)LOWC[r] * n0inv) & maskv;
+      const uint32_t qa = dpp_from_below<GEO::G>(quot_digit<UNITQ>(LOWC[r], n0inv)) & maskv;
       if constexpr (kFA > 0) {
         __builtin_amdgcn_sched_barrier(kNoValuCross);
         if (r > 0) {
@@ -211,7 +233,7 @@ __device__ __forceinline__ void mont_reduce_rows(uint64_t (&LOWC)[GEO::K], uint6
         __builtin_amdgcn_sched_barrier(kNoValuCross);
       }
     }
-    uint32_t q = and_bcast_lane0<GEO::G>(UNITQ ? (uint32_t)LOWC[r] : (uint32_t)LOWC[r] * n0inv, maskv);
+    uint32_t q = and_bcast_lane0<GEO::G>(quot_digit<UNITQ>(LOWC[r], n0inv), maskv);
     // fillers between the broadcast and its first use: the last two MACs of the previous row, and
     // the hand-over of column r-1, final since the previous row: its 29-bit limb belongs to lane x-1,
     // whose window overlaps it at its column K+r-1 -- so every lane adds the limb it received from
