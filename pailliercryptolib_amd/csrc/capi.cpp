@@ -1542,7 +1542,11 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
       const unsigned sblocks = (unsigned)((seq_waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
       RC_TRY(w.table.ensure((size_t)sblocks * pgpu::kWavesPerWG * seq_ipw * entries * 2 * L2 * sizeof(uint32_t), s));
       h.table = (uint32_t*)w.table.p;
-      if (!pgpu::launch_hensel_seq(hset->H, hset->K, h, sblocks, s))
+      static const unsigned lds_pad = [] {
+        const char* e = getenv("PGPU_SEQ_LDS_PAD");
+        return e ? (unsigned)atoi(e) : 0u;
+      }();
+      if (!pgpu::launch_hensel_seq(hset->H, hset->K, h, sblocks, s, lds_pad))
         return fail(PGPU_ERR_UNSUPPORTED, "sequential-halves decrypt kernel not compiled");
     } else if (ab) {
       // one A/B pair per 32 ciphertexts and side.  Workgroups of two pairs (one wavefront per SIMD) when the launch has

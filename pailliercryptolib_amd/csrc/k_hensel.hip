@@ -76,17 +76,27 @@ bool PGPU_PO_NAME(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream
   return false;
 }
 #elif PGPU_PART == 16
-bool launch_hensel_seq_part16(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
+bool launch_hensel_seq_part16(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad) {
   if (G == 4 && K == 14) {
-    hipLaunchKernelGGL((hensel_decrypt_seq_kernel<4, 14>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    if (lds_pad) {
+      static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_seq_kernel<4, 14>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (once != hipSuccess) return false;
+    }
+    hipLaunchKernelGGL((hensel_decrypt_seq_kernel<4, 14>), dim3(blocks), dim3(kWGThreads), lds_pad, s, a);
     return true;
   }
   return false;
 }
 #elif PGPU_PART == 17
-bool launch_hensel_seq_part17(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
+bool launch_hensel_seq_part17(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad) {
   if (G == 2 && K == 19) {
-    hipLaunchKernelGGL((hensel_decrypt_seq_kernel<2, 19>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    if (lds_pad) {
+      static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_seq_kernel<2, 19>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (once != hipSuccess) return false;
+    }
+    hipLaunchKernelGGL((hensel_decrypt_seq_kernel<2, 19>), dim3(blocks), dim3(kWGThreads), lds_pad, s, a);
     return true;
   }
   return false;

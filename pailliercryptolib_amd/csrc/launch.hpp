@@ -107,10 +107,12 @@ inline bool launch_hensel_ab(int K, int pairs_per_wg, const HenselArgs& a, unsig
 // CRT decrypt with both halves of a residue in the same lanes (hensel_seq.hpp; k_hensel.hip parts 16, 17): pair-row
 // ciphertexts, fixed-window scan, launches of two or more wavefronts per SIMD; (4,14): 3072-bit keys, (2,19): 2048-bit
 inline bool hensel_seq_has(int G, int K) { return (G == 4 && K == 14) || (G == 2 && K == 19); }
-bool launch_hensel_seq_part16(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s);
-bool launch_hensel_seq_part17(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s);
-inline bool launch_hensel_seq(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
-  return launch_hensel_seq_part16(G, K, a, blocks, s) || launch_hensel_seq_part17(G, K, a, blocks, s);
+// lds_pad: bytes of LDS the workgroup claims beyond what it uses (0: none) -- more than half a CU's LDS keeps a second
+// workgroup off the CU, so two half-chip launches on different streams spread over all CUs instead of stacking
+bool launch_hensel_seq_part16(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
+bool launch_hensel_seq_part17(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
+inline bool launch_hensel_seq(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad = 0) {
+  return launch_hensel_seq_part16(G, K, a, blocks, s, lds_pad) || launch_hensel_seq_part17(G, K, a, blocks, s, lds_pad);
 }
 
 bool launch_modmul(int G, int K, const ModmulArgs& a, unsigned blocks, hipStream_t s);
