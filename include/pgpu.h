@@ -282,7 +282,9 @@ int pgpu_decrypt_kernel_form(const pgpu_privkey* key, size_t count, int* split, 
  * fb_encrypt_kernel / modexp_kernel <Geo<*lanes, *limbs>>. */
 int pgpu_encrypt_kernel_form(const pgpu_pubkey* key, int m_words, size_t count, int* split, int* lanes, int* limbs);
 /* The same for the exponentiations modulo n^2 with per-element bases (CT x PT of a resident batch, the non-DJN
- * obfuscator r^n): *split = 1: hensel_modexp_kernel<*lanes / 2, *limbs>; *split = 0: modexp_kernel<Geo<*lanes, *limbs>>. */
+ * obfuscator r^n): *split = 1: hensel_modexp_kernel<*lanes / 2, *limbs>; *split = 2: the same for r^n, and for CT x PT
+ * of a resident batch (pair rows in and out, per-element exponents) hensel_modexp_seq_kernel<*lanes, *limbs> (both halves
+ * of a pair in the same *lanes lanes; PGPU_SEQ_DECRYPT=0 turns it off); *split = 0: modexp_kernel<Geo<*lanes, *limbs>>. */
 int pgpu_modexp_n2_kernel_form(const pgpu_pubkey* key, size_t count, int* split, int* lanes, int* limbs);
 
 #ifdef __cplusplus

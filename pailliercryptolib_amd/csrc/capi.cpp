@@ -1203,6 +1203,7 @@ const pgpu_pubkey::PubForm* split_modexp_form(const pgpu_pubkey* key, size_t cou
   const size_t ipw = 64 / (2 * (size_t)last->H);
   return (count + ipw - 1) / ipw > max_waves ? nullptr : last;
 }
+bool modexp_seq_form_pays(int H, int K, size_t count);
 int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::PubForm* form, const uint64_t* d_base, size_t base_stride,
                     int base_words, bool base_mont, const uint64_t* d_exp, size_t exp_stride, int exp_words,
                     int exp_bits, const SchedRef* sched, int final_mul, const uint64_t* d_m, size_t m_stride,
@@ -1242,7 +1243,10 @@ int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::Pu
   a.out = d_out;
   a.out_stride = (size_t)2 * key->n_words;
   a.count = count;
-  const size_t ipw = 64 / (2 * (size_t)H);
+  // both halves of a residue in the same lanes (hensel_seq.hpp) when the launch still puts a wavefront on every SIMD
+  // that way: resident rows in and out, per-element exponents
+  const bool seq = modexp_seq_form_pays(H, K, count) && base_pair && out_pair && !a.sched && final_mul == pgpu::FM_UNIT;
+  const size_t ipw = seq ? 64 / (size_t)H : 64 / (2 * (size_t)H);
   const size_t waves = (count + ipw - 1) / ipw;
   const unsigned blocks = (unsigned)((waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
   rt::StreamWork& w = d.work_for(s);
@@ -1250,7 +1254,10 @@ int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::Pu
   RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * ipw * entries * 2 * H * K * sizeof(uint32_t), s));
   a.table = (uint32_t*)w.table.p;
   TimerScope t(d, s, PGPU_KERNEL_MODEXP);
-  if (!pgpu::launch_hensel_modexp(H, K, a, blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "split-form modexp kernel not compiled");
+  if (seq) {
+    if (!pgpu::launch_hensel_modexp_seq(H, K, a, blocks, s))
+      return fail(PGPU_ERR_UNSUPPORTED, "sequential-halves modexp kernel not compiled");
+  } else if (!pgpu::launch_hensel_modexp(H, K, a, blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "split-form modexp kernel not compiled");
   HIP_TRY(hipGetLastError());
   t.stop();
   return PGPU_OK;
@@ -1453,6 +1460,13 @@ std::atomic<int> g_ab_policy{[] {
 }()};
 int ab_policy() { return g_ab_policy.load(); }
 
+bool modexp_seq_form_pays(int H, int K, size_t count) {
+  if (!pgpu::hensel_modexp_seq_has(H, K)) return false;
+  const size_t ipw = 64 / (size_t)H;
+  const size_t waves = (count + ipw - 1) / ipw;
+  const int pol = g_seq_policy.load();
+  return pol == 2 || (pol == 1 && waves >= kSimds);
+}
 // the sequential-halves form (csrc/hensel_seq.hpp) for a decrypt of `count` resident ciphertexts in form (H, K)?
 bool seq_form_pays(int H, int K, size_t count) {
   if (!pgpu::hensel_seq_has(H, K)) return false;
@@ -1887,8 +1901,13 @@ int pgpu_modexp_n2_kernel_form(const pgpu_pubkey* key, size_t count, int* split,
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_modexp_n2_kernel_form: bad argument");
   RC_TRY(check_gen(key->gen, "key"));
   if (const pgpu_pubkey::PubForm* mf = split_modexp_form(key, count)) {
-    *split = 1;
-    *lanes = 2 * mf->H;
+    if (pair_rows_enabled() && modexp_seq_form_pays(mf->H, mf->K, count)) {   // (resident rows, per-element exponents)
+      *split = 2;
+      *lanes = mf->H;
+    } else {
+      *split = 1;
+      *lanes = 2 * mf->H;
+    }
     *limbs = mf->K;
     return PGPU_OK;
   }

@@ -25,10 +25,12 @@
 namespace pgpu {
 
 // t = a*m (rows: the limbs of m, lane-distributed like a), digits of block S recorded in qd[S]
-template <int G, int K, bool SQR, bool UNITQ, int S>
+// (QLDS: the digits go through qs[S * kAbPad + .] in LDS instead of the registers qd -- forms whose G*K digits do not
+// fit beside 12 K other registers; the wavefront reads back what it wrote itself, LDS keeps that in order)
+template <int G, int K, bool SQR, bool UNITQ, int S, bool QLDS = false>
 __device__ __forceinline__ void seq_a_blocks(uint64_t (&c0)[K], uint64_t (&c1)[K], const uint32_t (&a)[K],
                                              const uint32_t (&a2)[K], const uint32_t (&n)[K], uint32_t n0inv,
-                                             const uint32_t (&m)[K], uint32_t (&qd)[G][K]) {
+                                             const uint32_t (&m)[K], uint32_t (&qd)[QLDS ? 1 : G][K], uint32_t* qs = nullptr) {
   using HG = Geo<G, K>;
   if constexpr (S < G) {
     uint32_t b[K];
@@ -49,16 +51,23 @@ __device__ __forceinline__ void seq_a_blocks(uint64_t (&c0)[K], uint64_t (&c1)[K
         else c1[r + j - K] += p;
       }
     }
-    mont_reduce_rows_q<HG, UNITQ, 1>(c0, c1, n, n0inv, qd[S], 0u);
-    seq_a_blocks<G, K, SQR, UNITQ, S + 1>(c1, c0, a, a2, n, n0inv, m, qd);
+    if constexpr (QLDS) {
+      uint32_t qrec[K];
+      mont_reduce_rows_q<HG, UNITQ, 1>(c0, c1, n, n0inv, qrec, 0u);
+      ab_store20<K>(qs + S * kAbPad, qrec);   // (every lane of the group holds the same digits)
+    } else {
+      mont_reduce_rows_q<HG, UNITQ, 1>(c0, c1, n, n0inv, qd[S], 0u);
+    }
+    seq_a_blocks<G, K, SQR, UNITQ, S + 1, QLDS>(c1, c0, a, a2, n, n0inv, m, qd, qs);
   }
 }
 
 // w = a*d + b*c + q: mc (= b, or 2b in a squaring) times the rows of c, md (= d) times the rows of a, the digits of A
-template <int G, int K, bool SQR, bool UNITQ, int S>
+template <int G, int K, bool SQR, bool UNITQ, int S, bool QLDS = false>
 __device__ __forceinline__ void seq_b_blocks(uint64_t (&c0)[K], uint64_t (&c1)[K], const uint32_t (&mc)[K],
                                              const uint32_t (&md)[K], const uint32_t (&a)[K], const uint32_t (&c)[K],
-                                             const uint32_t (&n)[K], uint32_t n0inv, uint32_t (&qd)[G][K], uint32_t sel0) {
+                                             const uint32_t (&n)[K], uint32_t n0inv, uint32_t (&qd)[QLDS ? 1 : G][K],
+                                             uint32_t sel0, const uint32_t* qs = nullptr) {
   using HG = Geo<G, K>;
   if constexpr (S < G) {
     uint32_t row[K];
@@ -86,20 +95,27 @@ __device__ __forceinline__ void seq_b_blocks(uint64_t (&c0)[K], uint64_t (&c1)[K
         }
       }
     }
-    mont_reduce_rows_q<HG, UNITQ, 2>(c0, c1, n, n0inv, qd[S], sel0);
-    seq_b_blocks<G, K, SQR, UNITQ, S + 1>(c1, c0, mc, md, a, c, n, n0inv, qd, sel0);
+    if constexpr (QLDS) {
+      uint32_t qin[K];
+      ab_load20<K>(qin, qs + S * kAbPad);
+      mont_reduce_rows_q<HG, UNITQ, 2>(c0, c1, n, n0inv, qin, sel0);
+    } else {
+      mont_reduce_rows_q<HG, UNITQ, 2>(c0, c1, n, n0inv, qd[S], sel0);
+    }
+    seq_b_blocks<G, K, SQR, UNITQ, S + 1, QLDS>(c1, c0, mc, md, a, c, n, n0inv, qd, sel0, qs);
   }
 }
 
 // (a, b) = (a, b) (x) (c, d): the Montgomery product of two pairs held in the same lanes (lazy: inputs < 8P -> outputs
 // < 2P).  A squaring passes c = a, d = b.
-template <int G, int K, bool SQR, bool UNITQ>
+template <int G, int K, bool SQR, bool UNITQ, bool QLDS = false>
 __device__ __forceinline__ void seq_pairmul(uint32_t (&a)[K], uint32_t (&b)[K], const uint32_t (&c)[K],
-                                            const uint32_t (&d)[K], const uint32_t (&n)[K], uint32_t n0inv, uint32_t sel0) {
+                                            const uint32_t (&d)[K], const uint32_t (&n)[K], uint32_t n0inv, uint32_t sel0,
+                                            uint32_t* qs = nullptr) {
   static_assert(3 * K + 6 < 64, "a column receives 3K products (+ relaxed limbs): must stay below 2^64");
   static_assert(G % 2 == 0, "blocks alternate between the two accumulator sets and end in the first");
   using HG = Geo<G, K>;
-  uint32_t qd[G][K];
+  uint32_t qd[QLDS ? 1 : G][K];
   uint32_t t[K];
   {
     uint64_t c0[K], c1[K];
@@ -110,7 +126,7 @@ __device__ __forceinline__ void seq_pairmul(uint32_t (&a)[K], uint32_t (&b)[K], 
       c1[j] = 0;
       a2[j] = SQR ? a[j] << 1 : 0;
     }
-    seq_a_blocks<G, K, SQR, UNITQ, 0>(c0, c1, a, a2, n, n0inv, c, qd);
+    seq_a_blocks<G, K, SQR, UNITQ, 0, QLDS>(c0, c1, a, a2, n, n0inv, c, qd, qs);
     montmul_finish<HG>(t, c0);
   }
   {
@@ -123,7 +139,7 @@ __device__ __forceinline__ void seq_pairmul(uint32_t (&a)[K], uint32_t (&b)[K], 
       mc[j] = SQR ? b[j] << 1 : b[j];
       md[j] = SQR ? 0u : d[j];
     }
-    seq_b_blocks<G, K, SQR, UNITQ, 0>(c0, c1, mc, md, a, c, n, n0inv, qd, sel0);
+    seq_b_blocks<G, K, SQR, UNITQ, 0, QLDS>(c0, c1, mc, md, a, c, n, n0inv, qd, sel0, qs);
     montmul_finish<HG>(b, c0);
   }
 #pragma unroll
@@ -286,6 +302,89 @@ __global__ __launch_bounds__(kWGThreads, 2) void hensel_decrypt_seq_kernel(Hense
     if (oe < A.count) A.out[(2 * oe + side) * A.out_stride + ww] = ww < W64 ? word_from_limbs(bl[gg], L2, ww) : 0;
   }
 #undef HCTX
+}
+
+// base[i]^exp[i] modulo n^2 with both halves in the same lanes: CT x PT on resident batches (hensel_modexp_kernel's
+// pair-row entry and exit, per-element exponents, fixed window), large launches.  G*K = 72 digits per product do not
+// fit in registers beside the operands: they go through LDS (320 B per exponentiation).
+template <int G, int K>
+__global__ __launch_bounds__(kWGThreads, 2) void hensel_modexp_seq_kernel(HenselModexpArgs A) {
+  constexpr int IPW = kWave / G, L2 = G * K, LQ = 2 * L2;
+  raise_wave_priority();
+  __shared__ __attribute__((aligned(16))) uint32_t qs_[kWavesPerWG][IPW][G * kAbPad];
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  const int grp = lane / G, x = lane % G;
+  uint32_t* qs = qs_[wv][grp];
+  uint32_t sel0 = x == 0 ? 1u : 0u;
+  asm("" : "+v"(sel0));
+  const size_t wave_id = (size_t)blockIdx.x * kWavesPerWG + wv;
+  const size_t first_inst = wave_id * IPW;
+  size_t inst = first_inst + grp;
+  if (inst >= A.count) inst = A.count - 1;
+  uint32_t n[K], a[K], b[K], ma[K], mb[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) n[j] = A.ctx.nhat[x * K + j];
+  const int w = A.window, tsize = 1 << w;
+  uint32_t* tbl = A.table + (wave_id * IPW + grp) * (size_t)tsize * LQ + x * K;   // entry e: a part at e*LQ, b part at e*LQ + L2
+  const uint64_t* ep = A.exp + inst * A.exp_stride;
+  const int nwin = (A.exp_bits + w - 1) / w;
+  auto digit = [&](int i) -> int {
+    int bit = i * w;
+    int word = bit >> 6, sh = bit & 63;
+    uint64_t v = (word < A.exp_words) ? ep[word] >> sh : 0;
+    if (sh + w > 64 && word + 1 < A.exp_words) v |= ep[word + 1] << (64 - sh);
+    return (int)(v & (uint64_t)(tsize - 1));
+  };
+  const bool gather = A.ct_gather != 0;
+  {
+    const uint32_t* row = A.base_pair + inst * A.base_pair_stride;
+    load_pair_row<K>(a, row, x);
+    load_pair_row<K>(b, row + L2, x);
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    ma[j] = a[j];
+    mb[j] = b[j];
+    tbl[(size_t)LQ + j] = a[j];
+    tbl[(size_t)LQ + L2 + j] = b[j];
+    tbl[j] = A.ctx.one[x * K + j];
+    tbl[L2 + j] = A.ctx.one[L2 + x * K + j];
+  }
+#pragma unroll 1
+  for (int e = 2; e < tsize; ++e) {
+    seq_pairmul<G, K, false, true, true>(a, b, ma, mb, n, 0, sel0, qs);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      tbl[(size_t)e * LQ + j] = a[j];
+      tbl[(size_t)e * LQ + L2 + j] = b[j];
+    }
+  }
+  int win = nwin - 2;
+  if (nwin > 0) {
+    const int d0 = digit(nwin - 1);
+    load_table_entry<K>(a, tbl, d0, tsize, LQ, gather);
+    load_table_entry<K>(b, tbl + L2, d0, tsize, LQ, gather);
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      a[j] = A.ctx.one[x * K + j];
+      b[j] = A.ctx.one[L2 + x * K + j];
+    }
+  }
+#pragma unroll 1
+  for (; nwin > 0 && win >= 0; --win) {
+    const int idx = digit(win);
+#pragma unroll 1
+    for (int i = 0; i < w; ++i) seq_pairmul<G, K, true, true, true>(a, b, a, b, n, 0, sel0, qs);
+    load_table_entry<K>(ma, tbl, idx, tsize, LQ, gather);   // (not ahead of the squarings: 2K registers the squarings need)
+    load_table_entry<K>(mb, tbl + L2, idx, tsize, LQ, gather);
+    seq_pairmul<G, K, false, true, true>(a, b, ma, mb, n, 0, sel0, qs);
+  }
+  if (first_inst + grp < A.count) {
+    uint32_t* out = A.out_pair + inst * (size_t)LQ;
+    store_pair_row<K>(out, a, x);
+    store_pair_row<K>(out + L2, b, x);
+  }
 }
 
 }  // namespace pgpu

@@ -5,7 +5,7 @@
 #include "launch.hpp"
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..17"
+#error "compile with -DPGPU_PART=0..18"
 #endif
 
 namespace pgpu {
@@ -97,6 +97,14 @@ bool launch_hensel_seq_part17(int G, int K, const HenselArgs& a, unsigned blocks
       if (once != hipSuccess) return false;
     }
     hipLaunchKernelGGL((hensel_decrypt_seq_kernel<2, 19>), dim3(blocks), dim3(kWGThreads), lds_pad, s, a);
+    return true;
+  }
+  return false;
+}
+#elif PGPU_PART == 18
+bool launch_hensel_modexp_seq_part18(int G, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
+  if (G == 4 && K == 18) {
+    hipLaunchKernelGGL((hensel_modexp_seq_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), 0, s, a);
     return true;
   }
   return false;

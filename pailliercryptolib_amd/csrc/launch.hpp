@@ -115,6 +115,13 @@ inline bool launch_hensel_seq(int G, int K, const HenselArgs& a, unsigned blocks
   return launch_hensel_seq_part16(G, K, a, blocks, s, lds_pad) || launch_hensel_seq_part17(G, K, a, blocks, s, lds_pad);
 }
 
+// per-element bases modulo n^2 in the same form (k_hensel.hip part 18): resident pair rows in and out, fixed window
+inline bool hensel_modexp_seq_has(int G, int K) { return G == 4 && K == 18; }
+bool launch_hensel_modexp_seq_part18(int G, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
+inline bool launch_hensel_modexp_seq(int G, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
+  return launch_hensel_modexp_seq_part18(G, K, a, blocks, s);
+}
+
 bool launch_modmul(int G, int K, const ModmulArgs& a, unsigned blocks, hipStream_t s);
 bool launch_crt(int G, int K, const CrtArgs& a, unsigned blocks, hipStream_t s);
 bool launch_fb_build(int G, int K, const FixedBaseBuildArgs& a, unsigned blocks, hipStream_t s);

@@ -289,3 +289,47 @@ def test_sequential_halves_decrypt_kernel_is_bit_identical(engine, bits, count):
             L.pgpu_debug_set_seq_decrypt(1)
     finally:
         R.close()
+
+
+@pytest.mark.parametrize("ebits,count", [(40, 530), (2048, 70)])
+def test_sequential_halves_ct_times_pt_is_bit_identical(engine, ebits, count):
+    """hensel_modexp_seq_kernel (csrc/hensel_seq.hpp): CT x PT of a resident batch with both halves of a residue in the
+    same lanes (the form launches of 16384+ elements take; forced here).  Same ciphertexts as pow() and as the paired
+    kernel, ragged batch, edge exponents, a one-row exponent batch, with and without the masked table gather."""
+    from pailliercryptolib_amd import _capi
+    bits = 2048
+    p, q, hs = key_case(bits, True)
+    n = p * q
+    nsq = n * n
+    nw = bits // 64
+    ew = (ebits + 63) // 64
+    rng = random.Random(ebits + count)
+    m = [rng.randrange(n) for _ in range(count)]
+    r = [rng.getrandbits(bits // 2) for _ in range(count)]
+    e = ([0, 1, 2, (1 << ebits) - 1] + [rng.getrandbits(ebits) for _ in range(count)])[:count]
+    L = _capi.lib()
+    pk, sk = engine.PublicKey(n, bits, hs=hs), engine.PrivateKey(p, q)
+    R = Res()
+    try:
+        c = R.op(L.pgpu_batch_encrypt, pk._h, R.up(m, nw), R.up(r, nw // 2), bits // 2)
+        assert L.pgpu_batch_row_limbs(c) > 0
+        oc = R.down(c)
+        want = [pow(a, b, nsq) for a, b in zip(oc, e)]
+        be = R.up(e, ew)
+        L.pgpu_debug_set_seq_decrypt(0)
+        assert R.down(R.op(L.pgpu_batch_ct_mul, pk._h, c, be, ebits)) == want       # the paired kernel
+        L.pgpu_debug_set_seq_decrypt(2)
+        try:
+            t = R.op(L.pgpu_batch_ct_mul, pk._h, c, be, ebits)
+            assert L.pgpu_batch_row_limbs(t) > 0
+            assert R.down(t) == want
+            assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, t)) == [a * b % n for a, b in zip(m, e)]
+            e1 = R.up([e[-1]], ew)
+            assert R.down(R.op(L.pgpu_batch_ct_mul, pk._h, c, e1, ebits)) == [pow(a, e[-1], nsq) for a in oc]
+            _capi.check(L.pgpu_set_table_gather_policy(1))
+            assert R.down(R.op(L.pgpu_batch_ct_mul, pk._h, c, be, ebits)) == want
+        finally:
+            _capi.check(L.pgpu_set_table_gather_policy(0))
+            L.pgpu_debug_set_seq_decrypt(1)
+    finally:
+        R.close()
