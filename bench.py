@@ -354,18 +354,28 @@ def modexp_n2_kernel(pk, count, per_element_exponents=False):
 
 def encrypt_kernel(pk, count, nw, key_bits, fbw):
     """(name, executed MAC32 per element, note) of the fixed-base DJN encrypt kernel: full-width products (2 s^2 + s,
-    s = 4096/32) or pair products of the split form (6 L2^2 limb products each, plus the way back to a full-width
-    residue: two products in Montgomery form)."""
+    s = 4096/32) or pair products of the split form (6 L2^2 limb products each issued; 5 L2^2 with both halves of a
+    residue in the same lanes), plus the exit: onto a pair row two half-width products (4 L2^2), back to full-width words
+    one more pair product and two full-width products."""
     from pailliercryptolib_amd import _capi
+    L = _capi.lib()
     split, lanes, limbs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    _capi.check(_capi.lib().pgpu_encrypt_kernel_form(pk._h, nw, count, ctypes.byref(split), ctypes.byref(lanes),
-                                                     ctypes.byref(limbs)))
+    _capi.check(L.pgpu_encrypt_kernel_form(pk._h, nw, count, ctypes.byref(split), ctypes.byref(lanes), ctypes.byref(limbs)))
     nprod = (key_bits // 2 + fbw - 1) // fbw - 1           # table products
     s = 2 * key_bits // 32
     if not split.value:
         return (f"fb_encrypt_kernel<Geo<{lanes.value},{limbs.value}>>", (2 * s * s + s) * (nprod + 2),
                 "fixed-base windowing w=%d: hs^r as %d table products, no squarings" % (fbw, nprod))
+    if split.value == 2:
+        l2 = lanes.value * limbs.value
+        return (f"hensel_fb_encrypt_seq_kernel<{lanes.value},{limbs.value}>", 5 * l2 * l2 * nprod + 4 * l2 * l2,
+                "fixed-base windowing w=%d in split form, both halves of a residue in the same lanes: hs^r as %d pair "
+                "products (no squarings), 1 + n*m as two half-width products, result stays a pair row" % (fbw, nprod))
     l2 = lanes.value // 2 * limbs.value
+    if os.environ.get("PGPU_PAIR_ROWS", "1") != "0":
+        return (f"hensel_fb_encrypt_kernel<{lanes.value // 2},{limbs.value}>", 6 * l2 * l2 * nprod + 4 * l2 * l2,
+                "fixed-base windowing w=%d in split form: hs^r as %d pair products (no squarings), 1 + n*m as two "
+                "half-width products, result stays a pair row" % (fbw, nprod))
     return (f"hensel_fb_encrypt_kernel<{lanes.value // 2},{limbs.value}>",
             6 * l2 * l2 * (nprod + 1) + 2 * l2 * l2 + 2 * (2 * s * s + s),
             "fixed-base windowing w=%d in split form: hs^r as %d pair products (no squarings), exit by 1 + n*m, two "
@@ -816,8 +826,14 @@ def run_config45(args, pa, L, B, N):
     row_limbs = L.pgpu_batch_row_limbs(st["s"])
     if row_limbs:
         l2 = row_limbs // 2
-        add_kernel = f"pair_ops_kernel<{8 if l2 == 112 else 4 if l2 == 72 else 2},{l2 // (8 if l2 == 112 else 4 if l2 == 72 else 2)}> (PO_MUL: CT+CT as one pair product on pair rows)"
-        exec_add = 6 * l2 * l2 * shard
+        split, lanes, limbs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _capi.check(L.pgpu_ct_add_kernel_form(pk._h, shard, ctypes.byref(split), ctypes.byref(lanes), ctypes.byref(limbs)))
+        if split.value == 2:   # both halves in the same lanes: a*c, a*d + b*c and two reductions, nothing idle: 5 L2^2
+            add_kernel = f"pair_mul_seq_kernel<{lanes.value},{limbs.value}> (CT+CT as one pair product on pair rows, both halves of a residue in the same lanes)"
+            exec_add = 5 * l2 * l2 * shard
+        else:                  # half A sits through half B's second product: 2 x 3 L2^2 issued
+            add_kernel = f"pair_ops_kernel<{lanes.value // 2},{limbs.value}> (PO_MUL: CT+CT as one pair product on pair rows)"
+            exec_add = 6 * l2 * l2 * shard
         row_bytes = 4 * row_limbs
     else:
         add_kernel = f"modmul_kernel<{geo_name(W, 2 * KEY_BITS, shard)}> (CT+CT on Montgomery-form words)"

@@ -278,14 +278,20 @@ int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, i
 int pgpu_decrypt_kernel_form(const pgpu_privkey* key, size_t count, int* split, int* lanes, int* limbs);
 /* The same for an encrypt of `count` plaintext rows of m_words words: *split = 1: hensel_fb_encrypt_kernel<*lanes / 2,
  * *limbs> (DJN keys with a fixed-base window, 1024- to 3072-bit keys, plaintext rows no wider than n, batches that
- * fill the chip); *split = 0:
- * fb_encrypt_kernel / modexp_kernel <Geo<*lanes, *limbs>>. */
+ * fill the chip); *split = 2: results that stay resident as pair rows, launches that still put a wavefront on every SIMD
+ * with half the lanes per element: hensel_fb_encrypt_seq_kernel<*lanes, *limbs> (PGPU_SEQ_DECRYPT=0 turns it off);
+ * *split = 0: fb_encrypt_kernel / modexp_kernel <Geo<*lanes, *limbs>>. */
 int pgpu_encrypt_kernel_form(const pgpu_pubkey* key, int m_words, size_t count, int* split, int* lanes, int* limbs);
 /* The same for the exponentiations modulo n^2 with per-element bases (CT x PT of a resident batch, the non-DJN
  * obfuscator r^n): *split = 1: hensel_modexp_kernel<*lanes / 2, *limbs>; *split = 2: the same for r^n, and for CT x PT
  * of a resident batch (pair rows in and out, per-element exponents) hensel_modexp_seq_kernel<*lanes, *limbs> (both halves
  * of a pair in the same *lanes lanes; PGPU_SEQ_DECRYPT=0 turns it off); *split = 0: modexp_kernel<Geo<*lanes, *limbs>>. */
 int pgpu_modexp_n2_kernel_form(const pgpu_pubkey* key, size_t count, int* split, int* lanes, int* limbs);
+/* The same for CT + CT of two resident batches of `count` elements (per device): *split = 1: pair_ops_kernel<*lanes / 2,
+ * *limbs> (one pair product on pair rows); *split = 2: pair_mul_seq_kernel<*lanes, *limbs> (both halves of a pair in the
+ * same *lanes lanes: launches that still put a wavefront on every SIMD that way); *split = 0: modmul_kernel<Geo<*lanes,
+ * *limbs>> on Montgomery-form words (keys without a pair form, PGPU_PAIR_ROWS=0). */
+int pgpu_ct_add_kernel_form(const pgpu_pubkey* key, size_t count, int* split, int* lanes, int* limbs);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,7 @@ SYMBOLS = [
     "pgpu_paillier_decrypt_crt_dev",
     "pgpu_dev_alloc", "pgpu_dev_free", "pgpu_copy_h2d", "pgpu_copy_d2h",
     "pgpu_set_fixed_base_window", "pgpu_set_timing", "pgpu_timing_collect",
-    "pgpu_kernel_geometry", "pgpu_decrypt_kernel_form", "pgpu_encrypt_kernel_form", "pgpu_modexp_n2_kernel_form",
+    "pgpu_kernel_geometry", "pgpu_decrypt_kernel_form", "pgpu_encrypt_kernel_form", "pgpu_modexp_n2_kernel_form", "pgpu_ct_add_kernel_form",
     "pgpu_init_all", "pgpu_pool_size", "pgpu_set_device", "pgpu_get_device", "pgpu_pool_transport",
     "pgpu_set_min_shard", "pgpu_shard_plan", "pgpu_synchronize", "pgpu_set_secret_exponent_policy", "pgpu_get_secret_exponent_policy",
     "pgpu_batch_create", "pgpu_batch_upload", "pgpu_batch_download", "pgpu_batch_destroy", "pgpu_batch_count",
@@ -102,6 +102,8 @@ def lib():
     L.pgpu_encrypt_kernel_form.restype = c_int
     L.pgpu_modexp_n2_kernel_form.argtypes = [c_void_p, c_size_t, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
     L.pgpu_modexp_n2_kernel_form.restype = c_int
+    L.pgpu_ct_add_kernel_form.argtypes = [c_void_p, c_size_t, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
+    L.pgpu_ct_add_kernel_form.restype = c_int
     L.pgpu_init_all.argtypes = [c_int]; L.pgpu_init_all.restype = c_int
     L.pgpu_pool_size.argtypes = []; L.pgpu_pool_size.restype = c_int
     L.pgpu_set_device.argtypes = [c_int]; L.pgpu_set_device.restype = c_int

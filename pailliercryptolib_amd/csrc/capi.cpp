@@ -1204,6 +1204,7 @@ const pgpu_pubkey::PubForm* split_modexp_form(const pgpu_pubkey* key, size_t cou
   return (count + ipw - 1) / ipw > max_waves ? nullptr : last;
 }
 bool modexp_seq_form_pays(int H, int K, size_t count);
+bool fb_encrypt_seq_pays(int H, int K, size_t count);
 int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::PubForm* form, const uint64_t* d_base, size_t base_stride,
                     int base_words, bool base_mont, const uint64_t* d_exp, size_t exp_stride, int exp_words,
                     int exp_bits, const SchedRef* sched, int final_mul, const uint64_t* d_m, size_t m_stride,
@@ -1343,9 +1344,15 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
       f.count = count;
       f.out_pair = d_pair;
       TimerScope t(d, s, PGPU_KERNEL_FB_ENCRYPT);
-      const int ipw = 64 / (2 * form->H);
+      // resident results of launches that still put a wavefront on every SIMD with half the lanes per element: both
+      // halves of a residue in the same lanes (hensel_seq.hpp)
+      const bool seq = d_pair && fb_encrypt_seq_pays(form->H, form->K, count);
+      const int ipw = seq ? 64 / form->H : 64 / (2 * form->H);
       const unsigned blocks = (unsigned)(((count + ipw - 1) / ipw + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
-      if (!pgpu::launch_hensel_fb_encrypt(form->H, form->K, f, blocks, s))
+      if (seq) {
+        if (!pgpu::launch_hensel_fb_encrypt_seq(form->H, form->K, f, blocks, s))
+          return fail(PGPU_ERR_UNSUPPORTED, "sequential-halves fixed-base kernel not compiled");
+      } else if (!pgpu::launch_hensel_fb_encrypt(form->H, form->K, f, blocks, s))
         return fail(PGPU_ERR_UNSUPPORTED, "split-form fixed-base kernel not compiled");
       HIP_TRY(hipGetLastError());
       t.stop();
@@ -1460,6 +1467,13 @@ std::atomic<int> g_ab_policy{[] {
 }()};
 int ab_policy() { return g_ab_policy.load(); }
 
+bool fb_encrypt_seq_pays(int H, int K, size_t count) {
+  if (!pgpu::hensel_fb_encrypt_seq_has(H, K)) return false;
+  const size_t ipw = 64 / (size_t)H;
+  const size_t waves = (count + ipw - 1) / ipw;
+  const int pol = g_seq_policy.load();
+  return pol == 2 || (pol == 1 && waves >= kSimds);
+}
 bool modexp_seq_form_pays(int H, int K, size_t count) {
   if (!pgpu::hensel_modexp_seq_has(H, K)) return false;
   const size_t ipw = 64 / (size_t)H;
@@ -1636,12 +1650,24 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
 }
 
 // ---------- pair rows: launches and conversions ----------
+bool pair_mul_seq_pays(int H, int K, size_t count) {
+  if (!pgpu::pair_mul_seq_has(H, K)) return false;
+  const size_t ipw = 64 / (size_t)H;
+  const size_t waves = (count + ipw - 1) / ipw;
+  const int pol = g_seq_policy.load();
+  return pol == 2 || (pol == 1 && waves >= kSimds);
+}
 int pair_op_launch(rt::Device& d, const pgpu_pubkey::PubForm* f, pgpu::PairOpsArgs& a, hipStream_t s, int kind) {
-  const size_t ipw = 64 / (2 * (size_t)f->H);
+  // CT + CT of launches that still put a wavefront on every SIMD with half the lanes per element: both halves of a
+  // residue in the same lanes (hensel_seq.hpp: pair_mul_seq_kernel)
+  const bool seq = a.op == pgpu::PO_MUL && pair_mul_seq_pays(f->H, f->K, a.count);
+  const size_t ipw = seq ? 64 / (size_t)f->H : 64 / (2 * (size_t)f->H);
   const size_t waves = (a.count + ipw - 1) / ipw;
   const unsigned blocks = (unsigned)((waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
   TimerScope t(d, s, kind);
-  if (!pgpu::launch_pair_ops(f->H, f->K, a, blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "pair-row kernel not compiled");
+  if (seq) {
+    if (!pgpu::launch_pair_mul_seq(f->H, f->K, a, blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "pair-row kernel not compiled");
+  } else if (!pgpu::launch_pair_ops(f->H, f->K, a, blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "pair-row kernel not compiled");
   HIP_TRY(hipGetLastError());
   t.stop();
   return PGPU_OK;
@@ -1885,6 +1911,14 @@ int pgpu_encrypt_kernel_form(const pgpu_pubkey* key, int m_words, size_t count, 
   RC_TRY(check_gen(key->gen, "key"));
   const pgpu_pubkey::PubForm* ef = key->djn && fixed_base_window() > 0 ? use_split_encrypt(key, m_words, count) : nullptr;
   if (ef) {
+    // resident results (pair rows) take the key's pair form, and from a launch size on both halves in the same lanes
+    const pgpu_pubkey::PubForm* pf = pair_form(key);
+    if (pf && m_words <= key->n_words && fb_encrypt_seq_pays(pf->H, pf->K, count)) {
+      *split = 2;
+      *lanes = pf->H;
+      *limbs = pf->K;
+      return PGPU_OK;
+    }
     *split = 1;
     *lanes = 2 * ef->H;
     *limbs = ef->K;
@@ -1913,6 +1947,23 @@ int pgpu_modexp_n2_kernel_form(const pgpu_pubkey* key, size_t count, int* split,
   }
   const GeoInfo lat = latency_geo(key->nsq->geo);
   const GeoInfo g = use_latency_geo(lat, key->nsq->geo, count) ? lat : launch_geo(key->nsq->geo, count);
+  *split = 0;
+  *lanes = g.G;
+  *limbs = g.K;
+  return PGPU_OK;
+}
+
+int pgpu_ct_add_kernel_form(const pgpu_pubkey* key, size_t count, int* split, int* lanes, int* limbs) {
+  if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_ct_add_kernel_form: bad argument");
+  RC_TRY(check_gen(key->gen, "key"));
+  if (const pgpu_pubkey::PubForm* f = pair_form(key)) {
+    const bool seq = pair_mul_seq_pays(f->H, f->K, count);
+    *split = seq ? 2 : 1;
+    *lanes = seq ? f->H : 2 * f->H;
+    *limbs = f->K;
+    return PGPU_OK;
+  }
+  const GeoInfo g = launch_geo(key->nsq->geo, count);
   *split = 0;
   *lanes = g.G;
   *limbs = g.K;

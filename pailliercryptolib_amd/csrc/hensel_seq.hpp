@@ -108,10 +108,11 @@ __device__ __forceinline__ void seq_b_blocks(uint64_t (&c0)[K], uint64_t (&c1)[K
 
 // (a, b) = (a, b) (x) (c, d): the Montgomery product of two pairs held in the same lanes (lazy: inputs < 8P -> outputs
 // < 2P).  A squaring passes c = a, d = b.
+// (QLDS, ts != null: the new a part waits in LDS -- kAbPad words of this LANE -- while the b part is computed: K registers)
 template <int G, int K, bool SQR, bool UNITQ, bool QLDS = false>
 __device__ __forceinline__ void seq_pairmul(uint32_t (&a)[K], uint32_t (&b)[K], const uint32_t (&c)[K],
                                             const uint32_t (&d)[K], const uint32_t (&n)[K], uint32_t n0inv, uint32_t sel0,
-                                            uint32_t* qs = nullptr) {
+                                            uint32_t* qs = nullptr, uint32_t* ts = nullptr) {
   static_assert(3 * K + 6 < 64, "a column receives 3K products (+ relaxed limbs): must stay below 2^64");
   static_assert(G % 2 == 0, "blocks alternate between the two accumulator sets and end in the first");
   using HG = Geo<G, K>;
@@ -128,6 +129,9 @@ __device__ __forceinline__ void seq_pairmul(uint32_t (&a)[K], uint32_t (&b)[K], 
     }
     seq_a_blocks<G, K, SQR, UNITQ, 0, QLDS>(c0, c1, a, a2, n, n0inv, c, qd, qs);
     montmul_finish<HG>(t, c0);
+    if constexpr (QLDS) {
+      if (ts) ab_store20<K>(ts, t);
+    }
   }
   {
     uint64_t c0[K], c1[K];
@@ -141,6 +145,12 @@ __device__ __forceinline__ void seq_pairmul(uint32_t (&a)[K], uint32_t (&b)[K], 
     }
     seq_b_blocks<G, K, SQR, UNITQ, 0, QLDS>(c0, c1, mc, md, a, c, n, n0inv, qd, sel0, qs);
     montmul_finish<HG>(b, c0);
+  }
+  if constexpr (QLDS) {
+    if (ts) {
+      ab_load20<K>(a, ts);
+      return;
+    }
   }
 #pragma unroll
   for (int j = 0; j < K; ++j) a[j] = t[j];
@@ -306,15 +316,18 @@ __global__ __launch_bounds__(kWGThreads, 2) void hensel_decrypt_seq_kernel(Hense
 
 // base[i]^exp[i] modulo n^2 with both halves in the same lanes: CT x PT on resident batches (hensel_modexp_kernel's
 // pair-row entry and exit, per-element exponents, fixed window), large launches.  G*K = 72 digits per product do not
-// fit in registers beside the operands: they go through LDS (320 B per exponentiation).
+// fit in registers beside the operands: they go through LDS (320 B per exponentiation), and the new a part of a
+// product waits there while its b part is computed (80 B per lane) -- no scratch in any loop.
 template <int G, int K>
 __global__ __launch_bounds__(kWGThreads, 2) void hensel_modexp_seq_kernel(HenselModexpArgs A) {
   constexpr int IPW = kWave / G, L2 = G * K, LQ = 2 * L2;
   raise_wave_priority();
   __shared__ __attribute__((aligned(16))) uint32_t qs_[kWavesPerWG][IPW][G * kAbPad];
+  __shared__ __attribute__((aligned(16))) uint32_t ts_[kWavesPerWG][kWave][kAbPad];
   const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
   const int grp = lane / G, x = lane % G;
   uint32_t* qs = qs_[wv][grp];
+  uint32_t* ts = ts_[wv][lane];
   uint32_t sel0 = x == 0 ? 1u : 0u;
   asm("" : "+v"(sel0));
   const size_t wave_id = (size_t)blockIdx.x * kWavesPerWG + wv;
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(kWGThreads, 2) void hensel_modexp_seq_kernel(Hensel
   }
 #pragma unroll 1
   for (int e = 2; e < tsize; ++e) {
-    seq_pairmul<G, K, false, true, true>(a, b, ma, mb, n, 0, sel0, qs);
+    seq_pairmul<G, K, false, true, true>(a, b, ma, mb, n, 0, sel0, qs, ts);
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       tbl[(size_t)e * LQ + j] = a[j];
@@ -374,11 +387,120 @@ __global__ __launch_bounds__(kWGThreads, 2) void hensel_modexp_seq_kernel(Hensel
 #pragma unroll 1
   for (; nwin > 0 && win >= 0; --win) {
     const int idx = digit(win);
-#pragma unroll 1
-    for (int i = 0; i < w; ++i) seq_pairmul<G, K, true, true, true>(a, b, a, b, n, 0, sel0, qs);
-    load_table_entry<K>(ma, tbl, idx, tsize, LQ, gather);   // (not ahead of the squarings: 2K registers the squarings need)
+    load_table_entry<K>(ma, tbl, idx, tsize, LQ, gather);   // the entry travels while the squarings run
     load_table_entry<K>(mb, tbl + L2, idx, tsize, LQ, gather);
-    seq_pairmul<G, K, false, true, true>(a, b, ma, mb, n, 0, sel0, qs);
+#pragma unroll 1
+    for (int i = 0; i < w; ++i) seq_pairmul<G, K, true, true, true>(a, b, a, b, n, 0, sel0, qs, ts);
+    seq_pairmul<G, K, false, true, true>(a, b, ma, mb, n, 0, sel0, qs, ts);
+  }
+  if (first_inst + grp < A.count) {
+    uint32_t* out = A.out_pair + inst * (size_t)LQ;
+    store_pair_row<K>(out, a, x);
+    store_pair_row<K>(out + L2, b, x);
+  }
+}
+
+// CT + CT on resident batches (pair_ops_kernel's PO_MUL) with both halves in the same lanes: one general pair product
+// per element -- the product in which the paired form leaves half A idle for a third of its multiply-accumulates.
+template <int G, int K>
+__global__ __launch_bounds__(kWGThreads, 2) void pair_mul_seq_kernel(PairOpsArgs A) {
+  constexpr int IPW = kWave / G, L2 = G * K, LQ = 2 * L2;
+  raise_wave_priority();
+  __shared__ __attribute__((aligned(16))) uint32_t qs_[kWavesPerWG][IPW][G * kAbPad];
+  __shared__ __attribute__((aligned(16))) uint32_t ts_[kWavesPerWG][kWave][kAbPad];
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  const int grp = lane / G, x = lane % G;
+  uint32_t* qs = qs_[wv][grp];
+  uint32_t* ts = ts_[wv][lane];
+  uint32_t sel0 = x == 0 ? 1u : 0u;
+  asm("" : "+v"(sel0));
+  size_t inst = ((size_t)blockIdx.x * kWavesPerWG + wv) * IPW + grp;
+  const bool live = inst < A.count;
+  if (!live) inst = A.count - 1;
+  uint32_t n[K], a[K], b[K], c[K], d[K];
+  const uint32_t* ra = A.a + inst * (size_t)LQ;
+  const uint32_t* rb = A.b + inst * A.b_stride;
+  load_pair_row<K>(a, ra, x);
+  load_pair_row<K>(b, ra + L2, x);
+  load_pair_row<K>(c, rb, x);
+  load_pair_row<K>(d, rb + L2, x);
+#pragma unroll
+  for (int j = 0; j < K; ++j) n[j] = A.ctx.nhat[x * K + j];
+  seq_pairmul<G, K, false, true, true>(a, b, c, d, n, 0, sel0, qs, ts);
+  if (live) {
+    uint32_t* out = A.out + inst * (size_t)LQ;
+    store_pair_row<K>(out, a, x);
+    store_pair_row<K>(out + L2, b, x);
+  }
+}
+
+// DJN encrypt of resident batches (hensel_fb_encrypt_kernel's pair-row exit) with both halves in the same lanes:
+// hs^r as nwin-1 general pair products of table entries -- every one of them a product in which the paired form
+// leaves half A idle for a third of its multiply-accumulates -- then (1 + n*m) as  b += (-k^-1 * m * a) mod n
+// (pair_times_gm without the hand-over between halves).  The table is the one hensel_fb_build_kernel wrote.
+template <int G, int K>
+__global__ __launch_bounds__(kWGThreads, 2) void hensel_fb_encrypt_seq_kernel(HenselFbArgs A) {
+  using HG = Geo<G, K>;
+  constexpr int IPW = kWave / G, L2 = G * K, LQ = 2 * L2;
+  raise_wave_priority();
+  __shared__ __attribute__((aligned(16))) uint32_t qs_[kWavesPerWG][IPW][G * kAbPad];
+  __shared__ __attribute__((aligned(16))) uint32_t ts_[kWavesPerWG][kWave][kAbPad];
+  __shared__ uint64_t io_[kWavesPerWG][IPW][HG::W64 + 1];
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  const int grp = lane / G, x = lane % G;
+  uint32_t* qs = qs_[wv][grp];
+  uint32_t* ts = ts_[wv][lane];
+  auto& io = io_[wv];
+  uint32_t sel0 = x == 0 ? 1u : 0u;
+  asm("" : "+v"(sel0));
+  const size_t first_inst = ((size_t)blockIdx.x * kWavesPerWG + wv) * IPW;
+  size_t inst = first_inst + grp;
+  if (inst >= A.count) inst = A.count - 1;
+  uint32_t n[K], a[K], b[K], ma[K], mb[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) n[j] = A.ctx.nhat[x * K + j];
+  const int w = A.w, tsize = 1 << w;
+  const uint64_t* ep = A.exp + inst * A.exp_stride;
+  auto digit = [&](int i) -> int {
+    int bit = i * w;
+    int word = bit >> 6, sh = bit & 63;
+    uint64_t v = (word < A.exp_words) ? ep[word] >> sh : 0;
+    if (sh + w > 64 && word + 1 < A.exp_words) v |= ep[word + 1] << (64 - sh);
+    return (int)(v & (uint64_t)(tsize - 1));
+  };
+  auto load_entry = [&](uint32_t (&da)[K], uint32_t (&db)[K], int i) {
+    const uint32_t* e = A.table + ((size_t)i * tsize + digit(i)) * LQ;
+    load_pair_row<K>(da, e, x);
+    load_pair_row<K>(db, e + L2, x);
+  };
+  load_entry(a, b, 0);
+  if (A.nwin > 1) load_entry(ma, mb, 1);
+  // the entry of the next step is fetched before the product of this one (latency hidden)
+#pragma unroll 1
+  for (int i = 1; i < A.nwin; ++i) {
+    uint32_t na[K], nb[K];
+    if (i + 1 < A.nwin) load_entry(na, nb, i + 1);
+    seq_pairmul<G, K, false, true, true>(a, b, ma, mb, n, 0, sel0, qs, ts);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      ma[j] = na[j];
+      mb[j] = nb[j];
+    }
+  }
+  // times 1 + n*m under the true modulus n:  b += montmul(montmul(m, gm), a)
+  stage_words<HG>(io, A.fm_words, A.fm_stride, 0, A.fm_nwords, first_inst, A.count, 1, lane);
+  wave_lds_sync();
+  {
+    uint32_t mv[K], u[K], v[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      n[j] = A.ctx.n[x * K + j];
+      ma[j] = A.ctx.gm[x * K + j];
+      mv[j] = limb_from_words(io[grp], x * K + j);
+    }
+    montmul_reg<HG, false, false>(u, mv, ma, n, A.ctx.n0inv);
+    montmul_reg<HG, false, false>(v, u, a, n, A.ctx.n0inv);
+    add_normalise<HG>(b, v);
   }
   if (first_inst + grp < A.count) {
     uint32_t* out = A.out_pair + inst * (size_t)LQ;

@@ -5,7 +5,7 @@
 #include "launch.hpp"
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..18"
+#error "compile with -DPGPU_PART=0..21"
 #endif
 
 namespace pgpu {
@@ -105,6 +105,30 @@ bool launch_hensel_seq_part17(int G, int K, const HenselArgs& a, unsigned blocks
 bool launch_hensel_modexp_seq_part18(int G, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
   if (G == 4 && K == 18) {
     hipLaunchKernelGGL((hensel_modexp_seq_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  return false;
+}
+#elif PGPU_PART == 19
+bool launch_pair_mul_seq_part19(int G, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s) {
+  if (G == 4 && K == 18) {
+    hipLaunchKernelGGL((pair_mul_seq_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  return false;
+}
+#elif PGPU_PART == 20
+bool launch_hensel_fb_encrypt_seq_part20(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
+  if (G == 4 && K == 18) {
+    hipLaunchKernelGGL((hensel_fb_encrypt_seq_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  return false;
+}
+#elif PGPU_PART == 21
+bool launch_hensel_fb_encrypt_seq_part21(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
+  if (G == 8 && K == 14) {
+    hipLaunchKernelGGL((hensel_fb_encrypt_seq_kernel<8, 14>), dim3(blocks), dim3(kWGThreads), 0, s, a);
     return true;
   }
   return false;

@@ -122,6 +122,21 @@ inline bool launch_hensel_modexp_seq(int G, int K, const HenselModexpArgs& a, un
   return launch_hensel_modexp_seq_part18(G, K, a, blocks, s);
 }
 
+// CT + CT on pair rows in the same form (k_hensel.hip part 19)
+inline bool pair_mul_seq_has(int G, int K) { return G == 4 && K == 18; }
+bool launch_pair_mul_seq_part19(int G, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s);
+inline bool launch_pair_mul_seq(int G, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s) {
+  return launch_pair_mul_seq_part19(G, K, a, blocks, s);
+}
+
+// DJN encrypt to pair rows in the same form (k_hensel.hip parts 20, 21): (4,18) 2048-bit keys, (8,14) 3072-bit keys
+inline bool hensel_fb_encrypt_seq_has(int G, int K) { return (G == 4 && K == 18) || (G == 8 && K == 14); }
+bool launch_hensel_fb_encrypt_seq_part20(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
+bool launch_hensel_fb_encrypt_seq_part21(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
+inline bool launch_hensel_fb_encrypt_seq(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
+  return launch_hensel_fb_encrypt_seq_part20(G, K, a, blocks, s) || launch_hensel_fb_encrypt_seq_part21(G, K, a, blocks, s);
+}
+
 bool launch_modmul(int G, int K, const ModmulArgs& a, unsigned blocks, hipStream_t s);
 bool launch_crt(int G, int K, const CrtArgs& a, unsigned blocks, hipStream_t s);
 bool launch_fb_build(int G, int K, const FixedBaseBuildArgs& a, unsigned blocks, hipStream_t s);

@@ -333,3 +333,79 @@ def test_sequential_halves_ct_times_pt_is_bit_identical(engine, ebits, count):
             L.pgpu_debug_set_seq_decrypt(1)
     finally:
         R.close()
+
+
+def test_sequential_halves_ct_plus_ct_is_bit_identical(engine):
+    """pair_mul_seq_kernel (csrc/hensel_seq.hpp): CT + CT of resident batches as one pair product with both halves of a
+    residue in the same lanes (launches of 16384+ elements; forced here): same ciphertexts as the product modulo n^2 and
+    as the paired kernel, ragged batch, a one-row operand, chained twice."""
+    from pailliercryptolib_amd import _capi
+    bits, count = 2048, 523
+    p, q, hs = key_case(bits, True)
+    n = p * q
+    nsq = n * n
+    nw = bits // 64
+    rng = random.Random(77)
+    m1 = ([0, 1, n - 1] + [rng.randrange(n) for _ in range(count)])[:count]
+    m2 = [rng.randrange(n) for _ in range(count)]
+    r1 = [rng.getrandbits(bits // 2) for _ in range(count)]
+    r2 = [rng.getrandbits(bits // 2) for _ in range(count)]
+    L = _capi.lib()
+    pk, sk = engine.PublicKey(n, bits, hs=hs), engine.PrivateKey(p, q)
+    R = Res()
+    try:
+        c1 = R.op(L.pgpu_batch_encrypt, pk._h, R.up(m1, nw), R.up(r1, nw // 2), bits // 2)
+        c2 = R.op(L.pgpu_batch_encrypt, pk._h, R.up(m2, nw), R.up(r2, nw // 2), bits // 2)
+        o1, o2 = R.down(c1), R.down(c2)
+        want = [a * b % nsq for a, b in zip(o1, o2)]
+        L.pgpu_debug_set_seq_decrypt(0)
+        assert R.down(R.op(L.pgpu_batch_ct_add, pk._h, c1, c2)) == want
+        L.pgpu_debug_set_seq_decrypt(2)
+        try:
+            s = R.op(L.pgpu_batch_ct_add, pk._h, c1, c2)
+            assert R.down(s) == want
+            s2 = R.op(L.pgpu_batch_ct_add, pk._h, s, c1)
+            assert R.down(s2) == [a * b % nsq for a, b in zip(want, o1)]
+            assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, s2)) == [(2 * a + b) % n for a, b in zip(m1, m2)]
+            one = R.up([o2[0]], 2 * nw)
+            assert R.down(R.op(L.pgpu_batch_ct_add, pk._h, c1, one)) == [a * o2[0] % nsq for a in o1]
+        finally:
+            L.pgpu_debug_set_seq_decrypt(1)
+    finally:
+        R.close()
+
+
+@pytest.mark.parametrize("bits,count", [(2048, 521), (3072, 150)])
+def test_sequential_halves_djn_encrypt_is_bit_identical(engine, bits, count):
+    """hensel_fb_encrypt_seq_kernel (csrc/hensel_seq.hpp): DJN encrypt onto pair rows with both halves of a residue in the
+    same lanes (launches of 16384+ / 8192+ elements; forced here).  Same ciphertexts as the oracle and as the paired kernel:
+    ragged batch, edge plaintexts and randomness."""
+    from oracle import paillier_oracle as orc
+    from pailliercryptolib_amd import _capi
+    p, q, hs = key_case(bits, True)
+    n = p * q
+    nw = bits // 64
+    rng = random.Random(bits + count)
+    m = ([0, 1, n - 1, n, (1 << (64 * nw)) - 1] + [rng.randrange(n) for _ in range(count)])[:count]
+    r = ([0, 1, (1 << (bits // 2)) - 1] + [rng.getrandbits(bits // 2) for _ in range(count)])[:count]
+    opk = orc.PublicKey(n, bits)
+    opk.set_djn(hs)
+    want = opk.encrypt(m, r)
+    L = _capi.lib()
+    pk, sk = engine.PublicKey(n, bits, hs=hs), engine.PrivateKey(p, q)
+    R = Res()
+    try:
+        bm, br = R.up(m, nw), R.up(r, nw // 2)
+        L.pgpu_debug_set_seq_decrypt(0)
+        c0 = R.op(L.pgpu_batch_encrypt, pk._h, bm, br, bits // 2)
+        assert L.pgpu_batch_row_limbs(c0) > 0 and R.down(c0) == want
+        L.pgpu_debug_set_seq_decrypt(2)
+        try:
+            c = R.op(L.pgpu_batch_encrypt, pk._h, bm, br, bits // 2)
+            assert L.pgpu_batch_row_limbs(c) > 0
+            assert R.down(c) == want
+            assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, c)) == [v % n for v in m]
+        finally:
+            L.pgpu_debug_set_seq_decrypt(1)
+    finally:
+        R.close()
