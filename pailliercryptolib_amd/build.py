@@ -53,7 +53,7 @@ def _objects():
         out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src] + kdeps))
     src = os.path.join(CSRC, "k_misc.hip")
     out.append((os.path.join(obj, "k_misc.o"), hip + ["-c", src, "-o", os.path.join(obj, "k_misc.o")], [src] + kdeps))
-    for part in range(22):
+    for part in range(25):
         src = os.path.join(CSRC, "k_hensel.hip")
         o = os.path.join(obj, f"k_hensel_{part}.o")
         out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src, os.path.join(CSRC, "hensel.hpp"), os.path.join(CSRC, "hensel_ab.hpp"), os.path.join(CSRC, "hensel_seq.hpp")] + kdeps))
@@ -104,6 +104,9 @@ def build_pgpu(force=False):
     todo = [(o, cmd) for o, cmd, deps in objs
             if force or _newer(o, deps + ([kdep] if cmd[-3].endswith(".hip") else [])) or (force_dev and cmd[-3].endswith(".hip"))]
     if todo:
+        # the 8-lane x 18-limb forms (4096-bit key class, parts 22-24) compile for 10-15 minutes each: start them first
+        slow = ("k_hensel_22.", "k_hensel_23.", "k_hensel_24.")
+        todo.sort(key=lambda oc: 0 if os.path.basename(oc[0]).startswith(slow) else 1)
         with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
             list(ex.map(lambda oc: compile_one(oc[0], oc[1]), todo))
     open(stamp, "w").close()

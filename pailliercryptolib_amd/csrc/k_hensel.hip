@@ -5,7 +5,7 @@
 #include "launch.hpp"
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..21"
+#error "compile with -DPGPU_PART=0..24"
 #endif
 
 namespace pgpu {
@@ -26,8 +26,12 @@ bool launch_hensel_part1(int H, int K, const HenselArgs& a, unsigned blocks, hip
   PGPU_HENSEL_ONE(4, 18) PGPU_HENSEL_ONE(4, 14) PGPU_HENSEL_ONE(4, 10)
   return false;
 }
-#elif PGPU_PART == 3 || PGPU_PART == 4 || PGPU_PART == 10
-#if PGPU_PART == 3
+#elif PGPU_PART == 3 || PGPU_PART == 4 || PGPU_PART == 10 || PGPU_PART == 22
+#if PGPU_PART == 22
+#define PGPU_FB_H 8
+#define PGPU_FB_K 18
+#define PGPU_FB_NAME(f) f##_part22
+#elif PGPU_PART == 3
 #define PGPU_FB_H 4
 #define PGPU_FB_K 18
 #define PGPU_FB_NAME(f) f##_part3
@@ -54,8 +58,12 @@ bool PGPU_FB_NAME(launch_hensel_fb_encrypt)(int H, int K, const HenselFbArgs& a,
   }
   return false;
 }
-#elif PGPU_PART == 11 || PGPU_PART == 12 || PGPU_PART == 13
-#if PGPU_PART == 11
+#elif PGPU_PART == 11 || PGPU_PART == 12 || PGPU_PART == 13 || PGPU_PART == 24
+#if PGPU_PART == 24
+#define PGPU_PO_H 8
+#define PGPU_PO_K 18
+#define PGPU_PO_NAME launch_pair_ops_part24
+#elif PGPU_PART == 11
 #define PGPU_PO_H 4
 #define PGPU_PO_K 18
 #define PGPU_PO_NAME launch_pair_ops_part11
@@ -189,6 +197,14 @@ bool launch_hensel_part7(int H, int K, const HenselArgs& a, unsigned blocks, hip
 bool launch_hensel_modexp_part5(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
   if (H == 4 && K == 18) {
     hipLaunchKernelGGL((hensel_modexp_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  return false;
+}
+#elif PGPU_PART == 23
+bool launch_hensel_modexp_part23(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
+  if (H == 8 && K == 18) {
+    hipLaunchKernelGGL((hensel_modexp_kernel<8, 18>), dim3(blocks), dim3(kWGThreads), 0, s, a);
     return true;
   }
   return false;

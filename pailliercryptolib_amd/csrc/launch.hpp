@@ -50,17 +50,21 @@ inline bool launch_hensel(int H, int K, bool packed, const HenselArgs& a, unsign
 }
 
 // split-form fixed-base DJN encrypt (hensel.hpp: hensel_fb_build_kernel / hensel_fb_encrypt_kernel; k_hensel.hip part 3)
-// (2,19): 1024-bit keys, (4,18): 2048, (8,14): 3072 (k_hensel.hip parts 10, 3, 4)
-inline bool hensel_fb_has(int H, int K) { return (H == 2 && K == 19) || (H == 4 && K == 18) || (H == 8 && K == 14); }
+// (2,19): 1024-bit keys, (4,18): 2048, (8,14): 3072, (8,18): 4096 (k_hensel.hip parts 10, 3, 4, 22)
+inline bool hensel_fb_has(int H, int K) {
+  return (H == 2 && K == 19) || (H == 4 && K == 18) || (H == 8 && (K == 14 || K == 18));
+}
 bool launch_hensel_fb_build_part3(int H, int K, const HenselFbBuildArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_fb_build_part4(int H, int K, const HenselFbBuildArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_fb_build_part10(int H, int K, const HenselFbBuildArgs& a, unsigned blocks, hipStream_t s);
+bool launch_hensel_fb_build_part22(int H, int K, const HenselFbBuildArgs& a, unsigned blocks, hipStream_t s);
+bool launch_hensel_fb_encrypt_part22(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_fb_encrypt_part3(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_fb_encrypt_part4(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_fb_encrypt_part10(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
 inline bool launch_hensel_fb_build(int H, int K, const HenselFbBuildArgs& a, unsigned blocks, hipStream_t s) {
   return launch_hensel_fb_build_part3(H, K, a, blocks, s) || launch_hensel_fb_build_part4(H, K, a, blocks, s) ||
-         launch_hensel_fb_build_part10(H, K, a, blocks, s);
+         launch_hensel_fb_build_part10(H, K, a, blocks, s) || launch_hensel_fb_build_part22(H, K, a, blocks, s);
 }
 // (8,9): the ENCRYPT kernel only, for batches that leave SIMDs idle under a 2048-bit key -- 16 lanes per element, the
 // same 72 limbs per half as (4,18): it reads the table the (4,18) build kernel wrote and writes the same pair rows
@@ -68,32 +72,39 @@ bool launch_hensel_fb_encrypt_part14(int H, int K, const HenselFbArgs& a, unsign
 inline bool hensel_fb_encrypt_has(int H, int K) { return hensel_fb_has(H, K) || (H == 8 && K == 9); }
 inline bool launch_hensel_fb_encrypt(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
   return launch_hensel_fb_encrypt_part3(H, K, a, blocks, s) || launch_hensel_fb_encrypt_part4(H, K, a, blocks, s) ||
-         launch_hensel_fb_encrypt_part10(H, K, a, blocks, s) || launch_hensel_fb_encrypt_part14(H, K, a, blocks, s);
+         launch_hensel_fb_encrypt_part10(H, K, a, blocks, s) || launch_hensel_fb_encrypt_part14(H, K, a, blocks, s) ||
+         launch_hensel_fb_encrypt_part22(H, K, a, blocks, s);
 }
 
 // split-form generic modexp modulo a square (hensel.hpp: hensel_modexp_kernel; k_hensel.hip parts 5, 6, 8, 9): roots of
-// up to 1024 bits -- (2,19) / (4,10) / (8,5), fewest to most lanes --, 2048 bits -- (4,18) / (8,9) --, 3072 bits -- (8,14)
+// up to 1024 bits -- (2,19) / (4,10) / (8,5), fewest to most lanes --, 2048 bits -- (4,18) / (8,9) --, 3072 bits -- (8,14),
+// 4096 bits -- (8,18) (part 23)
 inline bool hensel_modexp_has(int H, int K) {
-  return (H == 4 && (K == 18 || K == 10)) || (H == 8 && (K == 9 || K == 5 || K == 14)) || (H == 2 && K == 19);
+  return (H == 4 && (K == 18 || K == 10)) || (H == 8 && (K == 9 || K == 5 || K == 14 || K == 18)) || (H == 2 && K == 19);
 }
 bool launch_hensel_modexp_part5(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_modexp_part6(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_modexp_part8(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_modexp_part9(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
+bool launch_hensel_modexp_part23(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
 inline bool launch_hensel_modexp(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
   return launch_hensel_modexp_part5(H, K, a, blocks, s) || launch_hensel_modexp_part6(H, K, a, blocks, s) ||
-         launch_hensel_modexp_part8(H, K, a, blocks, s) || launch_hensel_modexp_part9(H, K, a, blocks, s);
+         launch_hensel_modexp_part8(H, K, a, blocks, s) || launch_hensel_modexp_part9(H, K, a, blocks, s) ||
+         launch_hensel_modexp_part23(H, K, a, blocks, s);
 }
 
 // element-wise operations on pair rows (hensel.hpp: pair_ops_kernel; k_hensel.hip parts 11-13): the throughput form of
-// each key class -- (2,19): 1024-bit keys, (4,18): 2048, (8,14): 3072
-inline bool pair_ops_has(int H, int K) { return (H == 2 && K == 19) || (H == 4 && K == 18) || (H == 8 && K == 14); }
+// each key class -- (2,19): 1024-bit keys, (4,18): 2048, (8,14): 3072, (8,18): 4096 (part 24)
+inline bool pair_ops_has(int H, int K) {
+  return (H == 2 && K == 19) || (H == 4 && K == 18) || (H == 8 && (K == 14 || K == 18));
+}
 bool launch_pair_ops_part11(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s);
 bool launch_pair_ops_part12(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s);
 bool launch_pair_ops_part13(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s);
+bool launch_pair_ops_part24(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s);
 inline bool launch_pair_ops(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s) {
   return launch_pair_ops_part11(H, K, a, blocks, s) || launch_pair_ops_part12(H, K, a, blocks, s) ||
-         launch_pair_ops_part13(H, K, a, blocks, s);
+         launch_pair_ops_part13(H, K, a, blocks, s) || launch_pair_ops_part24(H, K, a, blocks, s);
 }
 
 // CRT decrypt with the two halves of a residue in different wavefronts (hensel_ab.hpp; k_hensel.hip part 15): pair-row

@@ -51,12 +51,19 @@ def key_case(bits, djn):
     if bits == 2048:
         k = json.load(open(os.path.join(GOLD, "iso_kat.json")))
         return int(k["p"], 16), int(k["q"], 16), int(k["bench_hs"], 16) if djn else None
+    if bits == 4096:   # (no DJN fixture of this size: hs = (-x^2)^n mod n^2 as pub_key.cpp:40-49 forms it, x seeded)
+        k = json.load(open(os.path.join(GOLD, "primes_4096.json")))
+        p, q = int(k["p"], 16), int(k["q"], 16)
+        n = p * q
+        x = random.Random(4096).randrange(2, n)
+        return p, q, pow(n * n - x * x % (n * n), n, n * n) if djn else None
     c = [c for c in json.load(open(os.path.join(GOLD, "seeded_vectors.json")))["cases"] if c["bits"] == bits and c["djn"]][0]
     return int(c["p"], 16), int(c["q"], 16), int(c["hs"], 16) if djn else None
 
 
 @pytest.mark.parametrize("bits,djn,count", [(2048, True, 203), (2048, False, 37), (2048, True, 700), (1024, True, 131),
-                                            (1024, False, 19), (3072, True, 70), (3072, False, 9), (2048, True, 1)])
+                                            (1024, False, 19), (3072, True, 70), (3072, False, 9), (2048, True, 1),
+                                            (4096, True, 41), (4096, False, 5)])
 def test_resident_chain_in_pair_rows(engine, bits, djn, count):
     from oracle import paillier_oracle as orc
     p, q, hs = key_case(bits, djn)

@@ -12,6 +12,9 @@ count = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 G = os.path.join(os.path.dirname(__file__), "..", "tests", "golden")
 cases = {c["bits"]: c for c in json.load(open(os.path.join(G, "seeded_vectors.json")))["cases"] if c["djn"]}
 rng = np.random.default_rng(2)
+_k4 = json.load(open(os.path.join(G, "primes_4096.json")))
+_n4 = int(_k4["p"], 16) * int(_k4["q"], 16)
+cases[4096] = {"p": _k4["p"], "q": _k4["q"], "hs": hex(pow(_n4 * _n4 - 9, _n4, _n4 * _n4))}   # hs = (-x^2)^n, x = 3
 
 
 def ptr(a):
@@ -27,7 +30,7 @@ def timed(fn):
     return (time.perf_counter() - t0) * 1e3, h
 
 
-for bits in (1024, 2048, 3072):
+for bits in (1024, 2048, 3072, 4096):
     c = cases[bits]
     p, q, hs = int(c["p"], 16), int(c["q"], 16), int(c["hs"], 16)
     n = p * q
@@ -56,6 +59,12 @@ for bits in (1024, 2048, 3072):
             return h
         t_mul, cm = timed(mul)
 
+        def add():
+            h = ctypes.c_void_p()
+            _capi.check(L.pgpu_batch_ct_add(pk._h, ct, cm, ctypes.byref(h)))
+            return h
+        t_add, _ = timed(add)
+
         def dec():
             h = ctypes.c_void_p()
             _capi.check(L.pgpu_batch_decrypt_crt(sk._h, ct, ctypes.byref(h)))
@@ -65,6 +74,6 @@ for bits in (1024, 2048, 3072):
         _capi.check(L.pgpu_batch_download(dm, ptr(out)))
         assert np.array_equal(out, m)
         print(f"{bits}-bit key, {count} elements, split form {'on ' if mode else 'off'}: encrypt {t_enc:8.2f} ms   "
-              f"CT x PT (u32) {t_mul:8.2f} ms   decrypt {t_dec:8.2f} ms", flush=True)
+              f"CT x PT (u32) {t_mul:8.2f} ms   CT + CT {t_add:7.3f} ms   decrypt {t_dec:8.2f} ms", flush=True)
         del pk, sk
 pa.terminate()
