@@ -5,7 +5,8 @@ src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 
 def short(name):
-    for k in ("modexp_kernel", "hensel_decrypt_kernel", "crt_kernel", "modmul_kernel", "fixedbase", "fb_", "pair_ops_kernel"):
+    for k in ("modexp_kernel", "hensel_decrypt_kernel", "hensel_decrypt_seq_kernel", "hensel_modexp_seq_kernel", "crt_kernel",
+              "modmul_kernel", "fixedbase", "fb_", "pair_ops_kernel", "pair_mul_seq_kernel"):
         if k in name:
             return name.split("(")[0].replace("void pgpu::", "")
     return None
@@ -74,8 +75,9 @@ if fb and "hbm_bytes_fetch_x2_corrected" in fb:
 old = {}
 if os.path.exists("profiles/pmc_summary.json"):
     old = json.load(open("profiles/pmc_summary.json"))
-po = next((v for k, v in out.items() if k.startswith("pair_ops_kernel<")), None)
-if po and "hbm_bytes_fetch_x2_corrected" in po and float(po["dispatch"]["Grid_Size"]) >= 8e6:
+po = next((v for k, v in out.items() if k.startswith("pair_mul_seq_kernel<")), None) or \
+    next((v for k, v in out.items() if k.startswith("pair_ops_kernel<")), None)
+if po and "hbm_bytes_fetch_x2_corrected" in po and float(po["dispatch"]["Grid_Size"]) >= 4e6:
     summary = {"ct_add_pair_mul_hbm_bytes_per_launch": po["hbm_bytes_fetch_x2_corrected"],
                "ct_add_source": f"profiles/{tag}_pmc_counters.json"}
 if len(summary) > 1:
