@@ -1472,7 +1472,9 @@ bool fb_encrypt_seq_pays(int H, int K, size_t count) {
   const size_t ipw = 64 / (size_t)H;
   const size_t waves = (count + ipw - 1) / ipw;
   const int pol = g_seq_policy.load();
-  return pol == 2 || (pol == 1 && waves >= kSimds);
+  // (8-lane groups pay two DPP moves per row broadcast: alone on a SIMD the form is 2 % behind the paired kernel --
+  // 3072-bit keys, 8192 elements: 3.60 against 3.52 ms -- and 7 % ahead with two wavefronts per SIMD: 6.2 against 6.7 ms)
+  return pol == 2 || (pol == 1 && waves >= (H >= 8 ? 2 : 1) * kSimds);
 }
 bool modexp_seq_form_pays(int H, int K, size_t count) {
   if (!pgpu::hensel_modexp_seq_has(H, K)) return false;
