@@ -1652,6 +1652,17 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
 }
 
 // ---------- pair rows: launches and conversions ----------
+// the form an element-wise pair-row operation of `count` elements runs in: the key's pair form f, or -- while the
+// launch leaves SIMDs idle -- a compiled form with the same limbs per half on more lanes (2048-bit keys: (8,9))
+const pgpu_pubkey::PubForm* pair_op_form(const pgpu_pubkey* key, const pgpu_pubkey::PubForm* f, size_t count) {
+  for (const auto& alt : key->hforms) {
+    const size_t ipw = 64 / (2 * (size_t)alt->H);
+    if (alt->H * alt->K == f->H * f->K && alt->H > f->H && pgpu::pair_ops_alt_has(alt->H, alt->K) &&
+        (count + ipw - 1) / ipw <= kSimds)
+      return alt.get();
+  }
+  return f;
+}
 bool pair_mul_seq_pays(int H, int K, size_t count) {
   if (!pgpu::pair_mul_seq_has(H, K)) return false;
   const size_t ipw = 64 / (size_t)H;
@@ -1959,6 +1970,7 @@ int pgpu_ct_add_kernel_form(const pgpu_pubkey* key, size_t count, int* split, in
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_ct_add_kernel_form: bad argument");
   RC_TRY(check_gen(key->gen, "key"));
   if (const pgpu_pubkey::PubForm* f = pair_form(key)) {
+    f = pair_op_form(key, f, count);
     const bool seq = pair_mul_seq_pays(f->H, f->K, count);
     *split = seq ? 2 : 1;
     *lanes = seq ? f->H : 2 * f->H;
@@ -2850,14 +2862,15 @@ int pgpu_batch_ct_add(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_ba
       rt::Device& dev = rt::device(d);
       rt::DeviceGuard g(dev.ordinal);
       pgpu::PairOpsArgs pa{};
-      pa.ctx = hensel_pub_view(f, dev.index);
+      const pgpu_pubkey::PubForm* lf = pair_op_form(key, f, hi - lo);
+      pa.ctx = hensel_pub_view(lf, dev.index);
       pa.op = pgpu::PO_MUL;
       pa.a = a->prow(d);
       pa.b = b->prow(b->replicated ? d : (bcast ? 0 : d));
       pa.b_stride = bcast ? 0 : (size_t)2 * l2;
       pa.out = o->prow(d);
       pa.count = hi - lo;
-      RC_TRY(pair_op_launch(dev, f, pa, dev.bs(a->lane), PGPU_KERNEL_MODMUL));
+      RC_TRY(pair_op_launch(dev, lf, pa, dev.bs(a->lane), PGPU_KERNEL_MODMUL));
     }
     RC_TRY(lanes_order(b, a->lane, false));
     *out = o.release();
@@ -2920,7 +2933,8 @@ int pgpu_batch_ct_add_plain(const pgpu_pubkey* key, const pgpu_batch* a, const p
       rt::Device& dev = rt::device(d);
       rt::DeviceGuard g(dev.ordinal);
       pgpu::PairOpsArgs pa{};
-      pa.ctx = hensel_pub_view(pf, dev.index);
+      const pgpu_pubkey::PubForm* lf = pair_op_form(key, pf, hi - lo);
+      pa.ctx = hensel_pub_view(lf, dev.index);
       pa.op = pgpu::PO_TIMES_GM;
       pa.a = a->prow(d);
       pa.words = m->ptr(m->replicated ? d : (bcast ? 0 : d));
@@ -2928,7 +2942,7 @@ int pgpu_batch_ct_add_plain(const pgpu_pubkey* key, const pgpu_batch* a, const p
       pa.nwords = m->words;
       pa.out = o->prow(d);
       pa.count = hi - lo;
-      RC_TRY(pair_op_launch(dev, pf, pa, dev.bs(a->lane), PGPU_KERNEL_MODMUL));
+      RC_TRY(pair_op_launch(dev, lf, pa, dev.bs(a->lane), PGPU_KERNEL_MODMUL));
     }
     RC_TRY(lanes_order(m, a->lane, false));
     *out = o.release();

@@ -5,7 +5,7 @@
 #include "launch.hpp"
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..24"
+#error "compile with -DPGPU_PART=0..25"
 #endif
 
 namespace pgpu {
@@ -58,8 +58,12 @@ bool PGPU_FB_NAME(launch_hensel_fb_encrypt)(int H, int K, const HenselFbArgs& a,
   }
   return false;
 }
-#elif PGPU_PART == 11 || PGPU_PART == 12 || PGPU_PART == 13 || PGPU_PART == 24
-#if PGPU_PART == 24
+#elif PGPU_PART == 11 || PGPU_PART == 12 || PGPU_PART == 13 || PGPU_PART == 24 || PGPU_PART == 25
+#if PGPU_PART == 25
+#define PGPU_PO_H 8
+#define PGPU_PO_K 9
+#define PGPU_PO_NAME launch_pair_ops_part25
+#elif PGPU_PART == 24
 #define PGPU_PO_H 8
 #define PGPU_PO_K 18
 #define PGPU_PO_NAME launch_pair_ops_part24

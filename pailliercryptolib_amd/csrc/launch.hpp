@@ -98,13 +98,18 @@ inline bool launch_hensel_modexp(int H, int K, const HenselModexpArgs& a, unsign
 inline bool pair_ops_has(int H, int K) {
   return (H == 2 && K == 19) || (H == 4 && K == 18) || (H == 8 && (K == 14 || K == 18));
 }
+// (8,9) (part 25): CT + CT / CT + PT of batches that leave SIMDs idle under a 2048-bit key -- 16 lanes per element on
+// the same 144-limb rows as (4,18), a product's serial chain 40 % shorter
+inline bool pair_ops_alt_has(int H, int K) { return H == 8 && K == 9; }
+bool launch_pair_ops_part25(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s);
 bool launch_pair_ops_part11(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s);
 bool launch_pair_ops_part12(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s);
 bool launch_pair_ops_part13(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s);
 bool launch_pair_ops_part24(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s);
 inline bool launch_pair_ops(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s) {
   return launch_pair_ops_part11(H, K, a, blocks, s) || launch_pair_ops_part12(H, K, a, blocks, s) ||
-         launch_pair_ops_part13(H, K, a, blocks, s) || launch_pair_ops_part24(H, K, a, blocks, s);
+         launch_pair_ops_part13(H, K, a, blocks, s) || launch_pair_ops_part24(H, K, a, blocks, s) ||
+         launch_pair_ops_part25(H, K, a, blocks, s);
 }
 
 // CRT decrypt with the two halves of a residue in different wavefronts (hensel_ab.hpp; k_hensel.hip part 15): pair-row
