@@ -1,5 +1,8 @@
-// pailliercryptolib_amd -- CRT-decrypt exponentiation in split form with BOTH halves of a residue in the same lanes
-// (round 3): the form for launches that still put a wavefront on every SIMD with half the lanes per residue.
+// pailliercryptolib_amd -- the split form with BOTH halves of a residue in the same lanes (round 3): the form for launches
+// that still put a wavefront on every SIMD with half the lanes per residue.  Kernels: hensel_decrypt_seq_kernel (CRT
+// decrypt), hensel_modexp_seq_kernel (CT x PT), pair_mul_seq_kernel (CT + CT), hensel_fb_encrypt_seq_kernel (DJN
+// encrypt) -- all on resident batches (pair rows, kargs.hpp), all bit-identical with the paired kernels of hensel.hpp
+// (tests/test_gpu_pair_rows.py: test_sequential_halves_*); capi.cpp picks them by launch size (PGPU_SEQ_DECRYPT).
 //
 // hensel_decrypt_kernel (hensel.hpp) gives the a half and the b half of a pair x == a - P*b lanes of their own and runs
 // them through one instruction stream; half A then sits through the K^2 products of half B's 2*a*b although its own
