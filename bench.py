@@ -624,7 +624,58 @@ def extras(pa, L, B, pk, sk, n, p, q, hs, m_host, r_host, per_kind):
         out["two_streams"] = two_streams(L, pk, sk, m_host, r_host)
     except Exception as e:                                  # noqa: BLE001
         out["two_streams"] = {"error": str(e)[:300]}
+    # (6) opt-in PGPU_SEQ_DECRYPT=3, the mode for two batch lanes that are both kept busy: each lane's decrypt in the
+    # sequential-halves form (csrc/hensel_seq.hpp; 512 wavefronts for 8192 ciphertexts = half the chip, 11 % fewer
+    # instructions), workgroups claiming more than half a CU's LDS so that the two launches spread over all CUs
+    try:
+        out["sequential_halves_two_lanes"] = seq_two_lanes(L, B, pk, sk, m_host, r_host)
+    except Exception as e:                                  # noqa: BLE001
+        L.pgpu_debug_set_seq_decrypt(1)
+        out["sequential_halves_two_lanes"] = {"error": str(e)[:300]}
     return out
+
+
+def seq_two_lanes(L, B, pk, sk, m_host, r_host, steps=20):
+    from pailliercryptolib_amd import _capi
+    pw = r_host.shape[1]
+    sets = []
+    for ln in range(2):
+        _capi.check(L.pgpu_set_batch_lane(ln))
+        sets.append((B.up(m_host), B.up(r_host)))
+    _capi.check(L.pgpu_set_batch_lane(0))
+    st = {"c": [None, None], "o": [None, None], "i": 0}
+
+    def step():
+        k = st["i"] % 2
+        st["i"] += 1
+        B.free(st["c"][k], st["o"][k])
+        st["c"][k] = B.op(L.pgpu_batch_encrypt, pk._h, sets[k][0], sets[k][1], 64 * pw)
+        st["o"][k] = B.op(L.pgpu_batch_decrypt_crt, sk._h, st["c"][k])
+
+    def run():
+        for _ in range(4):
+            step()
+        _capi.check(L.pgpu_synchronize())
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        _capi.check(L.pgpu_synchronize())
+        return (time.perf_counter() - t0) / steps
+    t_def = run()
+    L.pgpu_debug_set_seq_decrypt(3)
+    try:
+        t_seq = run()
+        ok = all(bool(np.array_equal(B.down(o), m_host)) for o in st["o"])
+    finally:
+        L.pgpu_debug_set_seq_decrypt(1)
+    B.free(*st["c"], *st["o"], *[h for pair in sets for h in pair])
+    if not ok:
+        raise RuntimeError("round trip failed")
+    return {"what": "two batches in flight, %d steps each: default policy (paired decrypt kernel, 1024 wavefronts per launch) vs "
+                    "PGPU_SEQ_DECRYPT=3 (sequential-halves decrypt kernel, 512 wavefronts per launch on half the CUs, "
+                    "the two lanes' launches side by side); results checked" % steps,
+            "default_ms_per_step": round(t_def * 1e3, 3), "seq3_ms_per_step": round(t_seq * 1e3, 3),
+            "default_modexps_per_s": round(3 * BATCH / t_def, 1), "seq3_modexps_per_s": round(3 * BATCH / t_seq, 1)}
 
 
 def two_streams(L, pk, sk, m_host, r_host, steps=20):

@@ -1459,8 +1459,15 @@ const pgpu_privkey::HenselSet* pick_hensel(const pgpu_privkey* key, size_t count
 // fewer instructions per exponentiation on half the lanes.
 std::atomic<int> g_seq_policy{[] {
   const char* e = std::getenv("PGPU_SEQ_DECRYPT");
-  return e ? std::max(0, std::min(2, std::atoi(e))) : 1;
+  return e ? std::max(0, std::min(3, std::atoi(e))) : 1;
 }()};
+// (3: the mode for two batch lanes that are both kept busy -- a CRT decrypt also takes the form when it fills HALF the
+// chip, its workgroups claiming more than half a CU's LDS so that the two lanes' launches spread over all CUs; every
+// other operation as under 1)
+int seq_policy_by_size() {
+  const int p = g_seq_policy.load();
+  return p == 3 ? 1 : p;
+}
 std::atomic<int> g_ab_policy{[] {
   const char* e = std::getenv("PGPU_AB_DECRYPT");
   return e ? std::max(0, std::min(3, std::atoi(e))) : 0;
@@ -1471,7 +1478,7 @@ bool fb_encrypt_seq_pays(int H, int K, size_t count) {
   if (!pgpu::hensel_fb_encrypt_seq_has(H, K)) return false;
   const size_t ipw = 64 / (size_t)H;
   const size_t waves = (count + ipw - 1) / ipw;
-  const int pol = g_seq_policy.load();
+  const int pol = seq_policy_by_size();
   // (8-lane groups pay two DPP moves per row broadcast: alone on a SIMD the form is 2 % behind the paired kernel --
   // 3072-bit keys, 8192 elements: 3.60 against 3.52 ms -- and 7 % ahead with two wavefronts per SIMD: 6.2 against 6.7 ms)
   return pol == 2 || (pol == 1 && waves >= (H >= 8 ? 2 : 1) * kSimds);
@@ -1480,7 +1487,7 @@ bool modexp_seq_form_pays(int H, int K, size_t count) {
   if (!pgpu::hensel_modexp_seq_has(H, K)) return false;
   const size_t ipw = 64 / (size_t)H;
   const size_t waves = (count + ipw - 1) / ipw;
-  const int pol = g_seq_policy.load();
+  const int pol = seq_policy_by_size();
   return pol == 2 || (pol == 1 && waves >= kSimds);
 }
 // the sequential-halves form (csrc/hensel_seq.hpp) for a decrypt of `count` resident ciphertexts in form (H, K)?
@@ -1489,7 +1496,7 @@ bool seq_form_pays(int H, int K, size_t count) {
   const size_t ipw = 64 / (size_t)H;
   const size_t waves = 2 * ((count + ipw - 1) / ipw);
   const int pol = g_seq_policy.load();
-  return pol == 2 || (pol == 1 && waves >= kSimds);
+  return pol == 2 || (pol == 3 && 2 * waves >= kSimds) || (pol == 1 && waves >= kSimds);
 }
 int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m, size_t count,
                hipStream_t s, bool in_mont, const uint32_t* d_pair = nullptr, int in_pair_l2 = 0, bool other_lane_busy = false) {
@@ -1572,10 +1579,13 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
       const unsigned sblocks = (unsigned)((seq_waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
       RC_TRY(w.table.ensure((size_t)sblocks * pgpu::kWavesPerWG * seq_ipw * entries * 2 * L2 * sizeof(uint32_t), s));
       h.table = (uint32_t*)w.table.p;
-      static const unsigned lds_pad = [] {
+      static const int env_pad = [] {
         const char* e = getenv("PGPU_SEQ_LDS_PAD");
-        return e ? (unsigned)atoi(e) : 0u;
+        return e ? atoi(e) : -1;
       }();
+      // a launch that covers less than the chip leaves the other CUs to the neighbour lane's launch (policy 3)
+      const unsigned lds_pad = env_pad >= 0 ? (unsigned)env_pad
+                                            : (g_seq_policy.load() == 3 && seq_waves < kSimds ? 84000u : 0u);
       if (!pgpu::launch_hensel_seq(hset->H, hset->K, h, sblocks, s, lds_pad))
         return fail(PGPU_ERR_UNSUPPORTED, "sequential-halves decrypt kernel not compiled");
     } else if (ab) {
@@ -1667,7 +1677,7 @@ bool pair_mul_seq_pays(int H, int K, size_t count) {
   if (!pgpu::pair_mul_seq_has(H, K)) return false;
   const size_t ipw = 64 / (size_t)H;
   const size_t waves = (count + ipw - 1) / ipw;
-  const int pol = g_seq_policy.load();
+  const int pol = seq_policy_by_size();
   return pol == 2 || (pol == 1 && waves >= kSimds);
 }
 int pair_op_launch(rt::Device& d, const pgpu_pubkey::PubForm* f, pgpu::PairOpsArgs& a, hipStream_t s, int kind) {
@@ -2041,7 +2051,7 @@ void pgpu_debug_set_packed_decrypt(int on) { g_packed_decrypt.store(on != 0); }
 // tests / A-B measurements: the A/B-wavefront decrypt kernel (hensel_ab.hpp): 0 never, 1 whenever it applies, 2 when the
 // other batch lane is busy.  Not part of the public header.
 // tests / A-B measurements: hensel_seq.hpp (0 never, 1 by launch size, 2 whenever it applies).  Not part of the public header.
-void pgpu_debug_set_seq_decrypt(int policy) { g_seq_policy.store(policy < 0 ? 0 : (policy > 2 ? 2 : policy)); }
+void pgpu_debug_set_seq_decrypt(int policy) { g_seq_policy.store(policy < 0 ? 0 : (policy > 3 ? 3 : policy)); }
 void pgpu_debug_set_ab_decrypt(int policy) { g_ab_policy.store(policy < 0 ? 0 : (policy > 3 ? 3 : policy)); }
 
 int pgpu_set_timing(int enabled) {
