@@ -967,26 +967,27 @@ def run_ranks(args, world):
     n = p * q
     pk, sk = pa.PublicKey(n, KEY_BITS, hs=hs), pa.PrivateKey(p, q)
 
+    # the same step as the pool path (run_pool): resident batches of the rank's own GPU (a one-entry pool), ciphertexts
+    # stay in the library's device-side form, two batches in flight on its two batch lanes
     m_host, r_host = synth(rank, BATCH, nw, pw)
-    d_m = torch.from_numpy(m_host.view(np.int64)).cuda()
-    d_r = torch.from_numpy(r_host.view(np.int64)).cuda()
-    # two batches in flight per GPU, as in the pool path: consecutive steps alternate between two HIP streams
+    B = Batches(L, _capi.check)
     nfl = args.in_flight
-    streams = [torch.cuda.Stream() for _ in range(nfl)]
-    d_cs = [torch.empty((BATCH, 2 * nw), dtype=torch.int64, device="cuda") for _ in range(nfl)]
-    d_outs = [torch.empty((BATCH, nw), dtype=torch.int64, device="cuda") for _ in range(nfl)]
-    torch.cuda.synchronize()
-    counter = {"i": 0}
+    sets = []
+    for ln in range(nfl):
+        _capi.check(L.pgpu_set_batch_lane(ln))
+        sets.append((B.up(m_host), B.up(r_host)))
+    _capi.check(L.pgpu_set_batch_lane(0))
+    state = {"c": [None] * nfl, "out": [None] * nfl, "i": 0}
 
     def step():
-        k = counter["i"] % nfl
-        counter["i"] += 1
-        sptr = ctypes.c_void_p(streams[k].cuda_stream)
-        _capi.check(L.pgpu_paillier_encrypt_dev(pk._h, d_m.data_ptr(), nw, nw, d_r.data_ptr(), pw, pw, 64 * pw,
-                                                d_cs[k].data_ptr(), BATCH, sptr))
-        _capi.check(L.pgpu_paillier_decrypt_crt_dev(sk._h, d_cs[k].data_ptr(), d_outs[k].data_ptr(), BATCH, sptr))
+        k = state["i"] % nfl
+        state["i"] += 1
+        B.free(state["c"][k], state["out"][k])
+        state["c"][k] = B.op(L.pgpu_batch_encrypt, pk._h, sets[k][0], sets[k][1], 64 * pw)
+        state["out"][k] = B.op(L.pgpu_batch_decrypt_crt, sk._h, state["c"][k])
 
     def sync_all():
+        _capi.check(L.pgpu_synchronize())
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
@@ -1002,25 +1003,28 @@ def run_ranks(args, world):
     elapsed = time.perf_counter() - t0
     if nfl == 1:
         per_kind = collect_timing(L, 4 * args.steps + 8)
-    else:                       # per-kernel times from a short pass on ONE stream (launches do not overlap in it)
+    else:                       # per-kernel times from a short pass on ONE lane (launches do not overlap in it)
         _capi.check(L.pgpu_set_timing(1))
         for _ in range(6):
-            counter["i"] = 0
+            state["i"] = 0
             step()
-        torch.cuda.synchronize()
+        _capi.check(L.pgpu_synchronize())
         per_kind = collect_timing(L, 64)
     _capi.check(L.pgpu_set_timing(0))
-    d_c, d_out = d_cs[0], d_outs[0]
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    ok = all(bool(torch.equal(o, d_m)) for o in d_outs)
+    ok = all(bool(np.array_equal(B.down(o), m_host)) for o in state["out"])
     if rank == 0:
         from oracle import paillier_oracle as orc
         opk = orc.PublicKey(n, KEY_BITS)
         opk.set_djn(hs)
-        ok = ok and limbs_to_ints(d_c[:3].cpu().numpy().view(np.uint64)) == \
+        ok = ok and limbs_to_ints(B.down(state["c"][0])[:3]) == \
             opk.encrypt(limbs_to_ints(m_host[:3]), limbs_to_ints(r_host[:3]))
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)                 # every rank's round trip
+    ok = bool(flag.item())
+    row_limbs = L.pgpu_batch_row_limbs(state["c"][0])
     if not ok:
         raise SystemExit("bench: GPU results differ from the oracle / round trip failed")
     if rank == 0:
@@ -1030,10 +1034,12 @@ def run_ranks(args, world):
                       encrypt_kernel(pk, BATCH, nw, KEY_BITS, int(os.environ.get("PGPU_FB_WINDOW", "12"))))
         result["config"]["secret_exponent_policy"] = ["fixed-window", "sliding"][L.pgpu_get_secret_exponent_policy()]
         result["config"]["batches_in_flight_per_gpu"] = nfl
+        result["config"]["resident_ciphertext_form"] = ("pair rows (%d limbs)" % row_limbs) if row_limbs else "Montgomery-form words"
         if nfl == 2:
-            result["config"]["workload"] += ("; TWO batches in flight per GPU: consecutive steps alternate between two HIP "
-                                             "streams, exactly K steps timed")
+            result["config"]["workload"] += ("; TWO batches in flight per GPU: consecutive steps alternate between the "
+                                             "library's two batch lanes (streams), exactly K steps timed")
         print(json.dumps(result), flush=True)
+    B.free(*state["c"], *state["out"], *[h for pair in sets for h in pair])
     dist.barrier()
     dist.destroy_process_group()
     pa.terminate()
