@@ -53,7 +53,7 @@ def _objects():
         out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src] + kdeps))
     src = os.path.join(CSRC, "k_misc.hip")
     out.append((os.path.join(obj, "k_misc.o"), hip + ["-c", src, "-o", os.path.join(obj, "k_misc.o")], [src] + kdeps))
-    for part in range(26):
+    for part in range(30):
         src = os.path.join(CSRC, "k_hensel.hip")
         o = os.path.join(obj, f"k_hensel_{part}.o")
         out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src, os.path.join(CSRC, "hensel.hpp"), os.path.join(CSRC, "hensel_ab.hpp"), os.path.join(CSRC, "hensel_seq.hpp")] + kdeps))

@@ -1479,6 +1479,9 @@ bool fb_encrypt_seq_pays(int H, int K, size_t count) {
   const size_t ipw = 64 / (size_t)H;
   const size_t waves = (count + ipw - 1) / ipw;
   const int pol = seq_policy_by_size();
+  // (2-lane groups, 1024-bit keys: measured equal or behind the paired kernel at 65536 elements -- 1.04 against 1.02 ms,
+  // 0.96 against 0.92 ms: 19 limbs per lane and the LDS staging leave no register room -- so only when forced)
+  if (H == 2 && pol != 2) return false;
   // (8-lane groups pay two DPP moves per row broadcast: alone on a SIMD the form is 2 % behind the paired kernel --
   // 3072-bit keys, 8192 elements: 3.60 against 3.52 ms -- and 7 % ahead with two wavefronts per SIMD: 6.2 against 6.7 ms)
   return pol == 2 || (pol == 1 && waves >= (H >= 8 ? 2 : 1) * kSimds);
@@ -1488,7 +1491,10 @@ bool modexp_seq_form_pays(int H, int K, size_t count) {
   const size_t ipw = 64 / (size_t)H;
   const size_t waves = (count + ipw - 1) / ipw;
   const int pol = seq_policy_by_size();
-  return pol == 2 || (pol == 1 && waves >= kSimds);
+  // (2-lane groups, 1024-bit keys: measured equal or behind the paired kernel at 65536 elements -- 1.04 against 1.02 ms,
+  // 0.96 against 0.92 ms: 19 limbs per lane and the LDS staging leave no register room -- so only when forced)
+  if (H == 2 && pol != 2) return false;
+  return pol == 2 || (pol == 1 && waves >= (H >= 8 ? 2 : 1) * kSimds);   // (8-lane groups: see fb_encrypt_seq_pays)
 }
 // the sequential-halves form (csrc/hensel_seq.hpp) for a decrypt of `count` resident ciphertexts in form (H, K)?
 bool seq_form_pays(int H, int K, size_t count) {
@@ -1678,7 +1684,7 @@ bool pair_mul_seq_pays(int H, int K, size_t count) {
   const size_t ipw = 64 / (size_t)H;
   const size_t waves = (count + ipw - 1) / ipw;
   const int pol = seq_policy_by_size();
-  return pol == 2 || (pol == 1 && waves >= kSimds);
+  return pol == 2 || (pol == 1 && waves >= (H >= 8 ? 2 : 1) * kSimds);   // (8-lane groups: see fb_encrypt_seq_pays)
 }
 int pair_op_launch(rt::Device& d, const pgpu_pubkey::PubForm* f, pgpu::PairOpsArgs& a, hipStream_t s, int kind) {
   // CT + CT of launches that still put a wavefront on every SIMD with half the lanes per element: both halves of a

@@ -5,7 +5,7 @@
 #include "launch.hpp"
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..25"
+#error "compile with -DPGPU_PART=0..29"
 #endif
 
 namespace pgpu {
@@ -141,6 +141,54 @@ bool launch_hensel_fb_encrypt_seq_part20(int G, int K, const HenselFbArgs& a, un
 bool launch_hensel_fb_encrypt_seq_part21(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
   if (G == 8 && K == 14) {
     hipLaunchKernelGGL((hensel_fb_encrypt_seq_kernel<8, 14>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  return false;
+}
+#elif PGPU_PART == 26
+bool launch_hensel_modexp_seq_part26(int G, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
+  if (G == 8 && K == 14) {
+    hipLaunchKernelGGL((hensel_modexp_seq_kernel<8, 14>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  return false;
+}
+#elif PGPU_PART == 27
+bool launch_pair_mul_seq_part27(int G, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s) {
+  if (G == 8 && K == 14) {
+    hipLaunchKernelGGL((pair_mul_seq_kernel<8, 14>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  if (G == 2 && K == 19) {
+    hipLaunchKernelGGL((pair_mul_seq_kernel<2, 19>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  return false;
+}
+#elif PGPU_PART == 28
+bool launch_hensel_modexp_seq_part28(int G, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
+  if (G == 2 && K == 19) {
+    hipLaunchKernelGGL((hensel_modexp_seq_kernel<2, 19>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  return false;
+}
+bool launch_hensel_fb_encrypt_seq_part28(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
+  if (G == 2 && K == 19) {
+    hipLaunchKernelGGL((hensel_fb_encrypt_seq_kernel<2, 19>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    return true;
+  }
+  return false;
+}
+#elif PGPU_PART == 29
+bool launch_hensel_seq_part29(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad) {
+  if (G == 2 && K == 10) {
+    if (lds_pad) {
+      static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_seq_kernel<2, 10>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (once != hipSuccess) return false;
+    }
+    hipLaunchKernelGGL((hensel_decrypt_seq_kernel<2, 10>), dim3(blocks), dim3(kWGThreads), lds_pad, s, a);
     return true;
   }
   return false;

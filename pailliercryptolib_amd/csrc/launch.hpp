@@ -122,35 +122,44 @@ inline bool launch_hensel_ab(int K, int pairs_per_wg, const HenselArgs& a, unsig
 
 // CRT decrypt with both halves of a residue in the same lanes (hensel_seq.hpp; k_hensel.hip parts 16, 17): pair-row
 // ciphertexts, fixed-window scan, launches of two or more wavefronts per SIMD; (4,14): 3072-bit keys, (2,19): 2048-bit
-inline bool hensel_seq_has(int G, int K) { return (G == 4 && K == 14) || (G == 2 && K == 19); }
+inline bool hensel_seq_has(int G, int K) { return (G == 4 && K == 14) || (G == 2 && (K == 19 || K == 10)); }   // (2,10): 1024-bit keys (part 29)
 // lds_pad: bytes of LDS the workgroup claims beyond what it uses (0: none) -- more than half a CU's LDS keeps a second
 // workgroup off the CU, so two half-chip launches on different streams spread over all CUs instead of stacking
 bool launch_hensel_seq_part16(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
 bool launch_hensel_seq_part17(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
+bool launch_hensel_seq_part29(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
 inline bool launch_hensel_seq(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad = 0) {
-  return launch_hensel_seq_part16(G, K, a, blocks, s, lds_pad) || launch_hensel_seq_part17(G, K, a, blocks, s, lds_pad);
+  return launch_hensel_seq_part16(G, K, a, blocks, s, lds_pad) || launch_hensel_seq_part17(G, K, a, blocks, s, lds_pad) ||
+         launch_hensel_seq_part29(G, K, a, blocks, s, lds_pad);
 }
 
 // per-element bases modulo n^2 in the same form (k_hensel.hip part 18): resident pair rows in and out, fixed window
-inline bool hensel_modexp_seq_has(int G, int K) { return G == 4 && K == 18; }
+// (4,18): 2048-bit keys, (8,14): 3072 (part 26), (2,19): 1024 (part 28)
+inline bool hensel_modexp_seq_has(int G, int K) { return (G == 4 && K == 18) || (G == 8 && K == 14) || (G == 2 && K == 19); }
 bool launch_hensel_modexp_seq_part18(int G, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
+bool launch_hensel_modexp_seq_part26(int G, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
+bool launch_hensel_modexp_seq_part28(int G, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
 inline bool launch_hensel_modexp_seq(int G, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
-  return launch_hensel_modexp_seq_part18(G, K, a, blocks, s);
+  return launch_hensel_modexp_seq_part18(G, K, a, blocks, s) || launch_hensel_modexp_seq_part26(G, K, a, blocks, s) ||
+         launch_hensel_modexp_seq_part28(G, K, a, blocks, s);
 }
 
 // CT + CT on pair rows in the same form (k_hensel.hip part 19)
-inline bool pair_mul_seq_has(int G, int K) { return G == 4 && K == 18; }
+inline bool pair_mul_seq_has(int G, int K) { return (G == 4 && K == 18) || (G == 8 && K == 14) || (G == 2 && K == 19); }
 bool launch_pair_mul_seq_part19(int G, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s);
+bool launch_pair_mul_seq_part27(int G, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s);
 inline bool launch_pair_mul_seq(int G, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s) {
-  return launch_pair_mul_seq_part19(G, K, a, blocks, s);
+  return launch_pair_mul_seq_part19(G, K, a, blocks, s) || launch_pair_mul_seq_part27(G, K, a, blocks, s);
 }
 
-// DJN encrypt to pair rows in the same form (k_hensel.hip parts 20, 21): (4,18) 2048-bit keys, (8,14) 3072-bit keys
-inline bool hensel_fb_encrypt_seq_has(int G, int K) { return (G == 4 && K == 18) || (G == 8 && K == 14); }
+// DJN encrypt to pair rows in the same form (k_hensel.hip parts 20, 21, 28): (4,18) 2048-bit keys, (8,14) 3072, (2,19) 1024
+inline bool hensel_fb_encrypt_seq_has(int G, int K) { return (G == 4 && K == 18) || (G == 8 && K == 14) || (G == 2 && K == 19); }
+bool launch_hensel_fb_encrypt_seq_part28(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_fb_encrypt_seq_part20(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_fb_encrypt_seq_part21(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
 inline bool launch_hensel_fb_encrypt_seq(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
-  return launch_hensel_fb_encrypt_seq_part20(G, K, a, blocks, s) || launch_hensel_fb_encrypt_seq_part21(G, K, a, blocks, s);
+  return launch_hensel_fb_encrypt_seq_part20(G, K, a, blocks, s) || launch_hensel_fb_encrypt_seq_part21(G, K, a, blocks, s) ||
+         launch_hensel_fb_encrypt_seq_part28(G, K, a, blocks, s);
 }
 
 bool launch_modmul(int G, int K, const ModmulArgs& a, unsigned blocks, hipStream_t s);

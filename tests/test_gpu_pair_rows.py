@@ -263,7 +263,7 @@ def test_ab_wavefront_decrypt_kernel_is_bit_identical(engine):
         R.close()
 
 
-@pytest.mark.parametrize("bits,count", [(3072, 300), (2048, 515)])
+@pytest.mark.parametrize("bits,count", [(3072, 300), (2048, 515), (1024, 1100)])
 def test_sequential_halves_decrypt_kernel_is_bit_identical(engine, bits, count):
     """csrc/hensel_seq.hpp: both halves of a residue in the same lanes, one after the other (the form large launches take
     by default; forced here at test sizes).  Same plaintexts as the paired kernel and the oracle, ragged batch, with and
@@ -298,13 +298,12 @@ def test_sequential_halves_decrypt_kernel_is_bit_identical(engine, bits, count):
         R.close()
 
 
-@pytest.mark.parametrize("ebits,count", [(40, 530), (2048, 70)])
-def test_sequential_halves_ct_times_pt_is_bit_identical(engine, ebits, count):
+@pytest.mark.parametrize("bits,ebits,count", [(2048, 40, 530), (2048, 2048, 70), (3072, 33, 130), (1024, 64, 1000)])
+def test_sequential_halves_ct_times_pt_is_bit_identical(engine, bits, ebits, count):
     """hensel_modexp_seq_kernel (csrc/hensel_seq.hpp): CT x PT of a resident batch with both halves of a residue in the
     same lanes (the form launches of 16384+ elements take; forced here).  Same ciphertexts as pow() and as the paired
     kernel, ragged batch, edge exponents, a one-row exponent batch, with and without the masked table gather."""
     from pailliercryptolib_amd import _capi
-    bits = 2048
     p, q, hs = key_case(bits, True)
     n = p * q
     nsq = n * n
@@ -342,12 +341,12 @@ def test_sequential_halves_ct_times_pt_is_bit_identical(engine, ebits, count):
         R.close()
 
 
-def test_sequential_halves_ct_plus_ct_is_bit_identical(engine):
+@pytest.mark.parametrize("bits,count", [(2048, 523), (3072, 140), (1024, 1030)])
+def test_sequential_halves_ct_plus_ct_is_bit_identical(engine, bits, count):
     """pair_mul_seq_kernel (csrc/hensel_seq.hpp): CT + CT of resident batches as one pair product with both halves of a
     residue in the same lanes (launches of 16384+ elements; forced here): same ciphertexts as the product modulo n^2 and
     as the paired kernel, ragged batch, a one-row operand, chained twice."""
     from pailliercryptolib_amd import _capi
-    bits, count = 2048, 523
     p, q, hs = key_case(bits, True)
     n = p * q
     nsq = n * n
@@ -382,7 +381,7 @@ def test_sequential_halves_ct_plus_ct_is_bit_identical(engine):
         R.close()
 
 
-@pytest.mark.parametrize("bits,count", [(2048, 521), (3072, 150)])
+@pytest.mark.parametrize("bits,count", [(2048, 521), (3072, 150), (1024, 1050)])
 def test_sequential_halves_djn_encrypt_is_bit_identical(engine, bits, count):
     """hensel_fb_encrypt_seq_kernel (csrc/hensel_seq.hpp): DJN encrypt onto pair rows with both halves of a residue in the
     same lanes (launches of 16384+ / 8192+ elements; forced here).  Same ciphertexts as the oracle and as the paired kernel:
