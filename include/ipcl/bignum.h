@@ -18,9 +18,46 @@
 #include <cstdint>
 #include <ostream>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "ipcl/utils/serialize.hpp"
+
+namespace ipcl {
+namespace detail {
+// Limb storage of BigNumber.  An API call creates and destroys vectors of thousands of BigNumbers (8192 plaintexts in,
+// 8192 ciphertexts out): with one heap block per value, malloc / free are the bulk of the host time of such a call
+// (profiles/r03_api_stage_probe.txt).  A thread may therefore open a BULK SCOPE: while it is open, the limb blocks this
+// thread allocates are carved out of one arena with a bump pointer, and freed by a counter -- the arena returns to the
+// heap when its last block has died (so one surviving BigNumber of a batch keeps that batch's arena alive: a few MB).
+// Outside a scope, and when an arena is full, blocks come from malloc as before.  Every block carries a 16-byte header
+// that says where it came from, so any thread may free any block.
+void* limb_alloc(std::size_t bytes);
+void limb_free(void* p) noexcept;
+void limb_bulk_begin(std::size_t bytes_hint);
+void limb_bulk_end() noexcept;
+struct LimbBulkScope {
+  explicit LimbBulkScope(std::size_t bytes_hint) { limb_bulk_begin(bytes_hint); }
+  ~LimbBulkScope() { limb_bulk_end(); }
+  LimbBulkScope(const LimbBulkScope&) = delete;
+  LimbBulkScope& operator=(const LimbBulkScope&) = delete;
+};
+template <class T>
+struct LimbAllocator {
+  using value_type = T;
+  using is_always_equal = std::true_type;
+  LimbAllocator() noexcept = default;
+  template <class U>
+  LimbAllocator(const LimbAllocator<U>&) noexcept {}
+  T* allocate(std::size_t n) { return static_cast<T*>(limb_alloc(n * sizeof(T))); }
+  void deallocate(T* p, std::size_t) noexcept { limb_free(p); }
+  template <class U>
+  bool operator==(const LimbAllocator<U>&) const noexcept { return true; }
+  template <class U>
+  bool operator!=(const LimbAllocator<U>&) const noexcept { return false; }
+};
+}  // namespace detail
+}  // namespace ipcl
 
 typedef uint8_t Ipp8u;
 typedef uint32_t Ipp32u;
@@ -31,6 +68,7 @@ typedef enum { IppsBigNumNEG = 0, IppsBigNumPOS = 1 } IppsBigNumSGN;
 
 class BigNumber {
  public:
+  using Limbs = std::vector<uint64_t, ipcl::detail::LimbAllocator<uint64_t>>;
   BigNumber(Ipp32u value = 0);
   BigNumber(Ipp32s value);
   BigNumber(const Ipp32u* pData, int length = 1, IppsBigNumSGN sgn = IppsBigNumPOS);
@@ -111,7 +149,7 @@ class BigNumber {
   // Returns false if the magnitude does not fit.
   bool toLimbs64(uint64_t* out, std::size_t nlimbs) const;
   static BigNumber fromLimbs64(const uint64_t* limbs, std::size_t nlimbs);
-  const std::vector<uint64_t>& limbs64() const { return m_mag; }
+  const Limbs& limbs64() const { return m_mag; }
   bool isNegative() const { return m_neg; }
   bool isZero() const { return m_mag.empty(); }
 
@@ -124,7 +162,7 @@ class BigNumber {
   static void divmod(const BigNumber& a, const BigNumber& d, BigNumber* q, BigNumber* r);
 
  protected:
-  std::vector<uint64_t> m_mag;  // magnitude, little-endian, no leading zero limbs; empty == 0
+  Limbs m_mag;                  // magnitude, little-endian, no leading zero limbs; empty == 0
   bool m_neg = false;           // sign; never set for zero
   void trim();
 };

@@ -66,6 +66,10 @@ class PublicKey {
   // PublicKey, as in the reference (ciphertext.cpp:12-22), and must not drag a batch of BigNumbers along
   std::shared_ptr<const std::vector<BigNumber>> m_r;
   bool m_testv = false;
+  // device copy of the injected randomness (setRandom), built at the first encrypt that uses it: the same values feed
+  // every encrypt until setRandom is called again (pub_key.cpp:92-95), so they are packed and uploaded once
+  struct InjectedRandom;
+  mutable std::shared_ptr<InjectedRandom> m_r_dev;
   // device-side key (n^2 Montgomery context, hs; one copy per pool GPU): rebuilt by every mutator, read-only
   // in between, shared by copies of the key
   std::shared_ptr<detail::PubKeyDevice> m_dev;

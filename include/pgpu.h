@@ -85,6 +85,12 @@ int pgpu_device_count(void);       /* visible HIP devices */
 int pgpu_is_initialized(void);
 const char* pgpu_last_error(void);
 const char* pgpu_device_name(void); /* of the calling thread's current pool entry */
+/* What this library binary was built with (host-side query, needs no device): bit 0 = the split forms of the 4096-bit
+ * key class (build switch PGPU_BUILD_4096=1; without them such keys run the full-width kernels), bit 1 = the
+ * A/B-wavefront decrypt experiment (PGPU_BUILD_AB=1).  Results never depend on either. */
+#define PGPU_FEATURE_4096_SPLIT 1
+#define PGPU_FEATURE_AB_DECRYPT 2
+int pgpu_build_features(void);
 int pgpu_pool_size(void);           /* entries of the pool (0 before init) */
 int pgpu_set_device(int pool_index);/* pool entry addressed by this thread's `_dev` / dev_alloc / copy calls */
 int pgpu_get_device(void);
@@ -189,6 +195,18 @@ void pgpu_dev_free(void* d_ptr);
 int pgpu_copy_h2d(void* d_dst, const void* h_src, size_t bytes);
 int pgpu_copy_d2h(void* h_dst, const void* d_src, size_t bytes);
 
+/* ---- pinned host memory ----
+ * A caller buffer that lies inside a block from pgpu_host_alloc is the source / target of the DMA itself: every
+ * host-pointer entry point, pgpu_batch_upload and pgpu_batch_download then skip their staging copies (a host thread moves
+ * 8-10 GB/s between pageable and pinned memory, the link ~50 GB/s).  The reference's accelerator path does the same: HE-QAT
+ * takes its operand buffers from the device driver's pinned allocator (module/heqat/heqat/bnops.c: qaeMemAllocNUMA).
+ * pgpu_batch_upload from such a block only QUEUES the copy: the block must not be modified until pgpu_host_wait(ptr)
+ * has returned (pgpu_host_free waits too; every other entry point is synchronous as before).  Results that land in a
+ * block are complete on return.  Blocks are usable with every GPU of the pool and survive pgpu_shutdown. */
+int pgpu_host_alloc(size_t bytes, void** out);
+void pgpu_host_free(void* ptr);
+int pgpu_host_wait(const void* ptr /* any address inside a block */);
+
 /* ---- exponent schedules of private-key constants (see SIDE CHANNELS above) ---- */
 typedef enum pgpu_exp_policy {
   PGPU_EXP_FIXED_WINDOW = 0, /* default: key-independent operation sequence                     */
@@ -231,12 +249,15 @@ int pgpu_batch_is_montgomery(const pgpu_batch* b);   /* 1: a device-side domain 
  * the register image of the split-form kernels: CT+CT is ONE pair product, CT+PT two half-width products, encrypt /
  * CT*PT / CRT decrypt read and write the rows without any conversion.  PGPU_PAIR_ROWS=0 keeps Montgomery words. */
 int pgpu_batch_row_limbs(const pgpu_batch* b);
-/* Batch lanes: every GPU of the pool has TWO batch streams, so two independent chains of resident batches can be in
- * flight at once (their kernels share the SIMDs: a wavefront that is alone on a SIMD issues ~8 % slower than two).
- * Uploads and pgpu_batch_create take the calling thread's lane (default 0); every result inherits the lane of the
- * operation's first operand; operands of the other lane are ordered in by events. */
-int pgpu_set_batch_lane(int lane /* 0 | 1 */);
+/* Batch lanes: every GPU of the pool has pgpu_batch_lanes() (4) batch streams, so that many independent chains of
+ * resident batches can be in flight at once (their kernels share the chip: a wavefront that is alone on a SIMD issues
+ * ~8 % slower than two, and the sequential-halves kernels -- 11-17 % fewer instructions -- need 16384 ciphertexts in
+ * flight to reach every SIMD).  Uploads and pgpu_batch_create take the calling thread's lane (default 0); every result
+ * inherits the lane of the operation's first operand; operands of another lane are ordered in by events.  What a launch
+ * looks like depends on whether its neighbour lanes are busy when it is queued (pgpu_decrypt_kernel_form_ex). */
+int pgpu_set_batch_lane(int lane /* 0 .. pgpu_batch_lanes() - 1 */);
 int pgpu_batch_lane(const pgpu_batch* b);
+int pgpu_batch_lanes(void);
 /* c = Enc(m; r): m, r batches of `count` elements (PublicKey::encrypt, pub_key.cpp:112-129) */
 int pgpu_batch_encrypt(const pgpu_pubkey* key, const pgpu_batch* m, const pgpu_batch* r, int r_bits,
                        pgpu_batch** c);
@@ -264,6 +285,18 @@ typedef enum pgpu_kernel_kind {
 } pgpu_kernel_kind;
 int pgpu_set_timing(int enabled);
 int pgpu_timing_collect(int* kinds, double* ms, int max_entries);
+/* the same with the kernel FORM the launcher picked for each launch (forms may be NULL): bit 0 the paired split form
+ * (hensel.hpp: the two halves of a residue in neighbouring lanes), bit 1 the sequential-halves form (hensel_seq.hpp:
+ * both halves in the same lanes), bit 4 the launch claimed whole CUs (a half-chip launch beside a busy neighbour lane);
+ * 0: a full-width kernel.  With the adaptive policy the form depends on what the GPU's other batch lanes were doing
+ * at launch time, so a measurement reports what actually ran. */
+typedef enum pgpu_kernel_form {
+  PGPU_FORM_FULL_WIDTH = 0,
+  PGPU_FORM_PAIRED = 1,
+  PGPU_FORM_SEQ = 2,
+  PGPU_FORM_CU_CLAIM = 16
+} pgpu_kernel_form;
+int pgpu_timing_collect_ex(int* kinds, int* forms, double* ms, int max_entries);
 /* Kernel geometry a batch of `count` exponentiations / products under an odd modulus of mod_bits bits
  * (operand rows of in_words 64-bit words) is launched with: *lanes lanes per element, *limbs 29-bit limbs
  * per lane (modexp_kernel; small batches take a 16-lane latency split, large ones the wide split).  Pure
@@ -276,12 +309,18 @@ int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, i
  * lanes, launches that still put a wavefront on every SIMD that way (PGPU_SEQ_DECRYPT=0 turns it off); *split = 0:
  * the full-width modexp_kernel<Geo<*lanes, *limbs>>.  Host-side query. */
 int pgpu_decrypt_kernel_form(const pgpu_privkey* key, size_t count, int* split, int* lanes, int* limbs);
+/* ... when `busy_lanes` OTHER batch lanes of the GPU have work queued at launch time (round 4, the adaptive policy: a
+ * launch that will share the chip anyway takes the sequential-halves form as soon as waves * (1 + busy_lanes) covers the
+ * SIMDs; pgpu_decrypt_kernel_form is the busy_lanes = 0 case, a lone caller) */
+int pgpu_decrypt_kernel_form_ex(const pgpu_privkey* key, size_t count, int busy_lanes, int* split, int* lanes, int* limbs);
 /* The same for an encrypt of `count` plaintext rows of m_words words: *split = 1: hensel_fb_encrypt_kernel<*lanes / 2,
  * *limbs> (DJN keys with a fixed-base window, 1024- to 3072-bit keys, plaintext rows no wider than n, batches that
  * fill the chip); *split = 2: results that stay resident as pair rows, launches that still put a wavefront on every SIMD
  * with half the lanes per element: hensel_fb_encrypt_seq_kernel<*lanes, *limbs> (PGPU_SEQ_DECRYPT=0 turns it off);
  * *split = 0: fb_encrypt_kernel / modexp_kernel <Geo<*lanes, *limbs>>. */
 int pgpu_encrypt_kernel_form(const pgpu_pubkey* key, int m_words, size_t count, int* split, int* lanes, int* limbs);
+int pgpu_encrypt_kernel_form_ex(const pgpu_pubkey* key, int m_words, size_t count, int busy_lanes, int* split, int* lanes,
+                                int* limbs);
 /* The same for the exponentiations modulo n^2 with per-element bases (CT x PT of a resident batch, the non-DJN
  * obfuscator r^n): *split = 1: hensel_modexp_kernel<*lanes / 2, *limbs>; *split = 2: the same for r^n, and for CT x PT
  * of a resident batch (pair rows in and out, per-element exponents) hensel_modexp_seq_kernel<*lanes, *limbs> (both halves

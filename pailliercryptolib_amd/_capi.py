@@ -32,7 +32,10 @@ SYMBOLS = [
     "pgpu_set_fixed_base_budget", "pgpu_fixed_base_stats", "pgpu_pubkey_fixed_base_info",
     "pgpu_batch_row_limbs", "pgpu_set_batch_lane", "pgpu_batch_lane",
     "pgpu_set_table_gather_policy", "pgpu_get_table_gather_policy",
+    "pgpu_build_features", "pgpu_batch_lanes", "pgpu_timing_collect_ex", "pgpu_decrypt_kernel_form_ex",
+    "pgpu_encrypt_kernel_form_ex", "pgpu_host_alloc", "pgpu_host_free", "pgpu_host_wait",
 ]
+FEATURE_4096_SPLIT, FEATURE_AB_DECRYPT = 1, 2
 
 _lib = None
 
@@ -145,6 +148,16 @@ def lib():
     L.pgpu_batch_lane.argtypes = [c_void_p]; L.pgpu_batch_lane.restype = c_int
     L.pgpu_set_table_gather_policy.argtypes = [c_int]; L.pgpu_set_table_gather_policy.restype = c_int
     L.pgpu_get_table_gather_policy.argtypes = []; L.pgpu_get_table_gather_policy.restype = c_int
+    L.pgpu_build_features.argtypes = []; L.pgpu_build_features.restype = c_int
+    L.pgpu_batch_lanes.argtypes = []; L.pgpu_batch_lanes.restype = c_int
+    L.pgpu_host_alloc.argtypes = [c_size_t, POINTER(c_void_p)]; L.pgpu_host_alloc.restype = c_int
+    L.pgpu_host_free.argtypes = [c_void_p]; L.pgpu_host_free.restype = None
+    L.pgpu_host_wait.argtypes = [c_void_p]; L.pgpu_host_wait.restype = c_int
+    L.pgpu_timing_collect_ex.argtypes = [c_void_p, c_void_p, c_void_p, c_int]; L.pgpu_timing_collect_ex.restype = c_int
+    L.pgpu_decrypt_kernel_form_ex.argtypes = [c_void_p, c_size_t, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
+    L.pgpu_decrypt_kernel_form_ex.restype = c_int
+    L.pgpu_encrypt_kernel_form_ex.argtypes = [c_void_p, c_int, c_size_t, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
+    L.pgpu_encrypt_kernel_form_ex.restype = c_int
     _lib = L
     return L
 

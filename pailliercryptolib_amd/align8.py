@@ -167,7 +167,9 @@ def compile_hip_aligned(hipcc, flags, src, obj, workdir):
         return r.returncode == 0, r.stderr
     kept = align_assembly(raw_s, fix_s, assemble)
     run([os.path.join(llvm, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", dev_out, dev_o])
-    run([os.path.join(llvm, "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
+    # (--compress: the bundles are zstd/zlib-compressed like hipcc --offload-compress does -- straight-line multiply-
+    # accumulate code shrinks 3-4x, the runtime inflates a code object when its module is first used)
+    run([os.path.join(llvm, "clang-offload-bundler"), "-type=o", "-bundle-align=4096"] + ([] if os.environ.get("PGPU_NO_COMPRESS") == "1" else ["--compress"]) + [
          "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", "-input=" + dev_out,
          "-output=" + fatbin])
     run([hipcc] + flags + ["--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fatbin, "-c", src, "-o", obj])

@@ -34,13 +34,40 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: cannot build the HIP extension (there is no CPU fallback)")
 
 
+def build_4096():
+    """PGPU_BUILD_4096=1 also builds the split forms of the 4096-bit key class (k_hensel.hip parts 22-24 and the (4,18) /
+    (8,9) decrypt forms): beyond every BASELINE config and the reference's own 2048-bit cap (ipcl/keygen.cpp:10), and
+    10-15 minutes of compile time per translation unit.  Off by default: such keys take the full-width kernels."""
+    return os.environ.get("PGPU_BUILD_4096", "0") == "1"
+
+
+def build_ab():
+    """PGPU_BUILD_AB=1 also builds the A/B-wavefront decrypt experiment (csrc/hensel_ab.hpp, k_hensel.hip part 15):
+    bit-identical, measured slower than the default kernel, never selected by default"""
+    return os.environ.get("PGPU_BUILD_AB", "0") == "1"
+
+
+def _switches():
+    return [f"-DPGPU_WITH_4096={1 if build_4096() else 0}", f"-DPGPU_WITH_AB={1 if build_ab() else 0}"]
+
+
+def hensel_parts():
+    """translation units of k_hensel.hip that the current switches ask for"""
+    skip = set()
+    if not build_4096():
+        skip |= {22, 23, 24}
+    if not build_ab():
+        skip |= {15}
+    return [p for p in range(30) if p not in skip]
+
+
 def _objects():
     """(object file, compile command, dependencies) of every translation unit of libpgpu.so.  The device code
     is split so that it compiles in parallel (k_modexp.hip once per PGPU_PART, k_misc.hip) and a change of the
     host runtime never recompiles a kernel."""
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
-    hip = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + inc
-    host = ["g++", "-O2", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + inc
+    hip = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + _switches() + inc
+    host = ["g++", "-O2", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + _switches() + inc
     kdeps = [os.path.join(CSRC, f) for f in ("kernels.hpp", "mont_core.hpp", "kargs.hpp", "launch.hpp")]
     hdeps = [os.path.join(CSRC, f) for f in ("kargs.hpp", "launch.hpp", "runtime.hpp")]
     hdeps += [os.path.join(ROOT, "include", "pgpu.h"), os.path.join(ROOT, "include", "ipcl", "bignum.h"),
@@ -53,10 +80,13 @@ def _objects():
         out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src] + kdeps))
     src = os.path.join(CSRC, "k_misc.hip")
     out.append((os.path.join(obj, "k_misc.o"), hip + ["-c", src, "-o", os.path.join(obj, "k_misc.o")], [src] + kdeps))
-    for part in range(30):
+    for part in hensel_parts():
         src = os.path.join(CSRC, "k_hensel.hip")
         o = os.path.join(obj, f"k_hensel_{part}.o")
-        out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src, os.path.join(CSRC, "hensel.hpp"), os.path.join(CSRC, "hensel_ab.hpp"), os.path.join(CSRC, "hensel_seq.hpp")] + kdeps))
+        hdeps_k = [os.path.join(CSRC, f) for f in ("hensel.hpp", "hensel_q.hpp", "hensel_seq.hpp")]
+        if part == 15:
+            hdeps_k.append(os.path.join(CSRC, "hensel_ab.hpp"))
+        out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src] + hdeps_k + kdeps))
     for name in ("capi.cpp", "runtime.cpp", os.path.join("host", "bignum.cpp")):
         src = os.path.join(CSRC, name)
         o = os.path.join(obj, os.path.basename(name).replace(".cpp", ".o"))
@@ -81,10 +111,33 @@ def compile_one(obj, cmd, extra_flags=()):
             import align8
         flags = [c for c in cmd[1:] if c not in ("-c", src, "-o", cmd[cmd.index("-o") + 1])] + list(extra_flags)
         print("[build] (aligned)", " ".join([cmd[0]] + flags + ["-c", src, "-o", obj]), file=sys.stderr, flush=True)
-        align8.compile_hip_aligned(cmd[0], flags, src, obj, os.path.join(os.path.dirname(obj), "align8"))
-        return
+        # The pass re-creates hipcc's device pipeline by hand (clang -> lld -> clang-offload-bundler under
+        # /opt/rocm/lib/llvm/bin, ROCm 7.2 layout) and rewrites assembly text.  On another ROCm layout, or when the
+        # assembler rejects the rewrite, the translation unit is compiled by plain hipcc instead: the result is the same
+        # code without the placement guarantee (a lone wavefront then runs 0-10 % slower, profiles/r03_code_placement.txt).
+        # Which path an object took is recorded beside it (<object>.how) and printed.
+        try:
+            align8.compile_hip_aligned(cmd[0], flags, src, obj, os.path.join(os.path.dirname(obj), "align8"))
+            _note_how(obj, "aligned")
+            return
+        except (RuntimeError, OSError, subprocess.CalledProcessError) as e:
+            detail = getattr(e, "stderr", None) or str(e)
+            print(f"[build] WARNING: alignment pass failed for {os.path.basename(obj)} ({str(detail).strip()[-300:]}); "
+                  "falling back to plain hipcc", file=sys.stderr, flush=True)
+            _note_how(obj, "plain (alignment pass failed)")
+    else:
+        _note_how(obj, "plain")
     cmd[cmd.index("-o") + 1] = obj
+    if src.endswith(".hip") and os.environ.get("PGPU_NO_COMPRESS") != "1":
+        cmd = cmd + ["--offload-compress"]      # (the aligned pipeline passes --compress to the bundler itself)
     _run(cmd + list(extra_flags))
+
+
+def _note_how(obj, how):
+    try:
+        open(obj + ".how", "w").write(how + "\n")
+    except OSError:
+        pass
 
 
 def build_pgpu(force=False):
@@ -100,17 +153,28 @@ def build_pgpu(force=False):
         force_dev = True
     else:
         force_dev = False
+    # the build switches change what launch.hpp declares as compiled: every object that includes it is stale when they
+    # change (the k_hensel parts that hold gated forms, and the host side)
+    cfg = " ".join(_switches())
+    cfg_path = os.path.join(HERE, "build", "switches.txt")
+    old_cfg = open(cfg_path).read().strip() if os.path.exists(cfg_path) else None
+    cfg_changed = old_cfg is not None and old_cfg != cfg
+    gated = ("k_hensel_1.o", "k_hensel_2.o", "capi.o")
     kdep = os.path.join(HERE, "align8.py")
     todo = [(o, cmd) for o, cmd, deps in objs
-            if force or _newer(o, deps + ([kdep] if cmd[-3].endswith(".hip") else [])) or (force_dev and cmd[-3].endswith(".hip"))]
+            if force or _newer(o, deps + ([kdep] if cmd[-3].endswith(".hip") else [])) or (force_dev and cmd[-3].endswith(".hip"))
+            or (cfg_changed and os.path.basename(o) in gated)]
     if todo:
-        # the 8-lane x 18-limb forms (4096-bit key class, parts 22-24) compile for 10-15 minutes each: start them first
+        # the 8-lane x 18-limb forms (4096-bit key class, parts 22-24; PGPU_BUILD_4096=1) compile for 10-15 minutes each:
+        # start them first
         slow = ("k_hensel_22.", "k_hensel_23.", "k_hensel_24.")
         todo.sort(key=lambda oc: 0 if os.path.basename(oc[0]).startswith(slow) else 1)
         with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
             list(ex.map(lambda oc: compile_one(oc[0], oc[1]), todo))
     open(stamp, "w").close()
-    if todo or not os.path.exists(out):
+    open(cfg_path, "w").write(cfg + "\n")
+    relink = cfg_changed or old_cfg is None
+    if todo or relink or not os.path.exists(out):
         _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _, _ in objs]
              + ["-ldl", "-lpthread", "-o", out])
     return out

@@ -73,7 +73,7 @@ const GeoInfo* pick_geo(int in_words, int mod_bits, bool unit_q = false) {
 }
 
 void to_limbs29(const BigNumber& v, int L, uint32_t* out) {
-  const std::vector<uint64_t>& w = v.limbs64();
+  const BigNumber::Limbs& w = v.limbs64();
   for (int i = 0; i < L; ++i) {
     int bit = i * pgpu::kLimbBits;
     size_t word = (size_t)bit >> 6;
@@ -409,13 +409,15 @@ struct TimerScope {
   hipStream_t s;
   bool on;
   rt::TimedLaunch t{};
-  TimerScope(rt::Device& dev, hipStream_t st, int kind) : d(dev), s(st), on(g_timing.load()) {
+  TimerScope(rt::Device& dev, hipStream_t st, int kind, int form = 0) : d(dev), s(st), on(g_timing.load()) {
     if (!on) return;
     t.kind = kind;
+    t.form = form;
     t.e0 = d.pool_event();
     t.e1 = d.pool_event();
     (void)hipEventRecord(t.e0, s);
   }
+  void set_form(int form) { t.form = form; }
   void stop() {
     if (!on) return;
     (void)hipEventRecord(t.e1, s);
@@ -670,7 +672,7 @@ int new_batch(size_t count, int words, std::unique_ptr<pgpu_batch>* out, int pai
   b->count = count;
   b->words = words;
   b->gen = rt::pool_generation();
-  b->lane = lane < 0 ? t_batch_lane : (lane & 1);
+  b->lane = lane < 0 ? t_batch_lane : (lane % rt::kBatchLanes);
   b->replicated = count == 1 && rt::pool_size() > 1;
   b->ndev = b->replicated ? rt::pool_size() : rt::shard_devices(count);
   b->shard.resize((size_t)b->ndev);
@@ -921,7 +923,7 @@ int modexp_square_on(rt::Device& d, const SquareCtx& sq, const uint64_t* d_base,
   std::lock_guard<std::mutex> lk(w.mu);
   RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * ipw * entries * 2 * L2 * sizeof(uint32_t), s));
   a.table = (uint32_t*)w.table.p;
-  TimerScope t(d, s, PGPU_KERNEL_MODEXP);
+  TimerScope t(d, s, PGPU_KERNEL_MODEXP, PGPU_FORM_PAIRED);
   if (!pgpu::launch_hensel_modexp(f->H, f->K, a, blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "split-form modexp kernel not compiled");
   HIP_TRY(hipGetLastError());
   t.stop();
@@ -1036,7 +1038,7 @@ void fb_make_room(int dev, size_t need) {
           }
       }
     if (!vlist) return;   // everything left is pinned: the caller allocates beyond the budget rather than fail
-    g_fb_dev_bytes[(size_t)dev] -= victim->bytes;
+    g_fb_dev_bytes[(size_t)dev] -= std::min(g_fb_dev_bytes[(size_t)dev], victim->bytes);
     fb_free_table(*victim);
     vlist->erase(victim);
     g_fb_evictions.fetch_add(1);
@@ -1078,7 +1080,7 @@ int fb_table_get(const pgpu_pubkey* key, std::vector<std::list<FbTable>>& lists,
   for (auto it = list.begin(); it != list.end();) {
     if (it->pins == 0) {
       g_fb_dev_bytes.resize(std::max(g_fb_dev_bytes.size(), (size_t)d.index + 1), 0);
-      g_fb_dev_bytes[(size_t)d.index] -= it->bytes;
+      g_fb_dev_bytes[(size_t)d.index] -= std::min(g_fb_dev_bytes[(size_t)d.index], it->bytes);
       fb_free_table(*it);
       it = list.erase(it);
     } else {
@@ -1204,7 +1206,7 @@ const pgpu_pubkey::PubForm* split_modexp_form(const pgpu_pubkey* key, size_t cou
   return (count + ipw - 1) / ipw > max_waves ? nullptr : last;
 }
 bool modexp_seq_form_pays(int H, int K, size_t count);
-bool fb_encrypt_seq_pays(int H, int K, size_t count);
+bool fb_encrypt_seq_pays(int H, int K, size_t count, int busy = 0);
 int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::PubForm* form, const uint64_t* d_base, size_t base_stride,
                     int base_words, bool base_mont, const uint64_t* d_exp, size_t exp_stride, int exp_words,
                     int exp_bits, const SchedRef* sched, int final_mul, const uint64_t* d_m, size_t m_stride,
@@ -1254,7 +1256,7 @@ int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::Pu
   std::lock_guard<std::mutex> lk(w.mu);
   RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * ipw * entries * 2 * H * K * sizeof(uint32_t), s));
   a.table = (uint32_t*)w.table.p;
-  TimerScope t(d, s, PGPU_KERNEL_MODEXP);
+  TimerScope t(d, s, PGPU_KERNEL_MODEXP, seq ? PGPU_FORM_SEQ : PGPU_FORM_PAIRED);
   if (seq) {
     if (!pgpu::launch_hensel_modexp_seq(H, K, a, blocks, s))
       return fail(PGPU_ERR_UNSUPPORTED, "sequential-halves modexp kernel not compiled");
@@ -1287,7 +1289,7 @@ int fb_table_for_split(const pgpu_pubkey* key, const pgpu_pubkey::PubForm* form,
 
 int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_t m_stride, int m_words,
                const uint64_t* d_r, size_t r_stride, int r_words, int r_bits, uint64_t* d_c, size_t count,
-               hipStream_t s, bool out_mont, size_t total_count, uint32_t* d_pair = nullptr) {
+               hipStream_t s, bool out_mont, size_t total_count, uint32_t* d_pair = nullptr, int busy_lanes = 0) {
   // d_pair: the ciphertexts leave as pair rows (resident batches; the caller has checked that the key has a pair form,
   // that the plaintext rows are no wider than n and that the obfuscator runs through a split-form kernel)
   const int W = 2 * key->n_words;
@@ -1346,7 +1348,8 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
       TimerScope t(d, s, PGPU_KERNEL_FB_ENCRYPT);
       // resident results of launches that still put a wavefront on every SIMD with half the lanes per element: both
       // halves of a residue in the same lanes (hensel_seq.hpp)
-      const bool seq = d_pair && fb_encrypt_seq_pays(form->H, form->K, count);
+      const bool seq = d_pair && fb_encrypt_seq_pays(form->H, form->K, count, busy_lanes);
+      t.set_form(seq ? PGPU_FORM_SEQ : PGPU_FORM_PAIRED);
       const int ipw = seq ? 64 / form->H : 64 / (2 * form->H);
       const unsigned blocks = (unsigned)(((count + ipw - 1) / ipw + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
       if (seq) {
@@ -1459,14 +1462,34 @@ const pgpu_privkey::HenselSet* pick_hensel(const pgpu_privkey* key, size_t count
 // fewer instructions per exponentiation on half the lanes.
 std::atomic<int> g_seq_policy{[] {
   const char* e = std::getenv("PGPU_SEQ_DECRYPT");
-  return e ? std::max(0, std::min(3, std::atoi(e))) : 1;
+  return e ? std::max(0, std::min(4, std::atoi(e))) : 4;
 }()};
-// (3: the mode for two batch lanes that are both kept busy -- a CRT decrypt also takes the form when it fills HALF the
-// chip, its workgroups claiming more than half a CU's LDS so that the two lanes' launches spread over all CUs; every
-// other operation as under 1)
+// (3: the round-3 opt-in mode for two batch lanes that are both kept busy -- a CRT decrypt also takes the form when it
+// fills HALF the chip, its workgroups claiming more than half a CU's LDS so that the two lanes' launches spread over all
+// CUs; every other operation as under 1.
+//  4 (default since round 4): ADAPTIVE -- by launch size as under 1, and a launch that would leave SIMDs empty in this
+// form takes it all the same when the GPU's OTHER batch lanes have work queued at launch time, i.e. when this launch
+// will share the chip anyway: with b busy neighbours it needs waves * (1 + b) >= SIMDs.  One busy neighbour: the
+// launch claims the LDS that keeps a second workgroup off its CUs (two half-chip launches side by side, as under 3);
+// two or more: no claim (two workgroups per CU, the launches of four lanes fill every SIMD twice).  A lone caller
+// -- nothing queued beside it -- keeps the full-chip paired kernels.  The probe is a hipStreamQuery per lane: what it
+// costs when it is wrong is bounded by one launch (a neighbour that drains early leaves a half-chip launch to
+// finish alone: 8.1 instead of 4.6 ms for 8192 ciphertexts).)
 int seq_policy_by_size() {
   const int p = g_seq_policy.load();
-  return p == 3 ? 1 : p;
+  return (p == 3 || p == 4) ? 1 : p;
+}
+// with `busy` other batch lanes at work, does a launch of `waves` wavefronts of a sequential-halves form fill its share?
+bool seq_adaptive(size_t waves, int busy) {
+  return g_seq_policy.load() == 4 && busy >= 1 && waves * (size_t)(1 + busy) >= kSimds;
+}
+// batch lanes of `dev` other than `lane` that have work queued right now
+int busy_other_lanes(rt::Device& dev, int lane) {
+  int busy = 0;
+  for (int k = 0; k < rt::kBatchLanes; ++k)
+    if (k != lane && hipStreamQuery(dev.bs(k)) == hipErrorNotReady) ++busy;
+  (void)hipGetLastError();
+  return busy;
 }
 std::atomic<int> g_ab_policy{[] {
   const char* e = std::getenv("PGPU_AB_DECRYPT");
@@ -1474,11 +1497,14 @@ std::atomic<int> g_ab_policy{[] {
 }()};
 int ab_policy() { return g_ab_policy.load(); }
 
-bool fb_encrypt_seq_pays(int H, int K, size_t count) {
+bool fb_encrypt_seq_pays(int H, int K, size_t count, int busy) {
   if (!pgpu::hensel_fb_encrypt_seq_has(H, K)) return false;
   const size_t ipw = 64 / (size_t)H;
   const size_t waves = (count + ipw - 1) / ipw;
   const int pol = seq_policy_by_size();
+  // (adaptive: beside busy neighbour lanes the form of half the wavefronts -- and a sixth fewer multiply-accumulates --
+  // also for launches that would not fill the chip alone; 4-lane groups only, see below for the others)
+  if (H == 4 && seq_adaptive(waves, busy)) return true;
   // (2-lane groups, 1024-bit keys: measured equal or behind the paired kernel at 65536 elements -- 1.04 against 1.02 ms,
   // 0.96 against 0.92 ms: 19 limbs per lane and the LDS staging leave no register room -- so only when forced)
   if (H == 2 && pol != 2) return false;
@@ -1497,15 +1523,16 @@ bool modexp_seq_form_pays(int H, int K, size_t count) {
   return pol == 2 || (pol == 1 && waves >= (H >= 8 ? 2 : 1) * kSimds);   // (8-lane groups: see fb_encrypt_seq_pays)
 }
 // the sequential-halves form (csrc/hensel_seq.hpp) for a decrypt of `count` resident ciphertexts in form (H, K)?
-bool seq_form_pays(int H, int K, size_t count) {
+bool seq_form_pays(int H, int K, size_t count, int busy = 0) {
   if (!pgpu::hensel_seq_has(H, K)) return false;
   const size_t ipw = 64 / (size_t)H;
   const size_t waves = 2 * ((count + ipw - 1) / ipw);
   const int pol = g_seq_policy.load();
-  return pol == 2 || (pol == 3 && 2 * waves >= kSimds) || (pol == 1 && waves >= kSimds);
+  return pol == 2 || (pol == 3 && 2 * waves >= kSimds) || ((pol == 1 || pol == 4) && waves >= kSimds) || seq_adaptive(waves, busy);
 }
 int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m, size_t count,
-               hipStream_t s, bool in_mont, const uint32_t* d_pair = nullptr, int in_pair_l2 = 0, bool other_lane_busy = false) {
+               hipStream_t s, bool in_mont, const uint32_t* d_pair = nullptr, int in_pair_l2 = 0, int busy_lanes = 0) {
+  const bool other_lane_busy = busy_lanes > 0;
   // d_pair: the ciphertexts are pair rows of 2*in_pair_l2 limbs (d_c unused); needs a split form of the key
   const int nw = key->n_words;
   rt::StreamWork& w = d.work_for(s);
@@ -1580,7 +1607,8 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
                     (ab_policy() == 1 || ab_policy() == 3 || (ab_policy() == 2 && other_lane_busy));   // 3: always, four pairs per workgroup
     const size_t seq_ipw = 64 / (size_t)hset->H;
     const size_t seq_waves = 2 * ((count + seq_ipw - 1) / seq_ipw);
-    const bool seq = !ab && d_pair && !sliding && seq_form_pays(hset->H, hset->K, count);
+    const bool seq = !ab && d_pair && !sliding && seq_form_pays(hset->H, hset->K, count, busy_lanes);
+    t.set_form(seq ? PGPU_FORM_SEQ : (ab ? PGPU_FORM_PAIRED | 64 : PGPU_FORM_PAIRED));
     if (seq) {
       const unsigned sblocks = (unsigned)((seq_waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
       RC_TRY(w.table.ensure((size_t)sblocks * pgpu::kWavesPerWG * seq_ipw * entries * 2 * L2 * sizeof(uint32_t), s));
@@ -1590,8 +1618,10 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
         return e ? atoi(e) : -1;
       }();
       // a launch that covers less than the chip leaves the other CUs to the neighbour lane's launch (policy 3)
+      const int pol = g_seq_policy.load();
       const unsigned lds_pad = env_pad >= 0 ? (unsigned)env_pad
-                                            : (g_seq_policy.load() == 3 && seq_waves < kSimds ? 84000u : 0u);
+                               : (seq_waves < kSimds && (pol == 3 || (pol == 4 && busy_lanes == 1)) ? 84000u : 0u);
+      if (lds_pad) t.set_form(PGPU_FORM_SEQ | PGPU_FORM_CU_CLAIM);
       if (!pgpu::launch_hensel_seq(hset->H, hset->K, h, sblocks, s, lds_pad))
         return fail(PGPU_ERR_UNSUPPORTED, "sequential-halves decrypt kernel not compiled");
     } else if (ab) {
@@ -1693,7 +1723,7 @@ int pair_op_launch(rt::Device& d, const pgpu_pubkey::PubForm* f, pgpu::PairOpsAr
   const size_t ipw = seq ? 64 / (size_t)f->H : 64 / (2 * (size_t)f->H);
   const size_t waves = (a.count + ipw - 1) / ipw;
   const unsigned blocks = (unsigned)((waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
-  TimerScope t(d, s, kind);
+  TimerScope t(d, s, kind, seq ? PGPU_FORM_SEQ : PGPU_FORM_PAIRED);
   if (seq) {
     if (!pgpu::launch_pair_mul_seq(f->H, f->K, a, blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "pair-row kernel not compiled");
   } else if (!pgpu::launch_pair_ops(f->H, f->K, a, blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "pair-row kernel not compiled");
@@ -1878,14 +1908,35 @@ void pgpu_shutdown(void) {
   }
   drain_parked();
   {
-    // fixed-base tables of keys that outlive the pool are freed with their keys; the budget of the next pool starts empty
+    // Keys may outlive the pool (a caller's objects are destroyed after terminateContext), their fixed-base tables may
+    // not: a table of the old pool left registered would be picked as an LRU victim by the NEXT pool's fb_make_room,
+    // its bytes subtracted from a counter that never held them (size_t underflow: the budget then looks exceeded for
+    // good) and hipFree called on memory of a pool that is gone (round-3 advisor).  So every registered table is freed
+    // here, while its device is still up, and the registry starts empty; a key that is used again under a new pool is
+    // refused by check_gen anyway.
     std::lock_guard<std::mutex> lk(g_fb_mu);
+    for (const pgpu_pubkey* k : g_fb_keys)
+      for (auto* lists : {&k->fb, &k->fbh})
+        for (size_t d = 0; d < lists->size(); ++d) {
+          if ((*lists)[d].empty()) continue;
+          if ((int)d < rt::pool_size()) {
+            rt::DeviceGuard g(rt::device((int)d).ordinal);
+            for (FbTable& t : (*lists)[d]) fb_free_table(t);
+          } else {
+            for (FbTable& t : (*lists)[d]) fb_free_table(t);
+          }
+          (*lists)[d].clear();
+        }
+    g_fb_keys.clear();
     g_fb_dev_bytes.assign(g_fb_dev_bytes.size(), 0);
   }
   rt::pool_shutdown();
 }
 
 int pgpu_is_initialized(void) { return rt::initialized() ? 1 : 0; }
+int pgpu_build_features(void) {
+  return (PGPU_WITH_4096 ? PGPU_FEATURE_4096_SPLIT : 0) | (PGPU_WITH_AB ? PGPU_FEATURE_AB_DECRYPT : 0);
+}
 const char* pgpu_last_error(void) { return rt::g_err.c_str(); }
 const char* pgpu_device_name(void) { return rt::initialized() ? rt::current().name.c_str() : ""; }
 int pgpu_pool_size(void) { return rt::initialized() ? rt::pool_size() : 0; }
@@ -1902,8 +1953,7 @@ int pgpu_synchronize(void) {
   for (int i = 0; i < rt::pool_size(); ++i) {
     rt::Device& d = rt::device(i);
     rt::DeviceGuard g(d.ordinal);
-    HIP_TRY(hipStreamSynchronize(d.bstream));
-    HIP_TRY(hipStreamSynchronize(d.bstream1));
+    for (int k = 0; k < rt::kBatchLanes; ++k) HIP_TRY(hipStreamSynchronize(d.bs(k)));
     for (auto& lane : d.lanes) HIP_TRY(hipStreamSynchronize(lane->stream));
   }
   drain_parked();   // evicted per-modulus contexts (their hipFree waits for whatever still reads them)
@@ -1936,13 +1986,17 @@ int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, i
 }
 
 int pgpu_encrypt_kernel_form(const pgpu_pubkey* key, int m_words, size_t count, int* split, int* lanes, int* limbs) {
+  return pgpu_encrypt_kernel_form_ex(key, m_words, count, 0, split, lanes, limbs);
+}
+int pgpu_encrypt_kernel_form_ex(const pgpu_pubkey* key, int m_words, size_t count, int busy_lanes, int* split, int* lanes,
+                                int* limbs) {
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_encrypt_kernel_form: bad argument");
   RC_TRY(check_gen(key->gen, "key"));
   const pgpu_pubkey::PubForm* ef = key->djn && fixed_base_window() > 0 ? use_split_encrypt(key, m_words, count) : nullptr;
   if (ef) {
     // resident results (pair rows) take the key's pair form, and from a launch size on both halves in the same lanes
     const pgpu_pubkey::PubForm* pf = pair_form(key);
-    if (pf && m_words <= key->n_words && fb_encrypt_seq_pays(pf->H, pf->K, count)) {
+    if (pf && m_words <= key->n_words && fb_encrypt_seq_pays(pf->H, pf->K, count, busy_lanes)) {
       *split = 2;
       *lanes = pf->H;
       *limbs = pf->K;
@@ -2001,10 +2055,13 @@ int pgpu_ct_add_kernel_form(const pgpu_pubkey* key, size_t count, int* split, in
 }
 
 int pgpu_decrypt_kernel_form(const pgpu_privkey* key, size_t count, int* split, int* lanes, int* limbs) {
+  return pgpu_decrypt_kernel_form_ex(key, count, 0, split, lanes, limbs);
+}
+int pgpu_decrypt_kernel_form_ex(const pgpu_privkey* key, size_t count, int busy_lanes, int* split, int* lanes, int* limbs) {
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_decrypt_kernel_form: bad argument");
   RC_TRY(check_gen(key->gen, "key"));
   if (const pgpu_privkey::HenselSet* f = pick_hensel(key, count)) {
-    if (pair_rows_enabled() && secret_policy() != PGPU_EXP_SLIDING && ab_policy() == 0 && seq_form_pays(f->H, f->K, count)) {
+    if (pair_rows_enabled() && secret_policy() != PGPU_EXP_SLIDING && ab_policy() == 0 && seq_form_pays(f->H, f->K, count, busy_lanes)) {
       *split = 2;
       *lanes = f->H;
     } else {
@@ -2057,7 +2114,8 @@ void pgpu_debug_set_packed_decrypt(int on) { g_packed_decrypt.store(on != 0); }
 // tests / A-B measurements: the A/B-wavefront decrypt kernel (hensel_ab.hpp): 0 never, 1 whenever it applies, 2 when the
 // other batch lane is busy.  Not part of the public header.
 // tests / A-B measurements: hensel_seq.hpp (0 never, 1 by launch size, 2 whenever it applies).  Not part of the public header.
-void pgpu_debug_set_seq_decrypt(int policy) { g_seq_policy.store(policy < 0 ? 0 : (policy > 3 ? 3 : policy)); }
+void pgpu_debug_set_seq_decrypt(int policy) { g_seq_policy.store(policy < 0 ? 0 : (policy > 4 ? 4 : policy)); }
+int pgpu_debug_get_seq_decrypt(void) { return g_seq_policy.load(); }
 void pgpu_debug_set_ab_decrypt(int policy) { g_ab_policy.store(policy < 0 ? 0 : (policy > 3 ? 3 : policy)); }
 
 int pgpu_set_timing(int enabled) {
@@ -2065,7 +2123,9 @@ int pgpu_set_timing(int enabled) {
   return PGPU_OK;
 }
 
-int pgpu_timing_collect(int* kinds, double* ms, int max_entries) {
+int pgpu_timing_collect_ex(int* kinds, int* forms, double* ms, int max_entries);
+int pgpu_timing_collect(int* kinds, double* ms, int max_entries) { return pgpu_timing_collect_ex(kinds, nullptr, ms, max_entries); }
+int pgpu_timing_collect_ex(int* kinds, int* forms, double* ms, int max_entries) {
   if (!rt::initialized()) return 0;
   rt::Device& d = rt::current();
   rt::DeviceGuard g(d.ordinal);
@@ -2080,6 +2140,7 @@ int pgpu_timing_collect(int* kinds, double* ms, int max_entries) {
     if (hipEventSynchronize(t.e1) == hipSuccess && hipEventElapsedTime(&v, t.e0, t.e1) == hipSuccess &&
         n < max_entries && kinds && ms) {
       kinds[n] = t.kind;
+      if (forms) forms[n] = t.form;
       ms[n] = v;
       ++n;
     }
@@ -2129,6 +2190,11 @@ int pgpu_copy_d2h(void* h_dst, const void* d_src, size_t bytes) {
   });
   return tg.wait();
 }
+
+// ---- pinned host memory (include/pgpu.h) ----
+int pgpu_host_alloc(size_t bytes, void** out) { return rt::host_alloc(bytes, out); }
+void pgpu_host_free(void* p) { rt::host_free(p); }
+int pgpu_host_wait(const void* p) { return rt::host_wait(p); }
 
 // ===================== generic modexp =====================
 int pgpu_modexp_dev(const uint64_t* d_base, size_t base_stride, const uint64_t* d_exp,
@@ -2697,8 +2763,25 @@ int pgpu_batch_upload(const uint64_t* host, size_t count, int words, size_t stri
   if (words <= 0 || stride < (size_t)words) return fail(PGPU_ERR_INVALID_PARAM, "stride smaller than the row width");
   std::unique_ptr<pgpu_batch> b;
   RC_TRY(new_batch(count, words, &b));
-  rt::TaskGroup tg;
   pgpu_batch* bp = b.get();
+  if (stride == (size_t)words && rt::host_is_pinned(host, count * (size_t)words * 8)) {
+    // a buffer from pgpu_host_alloc is the DMA source itself: one copy per shard, queued from the calling thread on the
+    // batch lane, NOT waited for (pgpu_host_wait / pgpu_host_free do, include/pgpu.h)
+    for (int d = 0; d < bp->ndev; ++d) {
+      size_t lo, hi;
+      bp->bounds(d, &lo, &hi);
+      rt::Device& dev = rt::device(d);
+      rt::DeviceGuard g(dev.ordinal);
+      hipStream_t s = dev.bs(bp->lane);
+      const uint64_t* src = host + lo * (size_t)words;
+      const size_t bytes = (hi - lo) * (size_t)words * 8;
+      HIP_TRY(hipMemcpyAsync(bp->ptr(d), src, bytes, hipMemcpyHostToDevice, s));
+      rt::host_note_read(src, bytes, dev.index, s);
+    }
+    *out = b.release();
+    return PGPU_OK;
+  }
+  rt::TaskGroup tg;
   for (int d = 0; d < bp->ndev; ++d) {
     tg.run(rt::device(d), [=](rt::Lane& lane) -> int {
       size_t lo, hi;
@@ -2727,8 +2810,36 @@ int pgpu_batch_download(const pgpu_batch* b, uint64_t* host) {
   RC_TRY(rt::check_ready());
   if (!b || !host) return fail(PGPU_ERR_INVALID_PARAM, "null pointer");
   RC_TRY(check_gen(b->gen, "batch"));
-  rt::TaskGroup tg;
   const int nd = b->replicated ? 1 : b->ndev;
+  if (rt::host_is_pinned(host, b->count * (size_t)b->words * 8)) {
+    // pinned target (pgpu_host_alloc): conversion kernel (if any) and ONE DMA per shard, queued from the calling thread;
+    // then the shards are waited for
+    std::vector<rt::DevMem> plain((size_t)nd);
+    for (int d = 0; d < nd; ++d) {
+      size_t lo, hi;
+      b->bounds(d, &lo, &hi);
+      rt::Device& dev = rt::device(d);
+      rt::DeviceGuard g(dev.ordinal);
+      hipStream_t s = dev.bs(b->lane);
+      const size_t bytes = (hi - lo) * (size_t)b->words * 8;
+      const void* src = b->ptr(d);
+      if (b->pair_l2 || b->mont) {
+        RC_TRY(plain[(size_t)d].alloc(dev, s, bytes));
+        if (b->pair_l2) RC_TRY(pair_to_words_on(dev, b->pair_form.get(), b->prow(d), (uint64_t*)plain[(size_t)d].p, hi - lo, s));
+        else RC_TRY(modmul_on(dev, *b->mont, pgpu::MM_BY_ONE, b->ptr(d), nullptr, 0, 0, (uint64_t*)plain[(size_t)d].p, hi - lo, s));
+        src = plain[(size_t)d].p;
+      }
+      HIP_TRY(hipMemcpyAsync(host + lo * (size_t)b->words, src, bytes, hipMemcpyDeviceToHost, s));
+    }
+    for (int d = 0; d < nd; ++d) {
+      rt::Device& dev = rt::device(d);
+      rt::DeviceGuard g(dev.ordinal);
+      hipError_t e = hipStreamSynchronize(dev.bs(b->lane));
+      if (e != hipSuccess) return fail(PGPU_ERR_HIP, std::string("device -> host copy failed: ") + hipGetErrorString(e));
+    }
+    return PGPU_OK;
+  }
+  rt::TaskGroup tg;
   for (int d = 0; d < nd; ++d) {
     tg.run(rt::device(d), [=](rt::Lane& lane) -> int {
       size_t lo, hi;
@@ -2781,7 +2892,8 @@ int pgpu_batch_encrypt(const pgpu_pubkey* key, const pgpu_batch* m, const pgpu_b
     rt::DeviceGuard g(dev.ordinal);
     RC_TRY(lane_acquire(dev, r, m->lane));
     RC_TRY(encrypt_on(dev, key, m->ptr(d), (size_t)m->words, m->words, r->ptr(d), (size_t)r->words, r->words, r_bits,
-                      l2 ? nullptr : out->ptr(d), hi - lo, dev.bs(m->lane), true, m->count, l2 ? out->prow(d) : nullptr));
+                      l2 ? nullptr : out->ptr(d), hi - lo, dev.bs(m->lane), true, m->count, l2 ? out->prow(d) : nullptr,
+                      l2 ? busy_other_lanes(dev, m->lane) : 0));
     RC_TRY(lane_release(dev, r, m->lane));
   }
   if (key->djn) {
@@ -2821,9 +2933,8 @@ int pgpu_batch_decrypt_crt(const pgpu_privkey* key, const pgpu_batch* c, pgpu_ba
     rt::Device& dev = rt::device(d);
     rt::DeviceGuard g(dev.ordinal);
     if (c->pair_l2) {
-      // is the GPU's other batch lane busy right now?  Then this launch will share the SIMDs with another one
-      const bool busy = hipStreamQuery(dev.bs(c->lane ^ 1)) == hipErrorNotReady;
-      (void)hipGetLastError();
+      // are the GPU's other batch lanes busy right now?  Then this launch will share the chip with theirs
+      const int busy = busy_other_lanes(dev, c->lane);
       RC_TRY(decrypt_on(dev, key, nullptr, out->ptr(d), hi - lo, dev.bs(c->lane), false, c->prow(d), c->pair_l2, busy));
     }
     else
@@ -3056,11 +3167,12 @@ int pgpu_batch_ct_mul(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_ba
 }
 
 int pgpu_set_batch_lane(int lane) {
-  if (lane < 0 || lane > 1) return fail(PGPU_ERR_INVALID_PARAM, "batch lane must be 0 or 1");
+  if (lane < 0 || lane >= rt::kBatchLanes) return fail(PGPU_ERR_INVALID_PARAM, "batch lane out of range (pgpu_batch_lanes())");
   t_batch_lane = lane;
   return PGPU_OK;
 }
 int pgpu_batch_lane(const pgpu_batch* b) { return b ? b->lane : 0; }
+int pgpu_batch_lanes(void) { return rt::kBatchLanes; }
 int pgpu_batch_row_limbs(const pgpu_batch* b) { return b ? 2 * b->pair_l2 : 0; }
 
 // ---- diagnostics of the pool's self-checks and table budget ----

@@ -23,7 +23,7 @@
 #ifndef PAILLIERCRYPTOLIB_AMD_CSRC_HENSEL_SEQ_HPP_
 #define PAILLIERCRYPTOLIB_AMD_CSRC_HENSEL_SEQ_HPP_
 
-#include "hensel_ab.hpp"
+#include "hensel_q.hpp"
 
 namespace pgpu {
 

@@ -26,6 +26,7 @@ BaseText::BaseText(const BaseText& o) {
   m_size = o.m_size;
   m_dev = o.m_dev;
   m_host_valid = (bool)o.m_host_valid;
+  m_bits_hint = o.m_bits_hint;
 }
 
 BaseText& BaseText::operator=(const BaseText& o) {
@@ -35,7 +36,31 @@ BaseText& BaseText::operator=(const BaseText& o) {
   m_size = o.m_size;
   m_dev = o.m_dev;
   m_host_valid = (bool)o.m_host_valid;
+  m_bits_hint = o.m_bits_hint;
   return *this;
+}
+
+bool BaseText::adoptValues(const std::vector<BigNumber>& v) {
+  if (v.size() < 64 || !pgpu_is_initialized()) return false;   // (no GPU context yet: containers work without one)
+  std::size_t limbs = 0;
+  int bits = 0;
+  for (const BigNumber& x : v) {
+    if (x.isNegative()) return false;        // signs only live in BigNumbers
+    if (x.limbs64().size() > limbs) limbs = x.limbs64().size();
+  }
+  if (limbs == 0) limbs = 1;
+  if (v.size() * limbs * 8 < detail::kEagerUploadBytes) return false;
+  for (const BigNumber& x : v)
+    if (x.limbs64().size() == limbs) bits = std::max(bits, x.BitSize());
+  try {
+    m_dev = detail::DeviceBatch::upload_values(v, (int)limbs);
+  } catch (const std::exception&) {
+    m_dev.reset();
+    return false;
+  }
+  m_bits_hint = bits;
+  m_host_valid = false;
+  return true;
 }
 
 void BaseText::ensureHost() const {
@@ -49,10 +74,11 @@ void BaseText::ensureHost() const {
 void BaseText::invalidateDevice() {
   ensureHost();
   m_dev.reset();
+  m_bits_hint = -1;
 }
 
 int BaseText::maxBitsHint() const {
-  if (!m_host_valid) return 64 * m_dev->words;
+  if (!m_host_valid) return m_bits_hint >= 0 ? m_bits_hint : 64 * m_dev->words;
   return detail::max_bits(m_texts);
 }
 
@@ -91,7 +117,9 @@ BaseText::BaseText(const std::vector<uint32_t>& n_v) {
 
 BaseText::BaseText(const BigNumber& bn) : m_texts(1, bn), m_size(1) {}
 
-BaseText::BaseText(const std::vector<BigNumber>& bn_v) : m_texts(detail::copy_texts(bn_v)), m_size(bn_v.size()) {}
+BaseText::BaseText(const std::vector<BigNumber>& bn_v) : m_size(bn_v.size()) {
+  if (!adoptValues(bn_v)) m_texts = detail::copy_texts(bn_v);
+}
 
 BigNumber& BaseText::operator[](const std::size_t idx) {
   ERROR_CHECK(idx < m_size, "BaseText:operator[] index is out of range");
@@ -108,6 +136,7 @@ void BaseText::insert(const std::size_t pos, BigNumber& bn) {
 
 void BaseText::clear() {
   m_host_valid = true;
+  m_bits_hint = -1;
   m_dev.reset();
   m_texts.clear();
   m_size = 0;
@@ -168,6 +197,7 @@ void BaseText::load(serializer::InputArchive& ar) {
   for (auto& t : m_texts) t.load(ar);
   m_size = (size_t)size;
   m_host_valid = true;
+  m_bits_hint = -1;
   m_dev.reset();
 }
 

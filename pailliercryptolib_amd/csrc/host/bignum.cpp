@@ -13,9 +13,78 @@
 
 typedef unsigned __int128 u128;
 
+// ---- limb storage (bignum.h: LimbAllocator) ----
+#include <atomic>
+#include <new>
+namespace ipcl {
+namespace detail {
+namespace {
+struct LimbArena {
+  std::atomic<std::size_t> live;   // blocks handed out and not yet freed, + 1 while the scope that owns the arena is open
+  std::size_t cap, used;           // bytes behind the header
+};
+struct LimbHeader {                // in front of every block
+  LimbArena* arena;                // null: the block came from malloc
+  std::size_t pad;
+};
+static_assert(sizeof(LimbHeader) == 16, "blocks stay 16-byte aligned behind their header");
+constexpr std::size_t kArenaHead = (sizeof(LimbArena) + 15) & ~(std::size_t)15;
+thread_local LimbArena* t_arena = nullptr;
+thread_local int t_bulk_depth = 0;
+void arena_release(LimbArena* a) noexcept {
+  if (a->live.fetch_sub(1, std::memory_order_acq_rel) == 1) std::free(a);
+}
+}  // namespace
+
+void* limb_alloc(std::size_t bytes) {
+  const std::size_t need = sizeof(LimbHeader) + ((bytes + 15) & ~(std::size_t)15);
+  LimbArena* a = t_arena;
+  if (a && a->used + need <= a->cap) {
+    LimbHeader* h = reinterpret_cast<LimbHeader*>(reinterpret_cast<char*>(a) + kArenaHead + a->used);
+    a->used += need;
+    a->live.fetch_add(1, std::memory_order_relaxed);
+    h->arena = a;
+    return h + 1;
+  }
+  LimbHeader* h = static_cast<LimbHeader*>(std::malloc(need));
+  if (!h) throw std::bad_alloc();
+  h->arena = nullptr;
+  return h + 1;
+}
+
+void limb_free(void* p) noexcept {
+  if (!p) return;
+  LimbHeader* h = static_cast<LimbHeader*>(p) - 1;
+  if (h->arena) arena_release(h->arena);
+  else std::free(h);
+}
+
+void limb_bulk_begin(std::size_t bytes_hint) {
+  if (t_bulk_depth++ > 0) return;   // nested scopes share the outer arena
+  if (bytes_hint < 4096) return;    // not worth an arena
+  const std::size_t cap = (bytes_hint + 4095) & ~(std::size_t)4095;
+  LimbArena* a = static_cast<LimbArena*>(std::malloc(kArenaHead + cap));
+  if (!a) return;                   // no arena: blocks come from malloc
+  new (&a->live) std::atomic<std::size_t>(1);
+  a->cap = cap;
+  a->used = 0;
+  t_arena = a;
+}
+
+void limb_bulk_end() noexcept {
+  if (--t_bulk_depth > 0) return;
+  t_bulk_depth = 0;
+  if (LimbArena* a = t_arena) {
+    t_arena = nullptr;
+    arena_release(a);
+  }
+}
+}  // namespace detail
+}  // namespace ipcl
+
 namespace {
 
-typedef std::vector<uint64_t> Mag;
+typedef BigNumber::Limbs Mag;
 
 void mag_trim(Mag& a) {
   while (!a.empty() && a.back() == 0) a.pop_back();

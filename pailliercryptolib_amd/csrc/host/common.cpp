@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <random>
 #include <thread>
@@ -254,8 +255,19 @@ bool all_fit(const std::vector<BigNumber>& v, int words) {
   return !bad.load();
 }
 
+namespace {
+// bytes of limb storage (incl. block headers) a copy / unpack of `count` values of `words` limbs takes
+std::size_t arena_hint(std::size_t count, std::size_t words) { return count * (words * 8 + 32); }
+}  // namespace
+
 std::vector<BigNumber> copy_texts(const std::vector<BigNumber>& v) {
-  if (threads_for(v.size(), kGrain) <= 1) return v;
+  if (threads_for(v.size(), kGrain) <= 1) {
+    if (v.size() < 64) return v;
+    std::size_t limbs = 0;
+    for (const BigNumber& x : v) limbs += x.limbs64().size();
+    LimbBulkScope arena(limbs * 8 + v.size() * 32);   // one arena instead of v.size() heap blocks
+    return v;
+  }
   std::vector<BigNumber> out(v.size());
   parallel_for(v.size(), kGrain, [&](std::size_t i) { out[i] = v[i]; });
   return out;
@@ -271,12 +283,102 @@ std::vector<uint64_t> pack(const std::vector<BigNumber>& v, int words) {
   return flat;
 }
 
-std::vector<BigNumber> unpack(const std::vector<uint64_t>& flat, std::size_t count, int words) {
-  std::vector<BigNumber> v(count);
-  parallel_for(count, kGrain, [&](std::size_t i) {
-    v[i] = BigNumber::fromLimbs64(flat.data() + i * (size_t)words, (size_t)words);
+void pack_into(uint64_t* flat, const std::vector<BigNumber>& v, int words) {
+  std::atomic<bool> fits{true};
+  parallel_for(v.size(), kGrain, [&](std::size_t i) {
+    if (!v[i].toLimbs64(flat + i * (size_t)words, (size_t)words)) fits.store(false, std::memory_order_relaxed);
   });
+  ERROR_CHECK(fits.load(), "pack: value wider than the batch stride");
+}
+
+std::vector<BigNumber> unpack(const uint64_t* flat, std::size_t count, int words) {
+  std::vector<BigNumber> v(count);
+  if (threads_for(count, kGrain) <= 1) {
+    LimbBulkScope arena(count >= 64 ? arena_hint(count, (std::size_t)words) : 0);
+    for (std::size_t i = 0; i < count; ++i) v[i] = BigNumber::fromLimbs64(flat + i * (size_t)words, (size_t)words);
+    return v;
+  }
+  parallel_for(count, kGrain, [&](std::size_t i) { v[i] = BigNumber::fromLimbs64(flat + i * (size_t)words, (size_t)words); });
   return v;
+}
+std::vector<BigNumber> unpack(const std::vector<uint64_t>& flat, std::size_t count, int words) {
+  return unpack(flat.data(), count, words);
+}
+
+// ---- pinned staging blocks ----
+namespace {
+struct PinnedPool {
+  std::mutex mu;
+  std::map<std::size_t, std::vector<uint64_t*>> idle;   // [size class] -> blocks
+  std::size_t idle_bytes = 0;
+};
+PinnedPool& pinned_pool() {
+  static PinnedPool* p = new PinnedPool;   // (leaked on purpose: texts may die after static destruction began)
+  return *p;
+}
+constexpr std::size_t kPinnedIdleCap = (std::size_t)256 << 20;
+std::size_t size_class(std::size_t bytes) {
+  std::size_t c = 64 * 1024;
+  while (c < bytes) c <<= 1;
+  return c;
+}
+}  // namespace
+
+std::shared_ptr<PinnedBlock> PinnedBlock::acquire(std::size_t bytes) {
+  if (!pgpu_is_initialized()) return nullptr;
+  const std::size_t cls = size_class(bytes);
+  uint64_t* p = nullptr;
+  {
+    PinnedPool& pool = pinned_pool();
+    std::lock_guard<std::mutex> lk(pool.mu);
+    auto it = pool.idle.find(cls);
+    if (it != pool.idle.end() && !it->second.empty()) {
+      p = it->second.back();
+      it->second.pop_back();
+      pool.idle_bytes -= cls;
+    }
+  }
+  if (p) {
+    if (pgpu_host_wait(p) != PGPU_OK) {   // an upload that still reads the block: wait it out (normally long done)
+      pgpu_host_free(p);
+      p = nullptr;
+    }
+  }
+  if (!p) {
+    void* q = nullptr;
+    if (pgpu_host_alloc(cls, &q) != PGPU_OK) return nullptr;
+    p = static_cast<uint64_t*>(q);
+  }
+  auto b = std::make_shared<PinnedBlock>();
+  b->p = p;
+  b->bytes = cls;
+  return b;
+}
+
+void release_pinned_pool() {
+  PinnedPool& pool = pinned_pool();
+  std::map<std::size_t, std::vector<uint64_t*>> dead;
+  {
+    std::lock_guard<std::mutex> lk(pool.mu);
+    dead.swap(pool.idle);
+    pool.idle_bytes = 0;
+  }
+  for (auto& kv : dead)
+    for (uint64_t* p : kv.second) pgpu_host_free(p);
+}
+
+PinnedBlock::~PinnedBlock() {
+  if (!p) return;
+  PinnedPool& pool = pinned_pool();
+  {
+    std::lock_guard<std::mutex> lk(pool.mu);
+    if (pgpu_is_initialized() && pool.idle_bytes + bytes <= kPinnedIdleCap) {
+      pool.idle[bytes].push_back(p);
+      pool.idle_bytes += bytes;
+      return;
+    }
+  }
+  pgpu_host_free(p);
 }
 
 std::shared_ptr<DeviceBatch> DeviceBatch::adopt(pgpu_batch* h) {
@@ -294,7 +396,26 @@ std::shared_ptr<DeviceBatch> DeviceBatch::upload(const std::vector<uint64_t>& fl
   return adopt(h);
 }
 
+std::shared_ptr<DeviceBatch> DeviceBatch::upload_values(const std::vector<BigNumber>& v, int words) {
+  ensure_context();
+  const std::size_t bytes = v.size() * (std::size_t)words * 8;
+  std::shared_ptr<PinnedBlock> blk = bytes >= kEagerUploadBytes ? PinnedBlock::acquire(bytes) : nullptr;
+  if (!blk) return upload(pack(v, words), v.size(), words);
+  pack_into(blk->p, v, words);
+  pgpu_batch* h = nullptr;
+  IPCL_GPU_CHECK(pgpu_batch_upload(blk->p, v.size(), words, (size_t)words, &h), "device upload");
+  auto b = adopt(h);
+  b->src = std::move(blk);
+  return b;
+}
+
 std::vector<BigNumber> DeviceBatch::download() const {
+  const std::size_t bytes = count * (size_t)words * 8;
+  // the results land in a pinned block (one DMA, no unpacking copy) and become BigNumbers whose limbs share one arena
+  if (std::shared_ptr<PinnedBlock> blk = bytes >= kEagerUploadBytes ? PinnedBlock::acquire(bytes) : nullptr) {
+    IPCL_GPU_CHECK(pgpu_batch_download(h, blk->p), "device download");
+    return unpack(blk->p, count, words);
+  }
   std::vector<uint64_t> flat(count * (size_t)words);
   IPCL_GPU_CHECK(pgpu_batch_download(h, flat.data()), "device download");
   return unpack(flat, count, words);

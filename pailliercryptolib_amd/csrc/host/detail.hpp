@@ -58,7 +58,18 @@ void wipe(void* p, std::size_t bytes);
 
 // row-major [count][words] little-endian limbs of |v[i]|; every value must fit
 std::vector<uint64_t> pack(const std::vector<BigNumber>& v, int words);
+void pack_into(uint64_t* flat, const std::vector<BigNumber>& v, int words);
 std::vector<BigNumber> unpack(const std::vector<uint64_t>& flat, std::size_t count, int words);
+std::vector<BigNumber> unpack(const uint64_t* flat, std::size_t count, int words);   // (limb blocks from one arena)
+
+// Pinned staging block of the host layer (pgpu_host_alloc: the DMA reads / writes it directly).  Blocks are pooled by
+// size class; a block that still feeds an upload is waited for (pgpu_host_wait) before it is handed out again.
+struct PinnedBlock {
+  uint64_t* p = nullptr;
+  std::size_t bytes = 0;
+  ~PinnedBlock();
+  static std::shared_ptr<PinnedBlock> acquire(std::size_t bytes);   // null: no pinned memory (callers use the heap)
+};
 int max_bits(const std::vector<BigNumber>& v);
 void fill_random(void* dst, std::size_t n);   // kernel CSPRNG, bulk
 
@@ -70,13 +81,21 @@ struct DeviceBatch {
   pgpu_batch* h = nullptr;
   std::size_t count = 0;
   int words = 0;
+  std::shared_ptr<PinnedBlock> src;   // the pinned block the upload reads (kept until the batch dies; the pool waits
+                                      // for the copy before it recycles the block)
   ~DeviceBatch() {
     if (h) pgpu_batch_destroy(h);
   }
   static std::shared_ptr<DeviceBatch> adopt(pgpu_batch* h);
   static std::shared_ptr<DeviceBatch> upload(const std::vector<uint64_t>& flat, std::size_t count, int words);
+  // packs v (every value non-negative and no wider than `words`) into a pinned block and queues ONE copy to the GPU;
+  // returns without waiting for it
+  static std::shared_ptr<DeviceBatch> upload_values(const std::vector<BigNumber>& v, int words);
   std::vector<BigNumber> download() const;
 };
+void release_pinned_pool();
+// batches of at least this many bytes are uploaded as soon as a text is constructed around host values (base_text.cpp)
+constexpr std::size_t kEagerUploadBytes = 64 * 1024;
 
 struct PubKeyDevice {
   pgpu_pubkey* h = nullptr;

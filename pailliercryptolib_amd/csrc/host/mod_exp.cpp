@@ -79,7 +79,7 @@ std::vector<BigNumber> modExp(const std::vector<BigNumber>& base, const std::vec
     for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
     modexp_shared_mod(base, exp, mod[0], idx, out);
   } else {
-    std::map<std::vector<uint64_t>, std::vector<size_t>> groups;
+    std::map<BigNumber::Limbs, std::vector<size_t>> groups;
     for (size_t i = 0; i < mod.size(); ++i) groups[mod[i].limbs64()].push_back(i);
     for (auto& g : groups) modexp_shared_mod(base, exp, mod[g.second[0]], g.second, out);
   }

@@ -3,6 +3,9 @@
 // the two-wavefronts-per-SIMD build of the (2,19) decrypt form; 11-13: element-wise operations on pair rows).
 #include "hensel_seq.hpp"
 #include "launch.hpp"
+#if defined(PGPU_PART) && PGPU_PART == 15
+#include "hensel_ab.hpp"   // the A/B-wavefront experiment: built only with PGPU_BUILD_AB=1
+#endif
 
 #ifndef PGPU_PART
 #error "compile with -DPGPU_PART=0..29"
@@ -23,7 +26,10 @@ bool launch_hensel_part0(int H, int K, const HenselArgs& a, unsigned blocks, hip
 }
 #elif PGPU_PART == 1
 bool launch_hensel_part1(int H, int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
-  PGPU_HENSEL_ONE(4, 18) PGPU_HENSEL_ONE(4, 14) PGPU_HENSEL_ONE(4, 10)
+#if PGPU_WITH_4096
+  PGPU_HENSEL_ONE(4, 18)
+#endif
+  PGPU_HENSEL_ONE(4, 14) PGPU_HENSEL_ONE(4, 10)
   return false;
 }
 #elif PGPU_PART == 3 || PGPU_PART == 4 || PGPU_PART == 10 || PGPU_PART == 22
@@ -271,7 +277,10 @@ bool launch_hensel_modexp_part6(int H, int K, const HenselModexpArgs& a, unsigne
 }
 #else
 bool launch_hensel_part2(int H, int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
-  PGPU_HENSEL_ONE(8, 3) PGPU_HENSEL_ONE(8, 5) PGPU_HENSEL_ONE(8, 7) PGPU_HENSEL_ONE(8, 9)
+  PGPU_HENSEL_ONE(8, 3) PGPU_HENSEL_ONE(8, 5) PGPU_HENSEL_ONE(8, 7)
+#if PGPU_WITH_4096
+  PGPU_HENSEL_ONE(8, 9)
+#endif
   return false;
 }
 #endif

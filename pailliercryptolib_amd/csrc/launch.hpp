@@ -9,6 +9,19 @@
 
 #include "kargs.hpp"
 
+// Build switches (pailliercryptolib_amd/build.py passes them to every translation unit, device and host alike):
+//   PGPU_WITH_4096 (env PGPU_BUILD_4096=1)  the split forms of the 4096-bit key class -- (8,18) fixed-base / modexp / pair
+//                  rows, (4,18) and (8,9) CRT decrypt: beyond every BASELINE config and the reference's own 2048-bit cap
+//                  (ipcl/keygen.cpp:10), 10-15 minutes of compile time per translation unit.  Off: such keys run the
+//                  full-width kernels (Montgomery-form words), as all keys did before round 2.
+//   PGPU_WITH_AB   (env PGPU_BUILD_AB=1)    the A/B-wavefront decrypt experiment (hensel_ab.hpp; measured slower)
+#ifndef PGPU_WITH_4096
+#define PGPU_WITH_4096 0
+#endif
+#ifndef PGPU_WITH_AB
+#define PGPU_WITH_AB 0
+#endif
+
 namespace pgpu {
 
 // modexp_kernel lives in eight translation units (k_modexp.hip, PGPU_PART 0..7); launch_modexp tries each.
@@ -35,8 +48,8 @@ inline bool launch_modexp(int G, int K, bool regrows, const ModexpArgs& a, unsig
 // batches that leave SIMDs idle): 1024-bit keys (2,10) (4,5) (8,3); 2048: (2,19) (4,10) (8,5); 3072: (4,14) (8,7);
 // 4096: (4,18) (8,9).
 inline bool hensel_has(int H, int K) {
-  return (H == 2 && (K == 10 || K == 19)) || (H == 4 && (K == 5 || K == 10 || K == 14 || K == 18)) ||
-         (H == 8 && (K == 3 || K == 5 || K == 7 || K == 9));
+  return (H == 2 && (K == 10 || K == 19)) || (H == 4 && (K == 5 || K == 10 || K == 14 || (PGPU_WITH_4096 && K == 18))) ||
+         (H == 8 && (K == 3 || K == 5 || K == 7 || (PGPU_WITH_4096 && K == 9)));
 }
 bool launch_hensel_part0(int H, int K, const HenselArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_part1(int H, int K, const HenselArgs& a, unsigned blocks, hipStream_t s);
@@ -52,7 +65,7 @@ inline bool launch_hensel(int H, int K, bool packed, const HenselArgs& a, unsign
 // split-form fixed-base DJN encrypt (hensel.hpp: hensel_fb_build_kernel / hensel_fb_encrypt_kernel; k_hensel.hip part 3)
 // (2,19): 1024-bit keys, (4,18): 2048, (8,14): 3072, (8,18): 4096 (k_hensel.hip parts 10, 3, 4, 22)
 inline bool hensel_fb_has(int H, int K) {
-  return (H == 2 && K == 19) || (H == 4 && K == 18) || (H == 8 && (K == 14 || K == 18));
+  return (H == 2 && K == 19) || (H == 4 && K == 18) || (H == 8 && (K == 14 || (PGPU_WITH_4096 && K == 18)));
 }
 bool launch_hensel_fb_build_part3(int H, int K, const HenselFbBuildArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_fb_build_part4(int H, int K, const HenselFbBuildArgs& a, unsigned blocks, hipStream_t s);
@@ -64,7 +77,11 @@ bool launch_hensel_fb_encrypt_part4(int H, int K, const HenselFbArgs& a, unsigne
 bool launch_hensel_fb_encrypt_part10(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
 inline bool launch_hensel_fb_build(int H, int K, const HenselFbBuildArgs& a, unsigned blocks, hipStream_t s) {
   return launch_hensel_fb_build_part3(H, K, a, blocks, s) || launch_hensel_fb_build_part4(H, K, a, blocks, s) ||
-         launch_hensel_fb_build_part10(H, K, a, blocks, s) || launch_hensel_fb_build_part22(H, K, a, blocks, s);
+         launch_hensel_fb_build_part10(H, K, a, blocks, s)
+#if PGPU_WITH_4096
+         || launch_hensel_fb_build_part22(H, K, a, blocks, s)
+#endif
+      ;
 }
 // (8,9): the ENCRYPT kernel only, for batches that leave SIMDs idle under a 2048-bit key -- 16 lanes per element, the
 // same 72 limbs per half as (4,18): it reads the table the (4,18) build kernel wrote and writes the same pair rows
@@ -72,15 +89,18 @@ bool launch_hensel_fb_encrypt_part14(int H, int K, const HenselFbArgs& a, unsign
 inline bool hensel_fb_encrypt_has(int H, int K) { return hensel_fb_has(H, K) || (H == 8 && K == 9); }
 inline bool launch_hensel_fb_encrypt(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
   return launch_hensel_fb_encrypt_part3(H, K, a, blocks, s) || launch_hensel_fb_encrypt_part4(H, K, a, blocks, s) ||
-         launch_hensel_fb_encrypt_part10(H, K, a, blocks, s) || launch_hensel_fb_encrypt_part14(H, K, a, blocks, s) ||
-         launch_hensel_fb_encrypt_part22(H, K, a, blocks, s);
+         launch_hensel_fb_encrypt_part10(H, K, a, blocks, s) || launch_hensel_fb_encrypt_part14(H, K, a, blocks, s)
+#if PGPU_WITH_4096
+         || launch_hensel_fb_encrypt_part22(H, K, a, blocks, s)
+#endif
+      ;
 }
 
 // split-form generic modexp modulo a square (hensel.hpp: hensel_modexp_kernel; k_hensel.hip parts 5, 6, 8, 9): roots of
 // up to 1024 bits -- (2,19) / (4,10) / (8,5), fewest to most lanes --, 2048 bits -- (4,18) / (8,9) --, 3072 bits -- (8,14),
 // 4096 bits -- (8,18) (part 23)
 inline bool hensel_modexp_has(int H, int K) {
-  return (H == 4 && (K == 18 || K == 10)) || (H == 8 && (K == 9 || K == 5 || K == 14 || K == 18)) || (H == 2 && K == 19);
+  return (H == 4 && (K == 18 || K == 10)) || (H == 8 && (K == 9 || K == 5 || K == 14 || (PGPU_WITH_4096 && K == 18))) || (H == 2 && K == 19);
 }
 bool launch_hensel_modexp_part5(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_modexp_part6(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
@@ -89,14 +109,17 @@ bool launch_hensel_modexp_part9(int H, int K, const HenselModexpArgs& a, unsigne
 bool launch_hensel_modexp_part23(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s);
 inline bool launch_hensel_modexp(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
   return launch_hensel_modexp_part5(H, K, a, blocks, s) || launch_hensel_modexp_part6(H, K, a, blocks, s) ||
-         launch_hensel_modexp_part8(H, K, a, blocks, s) || launch_hensel_modexp_part9(H, K, a, blocks, s) ||
-         launch_hensel_modexp_part23(H, K, a, blocks, s);
+         launch_hensel_modexp_part8(H, K, a, blocks, s) || launch_hensel_modexp_part9(H, K, a, blocks, s)
+#if PGPU_WITH_4096
+         || launch_hensel_modexp_part23(H, K, a, blocks, s)
+#endif
+      ;
 }
 
 // element-wise operations on pair rows (hensel.hpp: pair_ops_kernel; k_hensel.hip parts 11-13): the throughput form of
 // each key class -- (2,19): 1024-bit keys, (4,18): 2048, (8,14): 3072, (8,18): 4096 (part 24)
 inline bool pair_ops_has(int H, int K) {
-  return (H == 2 && K == 19) || (H == 4 && K == 18) || (H == 8 && (K == 14 || K == 18));
+  return (H == 2 && K == 19) || (H == 4 && K == 18) || (H == 8 && (K == 14 || (PGPU_WITH_4096 && K == 18)));
 }
 // (8,9) (part 25): CT + CT / CT + PT of batches that leave SIMDs idle under a 2048-bit key -- 16 lanes per element on
 // the same 144-limb rows as (4,18), a product's serial chain 40 % shorter
@@ -108,16 +131,24 @@ bool launch_pair_ops_part13(int H, int K, const PairOpsArgs& a, unsigned blocks,
 bool launch_pair_ops_part24(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s);
 inline bool launch_pair_ops(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream_t s) {
   return launch_pair_ops_part11(H, K, a, blocks, s) || launch_pair_ops_part12(H, K, a, blocks, s) ||
-         launch_pair_ops_part13(H, K, a, blocks, s) || launch_pair_ops_part24(H, K, a, blocks, s) ||
-         launch_pair_ops_part25(H, K, a, blocks, s);
+         launch_pair_ops_part13(H, K, a, blocks, s) || launch_pair_ops_part25(H, K, a, blocks, s)
+#if PGPU_WITH_4096
+         || launch_pair_ops_part24(H, K, a, blocks, s)
+#endif
+      ;
 }
 
 // CRT decrypt with the two halves of a residue in different wavefronts (hensel_ab.hpp; k_hensel.hip part 15): pair-row
 // ciphertexts, fixed-window scan, 2048-bit keys (2 lanes x 19 limbs per half)
-inline bool hensel_ab_has(int K) { return K == 19; }
+inline bool hensel_ab_has(int K) { return PGPU_WITH_AB && K == 19; }
 bool launch_hensel_ab_part15(int K, int pairs_per_wg, const HenselArgs& a, unsigned blocks, hipStream_t s);
 inline bool launch_hensel_ab(int K, int pairs_per_wg, const HenselArgs& a, unsigned blocks, hipStream_t s) {
+#if PGPU_WITH_AB
   return launch_hensel_ab_part15(K, pairs_per_wg, a, blocks, s);
+#else
+  (void)K; (void)pairs_per_wg; (void)a; (void)blocks; (void)s;
+  return false;
+#endif
 }
 
 // CRT decrypt with both halves of a residue in the same lanes (hensel_seq.hpp; k_hensel.hip parts 16, 17): pair-row

@@ -341,7 +341,89 @@ void big_copy(void* dst, const void* src, size_t n) {
   pool->job.unlock();
 }
 
+// ---------------- pinned host blocks ----------------
 namespace {
+struct HostBlock {
+  size_t bytes = 0;
+  std::vector<hipEvent_t> last_read;   // [pool device]: behind the last upload that reads the block (null: none)
+};
+std::mutex g_host_mu;
+std::map<uintptr_t, HostBlock>& g_host_blocks = *new std::map<uintptr_t, HostBlock>();
+// g_host_mu held: the block that contains [p, p+bytes), or end()
+std::map<uintptr_t, HostBlock>::iterator host_lookup(const void* p, size_t bytes) {
+  const uintptr_t a = (uintptr_t)p;
+  auto it = g_host_blocks.upper_bound(a);
+  if (it == g_host_blocks.begin()) return g_host_blocks.end();
+  --it;
+  if (a >= it->first && a + bytes <= it->first + it->second.bytes) return it;
+  return g_host_blocks.end();
+}
+}  // namespace
+
+int host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_host_alloc: null pointer or zero size");
+  RC_TRY(check_ready());
+  void* p = nullptr;
+  HIP_TRY(hipHostMalloc(&p, bytes, hipHostMallocPortable));
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  g_host_blocks[(uintptr_t)p].bytes = bytes;
+  *out = p;
+  return PGPU_OK;
+}
+
+int host_wait(const void* p) {
+  std::vector<hipEvent_t> evs;
+  {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    auto it = host_lookup(p, 1);
+    if (it == g_host_blocks.end()) return PGPU_OK;   // not ours: nothing is ever pending on it
+    evs = it->second.last_read;
+  }
+  for (hipEvent_t e : evs)
+    if (e) HIP_TRY(hipEventSynchronize(e));
+  return PGPU_OK;
+}
+
+void host_free(void* p) {
+  if (!p) return;
+  (void)host_wait(p);
+  HostBlock b;
+  {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    auto it = g_host_blocks.find((uintptr_t)p);
+    if (it == g_host_blocks.end()) return;
+    b = it->second;
+    g_host_blocks.erase(it);
+  }
+  for (hipEvent_t e : b.last_read)
+    if (e) (void)hipEventDestroy(e);
+  (void)hipHostFree(p);
+}
+
+bool host_is_pinned(const void* p, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  return host_lookup(p, bytes) != g_host_blocks.end();
+}
+
+void host_note_read(const void* p, size_t bytes, int dev, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  auto it = host_lookup(p, bytes);
+  if (it == g_host_blocks.end() || dev < 0) return;
+  auto& ev = it->second.last_read;
+  if (ev.size() <= (size_t)dev) ev.resize((size_t)dev + 1, nullptr);
+  if (!ev[(size_t)dev] && hipEventCreateWithFlags(&ev[(size_t)dev], hipEventDisableTiming) != hipSuccess) {
+    ev[(size_t)dev] = nullptr;
+    (void)hipStreamSynchronize(s);   // no event to remember the copy by: wait for it here
+    return;
+  }
+  (void)hipEventRecord(ev[(size_t)dev], s);
+}
+
+namespace {
+size_t stage_piece(size_t bytes) {
+  const size_t quarter = ((bytes + 3) / 4 + 4095) & ~(size_t)4095;
+  return std::min(kStageBytes, std::max<size_t>((size_t)512 << 10, quarter));
+}
 int ensure_stage(Lane& l) {
   for (int i = 0; i < 2; ++i) {
     if (!l.stage[i]) HIP_TRY(hipHostMalloc(&l.stage[i], kStageBytes, hipHostMallocDefault));
@@ -354,11 +436,19 @@ int ensure_stage(Lane& l) {
 // host -> device: chunk i+1 is packed into the other pinned buffer while chunk i is on the wire.  The copies
 // are ordered on `s` (the stream the consumer kernels run on); nothing is waited for at the end.
 int Lane::h2d(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
+  if (bytes && host_is_pinned(h_src, bytes)) {   // a caller buffer from pgpu_host_alloc: it IS the DMA source
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s));
+    host_note_read(h_src, bytes, dev ? dev->index : -1, s);
+    return PGPU_OK;
+  }
   RC_TRY(ensure_stage(*this));
+  // pieces of a quarter of the transfer (0.5 - 8 MiB): packing piece i+1 overlaps the DMA of piece i also for the 1-4 MB
+  // operands of an 8192-element call, which used to go as ONE piece -- pack, then copy, nothing overlapping
+  const size_t piece = stage_piece(bytes);
   size_t off = 0;
   for (int i = 0; off < bytes; ++i) {
     const int b = i & 1;
-    const size_t n = std::min(kStageBytes, bytes - off);
+    const size_t n = std::min(piece, bytes - off);
     HIP_TRY(hipEventSynchronize(stage_ev[b]));   // the DMA that last used this buffer is done (no-op if never recorded)
     big_copy(stage[b], (const char*)h_src + off, n);
     HIP_TRY(hipMemcpyAsync((char*)d_dst + off, stage[b], n, hipMemcpyHostToDevice, s));
@@ -370,10 +460,17 @@ int Lane::h2d(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
 
 // device -> host, ordered behind the work queued on `s`: chunk i+1 is on the wire while chunk i is unpacked
 int Lane::d2h(void* h_dst, const void* d_src, size_t bytes, hipStream_t s) {
+  if (bytes && host_is_pinned(h_dst, bytes)) {   // pinned target: one DMA, no unpacking copy
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s));
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail(PGPU_ERR_HIP, std::string("device -> host copy failed: ") + hipGetErrorString(e));
+    return PGPU_OK;
+  }
   RC_TRY(ensure_stage(*this));
-  const int chunks = (int)((bytes + kStageBytes - 1) / kStageBytes);
+  const size_t piece = stage_piece(bytes);
+  const int chunks = (int)((bytes + piece - 1) / piece);
   auto issue = [&](int i) -> hipError_t {
-    const size_t off = (size_t)i * kStageBytes, n = std::min(kStageBytes, bytes - off);
+    const size_t off = (size_t)i * piece, n = std::min(piece, bytes - off);
     hipError_t r = hipEventSynchronize(stage_ev[i & 1]);
     if (r == hipSuccess) r = hipMemcpyAsync(stage[i & 1], (const char*)d_src + off, n, hipMemcpyDeviceToHost, s);
     return r == hipSuccess ? hipEventRecord(stage_ev[i & 1], s) : r;
@@ -384,7 +481,7 @@ int Lane::d2h(void* h_dst, const void* d_src, size_t bytes, hipStream_t s) {
     if (i + 1 < chunks) e = issue(i + 1);   // its buffer was unpacked in iteration i-1
     if (e == hipSuccess) e = hipEventSynchronize(stage_ev[i & 1]);
     if (e != hipSuccess) break;
-    const size_t off = (size_t)i * kStageBytes, n = std::min(kStageBytes, bytes - off);
+    const size_t off = (size_t)i * piece, n = std::min(piece, bytes - off);
     big_copy((char*)h_dst + off, stage[i & 1], n);
   }
   if (e != hipSuccess) return fail(PGPU_ERR_HIP, std::string("device -> host copy failed: ") + hipGetErrorString(e));
@@ -500,9 +597,10 @@ int pool_init(const std::vector<int>& ordinals) {
     d->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
       return fail(PGPU_ERR_NO_DEVICE, "device is not gfx950: " + d->name);
-    HIP_TRY(hipStreamCreateWithFlags(&d->bstream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&d->bstream1, hipStreamNonBlocking));
-    for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreateWithFlags(&d->xlane_ev[k], hipEventDisableTiming));
+    for (int k = 0; k < kBatchLanes; ++k) {
+      HIP_TRY(hipStreamCreateWithFlags(&d->bstreams[k], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&d->xlane_ev[k], hipEventDisableTiming));
+    }
     for (int l = 0; l < 2; ++l) {
       std::unique_ptr<Lane> lane(new Lane);
       lane->dev = d.get();
@@ -569,17 +667,28 @@ void pool_shutdown() {
       }
       if (lane->stream) (void)hipStreamDestroy(lane->stream);
     }
-    if (d->bstream) (void)hipStreamDestroy(d->bstream);
-    if (d->bstream1) (void)hipStreamDestroy(d->bstream1);
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < kBatchLanes; ++k) {
+      if (d->bstreams[k]) (void)hipStreamDestroy(d->bstreams[k]);
       if (d->xlane_ev[k]) (void)hipEventDestroy(d->xlane_ev[k]);
+    }
+  }
+  {
+    // pinned host blocks belong to their callers and survive; the events that remember uploads from them do not (the
+    // devices have drained above, and the next pool may number its entries differently)
+    std::lock_guard<std::mutex> hl(g_host_mu);
+    for (auto& kv : g_host_blocks) {
+      for (hipEvent_t e : kv.second.last_read)
+        if (e) (void)hipEventDestroy(e);
+      kv.second.last_read.clear();
+    }
   }
   if (!g_pool.empty()) (void)hipSetDevice(g_pool[0]->ordinal);
   for (auto& d : g_pool) {
     d->alive = false;
-    d->bstream = nullptr;
-    d->bstream1 = nullptr;
-    d->xlane_ev[0] = d->xlane_ev[1] = nullptr;
+    for (int k = 0; k < kBatchLanes; ++k) {
+      d->bstreams[k] = nullptr;
+      d->xlane_ev[k] = nullptr;
+    }
     d->lanes.clear();
     g_retired.push_back(std::move(d));
   }
@@ -595,7 +704,15 @@ void Replicated::scrub_and_free() {
     if (!d[i]) continue;
     if (gen == pool_generation() && i < g_pool.size()) {
       DeviceGuard g(g_pool[i]->ordinal);
-      if (secret_) (void)hipMemset(d[i], 0, bytes);   // key material does not outlive the key object
+      // Every stream of the library is hipStreamNonBlocking: a null-stream memset does NOT wait for kernels still queued
+      // on them, and a `_dev` call or a resident-batch operation only enqueues its kernel.  A secret image is therefore
+      // zeroed only after the device has drained (round-3 advisor: an LRU eviction or a key destroyed with operations in
+      // flight could otherwise hand zeroed constants to a queued kernel).  hipFree below synchronises anyway; the wait
+      // merely moves in front of the memset.
+      if (secret_) {
+        (void)hipDeviceSynchronize();
+        (void)hipMemset(d[i], 0, bytes);   // key material does not outlive the key object
+      }
       (void)hipFree(d[i]);
     } else {
       // the pool this copy was made for is gone (its devices were reset or re-enumerated): the address identifies
@@ -644,14 +761,14 @@ int Replicated::upload(const void* host, size_t nbytes, bool secret) {
     ncclResult_t r = g_rccl.GroupStart();
     for (int i = 0; i < D && r == ncclSuccess; ++i) {
       DeviceGuard g(device(i).ordinal);
-      r = g_rccl.Broadcast(d[0], d[(size_t)i], nbytes, ncclUint8, 0, g_rccl.comms[(size_t)i], device(i).bstream);
+      r = g_rccl.Broadcast(d[0], d[(size_t)i], nbytes, ncclUint8, 0, g_rccl.comms[(size_t)i], device(i).bs(0));
     }
     ncclResult_t r2 = g_rccl.GroupEnd();
     if (r == ncclSuccess) r = r2;
     if (r == ncclSuccess) {
       for (int i = 0; i < D; ++i) {
         DeviceGuard g(device(i).ordinal);
-        HIP_TRY(hipStreamSynchronize(device(i).bstream));
+        HIP_TRY(hipStreamSynchronize(device(i).bs(0)));
       }
       by_rccl = true;
     } else {

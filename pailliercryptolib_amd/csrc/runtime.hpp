@@ -88,10 +88,12 @@ struct StreamWork {
 
 struct TimedLaunch {
   int kind;
+  int form;   // pgpu_kernel_form bits (include/pgpu.h): what the launcher picked for this launch
   hipEvent_t e0, e1;
 };
 
 constexpr size_t kStageBytes = (size_t)8 << 20;
+constexpr int kBatchLanes = 4;
 
 struct Lane {
   Device* dev = nullptr;
@@ -110,11 +112,14 @@ struct Device {
   int ordinal = 0;   // HIP device ordinal (several pool entries may share one when oversubscribed)
   std::string name;
   bool alive = true;               // false once its pool has been shut down (objects may still point here)
-  hipStream_t bstream = nullptr;   // resident-batch operations: batch lane 0 (also key replication)
-  hipStream_t bstream1 = nullptr;  // batch lane 1: a second, independent chain of resident batches in flight
-  hipStream_t bs(int lane) const { return lane ? bstream1 : bstream; }
-  // cross-lane ordering (a batch of one lane consumed by an operation on the other): one event per direction
-  hipEvent_t xlane_ev[2] = {nullptr, nullptr};
+  // resident-batch operations run on the batch lanes: kBatchLanes independent chains of resident batches may be in
+  // flight on a GPU (lane 0 also carries the key replication).  Round 3 had two; the sequential-halves kernels need
+  // 16384 exponentiation pairs in flight to put a wavefront on every SIMD and 32768 for two, so an 8192-element step
+  // wants up to four of them side by side.
+  hipStream_t bstreams[kBatchLanes] = {};
+  hipStream_t bs(int lane) const { return bstreams[lane % kBatchLanes]; }
+  // cross-lane ordering (a batch of one lane consumed by an operation on another): one event per source lane
+  hipEvent_t xlane_ev[kBatchLanes] = {};
   std::mutex mu;                   // allocator, work map, timing, queue
 
   // ---- caching allocator (sizes rounded to 64 KiB; free lists per stream tag) ----
@@ -233,6 +238,18 @@ void set_min_shard(size_t n);
 
 // multi-threaded memcpy between pageable and pinned memory (one job at a time; falls back to memcpy when busy)
 void big_copy(void* dst, const void* src, size_t n);
+
+// ---- pinned host blocks handed to callers (pgpu_host_alloc) ----
+// A caller buffer that lies inside one of these blocks is the source / target of the DMA itself: Lane::h2d / d2h skip
+// their staging copies (8-10 GB/s per host thread against ~50 GB/s on the link).  Uploads from a block are not waited
+// for: the block remembers the last copy queued from it per pool device (an event) and host_wait / host_free wait for
+// those -- the owner of the block decides when it has to be reusable.
+int host_alloc(size_t bytes, void** out);
+void host_free(void* p);
+bool host_is_pinned(const void* p, size_t bytes);
+int host_wait(const void* p);
+// called by Lane::h2d after queueing a copy that READS [p, p+bytes) on stream s of pool entry `dev`
+void host_note_read(const void* p, size_t bytes, int dev, hipStream_t s);
 
 }  // namespace rt
 }  // namespace pgpu

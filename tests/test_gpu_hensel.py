@@ -64,6 +64,8 @@ def test_kat_and_fixtures_through_split_form(engine, hensel, form):
 def test_split_form_equals_full_width(engine, hensel, bits, count, policy, form):
     """Random elements of Z_{n^2} (mostly NOT encryptions, so L_p(c^(p-1)) has no structure to hide behind)."""
     from pailliercryptolib_amd import _capi
+    if bits == 4096 and not _capi.lib().pgpu_build_features() & _capi.FEATURE_4096_SPLIT:
+        pytest.skip("the split forms of the 4096-bit key class are not in this build (PGPU_BUILD_4096=1 builds them)")
     rng = random.Random(bits * 7 + count)
     if bits == 2048:
         kat = _kat()
