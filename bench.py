@@ -120,9 +120,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
                     help="2: BASELINE configs[1]+[2] (default, the headline); 4 / 5: configs[3] / configs[4]")
-    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
-                    help="resident batches in flight per GPU: consecutive steps alternate between the library's two "
-                         "batch lanes (2, default) or all run on one lane (1)")
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="resident batches in flight per GPU: consecutive steps rotate over that many of the library's "
+                         "batch lanes (default 2; 1: every step on one lane)")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+                    help="length of the sustained-rate run behind the timed region (N = 1; 0 skips it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the N=1 side measurements (end-to-end, API level, non-DJN variant)")
@@ -200,19 +202,22 @@ def run_pool(args):
         step()
     sync_all()
     # live per-kernel timing: the library brackets every launch with HIP events on the launch stream (no
-    # synchronisation inside the timed region); collected after the final synchronisation (pool entry 0).  With two
-    # batches in flight the launches of the two lanes overlap, so an event pair then spans BOTH kernels' share of the
-    # SIMDs: the per-kernel numbers of the roofline come from a short single-lane pass behind the timed region.
-    _capi.check(L.pgpu_set_timing(1 if nfl == 1 else 0))
+    # synchronisation inside the timed region) and records the kernel FORM it picked -- with several batches in flight
+    # the adaptive policy chooses per launch, from what the neighbour lanes are doing (include/pgpu.h), so the line says
+    # what actually ran.  With batches in flight the launches of the lanes overlap, so an event pair spans a SHARED
+    # stretch of the chip: per-kernel times of a lone launch come from a short single-lane pass behind the timed region,
+    # and the decrypt leg under overlap from a decrypt-only run on the same lanes (measured, not derived).
+    _capi.check(L.pgpu_set_timing(1))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
+    timed_forms = collect_forms(L, 8 * args.steps + 64)
+    single_ms = None
     if nfl == 1:
-        per_kind = collect_timing(L, 4 * args.steps + 8)
+        per_kind = forms_to_kinds(timed_forms)
     else:
-        _capi.check(L.pgpu_set_timing(1))
         t1 = time.perf_counter()
         for _ in range(10):
             state["i"] = 0          # lane 0 only
@@ -221,6 +226,22 @@ def run_pool(args):
         single_ms = (time.perf_counter() - t1) / 10 * 1e3
         per_kind = collect_timing(L, 64)
     _capi.check(L.pgpu_set_timing(0))
+    measured = {}
+    if N == 1:
+        measured["decrypt_leg"] = decrypt_leg_in_flight(L, B, sk, state["c"], nfl, nw)
+        if args.sustain_seconds > 0:
+            state["i"] = 0
+            k = max(nfl, int(args.sustain_seconds / (elapsed / args.steps)) // nfl * nfl)
+            sync_all()
+            t2 = time.perf_counter()
+            for _ in range(k):
+                step()
+            sync_all()
+            dt = time.perf_counter() - t2
+            measured["sustained"] = {"steps": k, "seconds": round(dt, 3), "ms_per_step": round(dt / k * 1e3, 4),
+                                     "modexps_per_s": round(3 * BATCH * N * k / dt, 1),
+                                     "what": "the same steps back to back for about %.0f s behind the timed region (the boxes "
+                                             "hold a lower clock over seconds than over the 0.1 s of a 20-step run)" % args.sustain_seconds}
 
     # ---- correctness of what was timed: full-size round trip + oracle spot checks ----
     ok = all(bool(np.array_equal(B.down(o), m_host)) for o in state["out"])
@@ -251,18 +272,60 @@ def run_pool(args):
     result["config"]["batches_in_flight_per_gpu"] = nfl
     result["config"]["resident_ciphertext_form"] = ("pair rows (%d limbs)" % L.pgpu_batch_row_limbs(state["c"])
                                                     if L.pgpu_batch_row_limbs(state["c"]) else "Montgomery-form words")
-    if nfl == 2:
-        result["config"]["workload"] += ("; TWO batches in flight per GPU: consecutive steps alternate between the "
-                                         "library's two batch lanes (streams), exactly K steps timed")
+    r = result["roofline"]
+    r["useful_mac32_per_launch"] = decrypt_useful_mac32(nw, KEY_BITS) * 2 * BATCH
+    r["frac_useful"] = sig(r["useful_mac32_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e12 / PEAK_TMAC32)
+    r["useful_note"] = ("useful = the multiply-accumulates the split form needs (sequential-halves count: symmetric a*a, no "
+                        "lane idling through another's products); executed - useful = slots the paired kernel spends on "
+                        "products nobody needs")
+    result["kernel_forms_in_timed_region"] = forms_summary(timed_forms)
+    if nfl > 1:
+        result["config"]["workload"] += ("; %d batches in flight per GPU: consecutive steps rotate over %d of the library's "
+                                         "batch lanes (streams), exactly K steps timed" % (nfl, nfl))
         result["one_batch_in_flight"] = {"ms_per_step": round(single_ms, 4), "modexps_per_s": round(3 * BATCH * N / (single_ms * 1e-3), 1),
-                                         "what": "the same steps on ONE lane, 10 steps behind the timed region; roofline.kernel_ms and "
-                                                 "the other per-kernel times are from this pass (launches do not overlap in it)"}
-        r = result["roofline"]
-        share = r["kernel_ms"] / single_ms
-        r["kernel_ms_effective_two_in_flight"] = round(result["ms_per_step"] * share, 3)
-        r["frac_two_in_flight"] = sig(r["executed_mac32_per_launch"] / (result["ms_per_step"] * share * 1e-3) / 1e12 / PEAK_TMAC32)
-        r["frac_two_in_flight_note"] = ("derived: the kernel's share of a single-lane step applied to the two-in-flight "
-                                        "ms_per_step (the launches of the two lanes share the SIMDs, two wavefronts each)")
+                                         "what": "the same steps on ONE lane, 10 steps behind the timed region (launches do not "
+                                                 "overlap in it): roofline.lone_launch and other_kernels are from this pass"}
+        # The roofline block describes the dominant kernel AS IT RAN in the timed region.  A lone launch (one lane) is
+        # kept beside it.  Under the adaptive policy a decrypt queued beside a busy neighbour lane runs the
+        # sequential-halves kernel on HALF the chip (its workgroups claim whole CUs, 128 of 256): its HIP-event duration
+        # is the time it holds that half, so its rate is priced against half the peak (chip_share).
+        lone = {k: r[k] for k in ("kernel", "kernel_ms", "achieved", "frac", "frac_useful", "executed_mac32_per_launch",
+                                  "canonical_achieved", "canonical_frac")}
+        lone["what"] = "the paired full-chip kernel a lone caller gets (nothing queued on the other lanes), single-lane pass"
+        r["lone_launch"] = lone
+        dec_timed = [(f, ms) for k, f, ms in timed_forms if k == K_MODEXP]
+        if dec_timed:
+            top = max({f for f, _ in dec_timed}, key=lambda f: sum(1 for g, _ in dec_timed if g == f))
+            ms_top = float(np.mean([ms for f, ms in dec_timed if f == top]))
+            name, per_exp = decrypt_kernel(sk, BATCH, nw, KEY_BITS, 1 if top & 2 else 0)
+            share = 0.5 if top == 18 else None        # CU claim: 128 workgroups on 128 of the 256 CUs
+            r["kernel"] = (f"{name} ({FORM_NAMES.get(top, top)}; CRT-decrypt leg: {2 * BATCH} half-width modexps per launch; "
+                           f"{sum(1 for g, _ in dec_timed if g == top)} of the {len(dec_timed)} decrypt launches of the timed region)")
+            r["executed_mac32_per_launch"] = per_exp * 2 * BATCH
+            r["kernel_ms"] = round(ms_top, 3)
+            r["kernel_ms_basis"] = "mean HIP-event duration of those launches INSIDE the timed region (rocprofv3 kernel-trace agrees)"
+            if share:
+                r["chip_share"] = share
+                r["achieved"] = sig(per_exp * 2 * BATCH / (ms_top * 1e-3) / 1e12, 3)
+                r["peak_of_share"] = round(PEAK_TMAC32 * share, 2)
+                r["frac"] = sig(per_exp * 2 * BATCH / (ms_top * 1e-3) / 1e12 / (PEAK_TMAC32 * share))
+                r["frac_useful"] = sig(r["useful_mac32_per_launch"] / (ms_top * 1e-3) / 1e12 / (PEAK_TMAC32 * share))
+                r["frac_basis"] = ("EXECUTED multiply-accumulates per launch / HIP-event duration of the launch / (peak x chip_share): "
+                                   "the launch holds 128 of the 256 CUs (one workgroup per CU by its LDS claim) while the neighbour "
+                                   "lane's launches use the rest; whole-chip accounting of the same leg: roofline.measured_in_flight")
+            elif "decrypt_leg" in measured:
+                r["achieved"] = sig(measured["decrypt_leg"]["executed_mac32"] / (measured["decrypt_leg"]["wall_ms"] * 1e-3) / 1e12, 3)
+                r["frac"] = measured["decrypt_leg"]["frac_executed"]
+                r["frac_useful"] = measured["decrypt_leg"]["frac_useful"]
+                r["frac_basis"] = ("launches of several lanes share the SIMDs: fraction from the decrypt-only run on the same lanes "
+                                   "(roofline.measured_in_flight), executed multiply-accumulates / wall time / peak")
+            r["canonical_achieved"] = None
+            for kk in ("canonical_frac",):
+                r[kk] = sig(r["canonical_mac32_per_launch"] / (ms_top * 1e-3) / 1e12 / (PEAK_TMAC32 * (share or 1.0))) if share else None
+    if "decrypt_leg" in measured:
+        r["measured_in_flight"] = measured["decrypt_leg"]
+    if "sustained" in measured:
+        result["sustained"] = measured["sustained"]
     result["pool"] = per_gpu
     # side measurements must never sink the contract line: a failure is reported inside it
     if N == 1 and not args.no_extras:
@@ -280,6 +343,77 @@ def run_pool(args):
     pa.terminate()
     ctypes.CDLL(None).fflush(None)
     print(json.dumps(result), flush=True)              # the ONE JSON line, last thing on stdout
+
+
+FORM_NAMES = {0: "full-width", 1: "paired", 2: "sequential-halves", 18: "sequential-halves+cu-claim", 65: "a/b-wavefronts"}
+
+
+def collect_forms(L, cap):
+    """[(kind, form, ms)] of the recorded launches of pool entry 0, in launch order"""
+    kinds, forms, kms = (ctypes.c_int * cap)(), (ctypes.c_int * cap)(), (ctypes.c_double * cap)()
+    n = L.pgpu_timing_collect_ex(kinds, forms, kms, cap)
+    return [(kinds[i], forms[i], kms[i]) for i in range(n)]
+
+
+def forms_to_kinds(rec):
+    per = {}
+    for k, _, ms in rec:
+        per.setdefault(k, []).append(ms)
+    return per
+
+
+def forms_summary(rec):
+    """launch counts per (kernel kind, form) of a timed region"""
+    names = {K_MODEXP: "decrypt_exponentiation", K_CRT: "crt", K_FB: "fixed_base_encrypt", K_MODMUL: "pair_ops"}
+    out = {}
+    for k, f, _ in rec:
+        key = names.get(k, str(k)) + ":" + FORM_NAMES.get(f, str(f))
+        out[key] = out.get(key, 0) + 1
+    return out
+
+
+def decrypt_leg_in_flight(L, B, sk, cts, nfl, nw, launches_per_lane=6):
+    """The CRT-decrypt leg MEASURED under the overlap the timed region runs with: decrypt-only steps on the same nfl batch
+    lanes (resident ciphertexts of the timed region), wall time / launches = the chip time one launch costs.  Fractions
+    by the executed count of the kernels that ran (forms recorded per launch) and by the useful count."""
+    from pailliercryptolib_amd import _capi
+    outs = [None] * nfl
+
+    def run(k):
+        for i in range(k):
+            ln = i % nfl
+            if outs[ln]:
+                L.pgpu_batch_destroy(outs[ln])
+            outs[ln] = B.op(L.pgpu_batch_decrypt_crt, sk._h, cts[ln])
+    run(2 * nfl)
+    _capi.check(L.pgpu_synchronize())
+    _capi.check(L.pgpu_set_timing(1))
+    k = launches_per_lane * nfl
+    t0 = time.perf_counter()
+    run(k)
+    _capi.check(L.pgpu_synchronize())
+    wall = time.perf_counter() - t0
+    rec = collect_forms(L, 4 * k + 16)
+    _capi.check(L.pgpu_set_timing(0))
+    for o in outs:
+        if o:
+            L.pgpu_batch_destroy(o)
+    dec = [(f, ms) for kind, f, ms in rec if kind == K_MODEXP]
+    executed = 0
+    for f, _ in dec:
+        busy = 1 if f & 2 else 0
+        executed += decrypt_kernel(sk, BATCH, nw, KEY_BITS, busy)[1] * 2 * BATCH
+    useful = decrypt_useful_mac32(nw, KEY_BITS) * 2 * BATCH * len(dec)
+    per_launch = wall / max(1, len(dec))
+    return {"what": "decrypt-only steps (exponentiation + CRT kernel) on the %d batch lanes of the timed region, %d launches; "
+                    "wall time / launches = chip time per 8192-ciphertext decrypt under that overlap" % (nfl, len(dec)),
+            "launches": len(dec), "wall_ms": round(wall * 1e3, 3), "ms_per_launch": round(per_launch * 1e3, 4),
+            "forms": forms_summary(rec),
+            "event_ms_per_launch_mean": round(float(np.mean([ms for _, ms in dec])), 3) if dec else None,
+            "event_note": "HIP-event span of one launch: it shares the chip with its neighbours for that long",
+            "executed_mac32": executed, "useful_mac32": useful,
+            "frac_executed": sig(executed / wall / 1e12 / PEAK_TMAC32),
+            "frac_useful": sig(useful / wall / 1e12 / PEAK_TMAC32)}
 
 
 def fixed_base_info(L, pk, dev=0):
@@ -311,15 +445,28 @@ def per_gpu_report(L, N, per_kind0):
     return out
 
 
-def decrypt_kernel(sk, count, nw, key_bits):
+def decrypt_useful_mac32(nw, key_bits):
+    """USEFUL multiply-accumulates of one half-width exponentiation of the CRT-decrypt leg: what the split form has to
+    compute, whatever kernel computes it -- the count of the sequential-halves form (csrc/hensel_seq.hpp), in which no lane
+    sits through another's products: a squaring is a*a with its symmetry (L2 (L2 + G) / 2) + 2ab (L2^2) + two reductions
+    (2 L2^2), a general product 3 half-width products + two reductions (5 L2^2).  The paired kernel EXECUTES 4 L2^2 / 6 L2^2
+    (half A idles through half B's second product and cannot use the symmetry): executed - useful = slots spent on
+    products nobody needs."""
+    g, l2 = {1024: (2, 20), 2048: (2, 38), 3072: (4, 56), 4096: (4, 72)}[key_bits]
+    e = key_bits // 2
+    nmul = (e + 4) // 5 + 30 + (2 * nw + e // 64 - 1) // (e // 64) + 2
+    return e * (l2 * (l2 + g) // 2 + 3 * l2 * l2) + nmul * 5 * l2 * l2
+
+
+def decrypt_kernel(sk, count, nw, key_bits, busy_lanes=0):
     """(name, executed MAC32 per half-width exponentiation) of the kernel a CRT decrypt of `count` ciphertexts runs:
     the split form (csrc/hensel.hpp: a residue modulo p^2 as two half-width numbers, L2 limbs each; a squaring is
     4 L2^2 limb products, a general product 6 L2^2) or the full-width modexp_kernel (executed = the canonical count
     within 1 %: 29-bit limbs cost x1.27, symmetric squaring gives x0.77 back)."""
     from pailliercryptolib_amd import _capi
     split, lanes, limbs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    _capi.check(_capi.lib().pgpu_decrypt_kernel_form(sk._h, count, ctypes.byref(split), ctypes.byref(lanes),
-                                                     ctypes.byref(limbs)))
+    _capi.check(_capi.lib().pgpu_decrypt_kernel_form_ex(sk._h, count, busy_lanes, ctypes.byref(split), ctypes.byref(lanes),
+                                                        ctypes.byref(limbs)))
     e = key_bits // 2
     if not split.value:
         return f"modexp_kernel<Geo<{lanes.value},{limbs.value}>>", algorithmic_mac32(key_bits, e)
@@ -332,7 +479,7 @@ def decrypt_kernel(sk, count, nw, key_bits):
     nmul += (2 * nw + e // 64 - 1) // (e // 64) + 2            # ciphertext chunks in, exit products
     if seq:    # both halves in the same lanes: the a*a of a squaring uses its symmetry, L2 (L2 + lanes) / 2 products
         sq = l2 * (l2 + lanes.value) // 2 + 3 * l2 * l2
-        return f"hensel_decrypt_seq_kernel<{lanes.value},{limbs.value}>", nsq * sq + nmul * 6 * l2 * l2
+        return f"hensel_decrypt_seq_kernel<{lanes.value},{limbs.value}>", nsq * sq + nmul * 5 * l2 * l2
     return f"hensel_decrypt_kernel<{lanes.value // 2},{limbs.value}>", nsq * 4 * l2 * l2 + nmul * 6 * l2 * l2
 
 
@@ -461,6 +608,7 @@ def headline(args, world, elapsed, per_kind, nw, pw, parallelism, dec_kernel=Non
             "frac_basis": "EXECUTED multiply-accumulates (limb products of 29-bit limbs counted as MAC32 one for one) "
                           "per launch / kernel time / peak; two significant digits (box-to-box spread 2-4 %)",
             "traffic": pmc.get("modexp_decrypt_hbm_bytes_per_launch"),
+            "traffic_source": pmc_source(pmc, "modexp_decrypt_kernel"),
             "kernel_ms": round(dec_ms, 3),
             "executed_mac32_per_launch": dec_exec * 2 * BATCH,
             # the SURVEY 8(d) count, whatever the kernel executes: full-width Montgomery products, squarings counted
@@ -488,6 +636,7 @@ def headline(args, world, elapsed, per_kind, nw, pw, parallelism, dec_kernel=Non
                     "fixed_base_table": fb,
                     "algorithmic_bytes_per_launch": alg_bytes_enc,
                     "traffic": pmc.get("fb_encrypt_hbm_bytes_per_launch"),
+                    "traffic_source": pmc_source(pmc, "fb_encrypt_kernel"),
                     "note": enc_note,
                 },
             },
@@ -495,6 +644,16 @@ def headline(args, world, elapsed, per_kind, nw, pw, parallelism, dec_kernel=Non
         # the conservative reading of the headline: the CRT-decrypt leg alone (no fixed-base shortcut in it)
         "decrypt_only_modexps_per_s": round(2 * BATCH / ((dec_ms + crt_ms) * 1e-3), 1),
     }
+
+
+def pmc_source(pmc, kernel_key):
+    """where a `traffic` figure comes from: PMC counters cannot be read inside bench.py (rocprofv3 owns them), so the
+    number is the per-launch average of a committed rocprofv3 --pmc pass (its own run, no trace domains) of THIS command
+    on the build named there -- the same on every box until that pass is repeated"""
+    if not pmc:
+        return None
+    return {"file": "profiles/pmc_summary.json", "measured_on_kernel": pmc.get(kernel_key), "how": pmc.get("source"),
+            "build": pmc.get("build"), "note": "constant read from the committed summary, not measured in this run"}
 
 
 def best_of(fn, reps):
@@ -523,10 +682,80 @@ def extras(pa, L, B, pk, sk, n, p, q, hs, m_host, r_host, per_kind):
     e2e_enc(); e2e_dec()
     te, td = best_of(e2e_enc, 5), best_of(e2e_dec, 5)
     assert np.array_equal(d_host, m_host)
-    out["end_to_end"] = {"what": "pgpu_paillier_encrypt + pgpu_paillier_decrypt_crt on caller-owned host arrays "
-                                 "(pinned staging, H2D + kernels + D2H inside the call)",
+    out["end_to_end"] = {"what": "pgpu_paillier_encrypt + pgpu_paillier_decrypt_crt on caller-owned PAGEABLE host arrays, one "
+                                 "synchronous caller (H2D + kernels + D2H inside each call; staging through pinned bounce "
+                                 "buffers in quarter-transfer pieces)",
                          "encrypt_ms": round(te * 1e3, 3), "decrypt_ms": round(td * 1e3, 3),
-                         "modexps_per_s": round(3 * BATCH / (te + td), 1)}
+                         "modexps_per_s": round(3 * BATCH / (te + td), 1),
+                         "floor_note": "a synchronous call cannot end before its kernels do: the kernels of one encrypt + one "
+                                       "decrypt call are %.2f ms of the %.2f ms measured"
+                                       % (float(np.mean(per_kind[K_FB])) + float(np.mean(per_kind[K_MODEXP])) + float(np.mean(per_kind[K_CRT])),
+                                          (te + td) * 1e3)}
+    # (1b) the same calls on buffers from pgpu_host_alloc: the DMA reads / writes the caller's arrays, no staging copy
+    try:
+        blocks = []
+
+        def pinned(shape):
+            nbytes = int(np.prod(shape)) * 8
+            pp = ctypes.c_void_p()
+            _capi.check(L.pgpu_host_alloc(nbytes, ctypes.byref(pp)))
+            blocks.append(pp)
+            return pp, np.frombuffer((ctypes.c_uint8 * nbytes).from_address(pp.value), dtype=np.uint64).reshape(shape)
+        pm, am = pinned((BATCH, nw)); pr, ar = pinned((BATCH, pw)); pc, ac = pinned((BATCH, 2 * nw)); pd, ad = pinned((BATCH, nw))
+        am[:], ar[:] = m_host, r_host
+
+        def pe():
+            _capi.check(L.pgpu_paillier_encrypt(pk._h, pm, nw, nw, pr, pw, pw, 64 * pw, pc, BATCH))
+
+        def pdq():
+            _capi.check(L.pgpu_paillier_decrypt_crt(sk._h, pc, pd, BATCH))
+        pe(); pdq()
+        tpe, tpd = best_of(pe, 5), best_of(pdq, 5)
+        assert np.array_equal(ad, m_host) and np.array_equal(ac, c_host)
+        out["end_to_end_pinned"] = {"what": "the same two calls on caller buffers from pgpu_host_alloc (pinned: the DMA source / target "
+                                            "is the caller's array itself), one synchronous caller",
+                                    "encrypt_ms": round(tpe * 1e3, 3), "decrypt_ms": round(tpd * 1e3, 3),
+                                    "modexps_per_s": round(3 * BATCH / (tpe + tpd), 1)}
+        for b in blocks:
+            L.pgpu_host_free(b)
+    except Exception as e:                                  # noqa: BLE001
+        out["end_to_end_pinned"] = {"error": repr(e)[:300]}
+    # (1c) TWO synchronous callers (host threads, pageable arrays of their own): what a service with more than one
+    # request in flight sees -- one caller's copies run under the other's kernels, and the kernels of the two share the
+    # chip (the reference's own tests call encrypt / decrypt from four OpenMP threads, test_cryptography.cpp:45-57)
+    try:
+        import threading
+        reps, ncall = 6, 2
+        bufs = [(m_host.copy(), r_host.copy(), np.empty((BATCH, 2 * nw), dtype=np.uint64), np.empty((BATCH, nw), dtype=np.uint64))
+                for _ in range(ncall)]
+        bar = threading.Barrier(ncall + 1)
+        errs = []
+
+        def caller(k):
+            mm, rr, cc, dd = bufs[k]
+            try:
+                for it in range(reps + 1):
+                    if it == 1:
+                        bar.wait()
+                    _capi.check(L.pgpu_paillier_encrypt(pk._h, ptr(mm), nw, nw, ptr(rr), pw, pw, 64 * pw, ptr(cc), BATCH))
+                    _capi.check(L.pgpu_paillier_decrypt_crt(sk._h, ptr(cc), ptr(dd), BATCH))
+            except Exception as e:                          # noqa: BLE001
+                errs.append(repr(e))
+        th = [threading.Thread(target=caller, args=(k,)) for k in range(ncall)]
+        for t in th:
+            t.start()
+        bar.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        wall = time.perf_counter() - t0
+        assert not errs and all(np.array_equal(b[3], m_host) for b in bufs), errs
+        out["end_to_end_two_callers"] = {"what": "two host threads, each calling pgpu_paillier_encrypt + pgpu_paillier_decrypt_crt "
+                                                 "synchronously on pageable arrays of its own, %d rounds each; aggregate rate" % reps,
+                                         "wall_ms": round(wall * 1e3, 3), "ms_per_encrypt_plus_decrypt": round(wall / (reps * ncall) * 1e3, 3),
+                                         "modexps_per_s": round(3 * BATCH * reps * ncall / wall, 1)}
+    except Exception as e:                                  # noqa: BLE001
+        out["end_to_end_two_callers"] = {"error": repr(e)[:300]}
     # (2) the API-visible timing of the reference's own benchmark: ipcl::PublicKey::encrypt / PrivateKey::decrypt with
     # std::vector<BigNumber> in and out (benchmark/bench_cryptography.cpp:73-121)
     try:
@@ -921,6 +1150,7 @@ def run_config45(args, pa, L, B, N):
                      "frac_basis": "executed multiply-accumulates per launch / kernel time / peak",
                      "canonical_frac": sig(mac_add / (mm_ms * 1e-3) / 1e12 / PEAK_TMAC32),
                      "traffic": pmc.get("ct_add_pair_mul_hbm_bytes_per_launch") if row_limbs else None,
+                     "traffic_source": pmc_source(pmc, "ct_add_kernel") if row_limbs else None,
                      "kernel_ms": round(mm_ms, 4), "executed_mac32_per_launch": exec_add,
                      "algorithmic_bytes_per_launch": 3 * row_bytes * shard,
                      "hbm_achieved_GBs": round(3 * row_bytes * shard / (mm_ms * 1e-3) / 1e9, 1), "hbm_peak_GBs": HBM_PEAK_GBS,
@@ -1124,6 +1354,10 @@ def cpu_baseline(n, p, q, hs, m_host, r_host):
     what = {"ifma": "oracle/ifma_oracle.c (8-lane AVX512-IFMA radix-2^52 restatement of the reference's mb8 path)",
             "openssl": "OpenSSL BN_mod_exp_mont", "scalar": "oracle/modexp_oracle.c (64-bit CIOS)"}[best]
     return {"value": legs[best]["value"], "unit": "modexps/s", "cores": threads, "kind": "port",
+            "encrypt_like_for_like": False,
+            "encrypt_note": "every CPU leg computes hs^r by square-and-multiply (1259 products per element); the GPU step runs it as "
+                            "a fixed-base product over a per-key table (85 products, table built outside the timed region): "
+                            "compare decrypt_only_modexps_per_s for like-for-like",
             "sample": f"{legs[best]['elements']} elements (the same batch, from its start, repeated if shorter than the "
                       f"time target), encrypt + CRT decrypt "
                       f"({3 * legs[best]['elements']} modexps) in {legs[best]['seconds']} s; {what}, gcc -O3 "

@@ -44,7 +44,8 @@
  * for the randomness r of the DJN fixed-base product and for CT*PT exponents), i.e. the engine
  * is not hardened against a co-resident observer of the memory system -- unless
  * pgpu_set_table_gather_policy(1) is chosen, which makes the split-form kernels read every entry of
- * a window table and select (the fixed-base table of DJN encrypt stays digit-addressed).  Device copies of
+ * a window table and select; since round 4 that covers the DJN fixed-base product as well (a table of its own
+ * with a 4-bit window: 256 products of 16 candidates each instead of 85 indexed ones).  Device copies of
  * private-key constants are zeroed before they are freed.
  *
  * ERRORS.  Every function returns PGPU_OK (0) or a negative pgpu_status; nothing calls
@@ -218,8 +219,11 @@ int pgpu_get_secret_exponent_policy(void);
  * 0 (default) the entry is addressed by the exponent digit; 1 every entry of the table is read and the wanted one
  * selected, so that the address stream does not depend on the exponent -- what the reference's mbx_exp_mb8 does
  * (SURVEY Appendix B).  Costs 2^w x the table loads plus as many selects per multiplication (bench.py reports it).
- * The fixed-base table of DJN encrypt (2^12 entries per window) is always addressed by the digits of r.  Env
- * PGPU_CT_GATHER=1. */
+ * DJN encrypt (round 4): with the policy on, hs^r runs as a fixed-base product over a SMALL-window table of its own
+ * (w = 4, env PGPU_FB_MASKED_WINDOW 1..5: all 2^w entries of a window are read at every step and the wanted one is
+ * selected) instead of the 2^12-entry windows addressed by the digits of r -- about 3x the indexed encrypt, 1/5 of a
+ * masked square-and-multiply.  Both tables of a key may be live (2.4 MB + 203 MB for a 2048-bit key).  Not covered: the
+ * full-width modexp_kernel (keys without a split form, PGPU_HENSEL=0).  Env PGPU_CT_GATHER=1. */
 int pgpu_set_table_gather_policy(int masked);
 int pgpu_get_table_gather_policy(void);
 

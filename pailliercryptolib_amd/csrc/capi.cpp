@@ -387,6 +387,7 @@ int make_schedule(const BigNumber& e, int w, ExpSchedule* out, bool secret) {
 
 // window width of the fixed-base table for the DJN obfuscator; PGPU_FB_WINDOW=0 selects the
 // generic (per-instance table, square-and-multiply) kernel instead.
+constexpr int kFbMaskedMaxW = 5;   // tables of windows up to this width belong to the masked product (kept beside the indexed table)
 std::atomic<int> g_fb_window{-1};
 std::atomic<bool> g_fb_window_explicit{false};   // set through the environment or pgpu_set_fixed_base_window
 int fixed_base_window() {
@@ -397,6 +398,14 @@ int fixed_base_window() {
     if (e) g_fb_window_explicit.store(true);
   }
   return g_fb_window.load();
+}
+// window of the MASKED fixed-base product (every entry of a window is read and selected): small on purpose
+int masked_fb_window() {
+  static const int w = [] {
+    const char* e = std::getenv("PGPU_FB_MASKED_WINDOW");
+    return e ? std::max(1, std::min(kFbMaskedMaxW, std::atoi(e))) : 4;
+  }();
+  return w;
 }
 // A key that has encrypted little so far starts with an 8-bit window (table 16x smaller, built in ~2 ms
 // instead of ~37 ms) and moves to the configured one once this many elements have gone through it.
@@ -1076,9 +1085,10 @@ int fb_table_get(const pgpu_pubkey* key, std::vector<std::list<FbTable>>& lists,
       out->t = &t;
       return PGPU_OK;
     }
-  // a key keeps ONE table per device: a wider window replaces the young key's narrow one
+  // a key keeps ONE table per device and access mode: a wider window replaces the young key's narrow one (the small table
+  // of the masked product lives beside the indexed one, so that switching the gather policy does not rebuild tables)
   for (auto it = list.begin(); it != list.end();) {
-    if (it->pins == 0) {
+    if (it->pins == 0 && (it->w <= kFbMaskedMaxW) == (w <= kFbMaskedMaxW)) {
       g_fb_dev_bytes.resize(std::max(g_fb_dev_bytes.size(), (size_t)d.index + 1), 0);
       g_fb_dev_bytes[(size_t)d.index] -= std::min(g_fb_dev_bytes[(size_t)d.index], it->bytes);
       fb_free_table(*it);
@@ -1301,8 +1311,14 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
     return fail(PGPU_ERR_INVALID_PARAM, "r_bits/r_words inconsistent");
   const int vflags = out_mont ? VF_GM_MONT : VF_NONE;
   int fbw = fixed_base_window();
+  // Masked gather (pgpu_set_table_gather_policy(1); round 4): the fixed-base product runs over a table of its own with a
+  // SMALL window -- every one of its 2^w entries is read at each step and the wanted one selected, so the address stream
+  // does not depend on the digits of r (what the reference's mbx_exp_mb8 does with its window table, mod_exp.cpp:508-516).
+  // w = 4: 256 products of 16 candidates each for a 1024-bit r instead of 85 indexed ones (PGPU_FB_MASKED_WINDOW: 1..5).
+  const bool masked = key->djn && fbw > 0 && g_ct_gather.load() != 0;
+  if (masked) fbw = masked_fb_window();
   if (key->djn && fbw > 0) {
-    {
+    if (!masked) {
       std::lock_guard<std::mutex> lk(key->mu);
       if (fbw > 8 && !g_fb_window_explicit.load() && key->fb_elems + total_count < kFbGrowAfter) fbw = 8;
     }
@@ -1345,6 +1361,7 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
       f.out_stride = (size_t)W;
       f.count = count;
       f.out_pair = d_pair;
+      f.ct_gather = masked ? 1 : 0;
       TimerScope t(d, s, PGPU_KERNEL_FB_ENCRYPT);
       // resident results of launches that still put a wavefront on every SIMD with half the lanes per element: both
       // halves of a residue in the same lanes (hensel_seq.hpp)
@@ -1376,6 +1393,7 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
     f.out = d_c;
     f.out_stride = (size_t)W;
     f.count = count;
+    f.ct_gather = masked ? 1 : 0;
     TimerScope t(d, s, PGPU_KERNEL_FB_ENCRYPT);
     const GeoInfo lgeo = launch_geo(geo, count);
     if (!pgpu::launch_fb_encrypt(lgeo.G, lgeo.K, f, blocks_for(count, lgeo), s))
@@ -1479,6 +1497,12 @@ int seq_policy_by_size() {
   const int p = g_seq_policy.load();
   return (p == 3 || p == 4) ? 1 : p;
 }
+// tuning knobs of the adaptive policy (tools/probe_lanes.py; pgpu_debug_set_adaptive / PGPU_ADAPT_ENC_SEQ,
+// PGPU_ADAPT_CLAIM_BUSY): does the DJN encrypt follow the decrypt into the sequential-halves form beside busy lanes
+// (measured r04: no -- its 512 wavefronts without a CU claim stack onto a neighbour's CUs, 0.79 -> 1.7 ms), and up to how
+// many busy neighbours a part-chip decrypt claims whole CUs
+std::atomic<int> g_adapt_enc_seq{[] { const char* e = std::getenv("PGPU_ADAPT_ENC_SEQ"); return e ? std::atoi(e) : 0; }()};
+std::atomic<int> g_adapt_claim_busy{[] { const char* e = std::getenv("PGPU_ADAPT_CLAIM_BUSY"); return e ? std::atoi(e) : 3; }()};
 // with `busy` other batch lanes at work, does a launch of `waves` wavefronts of a sequential-halves form fill its share?
 bool seq_adaptive(size_t waves, int busy) {
   return g_seq_policy.load() == 4 && busy >= 1 && waves * (size_t)(1 + busy) >= kSimds;
@@ -1504,7 +1528,7 @@ bool fb_encrypt_seq_pays(int H, int K, size_t count, int busy) {
   const int pol = seq_policy_by_size();
   // (adaptive: beside busy neighbour lanes the form of half the wavefronts -- and a sixth fewer multiply-accumulates --
   // also for launches that would not fill the chip alone; 4-lane groups only, see below for the others)
-  if (H == 4 && seq_adaptive(waves, busy)) return true;
+  if (H == 4 && g_adapt_enc_seq.load() && seq_adaptive(waves, busy)) return true;
   // (2-lane groups, 1024-bit keys: measured equal or behind the paired kernel at 65536 elements -- 1.04 against 1.02 ms,
   // 0.96 against 0.92 ms: 19 limbs per lane and the LDS staging leave no register room -- so only when forced)
   if (H == 2 && pol != 2) return false;
@@ -1620,7 +1644,7 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
       // a launch that covers less than the chip leaves the other CUs to the neighbour lane's launch (policy 3)
       const int pol = g_seq_policy.load();
       const unsigned lds_pad = env_pad >= 0 ? (unsigned)env_pad
-                               : (seq_waves < kSimds && (pol == 3 || (pol == 4 && busy_lanes == 1)) ? 84000u : 0u);
+                               : (seq_waves < kSimds && (pol == 3 || (pol == 4 && busy_lanes >= 1 && busy_lanes <= g_adapt_claim_busy.load())) ? 84000u : 0u);
       if (lds_pad) t.set_form(PGPU_FORM_SEQ | PGPU_FORM_CU_CLAIM);
       if (!pgpu::launch_hensel_seq(hset->H, hset->K, h, sblocks, s, lds_pad))
         return fail(PGPU_ERR_UNSUPPORTED, "sequential-halves decrypt kernel not compiled");
@@ -2116,6 +2140,10 @@ void pgpu_debug_set_packed_decrypt(int on) { g_packed_decrypt.store(on != 0); }
 // tests / A-B measurements: hensel_seq.hpp (0 never, 1 by launch size, 2 whenever it applies).  Not part of the public header.
 void pgpu_debug_set_seq_decrypt(int policy) { g_seq_policy.store(policy < 0 ? 0 : (policy > 4 ? 4 : policy)); }
 int pgpu_debug_get_seq_decrypt(void) { return g_seq_policy.load(); }
+void pgpu_debug_set_adaptive(int enc_seq, int claim_busy) {
+  g_adapt_enc_seq.store(enc_seq);
+  g_adapt_claim_busy.store(claim_busy);
+}
 void pgpu_debug_set_ab_decrypt(int policy) { g_ab_policy.store(policy < 0 ? 0 : (policy > 3 ? 3 : policy)); }
 
 int pgpu_set_timing(int enabled) {
@@ -2743,6 +2771,43 @@ int pgpu_paillier_decrypt_crt(const pgpu_privkey* key, const uint64_t* c, uint64
 }
 
 // ===================== sharded device-resident batches =====================
+namespace {
+// per-thread pinned bounce buffer for small uploads / downloads issued from the calling thread itself
+constexpr size_t kBounceBytes = (size_t)256 << 10;
+struct Bounce {
+  void* p = nullptr;
+  hipEvent_t ev = nullptr;
+  bool pending = false;      // an upload still reads the buffer
+  uint64_t gen = 0;
+  int ready() {
+    if (p && gen != rt::pool_generation()) {   // the pool this buffer's event belongs to is gone
+      if (ev) (void)hipEventDestroy(ev);
+      ev = nullptr;
+      pending = false;
+    }
+    if (!p) HIP_TRY(hipHostMalloc(&p, kBounceBytes, hipHostMallocPortable));
+    if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    gen = rt::pool_generation();
+    if (pending) {
+      HIP_TRY(hipEventSynchronize(ev));
+      pending = false;
+    }
+    return PGPU_OK;
+  }
+  ~Bounce() {
+    // (a thread that ends while the pool is up gives its buffer back; at process exit the HIP runtime may already be
+    // shutting down, so nothing is touched then and the driver reclaims the memory)
+    if (!rt::initialized() || gen != rt::pool_generation()) return;
+    if (ev) (void)hipEventDestroy(ev);
+    if (p) (void)hipHostFree(p);
+  }
+};
+Bounce& bounce() {
+  thread_local Bounce b;
+  return b;
+}
+}  // namespace
+
 int pgpu_batch_create(size_t count, int words, pgpu_batch** out) {
   RC_TRY(rt::check_ready());
   if (!out) return fail(PGPU_ERR_INVALID_PARAM, "null output pointer");
@@ -2778,6 +2843,22 @@ int pgpu_batch_upload(const uint64_t* host, size_t count, int words, size_t stri
       HIP_TRY(hipMemcpyAsync(bp->ptr(d), src, bytes, hipMemcpyHostToDevice, s));
       rt::host_note_read(src, bytes, dev.index, s);
     }
+    *out = b.release();
+    return PGPU_OK;
+  }
+  if (bp->ndev == 1 && stride == (size_t)words && count * (size_t)words * 8 <= kBounceBytes) {
+    // small transfer: through the calling thread's own pinned bounce buffer -- no hand-over to a worker lane (a thread
+    // wake-up costs more than the copy: Add_CTCT(16) at the ipcl:: API is 60 us of which the GPU works 10)
+    rt::Device& dev = rt::device(0);
+    rt::DeviceGuard g(dev.ordinal);
+    Bounce& bn = bounce();
+    RC_TRY(bn.ready());
+    const size_t bytes = count * (size_t)words * 8;
+    std::memcpy(bn.p, host, bytes);
+    hipStream_t s = dev.bs(bp->lane);
+    HIP_TRY(hipMemcpyAsync(bp->ptr(0), bn.p, bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(bn.ev, s));
+    bn.pending = true;
     *out = b.release();
     return PGPU_OK;
   }
@@ -2837,6 +2918,27 @@ int pgpu_batch_download(const pgpu_batch* b, uint64_t* host) {
       hipError_t e = hipStreamSynchronize(dev.bs(b->lane));
       if (e != hipSuccess) return fail(PGPU_ERR_HIP, std::string("device -> host copy failed: ") + hipGetErrorString(e));
     }
+    return PGPU_OK;
+  }
+  if (nd == 1 && b->count * (size_t)b->words * 8 <= kBounceBytes) {   // small transfer: the calling thread's bounce buffer
+    rt::Device& dev = rt::device(0);
+    rt::DeviceGuard g(dev.ordinal);
+    Bounce& bn = bounce();
+    RC_TRY(bn.ready());
+    hipStream_t s = dev.bs(b->lane);
+    const size_t bytes = b->count * (size_t)b->words * 8;
+    rt::DevMem plain;
+    const void* src = b->ptr(0);
+    if (b->pair_l2 || b->mont) {
+      RC_TRY(plain.alloc(dev, s, bytes));
+      if (b->pair_l2) RC_TRY(pair_to_words_on(dev, b->pair_form.get(), b->prow(0), (uint64_t*)plain.p, b->count, s));
+      else RC_TRY(modmul_on(dev, *b->mont, pgpu::MM_BY_ONE, b->ptr(0), nullptr, 0, 0, (uint64_t*)plain.p, b->count, s));
+      src = plain.p;
+    }
+    HIP_TRY(hipMemcpyAsync(bn.p, src, bytes, hipMemcpyDeviceToHost, s));
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail(PGPU_ERR_HIP, std::string("device -> host copy failed: ") + hipGetErrorString(e));
+    std::memcpy(host, bn.p, bytes);
     return PGPU_OK;
   }
   rt::TaskGroup tg;

@@ -161,36 +161,6 @@ __device__ __forceinline__ uint32_t sub_limbs(uint32_t (&d)[GEO::K], const uint3
   return (uint32_t)__shfl((int)top_borrow, top_lane);
 }
 
-// Window-table entry `idx` of this lane's slice (entries are LQ limbs apart).  gather: read EVERY entry and keep the one
-// wanted -- the address stream is then the same for every exponent, as in the reference's mbx_exp_mb8, which gathers its
-// table in constant time; costs tsize*K loads and selects per multiplication instead of K loads.
-template <int K>
-__device__ __forceinline__ void load_table_entry(uint32_t (&dst)[K], const uint32_t* tbl, int idx, int tsize, size_t stride,
-                                                 bool gather) {
-  if (!gather) {
-#pragma unroll
-    for (int j = 0; j < K; ++j) dst[j] = tbl[(size_t)idx * stride + j];
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < K; ++j) dst[j] = 0;
-  // two entries per trip: their loads are in flight together (a trip is latency-bound otherwise: 2^w round trips to
-  // L2 per multiplication); tsize is a power of two >= 2 whenever a table is used
-#pragma unroll 1
-  for (int e = 0; e < tsize; e += 2) {
-    uint32_t t0[K], t1[K];
-    const int e1 = e + 1 < tsize ? e + 1 : e;
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      t0[j] = tbl[(size_t)e * stride + j];
-      t1[j] = tbl[(size_t)e1 * stride + j];
-    }
-    const uint32_t k0 = 0u - (uint32_t)(e == idx), k1 = 0u - (uint32_t)(e1 == idx);
-#pragma unroll
-    for (int j = 0; j < K; ++j) dst[j] |= (t0[j] & k0) | (t1[j] & k1);
-  }
-}
-
 // One wavefront = 64/(2H) groups = that many ciphertexts of ONE side (wave parity: even = p, odd = q), so context,
 // exponent and schedule are wave-uniform.  Output: row 2i = mp, row 2i+1 = mq (canonical words) for crt_kernel
 // (have_m).  H = 2: the throughput form (16 ciphertexts per wavefront); H = 8: the latency form for small batches
@@ -711,10 +681,8 @@ __global__ __launch_bounds__(kWGThreads, K <= 14 ? 2 : 1) void hensel_fb_encrypt
     if (sh + w > 64 && word + 1 < A.exp_words) v |= ep[word + 1] << (64 - sh);
     return (int)(v & (uint64_t)(tsize - 1));
   };
-  auto load_entry = [&](uint32_t (&dst)[K], int i) {
-    const uint32_t* e = A.table + ((size_t)i * tsize + digit(i)) * LQ + xg * K;
-#pragma unroll
-    for (int j = 0; j < K; ++j) dst[j] = e[j];
+  auto load_entry = [&](uint32_t (&dst)[K], int i) {   // (masked: the address stream does not depend on the digits of r)
+    load_table_entry<K>(dst, A.table + (size_t)i * tsize * LQ + xg * K, digit(i), tsize, LQ, A.ct_gather != 0);
   };
   load_entry(own, 0);
   if (A.nwin > 1) load_entry(mreg, 1);

@@ -472,6 +472,12 @@ __global__ __launch_bounds__(kWGThreads, 2) void hensel_fb_encrypt_seq_kernel(He
     return (int)(v & (uint64_t)(tsize - 1));
   };
   auto load_entry = [&](uint32_t (&da)[K], uint32_t (&db)[K], int i) {
+    if (A.ct_gather) {   // masked: every entry of the window is read, the address stream does not depend on the digits of r
+      const uint32_t* wb = A.table + (size_t)i * tsize * LQ + x * K;
+      load_table_entry<K>(da, wb, digit(i), tsize, LQ, true);
+      load_table_entry<K>(db, wb + L2, digit(i), tsize, LQ, true);
+      return;
+    }
     const uint32_t* e = A.table + ((size_t)i * tsize + digit(i)) * LQ;
     load_pair_row<K>(da, e, x);
     load_pair_row<K>(db, e + L2, x);

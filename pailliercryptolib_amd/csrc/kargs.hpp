@@ -225,6 +225,7 @@ struct HenselFbArgs {
   size_t out_stride;
   size_t count;
   uint32_t* out_pair;        // non-null: ciphertexts leave as pair rows [count][2*L2] (out unused)
+  int ct_gather;             // 1: every entry of a window is read and the wanted one selected (masked fixed-base product)
 };
 
 // base[i]^exp[i] modulo n^2 in split form (hensel.hpp: hensel_modexp_kernel): CT x PT and the non-DJN obfuscator r^n.
@@ -295,6 +296,7 @@ struct FixedBaseArgs {
   uint64_t* out;         // [count][out_stride]
   size_t out_stride;
   size_t count;
+  int ct_gather;         // 1: every entry of a window is read and the wanted one selected (include/pgpu.h, SIDE CHANNELS)
 };
 
 struct FixedBaseBuildArgs {

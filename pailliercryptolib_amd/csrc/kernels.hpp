@@ -533,6 +533,36 @@ __global__ __launch_bounds__(kWGThreads) void fb_build_kernel(FixedBaseBuildArgs
   }
 }
 
+// Window-table entry `idx` of this lane's slice (entries are LQ limbs apart).  gather: read EVERY entry and keep the one
+// wanted -- the address stream is then the same for every exponent, as in the reference's mbx_exp_mb8, which gathers its
+// table in constant time; costs tsize*K loads and selects per multiplication instead of K loads.
+template <int K>
+__device__ __forceinline__ void load_table_entry(uint32_t (&dst)[K], const uint32_t* tbl, int idx, int tsize, size_t stride,
+                                                 bool gather) {
+  if (!gather) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) dst[j] = tbl[(size_t)idx * stride + j];
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) dst[j] = 0;
+  // two entries per trip: their loads are in flight together (a trip is latency-bound otherwise: 2^w round trips to
+  // L2 per multiplication); tsize is a power of two >= 2 whenever a table is used
+#pragma unroll 1
+  for (int e = 0; e < tsize; e += 2) {
+    uint32_t t0[K], t1[K];
+    const int e1 = e + 1 < tsize ? e + 1 : e;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      t0[j] = tbl[(size_t)e * stride + j];
+      t1[j] = tbl[(size_t)e1 * stride + j];
+    }
+    const uint32_t k0 = 0u - (uint32_t)(e == idx), k1 = 0u - (uint32_t)(e1 == idx);
+#pragma unroll
+    for (int j = 0; j < K; ++j) dst[j] |= (t0[j] & k0) | (t1[j] & k1);
+  }
+}
+
 template <class GEO>
 __global__ __launch_bounds__(kWGThreads, 2) void fb_encrypt_kernel(FixedBaseArgs A) {
   constexpr int K = GEO::K, L = GEO::L, G = GEO::G, IPW = GEO::IPW;
@@ -560,10 +590,8 @@ __global__ __launch_bounds__(kWGThreads, 2) void fb_encrypt_kernel(FixedBaseArgs
     if (sh + w > 64 && word + 1 < A.exp_words) v |= ep[word + 1] << (64 - sh);
     return (int)(v & (uint64_t)(tsize - 1));
   };
-  auto load_entry = [&](uint32_t (&dst)[K], int i) {
-    const uint32_t* e = A.table + ((size_t)i * tsize + digit(i)) * L + x * K;
-#pragma unroll
-    for (int j = 0; j < K; ++j) dst[j] = e[j];
+  auto load_entry = [&](uint32_t (&dst)[K], int i) {   // (masked: the address stream does not depend on the digits of r)
+    load_table_entry<K>(dst, A.table + (size_t)i * tsize * L + x * K, digit(i), tsize, L, A.ct_gather != 0);
   };
   // step 0: acc = m * (n*R) * R^-1 + 1 = g^m (plain domain, lazy); multiplier staged = n*R
   stage_words<GEO>(io, A.fm_words, A.fm_stride, 0, A.fm_nwords, first_inst, A.count, 1, lane);

@@ -244,6 +244,77 @@ TEST(negative_and_wide_plaintexts) {
 
 // the host layer's per-element loops on a batch large enough for the thread team (IPCL_NUM_THREADS > 1 in the pool run of
 // tests/test_gpu_cpp_api.py; one thread otherwise): 4096 elements through every marshalling loop
+// Round 4: texts built around >= 64 KB of non-negative host values go straight to the GPU (base_text.cpp: adoptValues);
+// every accessor must still see exactly the values the caller handed in, mutation must still work, negative values keep
+// the BigNumber path, and the injected randomness is packed and uploaded once per setRandom (pub_key.cpp).
+TEST(eager_upload_texts_and_cached_randomness) {
+  BigNumber p(KAT_P), q(KAT_Q), n = p * q, nsq = n * n;
+  ipcl::PublicKey pk(n, 2048, true);
+  ipcl::PrivateKey sk(pk, p, q);
+  pk.setHS(BigNumber(KAT_BENCH_HS));
+  const size_t N = 700;                       // 700 x 2048 bits = 175 KB: above the eager threshold
+  std::vector<BigNumber> m(N), r(N);
+  for (size_t i = 0; i < N; i++) {
+    m[i] = p - BigNumber((unsigned int)(i * 1024));
+    r[i] = BigNumber(KAT_BENCH_R) - BigNumber((unsigned int)i);
+  }
+  m[1] = BigNumber::Zero();
+  m[2] = BigNumber::One();
+  ipcl::PlainText pt(m);
+  EXPECT_TRUE(pt.isDeviceResident());         // no BigNumber copy was made
+  for (size_t i : {(size_t)0, (size_t)1, (size_t)2, N / 2, N - 1}) EXPECT_EQ(pt.getElement(i), m[i]);
+  std::vector<BigNumber> back = ipcl::PlainText(m).getTexts();
+  EXPECT_EQ(back.size(), N);
+  bool same = true;
+  for (size_t i = 0; i < N; i++) same = same && back[i] == m[i];
+  EXPECT_TRUE(same);
+  // mutation after the eager upload: the device copy is dropped, the change is seen by encrypt
+  ipcl::PlainText pt2(m);
+  pt2[5] = BigNumber((unsigned int)12345);
+  EXPECT_EQ(pt2.getElement(5), BigNumber((unsigned int)12345));
+  EXPECT_EQ(pt2.getElement(6), m[6]);
+  // injected randomness: first encrypt packs + uploads it, the second reuses the device copy -- identical ciphertexts,
+  // both bit-exact against the definition; a new setRandom replaces it
+  pk.setRandom(r);
+  ipcl::CipherText c1 = pk.encrypt(pt), c2 = pk.encrypt(pt), c3 = pk.encrypt(pt2);
+  for (size_t i : {(size_t)0, (size_t)3, N - 1}) {
+    BigNumber obf = ipcl::modExp(BigNumber(KAT_BENCH_HS), r[i], nsq);
+    EXPECT_EQ(c1.getElement(i), nsq.ModMul((n * m[i] + 1) % nsq, obf));
+    EXPECT_EQ(c2.getElement(i), c1.getElement(i));
+  }
+  EXPECT_EQ(sk.decrypt(c3).getElement(5), BigNumber((unsigned int)12345));
+  // a CipherText built around host values (what BM_Decrypt does) takes the same road
+  std::vector<BigNumber> cv = c1.getTexts();
+  ipcl::CipherText chost(pk, cv);
+  EXPECT_TRUE(chost.isDeviceResident());
+  ipcl::PlainText d = sk.decrypt(chost);
+  same = true;
+  for (size_t i = 0; i < N; i++) same = same && d.getElement(i) == m[i];
+  EXPECT_TRUE(same);
+  EXPECT_EQ(chost.getElement(N - 1), cv[N - 1]);
+  // negative plaintexts keep their BigNumbers (signs only live there) and still encrypt as their residues
+  std::vector<BigNumber> neg(m);
+  neg[7] = BigNumber::Zero() - BigNumber((unsigned int)9);
+  ipcl::PlainText pneg(neg);
+  EXPECT_TRUE(!pneg.isDeviceResident());
+  EXPECT_EQ(pneg.getElement(7), neg[7]);
+  ipcl::PublicKey pk2(n, 2048, true);
+  pk2.setHS(BigNumber(KAT_BENCH_HS));
+  EXPECT_EQ(sk.decrypt(pk2.encrypt(pneg)).getElement(7), n - BigNumber((unsigned int)9));
+  // values of uneven width: the batch is as wide as the widest, small ones read back unchanged
+  std::vector<BigNumber> uneven(N);
+  for (size_t i = 0; i < N; i++) uneven[i] = (i % 3 == 0) ? m[i] : BigNumber((unsigned int)i);
+  ipcl::PlainText pu(uneven);
+  EXPECT_EQ(pu.getElement(4), BigNumber((unsigned int)4));
+  EXPECT_EQ(sk.decrypt(pk2.encrypt(pu)).getElement(4), BigNumber((unsigned int)4));
+  // CT * PT with small exponents built eagerly: the exponent width hint stays exact (no rounding up to 64-bit words)
+  std::vector<BigNumber> e(N * 8, BigNumber((unsigned int)3)), ones(N * 8, BigNumber((unsigned int)2));
+  ipcl::PlainText pe(e), pones(ones);          // 5600 x 1 word = 44 KB: below the threshold, BigNumber path
+  EXPECT_TRUE(!pe.isDeviceResident());
+  ipcl::PublicKey pk3(n, 2048, true);
+  EXPECT_EQ(sk.decrypt(pk3.encrypt(pones) * pe).getElement(17), BigNumber((unsigned int)6));
+}
+
 TEST(large_batch_marshalling) {
   ipcl::KeyPair& key = shared_key();
   const size_t N = 4096;

