@@ -120,9 +120,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
                     help="2: BASELINE configs[1]+[2] (default, the headline); 4 / 5: configs[3] / configs[4]")
-    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
+    ap.add_argument("--in-flight", type=int, default=4, choices=[1, 2, 3, 4],
                     help="resident batches in flight per GPU: consecutive steps rotate over that many of the library's "
-                         "batch lanes (default 2; 1: every step on one lane)")
+                         "batch lanes (default: all four; 1: every step on one lane)")
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="length of the sustained-rate run behind the timed region (N = 1; 0 skips it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -218,6 +218,12 @@ def run_pool(args):
     if nfl == 1:
         per_kind = forms_to_kinds(timed_forms)
     else:
+        time.sleep(0.15)            # (the other lanes count as active for 50 ms after they were last fed: let that lapse)
+        for _ in range(2):
+            state["i"] = 0
+            step()
+        sync_all()
+        collect_forms(L, 64)
         t1 = time.perf_counter()
         for _ in range(10):
             state["i"] = 0          # lane 0 only
@@ -298,7 +304,9 @@ def run_pool(args):
             top = max({f for f, _ in dec_timed}, key=lambda f: sum(1 for g, _ in dec_timed if g == f))
             ms_top = float(np.mean([ms for f, ms in dec_timed if f == top]))
             name, per_exp = decrypt_kernel(sk, BATCH, nw, KEY_BITS, 1 if top & 2 else 0)
-            share = 0.5 if top == 18 else None        # CU claim: 128 workgroups on 128 of the 256 CUs
+            # CU claim: 128 workgroups on 128 of the 256 CUs -- with TWO lanes a launch holds its half from its first
+            # wavefront to its last; with more lanes a launch also waits for a free half inside its event span
+            share = 0.5 if (top == 18 and nfl == 2) else None
             r["kernel"] = (f"{name} ({FORM_NAMES.get(top, top)}; CRT-decrypt leg: {2 * BATCH} half-width modexps per launch; "
                            f"{sum(1 for g, _ in dec_timed if g == top)} of the {len(dec_timed)} decrypt launches of the timed region)")
             r["executed_mac32_per_launch"] = per_exp * 2 * BATCH
@@ -670,6 +678,12 @@ def extras(pa, L, B, pk, sk, n, p, q, hs, m_host, r_host, per_kind):
     from pailliercryptolib_amd import _capi
     nw, pw = m_host.shape[1], r_host.shape[1]
     out = {}
+    # (0) the resident step with 1..4 batches in flight, ~0.8 s each (sustained rates; the headline's --in-flight is one of them)
+    try:
+        out["batches_in_flight_sweep"] = lanes_sweep(L, B, pk, sk, m_host, r_host)
+    except Exception as e:                                  # noqa: BLE001
+        out["batches_in_flight_sweep"] = {"error": repr(e)[:300]}
+    time.sleep(0.15)
     # (1) the same step through the synchronous host-pointer entry points: H2D + kernels + D2H per call
     c_host = np.empty((BATCH, 2 * nw), dtype=np.uint64)
     d_host = np.empty((BATCH, nw), dtype=np.uint64)
@@ -683,8 +697,8 @@ def extras(pa, L, B, pk, sk, n, p, q, hs, m_host, r_host, per_kind):
     te, td = best_of(e2e_enc, 5), best_of(e2e_dec, 5)
     assert np.array_equal(d_host, m_host)
     out["end_to_end"] = {"what": "pgpu_paillier_encrypt + pgpu_paillier_decrypt_crt on caller-owned PAGEABLE host arrays, one "
-                                 "synchronous caller (H2D + kernels + D2H inside each call; staging through pinned bounce "
-                                 "buffers in quarter-transfer pieces)",
+                                 "synchronous caller (H2D + kernels + D2H inside each call; staging through the library's "
+                                 "pinned bounce buffers)",
                          "encrypt_ms": round(te * 1e3, 3), "decrypt_ms": round(td * 1e3, 3),
                          "modexps_per_s": round(3 * BATCH / (te + td), 1),
                          "floor_note": "a synchronous call cannot end before its kernels do: the kernels of one encrypt + one "
@@ -723,39 +737,12 @@ def extras(pa, L, B, pk, sk, n, p, q, hs, m_host, r_host, per_kind):
     # (1c) TWO synchronous callers (host threads, pageable arrays of their own): what a service with more than one
     # request in flight sees -- one caller's copies run under the other's kernels, and the kernels of the two share the
     # chip (the reference's own tests call encrypt / decrypt from four OpenMP threads, test_cryptography.cpp:45-57)
-    try:
-        import threading
-        reps, ncall = 6, 2
-        bufs = [(m_host.copy(), r_host.copy(), np.empty((BATCH, 2 * nw), dtype=np.uint64), np.empty((BATCH, nw), dtype=np.uint64))
-                for _ in range(ncall)]
-        bar = threading.Barrier(ncall + 1)
-        errs = []
-
-        def caller(k):
-            mm, rr, cc, dd = bufs[k]
-            try:
-                for it in range(reps + 1):
-                    if it == 1:
-                        bar.wait()
-                    _capi.check(L.pgpu_paillier_encrypt(pk._h, ptr(mm), nw, nw, ptr(rr), pw, pw, 64 * pw, ptr(cc), BATCH))
-                    _capi.check(L.pgpu_paillier_decrypt_crt(sk._h, ptr(cc), ptr(dd), BATCH))
-            except Exception as e:                          # noqa: BLE001
-                errs.append(repr(e))
-        th = [threading.Thread(target=caller, args=(k,)) for k in range(ncall)]
-        for t in th:
-            t.start()
-        bar.wait()
-        t0 = time.perf_counter()
-        for t in th:
-            t.join()
-        wall = time.perf_counter() - t0
-        assert not errs and all(np.array_equal(b[3], m_host) for b in bufs), errs
-        out["end_to_end_two_callers"] = {"what": "two host threads, each calling pgpu_paillier_encrypt + pgpu_paillier_decrypt_crt "
-                                                 "synchronously on pageable arrays of its own, %d rounds each; aggregate rate" % reps,
-                                         "wall_ms": round(wall * 1e3, 3), "ms_per_encrypt_plus_decrypt": round(wall / (reps * ncall) * 1e3, 3),
-                                         "modexps_per_s": round(3 * BATCH * reps * ncall / wall, 1)}
-    except Exception as e:                                  # noqa: BLE001
-        out["end_to_end_two_callers"] = {"error": repr(e)[:300]}
+    for variant in ("pageable", "pinned"):
+        key = "end_to_end_two_callers" + ("" if variant == "pageable" else "_pinned")
+        try:
+            out[key] = two_callers(L, pk, sk, m_host, r_host, variant)
+        except Exception as e:                              # noqa: BLE001
+            out[key] = {"error": repr(e)[:300]}
     # (2) the API-visible timing of the reference's own benchmark: ipcl::PublicKey::encrypt / PrivateKey::decrypt with
     # std::vector<BigNumber> in and out (benchmark/bench_cryptography.cpp:73-121)
     try:
@@ -863,6 +850,103 @@ def extras(pa, L, B, pk, sk, n, p, q, hs, m_host, r_host, per_kind):
         L.pgpu_debug_set_seq_decrypt(1)
         out["sequential_halves_two_lanes"] = {"error": str(e)[:300]}
     return out
+
+
+def two_callers(L, pk, sk, m_host, r_host, variant, reps=6, ncall=2):
+    import threading
+    from pailliercryptolib_amd import _capi
+    nw, pw = m_host.shape[1], r_host.shape[1]
+    held = []
+
+    def pin(shape):
+        nbytes = int(np.prod(shape)) * 8
+        pp = ctypes.c_void_p()
+        _capi.check(L.pgpu_host_alloc(nbytes, ctypes.byref(pp)))
+        held.append(pp)
+        return np.frombuffer((ctypes.c_uint8 * nbytes).from_address(pp.value), dtype=np.uint64).reshape(shape)
+    bufs = []
+    for _ in range(ncall):
+        if variant == "pageable":
+            bufs.append((m_host.copy(), r_host.copy(), np.empty((BATCH, 2 * nw), dtype=np.uint64), np.empty((BATCH, nw), dtype=np.uint64)))
+        else:
+            a, b2 = pin((BATCH, nw)), pin((BATCH, pw))
+            a[:], b2[:] = m_host, r_host
+            bufs.append((a, b2, pin((BATCH, 2 * nw)), pin((BATCH, nw))))
+    bar = threading.Barrier(ncall + 1)
+    errs = []
+
+    def caller(k):
+        mm, rr, cc, dd = bufs[k]
+        try:
+            for it in range(reps + 1):
+                if it == 1:
+                    bar.wait()
+                _capi.check(L.pgpu_paillier_encrypt(pk._h, ptr(mm), nw, nw, ptr(rr), pw, pw, 64 * pw, ptr(cc), BATCH))
+                _capi.check(L.pgpu_paillier_decrypt_crt(sk._h, ptr(cc), ptr(dd), BATCH))
+        except Exception as e:                              # noqa: BLE001
+            errs.append(repr(e))
+            try:
+                bar.abort()
+            except Exception:                               # noqa: BLE001
+                pass
+    th = [threading.Thread(target=caller, args=(k,)) for k in range(ncall)]
+    for t in th:
+        t.start()
+    bar.wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    ok = not errs and all(bool(np.array_equal(b[3], m_host)) for b in bufs)
+    for pp in held:
+        L.pgpu_host_free(pp)
+    if not ok:
+        raise RuntimeError("two callers: " + "; ".join(errs)[:200])
+    return {"what": "two host threads, each calling pgpu_paillier_encrypt + pgpu_paillier_decrypt_crt synchronously on %s arrays "
+                    "of its own, %d rounds each; aggregate rate" % (variant, reps),
+            "wall_ms": round(wall * 1e3, 3), "ms_per_encrypt_plus_decrypt": round(wall / (reps * ncall) * 1e3, 3),
+            "modexps_per_s": round(3 * BATCH * reps * ncall / wall, 1)}
+
+
+def lanes_sweep(L, B, pk, sk, m_host, r_host, seconds=0.8):
+    from pailliercryptolib_amd import _capi
+    pw = r_host.shape[1]
+    res = {"what": "encrypt + decrypt steps of 8192 rotating over k batch lanes, ~%.1f s back to back per k, default policies; "
+                   "results checked" % seconds}
+    for nl in range(1, L.pgpu_batch_lanes() + 1):
+        time.sleep(0.12)
+        sets = []
+        for ln in range(nl):
+            _capi.check(L.pgpu_set_batch_lane(ln))
+            sets.append((B.up(m_host), B.up(r_host)))
+        _capi.check(L.pgpu_set_batch_lane(0))
+        st = {"c": [None] * nl, "o": [None] * nl, "i": 0}
+
+        def step():
+            k = st["i"] % nl
+            st["i"] += 1
+            B.free(st["c"][k], st["o"][k])
+            st["c"][k] = B.op(L.pgpu_batch_encrypt, pk._h, sets[k][0], sets[k][1], 64 * pw)
+            st["o"][k] = B.op(L.pgpu_batch_decrypt_crt, sk._h, st["c"][k])
+        for _ in range(2 * nl):
+            step()
+        _capi.check(L.pgpu_synchronize())
+        k = max(nl, int(seconds / 5.2e-3) // nl * nl)
+        _capi.check(L.pgpu_set_timing(1))
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        _capi.check(L.pgpu_synchronize())
+        dt = time.perf_counter() - t0
+        rec = collect_forms(L, 8 * k + 64)
+        _capi.check(L.pgpu_set_timing(0))
+        ok = all(bool(np.array_equal(B.down(o), m_host)) for o in st["o"])
+        B.free(*st["c"], *st["o"], *[h for pair in sets for h in pair])
+        if not ok:
+            raise RuntimeError("round trip failed with %d lanes" % nl)
+        res[str(nl)] = {"steps": k, "ms_per_step": round(dt / k * 1e3, 4), "modexps_per_s": round(3 * BATCH * k / dt, 1),
+                        "forms": forms_summary(rec)}
+    return res
 
 
 def seq_two_lanes(L, B, pk, sk, m_host, r_host, steps=20):
@@ -1243,6 +1327,11 @@ def run_ranks(args, world):
     if nfl == 1:
         per_kind = collect_timing(L, 4 * args.steps + 8)
     else:                       # per-kernel times from a short pass on ONE lane (launches do not overlap in it)
+        time.sleep(0.15)        # (the other lanes count as active for 50 ms after they last worked: let that lapse)
+        for _ in range(2):
+            state["i"] = 0
+            step()
+        _capi.check(L.pgpu_synchronize())
         _capi.check(L.pgpu_set_timing(1))
         for _ in range(6):
             state["i"] = 0

@@ -421,8 +421,14 @@ void host_note_read(const void* p, size_t bytes, int dev, hipStream_t s) {
 
 namespace {
 size_t stage_piece(size_t bytes) {
-  const size_t quarter = ((bytes + 3) / 4 + 4095) & ~(size_t)4095;
-  return std::min(kStageBytes, std::max<size_t>((size_t)512 << 10, quarter));
+  // Whole staging buffers.  (Round 4 tried quarter-transfer pieces so that packing piece i+1 overlaps the DMA of piece i
+  // for the 1-4 MB operands of an 8192-element call: a lone caller gained nothing -- the per-piece event waits cost what
+  // the overlap saved -- and with a second caller's kernels on the chip the small copies queued behind them: two callers
+  // 9.1 instead of 6.0 ms per encrypt + decrypt.  PGPU_STAGE_PIECES=4 brings the pieces back for A/B runs.)
+  static const int pieces = [] { const char* e = std::getenv("PGPU_STAGE_PIECES"); return e ? std::max(1, std::atoi(e)) : 1; }();
+  if (pieces <= 1) return kStageBytes;
+  const size_t part = ((bytes + pieces - 1) / pieces + 4095) & ~(size_t)4095;
+  return std::min(kStageBytes, std::max<size_t>((size_t)512 << 10, part));
 }
 int ensure_stage(Lane& l) {
   for (int i = 0; i < 2; ++i) {
@@ -442,8 +448,6 @@ int Lane::h2d(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
     return PGPU_OK;
   }
   RC_TRY(ensure_stage(*this));
-  // pieces of a quarter of the transfer (0.5 - 8 MiB): packing piece i+1 overlaps the DMA of piece i also for the 1-4 MB
-  // operands of an 8192-element call, which used to go as ONE piece -- pack, then copy, nothing overlapping
   const size_t piece = stage_piece(bytes);
   size_t off = 0;
   for (int i = 0; off < bytes; ++i) {

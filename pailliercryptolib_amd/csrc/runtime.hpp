@@ -19,6 +19,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -120,6 +121,9 @@ struct Device {
   hipStream_t bs(int lane) const { return bstreams[lane % kBatchLanes]; }
   // cross-lane ordering (a batch of one lane consumed by an operation on another): one event per source lane
   hipEvent_t xlane_ev[kBatchLanes] = {};
+  // host clock (ns, steady) of the last operation queued on each batch lane: a lane that was fed a moment ago counts as
+  // active for the adaptive kernel-form policy even if the GPU has just drained it (capi.cpp: busy_other_lanes)
+  std::atomic<int64_t> lane_fed_ns[kBatchLanes] = {};
   std::mutex mu;                   // allocator, work map, timing, queue
 
   // ---- caching allocator (sizes rounded to 64 KiB; free lists per stream tag) ----
