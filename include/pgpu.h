@@ -301,6 +301,9 @@ typedef enum pgpu_kernel_form {
   PGPU_FORM_CU_CLAIM = 16
 } pgpu_kernel_form;
 int pgpu_timing_collect_ex(int* kinds, int* forms, double* ms, int max_entries);
+/* ... and as a small kernel trace: batch lane of each launch (-1: another stream) and its start relative to the first
+ * recorded launch, from the same HIP events (any of forms / lanes / start_ms may be NULL) */
+int pgpu_timing_collect_trace(int* kinds, int* forms, int* lanes, double* start_ms, double* ms, int max_entries);
 /* Kernel geometry a batch of `count` exponentiations / products under an odd modulus of mod_bits bits
  * (operand rows of in_words 64-bit words) is launched with: *lanes lanes per element, *limbs 29-bit limbs
  * per lane (modexp_kernel; small batches take a 16-lane latency split, large ones the wide split).  Pure

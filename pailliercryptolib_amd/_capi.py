@@ -34,6 +34,7 @@ SYMBOLS = [
     "pgpu_set_table_gather_policy", "pgpu_get_table_gather_policy",
     "pgpu_build_features", "pgpu_batch_lanes", "pgpu_timing_collect_ex", "pgpu_decrypt_kernel_form_ex",
     "pgpu_encrypt_kernel_form_ex", "pgpu_host_alloc", "pgpu_host_free", "pgpu_host_wait",
+    "pgpu_timing_collect_trace",
 ]
 FEATURE_4096_SPLIT, FEATURE_AB_DECRYPT = 1, 2
 
@@ -153,6 +154,8 @@ def lib():
     L.pgpu_host_alloc.argtypes = [c_size_t, POINTER(c_void_p)]; L.pgpu_host_alloc.restype = c_int
     L.pgpu_host_free.argtypes = [c_void_p]; L.pgpu_host_free.restype = None
     L.pgpu_host_wait.argtypes = [c_void_p]; L.pgpu_host_wait.restype = c_int
+    L.pgpu_timing_collect_trace.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]
+    L.pgpu_timing_collect_trace.restype = c_int
     L.pgpu_timing_collect_ex.argtypes = [c_void_p, c_void_p, c_void_p, c_int]; L.pgpu_timing_collect_ex.restype = c_int
     L.pgpu_decrypt_kernel_form_ex.argtypes = [c_void_p, c_size_t, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
     L.pgpu_decrypt_kernel_form_ex.restype = c_int

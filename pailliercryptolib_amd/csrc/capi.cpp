@@ -423,6 +423,7 @@ struct TimerScope {
     if (!on) return;
     t.kind = kind;
     t.form = form;
+    t.stream = st;
     t.e0 = d.pool_event();
     t.e1 = d.pool_event();
     (void)hipEventRecord(t.e0, s);
@@ -1218,6 +1219,7 @@ const pgpu_pubkey::PubForm* split_modexp_form(const pgpu_pubkey* key, size_t cou
 }
 bool modexp_seq_form_pays(int H, int K, size_t count);
 bool fb_encrypt_seq_pays(int H, int K, size_t count, int busy = 0);
+unsigned adaptive_cu_claim(size_t waves, int busy_lanes);
 int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::PubForm* form, const uint64_t* d_base, size_t base_stride,
                     int base_words, bool base_mont, const uint64_t* d_exp, size_t exp_stride, int exp_words,
                     int exp_bits, const SchedRef* sched, int final_mul, const uint64_t* d_m, size_t m_stride,
@@ -1371,7 +1373,11 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
       const int ipw = seq ? 64 / form->H : 64 / (2 * form->H);
       const unsigned blocks = (unsigned)(((count + ipw - 1) / ipw + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
       if (seq) {
-        if (!pgpu::launch_hensel_fb_encrypt_seq(form->H, form->K, f, blocks, s))
+        // a part-chip launch beside busy neighbour lanes claims whole CUs, like the decrypt it feeds (decrypt_on)
+        const size_t seq_waves = (count + ipw - 1) / ipw;
+        const unsigned lds_pad = adaptive_cu_claim(seq_waves, busy_lanes);
+        if (lds_pad) t.set_form(PGPU_FORM_SEQ | PGPU_FORM_CU_CLAIM);
+        if (!pgpu::launch_hensel_fb_encrypt_seq(form->H, form->K, f, blocks, s, lds_pad))
           return fail(PGPU_ERR_UNSUPPORTED, "sequential-halves fixed-base kernel not compiled");
       } else if (!pgpu::launch_hensel_fb_encrypt(form->H, form->K, f, blocks, s))
         return fail(PGPU_ERR_UNSUPPORTED, "split-form fixed-base kernel not compiled");
@@ -1507,6 +1513,11 @@ std::atomic<int> g_adapt_claim_busy{[] { const char* e = std::getenv("PGPU_ADAPT
 // with `busy` other batch lanes at work, does a launch of `waves` wavefronts of a sequential-halves form fill its share?
 bool seq_adaptive(size_t waves, int busy) {
   return g_seq_policy.load() == 4 && busy >= 1 && waves * (size_t)(1 + busy) >= kSimds;
+}
+// LDS bytes a part-chip launch of a sequential-halves form claims beyond its needs under the adaptive policy (more than
+// half a CU's LDS: one workgroup per CU, so that the launches of neighbour lanes spread over the chip); 0: no claim
+unsigned adaptive_cu_claim(size_t waves, int busy_lanes) {
+  return (g_seq_policy.load() == 4 && waves < kSimds && busy_lanes >= 1 && busy_lanes <= g_adapt_claim_busy.load()) ? 84000u : 0u;
 }
 // Batch lanes of `dev` other than `lane` that are ACTIVE: work queued right now, or fed within the last few tens of
 // milliseconds (PGPU_LANE_ACTIVE_MS, default 50).  The second clause is what keeps a caller that rotates over the lanes
@@ -2175,8 +2186,12 @@ int pgpu_set_timing(int enabled) {
 }
 
 int pgpu_timing_collect_ex(int* kinds, int* forms, double* ms, int max_entries);
+int pgpu_timing_collect_trace(int* kinds, int* forms, int* lanes, double* start_ms, double* ms, int max_entries);
 int pgpu_timing_collect(int* kinds, double* ms, int max_entries) { return pgpu_timing_collect_ex(kinds, nullptr, ms, max_entries); }
 int pgpu_timing_collect_ex(int* kinds, int* forms, double* ms, int max_entries) {
+  return pgpu_timing_collect_trace(kinds, forms, nullptr, nullptr, ms, max_entries);
+}
+int pgpu_timing_collect_trace(int* kinds, int* forms, int* lanes, double* start_ms, double* ms, int max_entries) {
   if (!rt::initialized()) return 0;
   rt::Device& d = rt::current();
   rt::DeviceGuard g(d.ordinal);
@@ -2192,6 +2207,15 @@ int pgpu_timing_collect_ex(int* kinds, int* forms, double* ms, int max_entries) 
         n < max_entries && kinds && ms) {
       kinds[n] = t.kind;
       if (forms) forms[n] = t.form;
+      if (lanes) {
+        lanes[n] = -1;
+        for (int k = 0; k < rt::kBatchLanes; ++k)
+          if (t.stream == d.bs(k)) lanes[n] = k;
+      }
+      if (start_ms) {   // start of this launch relative to the start of the first launch of the record
+        float off = 0;
+        start_ms[n] = (hipEventElapsedTime(&off, rec.front().e0, t.e0) == hipSuccess) ? off : -1.0;
+      }
       ms[n] = v;
       ++n;
     }

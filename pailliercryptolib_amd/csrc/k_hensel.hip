@@ -136,9 +136,14 @@ bool launch_pair_mul_seq_part19(int G, int K, const PairOpsArgs& a, unsigned blo
   return false;
 }
 #elif PGPU_PART == 20
-bool launch_hensel_fb_encrypt_seq_part20(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
+bool launch_hensel_fb_encrypt_seq_part20(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad) {
   if (G == 4 && K == 18) {
-    hipLaunchKernelGGL((hensel_fb_encrypt_seq_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    if (lds_pad) {   // (whole-CU claim of a part-chip launch beside a busy neighbour lane, as launch_hensel_seq)
+      static const hipError_t once = hipFuncSetAttribute((const void*)hensel_fb_encrypt_seq_kernel<4, 18>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (once != hipSuccess) return false;
+    }
+    hipLaunchKernelGGL((hensel_fb_encrypt_seq_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), lds_pad, s, a);
     return true;
   }
   return false;

@@ -186,10 +186,11 @@ inline bool launch_pair_mul_seq(int G, int K, const PairOpsArgs& a, unsigned blo
 // DJN encrypt to pair rows in the same form (k_hensel.hip parts 20, 21, 28): (4,18) 2048-bit keys, (8,14) 3072, (2,19) 1024
 inline bool hensel_fb_encrypt_seq_has(int G, int K) { return (G == 4 && K == 18) || (G == 8 && K == 14) || (G == 2 && K == 19); }
 bool launch_hensel_fb_encrypt_seq_part28(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
-bool launch_hensel_fb_encrypt_seq_part20(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
+bool launch_hensel_fb_encrypt_seq_part20(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
 bool launch_hensel_fb_encrypt_seq_part21(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
-inline bool launch_hensel_fb_encrypt_seq(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
-  return launch_hensel_fb_encrypt_seq_part20(G, K, a, blocks, s) || launch_hensel_fb_encrypt_seq_part21(G, K, a, blocks, s) ||
+// lds_pad: whole-CU claim (see launch_hensel_seq); honoured by the (4,18) form, the one the adaptive policy uses part-chip
+inline bool launch_hensel_fb_encrypt_seq(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad = 0) {
+  return launch_hensel_fb_encrypt_seq_part20(G, K, a, blocks, s, lds_pad) || launch_hensel_fb_encrypt_seq_part21(G, K, a, blocks, s) ||
          launch_hensel_fb_encrypt_seq_part28(G, K, a, blocks, s);
 }
 

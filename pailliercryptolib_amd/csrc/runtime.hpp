@@ -90,6 +90,7 @@ struct StreamWork {
 struct TimedLaunch {
   int kind;
   int form;   // pgpu_kernel_form bits (include/pgpu.h): what the launcher picked for this launch
+  hipStream_t stream;
   hipEvent_t e0, e1;
 };
 
