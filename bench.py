@@ -120,9 +120,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
                     help="2: BASELINE configs[1]+[2] (default, the headline); 4 / 5: configs[3] / configs[4]")
-    ap.add_argument("--in-flight", type=int, default=4, choices=[1, 2, 3, 4],
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
                     help="resident batches in flight per GPU: consecutive steps rotate over that many of the library's "
-                         "batch lanes (default: all four; 1: every step on one lane)")
+                         "four batch lanes (default 2: each lane then owns half the chip, and a 20-step run is as fast as a "
+                         "long one; 4 sustains ~4 %% more over seconds but needs ~10 steps to fall out of lock-step: "
+                         "batches_in_flight_sweep in the line)")
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="length of the sustained-rate run behind the timed region (N = 1; 0 skips it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -211,6 +213,7 @@ def run_pool(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_issue = time.perf_counter() - t0          # the calling thread has queued every launch of the timed region
     sync_all()
     elapsed = time.perf_counter() - t0
     timed_forms = collect_forms(L, 8 * args.steps + 64)
@@ -285,6 +288,9 @@ def run_pool(args):
                         "lane idling through another's products); executed - useful = slots the paired kernel spends on "
                         "products nobody needs")
     result["kernel_forms_in_timed_region"] = forms_summary(timed_forms)
+    result["host_issue_ms_per_step"] = round(t_issue / args.steps * 1e3, 4)
+    result["host_issue_note"] = ("time the ONE calling thread spends queueing a step's launches over the %d pool entries (3 launches "
+                                 "+ allocations per GPU and step); %.1f %% of a step" % (N, 100 * t_issue / elapsed))
     if nfl > 1:
         result["config"]["workload"] += ("; %d batches in flight per GPU: consecutive steps rotate over %d of the library's "
                                          "batch lanes (streams), exactly K steps timed" % (nfl, nfl))
@@ -489,6 +495,50 @@ def decrypt_kernel(sk, count, nw, key_bits, busy_lanes=0):
         sq = l2 * (l2 + lanes.value) // 2 + 3 * l2 * l2
         return f"hensel_decrypt_seq_kernel<{lanes.value},{limbs.value}>", nsq * sq + nmul * 5 * l2 * l2
     return f"hensel_decrypt_kernel<{lanes.value // 2},{limbs.value}>", nsq * 4 * l2 * l2 + nmul * 6 * l2 * l2
+
+
+def nondjn_executed(key_bits, l2=72):
+    """executed multiply-accumulates of r^n * (1 + n*m) per element through hensel_modexp_kernel<4,18> (2048-bit keys)"""
+    e = key_bits
+    nsq, nmul = e - 1, e // 7 + 32 + 4 + 2          # squarings; window products + odd-power table + entry chunks + exit
+    return nsq * 4 * l2 * l2 + nmul * 6 * l2 * l2
+
+
+def fixed_window(exp_bits):
+    """the library's window for per-element exponents (csrc/capi.cpp: pick_window): w in 1..5 that minimises the table
+    products 2^w - 2 plus the window products ceil(e / w)"""
+    return min(range(1, 6), key=lambda w: ((1 << w) - 2) + (exp_bits + w - 1) // w)
+
+
+def ctpt_block(pk, shard, e_bits, t_mul, total, me_ms, mac_canonical, pmc):
+    """config 5 (ii): CT x PT with e_bits-bit plaintexts -- executed and useful multiply-accumulates of the kernel that ran
+    (pair rows in and out: no entry or exit products).  Fixed window w: 2^w - 2 table products, then per remaining window
+    w squarings and one product."""
+    from pailliercryptolib_amd import _capi
+    split, lanes, limbs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _capi.check(_capi.lib().pgpu_modexp_n2_kernel_form(pk._h, shard, ctypes.byref(split), ctypes.byref(lanes), ctypes.byref(limbs)))
+    w = fixed_window(e_bits)
+    nwin = (e_bits + w - 1) // w
+    nsq, nmul = w * (nwin - 1), (1 << w) - 2 + (nwin - 1)
+    out = {"ms_per_step": round(t_mul * 1e3, 3), "modexps_per_s": round(total / t_mul, 1),
+           "kernel": modexp_n2_kernel(pk, shard, True), "kernel_ms": round(me_ms, 3),
+           "schedule": "fixed window w = %d: %d squarings + %d products per element" % (w, nsq, nmul)}
+    if split.value:
+        g = lanes.value if split.value == 2 else lanes.value // 2
+        l2 = g * limbs.value
+        useful = nsq * (l2 * (l2 + g) // 2 + 3 * l2 * l2) + nmul * 5 * l2 * l2
+        executed = useful if split.value == 2 else nsq * 4 * l2 * l2 + nmul * 6 * l2 * l2
+        out.update({"executed_mac32_per_launch": executed * shard, "useful_mac32_per_launch": useful * shard,
+                    "frac": sig(executed * shard / (me_ms * 1e-3) / 1e12 / PEAK_TMAC32),
+                    "frac_useful": sig(useful * shard / (me_ms * 1e-3) / 1e12 / PEAK_TMAC32),
+                    "frac_basis": "EXECUTED multiply-accumulates per launch / kernel time (HIP events) / peak"})
+    out["canonical_mac32_per_launch"] = mac_canonical
+    out["canonical_frac"] = sig(mac_canonical / (me_ms * 1e-3) / 1e12 / PEAK_TMAC32)
+    out["canonical_note"] = ("SURVEY 8(d) count (full-width products, squarings as products, w = 2 for short exponents) / time / peak: "
+                             "not a utilisation (the split form executes about half of it); the utilisation figure is frac")
+    out["traffic"] = pmc.get("ct_mul_hbm_bytes_per_launch")
+    out["traffic_source"] = pmc_source(pmc, "ct_mul_kernel") if pmc.get("ct_mul_hbm_bytes_per_launch") else None
+    return out
 
 
 def modexp_n2_kernel(pk, count, per_element_exponents=False):
@@ -769,7 +819,13 @@ def extras(pa, L, B, pk, sk, n, p, q, hs, m_host, r_host, per_kind):
     out["config2_nondjn"] = {"what": "encrypt batch=8192 with the non-DJN obfuscator r^n mod n^2 (e = n, 2048 b), resident",
                              "kernel": modexp_n2_kernel(pk2, BATCH),
                              "encrypt_ms": round(tn * 1e3, 3), "encrypts_per_s": round(BATCH / tn, 1),
-                             "canonical_frac": sig(mac / tn / 1e12 / PEAK_TMAC32),   # canonical MAC32 count (> 1 is possible: see roofline.canonical_step_note)
+                             # executed: sliding-window schedule of the PUBLIC exponent n (w = 6: ~e/7 + 32 products), paired split
+                             # form with L2 = 72 limbs per half: 4 L2^2 per squaring, 6 L2^2 per product, + entry / exit products
+                             "executed_mac32_per_launch": nondjn_executed(KEY_BITS) * BATCH,
+                             "frac": sig(nondjn_executed(KEY_BITS) * BATCH / tn / 1e12 / PEAK_TMAC32),
+                             "frac_basis": "EXECUTED multiply-accumulates / call time (launch + synchronise) / peak",
+                             "canonical_frac": sig(mac / tn / 1e12 / PEAK_TMAC32),
+                             "canonical_note": "SURVEY 8(d) count / time / peak: not a utilisation (see roofline.canonical_step_note)",
                              "step_modexps_per_s_with_it": round(
                                  3 * BATCH / (tn + (np.mean(per_kind[K_MODEXP]) + np.mean(per_kind[K_CRT])) * 1e-3), 1)}
     B.free(hold.get("c"), dec, bm, br2)
@@ -1089,6 +1145,7 @@ def run_config45(args, pa, L, B, N):
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        t_issue = time.perf_counter() - t0
         sync()
         elapsed = time.perf_counter() - t0
         per = collect_timing(L, 4 * args.steps + 8)
@@ -1112,6 +1169,14 @@ def run_config45(args, pa, L, B, N):
         mac_dec = 2 * algorithmic_mac32(bits, bits // 2) * shard
         dec_name, dec_exec = decrypt_kernel(sk, shard, nw, bits)
         exec_dec = dec_exec * 2 * shard
+        useful_dec = decrypt_useful_mac32(nw, bits) * 2 * shard
+        fb4 = fixed_base_info(L, pk)
+        enc_name, enc_per_elt, enc_note = encrypt_kernel(pk, shard, nw, bits, fb4["window"] or 12)
+        enc_ms = float(np.mean(per[K_FB]))
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
         return {
             "metric": "3072-bit modexps/sec (encrypt+decrypt), batch=65536 sharded over the GPUs",
             "value": round(3 * total * args.steps / elapsed, 1), "unit": "modexps/s", "n_gpus": N, "steps": args.steps,
@@ -1125,13 +1190,29 @@ def run_config45(args, pa, L, B, N):
                                                        f"{2 * shard} half-width modexps per launch per GPU)",
                          "achieved": sig(exec_dec / (dec_ms * 1e-3) / 1e12, 3), "peak": PEAK_TMAC32, "unit": "TMAC32/s",
                          "frac": sig(exec_dec / (dec_ms * 1e-3) / 1e12 / PEAK_TMAC32),
-                         "frac_basis": "executed multiply-accumulates", "traffic": None,
+                         "frac_basis": "EXECUTED multiply-accumulates per launch / kernel time (HIP events, launches do not "
+                                       "overlap in this run) / peak",
+                         "executed_mac32_per_launch": exec_dec, "useful_mac32_per_launch": useful_dec,
+                         "frac_useful": sig(useful_dec / (dec_ms * 1e-3) / 1e12 / PEAK_TMAC32),
+                         "traffic": pmc.get("config4_decrypt_hbm_bytes_per_launch"),
+                         "traffic_source": pmc_source(pmc, "config4_decrypt_kernel") if pmc.get("config4_decrypt_hbm_bytes_per_launch") else None,
+                         "algorithmic_bytes_per_launch": (4 * L.pgpu_batch_row_limbs(st["c"]) or 2 * nw * 8) * shard + nw * 8 * shard,
+                         "canonical_mac32_per_launch": mac_dec,
                          "canonical_frac": sig(mac_dec / (dec_ms * 1e-3) / 1e12 / PEAK_TMAC32),
+                         "canonical_note": "SURVEY 8(d) count (full-width products, squarings as products) / time / peak; the "
+                                           "utilisation figure is frac",
                          "kernel_ms": round(dec_ms, 4),
-                         "other_kernels": {"fb_encrypt_kernel": {"ms": round(float(np.mean(per[K_FB])), 4)},
+                         "other_kernels": {enc_name: {"ms": round(enc_ms, 4), "executed_mac32_per_launch": enc_per_elt * shard,
+                                                      "frac": sig(enc_per_elt * shard / (enc_ms * 1e-3) / 1e12 / PEAK_TMAC32),
+                                                      "fixed_base_table": fb4, "note": enc_note,
+                                                      "traffic": pmc.get("config4_encrypt_hbm_bytes_per_launch"),
+                                                      "traffic_source": pmc_source(pmc, "config4_encrypt_kernel") if pmc.get("config4_encrypt_hbm_bytes_per_launch") else None},
                                            "crt_kernel": {"ms": round(float(np.mean(per[K_CRT])), 4)}}},
             "end_to_end": {"what": "the same step from caller-owned host arrays (H2D + kernels + D2H)",
                            "ms_per_step": round(t_e2e * 1e3, 3), "modexps_per_s": round(3 * total / t_e2e, 1)},
+            "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 4),
+            "host_issue_note": "time the calling thread spends queueing a step's launches over the %d pool entries; %.2f %% of a step"
+                               % (N, 100 * t_issue / elapsed),
         }
     # ---- config 5: 2048-bit CT+CT and CT x PT on 1 M elements ----
     p, q, hs = iso_key()
@@ -1167,6 +1248,7 @@ def run_config45(args, pa, L, B, N):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         add()
+    t_issue_add = (time.perf_counter() - t0) / args.steps
     sync()
     t_add = (time.perf_counter() - t0) / args.steps
     per_add = collect_timing(L, args.steps + 8)
@@ -1239,9 +1321,10 @@ def run_config45(args, pa, L, B, N):
                      "algorithmic_bytes_per_launch": 3 * row_bytes * shard,
                      "hbm_achieved_GBs": round(3 * row_bytes * shard / (mm_ms * 1e-3) / 1e9, 1), "hbm_peak_GBs": HBM_PEAK_GBS,
                      "hbm_frac": sig(3 * row_bytes * shard / (mm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)},
-        "config5_mul_ctpt_u32": {"ms_per_step": round(t_mul * 1e3, 3), "modexps_per_s": round(total / t_mul, 1),
-                                 "kernel": modexp_n2_kernel(pk, shard, True), "kernel_ms": round(me_ms, 3),
-                                 "canonical_frac": sig(mac_mul / (me_ms * 1e-3) / 1e12 / PEAK_TMAC32)},
+        "config5_mul_ctpt_u32": ctpt_block(pk, shard, 32, t_mul, total, me_ms, mac_mul, pmc),
+        "host_issue_ms_per_step": round(t_issue_add * 1e3, 4),
+        "host_issue_note": "time the calling thread spends queueing one CT+CT step over the %d pool entries; %.1f %% of a step"
+                           % (N, 100 * t_issue_add / t_add),
         "end_to_end": {"what": "CT+CT through pgpu_modmul on caller-owned host arrays (plain operands: two products, "
                                "H2D + kernel + D2H pipelined in sub-batches over the worker lanes)",
                        "ms_per_step": round(t_e2e * 1e3, 3), "modmuls_per_s": round(total / t_e2e, 1),

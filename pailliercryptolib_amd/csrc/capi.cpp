@@ -1505,10 +1505,12 @@ int seq_policy_by_size() {
   return (p == 3 || p == 4) ? 1 : p;
 }
 // tuning knobs of the adaptive policy (tools/probe_lanes.py; pgpu_debug_set_adaptive / PGPU_ADAPT_ENC_SEQ,
-// PGPU_ADAPT_CLAIM_BUSY): does the DJN encrypt follow the decrypt into the sequential-halves form beside busy lanes
-// (measured r04: no -- its 512 wavefronts without a CU claim stack onto a neighbour's CUs, 0.79 -> 1.7 ms), and up to how
-// many busy neighbours a part-chip decrypt claims whole CUs
-std::atomic<int> g_adapt_enc_seq{[] { const char* e = std::getenv("PGPU_ADAPT_ENC_SEQ"); return e ? std::atoi(e) : 0; }()};
+// PGPU_ADAPT_CLAIM_BUSY): up to how many busy neighbours the DJN encrypt follows the decrypt into the sequential-halves
+// form with a CU claim (measured r04, profiles/r04_lanes.txt: with ONE busy neighbour -- two lanes, each owning half the
+// chip -- the step goes 4.92 -> 4.87 ms; with three the paired full-chip encrypt hides better under the neighbours'
+// decrypts, 4.72 against 4.87 ms; without the claim its 512 wavefronts stack onto a neighbour's CUs: 0.79 -> 1.7 ms), and
+// up to how many busy neighbours a part-chip launch claims whole CUs
+std::atomic<int> g_adapt_enc_seq{[] { const char* e = std::getenv("PGPU_ADAPT_ENC_SEQ"); return e ? std::atoi(e) : 1; }()};
 std::atomic<int> g_adapt_claim_busy{[] { const char* e = std::getenv("PGPU_ADAPT_CLAIM_BUSY"); return e ? std::atoi(e) : 3; }()};
 // with `busy` other batch lanes at work, does a launch of `waves` wavefronts of a sequential-halves form fill its share?
 bool seq_adaptive(size_t waves, int busy) {
@@ -1553,7 +1555,7 @@ bool fb_encrypt_seq_pays(int H, int K, size_t count, int busy) {
   const int pol = seq_policy_by_size();
   // (adaptive: beside busy neighbour lanes the form of half the wavefronts -- and a sixth fewer multiply-accumulates --
   // also for launches that would not fill the chip alone; 4-lane groups only, see below for the others)
-  if (H == 4 && g_adapt_enc_seq.load() && seq_adaptive(waves, busy)) return true;
+  if (H == 4 && busy <= g_adapt_enc_seq.load() && seq_adaptive(waves, busy)) return true;
   // (2-lane groups, 1024-bit keys: measured equal or behind the paired kernel at 65536 elements -- 1.04 against 1.02 ms,
   // 0.96 against 0.92 ms: 19 limbs per lane and the LDS staging leave no register room -- so only when forced)
   if (H == 2 && pol != 2) return false;

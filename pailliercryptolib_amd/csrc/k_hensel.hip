@@ -139,8 +139,10 @@ bool launch_pair_mul_seq_part19(int G, int K, const PairOpsArgs& a, unsigned blo
 bool launch_hensel_fb_encrypt_seq_part20(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad) {
   if (G == 4 && K == 18) {
     if (lds_pad) {   // (whole-CU claim of a part-chip launch beside a busy neighbour lane, as launch_hensel_seq)
+      // (the kernel's own ~45 KB of LDS + the 84 000-byte claim fit a CU's 160 KB once, not twice; a 128 KB allowance
+      // on top of the static part would exceed the CU and the attribute call fails)
       static const hipError_t once = hipFuncSetAttribute((const void*)hensel_fb_encrypt_seq_kernel<4, 18>,
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
       if (once != hipSuccess) return false;
     }
     hipLaunchKernelGGL((hensel_fb_encrypt_seq_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), lds_pad, s, a);
