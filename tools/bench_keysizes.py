@@ -73,7 +73,17 @@ for bits in (1024, 2048, 3072, 4096):
         out = np.empty((count, nw), dtype=np.uint64)
         _capi.check(L.pgpu_batch_download(dm, ptr(out)))
         assert np.array_equal(out, m)
+        # decrypt leg as a fraction of the int-ALU peak (bench.py's counts: executed by the kernel form that ran, and the
+        # useful count of the split form); wall time of the call incl. launch overhead and the CRT kernel
+        import bench as _b
+        if bits in (1024, 2048, 3072) or (bits == 4096 and mode == 0):
+            name, per_exp = _b.decrypt_kernel(sk, count, nw, bits)
+            fe = per_exp * 2 * count / (t_dec * 1e-3) / 1e12 / _b.PEAK_TMAC32
+            fu = _b.decrypt_useful_mac32(nw, bits) * 2 * count / (t_dec * 1e-3) / 1e12 / _b.PEAK_TMAC32
+            frac = f"   [{name}: {fe:.2f} executed" + (f", {fu:.2f} useful]" if mode else "]")
+        else:
+            frac = ""
         print(f"{bits}-bit key, {count} elements, split form {'on ' if mode else 'off'}: encrypt {t_enc:8.2f} ms   "
-              f"CT x PT (u32) {t_mul:8.2f} ms   CT + CT {t_add:7.3f} ms   decrypt {t_dec:8.2f} ms", flush=True)
+              f"CT x PT (u32) {t_mul:8.2f} ms   CT + CT {t_add:7.3f} ms   decrypt {t_dec:8.2f} ms{frac}", flush=True)
         del pk, sk
 pa.terminate()
