@@ -1513,6 +1513,20 @@ def cpu_baseline(n, p, q, hs, m_host, r_host):
 
     legs = {}
     backends = []
+    fb_info = None
+    if c_oracle.ifma_lib() is not None and hasattr(c_oracle.ifma_lib(), "orc_ifma_fb_build"):
+        # like for like with the GPU step: hs^r as a fixed-base product over a per-key table (built here, outside the timed
+        # samples, as the GPU's is), the decrypt leg by square-and-multiply
+        t0 = time.perf_counter()
+        nsq_l = ints_to_limbs([n * n], 2 * nw)[0]
+        fbw = int(os.environ.get("BENCH_CPU_FB_WINDOW", "8"))
+        fb = c_oracle.IfmaFixedBase(hs_l, nsq_l, 64 * pw, fbw)
+        fb_info = {"window": fbw, "table_bytes": ((64 * pw + fbw - 1) // fbw) * (1 << fbw) * ((2 * KEY_BITS + 2 + 51) // 52) * 8,
+                   "build_s": round(time.perf_counter() - t0, 3)}
+
+        def fb_backend(base, exp, mod):
+            return fb(base, exp) if base.shape[1] == 2 * nw and exp.shape[1] == pw else c_oracle.ifma_modexp_batch(base, exp, mod)
+        backends.append(("ifma_fixed_base", fb_backend, 6.0))
     if c_oracle.ifma_lib() is not None:
         backends.append(("ifma", c_oracle.ifma_modexp_batch, 6.0))
     if c_oracle.openssl_lib() is not None:
@@ -1523,13 +1537,17 @@ def cpu_baseline(n, p, q, hs, m_host, r_host):
         legs[name]["one_thread"] = measure(be, 2.0, 1)
     c_oracle.set_threads(threads)
     best = max(legs, key=lambda k: legs[k]["value"])
-    what = {"ifma": "oracle/ifma_oracle.c (8-lane AVX512-IFMA radix-2^52 restatement of the reference's mb8 path)",
+    if fb_info:
+        legs["ifma_fixed_base"]["fixed_base_table"] = fb_info
+    what = {"ifma_fixed_base": "oracle/ifma_oracle.c with hs^r as a fixed-base product (orc_ifma_fb_*: the GPU step's algorithm on "
+                               "the CPU; decrypt by square-and-multiply)",
+            "ifma": "oracle/ifma_oracle.c (8-lane AVX512-IFMA radix-2^52 restatement of the reference's mb8 path)",
             "openssl": "OpenSSL BN_mod_exp_mont", "scalar": "oracle/modexp_oracle.c (64-bit CIOS)"}[best]
     return {"value": legs[best]["value"], "unit": "modexps/s", "cores": threads, "kind": "port",
-            "encrypt_like_for_like": False,
-            "encrypt_note": "every CPU leg computes hs^r by square-and-multiply (1259 products per element); the GPU step runs it as "
-                            "a fixed-base product over a per-key table (85 products, table built outside the timed region): "
-                            "compare decrypt_only_modexps_per_s for like-for-like",
+            "encrypt_like_for_like": best == "ifma_fixed_base",
+            "encrypt_note": "legs.ifma_fixed_base computes hs^r as the GPU step does -- a fixed-base product over a per-key table "
+                            "built outside the timed region (CPU: w = 8, 127 products; GPU: w = 12, 85 products); the other legs "
+                            "square-and-multiply it (1259 products per element) as the reference's ippMBModExp does",
             "sample": f"{legs[best]['elements']} elements (the same batch, from its start, repeated if shorter than the "
                       f"time target), encrypt + CRT decrypt "
                       f"({3 * legs[best]['elements']} modexps) in {legs[best]['seconds']} s; {what}, gcc -O3 "

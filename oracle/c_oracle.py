@@ -173,6 +173,13 @@ def ifma_lib():
             return None
         vp, sz, i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
         L.orc_ifma_modexp_batch.argtypes = [vp, sz, vp, sz, i, vp, i, vp, sz]
+        if hasattr(L, "orc_ifma_fb_build"):
+            L.orc_ifma_fb_build.argtypes = [vp, vp, i, i, i]
+            L.orc_ifma_fb_build.restype = vp
+            L.orc_ifma_fb_free.argtypes = [vp]
+            L.orc_ifma_fb_free.restype = None
+            L.orc_ifma_fb_modexp_batch.argtypes = [vp, vp, sz, i, vp, sz]
+            L.orc_ifma_fb_modexp_batch.restype = i
         _ifma = L
     return _ifma
 
@@ -191,6 +198,35 @@ def ifma_modexp_batch(base, exp, mod):
                                  mod.shape[0], _p(out), base.shape[0])
     assert rc == 0, rc
     return out
+
+
+class IfmaFixedBase:
+    """base^exp[i] for ONE base through a fixed-base table (oracle/ifma_oracle.c: orc_ifma_fb_*): the CPU counterpart of the
+    GPU's DJN obfuscator; the table is built once (outside any timed region, like the GPU's)."""
+
+    def __init__(self, base, mod, exp_bits, w=8):
+        self.L = ifma_lib()
+        if self.L is None or not hasattr(self.L, "orc_ifma_fb_build"):
+            raise RuntimeError("libifma_oracle.so (with the fixed-base leg) is not available on this host")
+        self.mod = np.ascontiguousarray(mod, dtype=np.uint64)
+        base = np.ascontiguousarray(base, dtype=np.uint64)
+        assert base.shape[0] == self.mod.shape[0]
+        self.h = self.L.orc_ifma_fb_build(_p(base), _p(self.mod), self.mod.shape[0], int(exp_bits), int(w))
+        if not self.h:
+            raise RuntimeError("orc_ifma_fb_build failed")
+
+    def __call__(self, base_ignored, exp, mod_ignored=None):
+        exp = np.ascontiguousarray(exp, dtype=np.uint64)
+        out = np.empty((exp.shape[0], self.mod.shape[0]), dtype=np.uint64)
+        rc = self.L.orc_ifma_fb_modexp_batch(self.h, _p(exp), exp.shape[1], exp.shape[1], _p(out), exp.shape[0])
+        if rc != 0:
+            raise RuntimeError(f"orc_ifma_fb_modexp_batch failed: {rc}")
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.orc_ifma_fb_free(self.h)
+            self.h = None
 
 
 # ---- the same encrypt / CRT-decrypt flows with the modexps done by another backend -------------------

@@ -327,3 +327,175 @@ int orc_ifma_modexp_batch(const u64* base, size_t base_stride, const u64* exp, s
   free(r2d);
   return bad ? -3 : 0;
 }
+
+/* ---- fixed-base exponentiation base^exp[i] for ONE base (round 4: cpu_baseline.legs.ifma_fixed_base) ----
+ * What the GPU step does for the DJN obfuscator hs^r (pub_key.cpp:51-64 computes it by square-and-multiply through
+ * ippMBModExp): hs is a key constant, so hs^r = prod_i T[i][d_i] with T[i][d] = hs^(d * 2^(w i)) and d_i the i-th w-bit
+ * digit of r -- ceil(bits / w) - 1 products, no squarings, against a per-key table built once.  This is the same
+ * algorithm on the 8-lane IFMA arithmetic above, so that the encrypt third of bench.py's CPU baseline can be compared
+ * like for like.  Table: nwin x 2^w entries of L radix-2^52 digits (Montgomery form), built by orc_ifma_fb_build --
+ * outside the timed region, like the GPU's -- and gathered per lane.  Results are canonical and bit-identical with
+ * orc_ifma_modexp_batch (tests/test_oracle_c.py). */
+typedef struct orc_fb_table {
+  int L, w, nwin, mod_words;
+  u64 k0s;
+  u64* nd;   /* L digits of the modulus */
+  u64* tab;  /* [nwin][2^w][L] */
+} orc_fb_table;
+
+void orc_ifma_fb_free(orc_fb_table* t) {
+  if (!t) return;
+  free(t->nd);
+  free(t->tab);
+  free(t);
+}
+
+orc_fb_table* orc_ifma_fb_build(const u64* base, const u64* mod, int mod_words, int exp_bits, int w) {
+  if (!(mod[0] & 1) || mod_words < 1 || w < 1 || w > 12 || exp_bits < 1) return NULL;
+  const int nbits = top_bit(mod, mod_words);
+  const int L = (nbits + 2 + 51) / 52;
+  if (L > MAXL || mod_words > 2 * MAXL - 2) return NULL;
+  if (64 * mod_words > 52 * L && top_bit(base, mod_words) > 52 * L) return NULL;
+  orc_fb_table* T = (orc_fb_table*)calloc(1, sizeof(*T));
+  T->L = L;
+  T->w = w;
+  T->nwin = (exp_bits + w - 1) / w;
+  T->mod_words = mod_words;
+  T->nd = (u64*)calloc((size_t)L, 8);
+  const size_t ent = (size_t)1 << w;
+  T->tab = (u64*)aligned_alloc(64, (((size_t)T->nwin * ent * (size_t)L * 8) + 63) & ~(size_t)63);
+  const int W1 = mod_words + 2;
+  u64* r2d = (u64*)calloc((size_t)L, 8);
+  u64* x = (u64*)calloc((size_t)W1, 8);
+  u64* nw = (u64*)calloc((size_t)W1, 8);
+  memcpy(nw, mod, (size_t)mod_words * 8);
+  to52(T->nd, L, mod, mod_words);
+  x[0] = 1;
+  for (int i = 0; i < 2 * 52 * L; ++i) {
+    u64 carry = 0;
+    for (int k = 0; k < W1; ++k) {
+      const u64 v = x[k];
+      x[k] = (v << 1) | carry;
+      carry = v >> 63;
+    }
+    if (ge_words(x, nw, W1)) sub_words(x, nw, W1);
+  }
+  to52(r2d, L, x, mod_words);
+  u64 inv = 1;
+  for (int i = 0; i < 6; ++i) inv *= 2 - mod[0] * inv;
+  T->k0s = (0 - inv) & MASK52;
+  free(x);
+  free(nw);
+  const size_t vec = (size_t)L;
+  /* g[i] = base^(2^(w i)) in the Montgomery domain: one chain of squarings (every lane the same value) */
+  u64* g = (u64*)calloc((size_t)T->nwin * vec, 8);
+  u64 bd[MAXL];
+  to52(bd, L, base, mod_words);
+  {
+    v8* mem = (v8*)aligned_alloc(64, sizeof(v8) * (vec * 4 + 2 * vec + 4));
+    v8 *N = mem, *R2 = N + vec, *acc = R2 + vec, *one = acc + vec, *t = one + vec;
+    const v8 k0 = _mm512_set1_epi64((long long)T->k0s);
+    for (int j = 0; j < L; ++j) {
+      N[j] = _mm512_set1_epi64((long long)T->nd[j]);
+      R2[j] = _mm512_set1_epi64((long long)r2d[j]);
+      acc[j] = _mm512_set1_epi64((long long)bd[j]);
+    }
+    amm(acc, acc, R2, N, k0, L, t);
+    for (int i = 0; i < T->nwin; ++i) {
+      for (int j = 0; j < L; ++j) g[(size_t)i * vec + j] = ((const u64*)&acc[j])[0];
+      if (i + 1 < T->nwin)
+        for (int s = 0; s < w; ++s) ams(acc, acc, N, k0, L, t);
+    }
+    free(mem);
+  }
+  /* rows: eight windows per vector, T[i][d] = T[i][d-1] * g[i]; T[i][0] = R mod N */
+  const int groups = (T->nwin + 7) / 8;
+#pragma omp parallel
+  {
+    v8* mem = (v8*)aligned_alloc(64, sizeof(v8) * (vec * 5 + 2 * vec + 4));
+    v8 *N = mem, *R2 = N + vec, *acc = R2 + vec, *gv = acc + vec, *one = gv + vec, *t = one + vec;
+    const v8 k0 = _mm512_set1_epi64((long long)T->k0s);
+    for (int j = 0; j < L; ++j) {
+      N[j] = _mm512_set1_epi64((long long)T->nd[j]);
+      R2[j] = _mm512_set1_epi64((long long)r2d[j]);
+      one[j] = _mm512_set1_epi64(j == 0 ? 1 : 0);
+    }
+#pragma omp for schedule(dynamic, 1)
+    for (int gr = 0; gr < groups; ++gr) {
+      int win[8];
+      for (int l = 0; l < 8; ++l) win[l] = gr * 8 + l < T->nwin ? gr * 8 + l : T->nwin - 1;
+      for (int j = 0; j < L; ++j) {
+        u64 lane[8];
+        for (int l = 0; l < 8; ++l) lane[l] = g[(size_t)win[l] * vec + j];
+        gv[j] = _mm512_loadu_si512((const void*)lane);
+      }
+      amm(acc, R2, one, N, k0, L, t);                 /* R mod N: entry 0 */
+      for (size_t d = 0; d < ent; ++d) {
+        if (d == 1) memcpy(acc, gv, sizeof(v8) * vec);
+        else if (d > 1) amm(acc, acc, gv, N, k0, L, t);
+        for (int l = 0; l < 8; ++l) {
+          if (gr * 8 + l >= T->nwin) continue;
+          u64* dst = T->tab + ((size_t)win[l] * ent + d) * vec;
+          for (int j = 0; j < L; ++j) dst[j] = ((const u64*)&acc[j])[l];
+        }
+      }
+    }
+    free(mem);
+  }
+  free(g);
+  free(r2d);
+  return T;
+}
+
+int orc_ifma_fb_modexp_batch(const orc_fb_table* T, const u64* exp, size_t exp_stride, int exp_words, u64* out, size_t count) {
+  if (!T) return -1;
+  const int L = T->L, w = T->w, nwin = T->nwin, mod_words = T->mod_words;
+  const size_t vec = (size_t)L, ent = (size_t)1 << w;
+  u64 modw[2 * MAXL];
+  from52(modw, mod_words, T->nd, L);
+  for (size_t i = 0; i < count; ++i)
+    if (top_bit(exp + i * exp_stride, exp_words) > w * nwin) return -2;   /* exponent wider than the table covers */
+  const size_t groups = (count + 7) / 8;
+#pragma omp parallel
+  {
+    v8* mem = (v8*)aligned_alloc(64, sizeof(v8) * (vec * 4 + 2 * vec + 4));
+    v8 *N = mem, *acc = N + vec, *mul = acc + vec, *one = mul + vec, *t = one + vec;
+    const v8 k0 = _mm512_set1_epi64((long long)T->k0s);
+    u64 wtmp[2 * MAXL];
+    for (int j = 0; j < L; ++j) {
+      N[j] = _mm512_set1_epi64((long long)T->nd[j]);
+      one[j] = _mm512_set1_epi64(j == 0 ? 1 : 0);
+    }
+#pragma omp for schedule(dynamic, 4)
+    for (long g = 0; g < (long)groups; ++g) {
+      const size_t first = (size_t)g * 8;
+      const int live = count - first < 8 ? (int)(count - first) : 8;
+      const u64* ep[8];
+      for (int l = 0; l < 8; ++l) ep[l] = exp + (first + (size_t)(l < live ? l : 0)) * exp_stride;
+      for (int i = 0; i < nwin; ++i) {
+        long long idx[8];
+        for (int l = 0; l < 8; ++l) {
+          const int pos = i * w, k = pos >> 6, s = pos & 63;
+          u64 v = k < exp_words ? ep[l][k] >> s : 0;
+          if (s + w > 64 && k + 1 < exp_words) v |= ep[l][k + 1] << (64 - s);
+          idx[l] = (long long)(((size_t)i * ent + (size_t)(v & (ent - 1))) * vec);
+        }
+        const v8 vidx = _mm512_loadu_si512((const void*)idx);
+        v8* dst = i == 0 ? acc : mul;
+        for (int j = 0; j < L; ++j)
+          dst[j] = _mm512_i64gather_epi64(_mm512_add_epi64(vidx, _mm512_set1_epi64(j)), (const void*)T->tab, 8);
+        if (i > 0) amm(acc, acc, mul, N, k0, L, t);
+      }
+      amm(acc, acc, one, N, k0, L, t);
+      for (int l = 0; l < live; ++l) {
+        u64 d[MAXL];
+        for (int j = 0; j < L; ++j) d[j] = ((const u64*)&acc[j])[l];
+        from52(wtmp, mod_words + 1, d, L);
+        if (wtmp[mod_words] || ge_words(wtmp, modw, mod_words)) sub_words(wtmp, modw, mod_words);
+        memcpy(out + (first + (size_t)l) * (size_t)mod_words, wtmp, (size_t)mod_words * 8);
+      }
+    }
+    free(mem);
+  }
+  return 0;
+}

@@ -97,6 +97,39 @@ def test_ifma_leg_agrees_with_pow():
         assert got == [pow(b, e, mod) for b, e in zip(base, exp)], (bits, ebits)
 
 
+def test_ifma_fixed_base_leg_agrees_with_pow_and_square_and_multiply():
+    """oracle/ifma_oracle.c: orc_ifma_fb_* (round 4, cpu_baseline.legs.ifma_fixed_base): base^e through a per-base table of
+    base^(d * 2^(w i)) -- the CPU counterpart of the GPU's DJN obfuscator -- against CPython pow and against the
+    square-and-multiply leg, edge exponents and the 8-lane tail included; DJN encrypt of the benchmark key through it
+    equals the scalar port's."""
+    if c_oracle.ifma_lib() is None or not hasattr(c_oracle.ifma_lib(), "orc_ifma_fb_build"):
+        pytest.skip("no avx512ifma on this host")
+    rng = random.Random(77)
+    for bits, ebits, w, cnt in ((4096, 1024, 8, 21), (4096, 1024, 5, 9), (2048, 512, 10, 16), (1000, 333, 7, 3), (6144, 1536, 8, 5)):
+        mod = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+        base = rng.randrange(mod)
+        exp = [rng.getrandbits(ebits) for _ in range(cnt)]
+        exp[0], exp[1], exp[-1] = 0, 1, (1 << ebits) - 1
+        W, E = (bits + 63) // 64, (ebits + 63) // 64
+        fb = c_oracle.IfmaFixedBase(ints_to_limbs([base], W)[0], ints_to_limbs([mod], W)[0], ebits, w)
+        got = limbs_to_ints(fb(None, ints_to_limbs(exp, E)))
+        fb.close()
+        assert got == [pow(base, e, mod) for e in exp], (bits, ebits, w)
+        ref = limbs_to_ints(c_oracle.ifma_modexp_batch(ints_to_limbs([base] * cnt, W), ints_to_limbs(exp, E),
+                                                       ints_to_limbs([mod], W)[0]))
+        assert got == ref
+    k = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "iso_kat.json")))
+    p, q, hs = int(k["p"], 16), int(k["q"], 16), int(k["bench_hs"], 16)
+    n = p * q
+    m = [rng.randrange(n) for _ in range(19)]
+    r = [rng.getrandbits(1024) for _ in range(19)]
+    n_l, hs_l = ints_to_limbs([n], 32)[0], ints_to_limbs([hs], 64)[0]
+    fb = c_oracle.IfmaFixedBase(hs_l, ints_to_limbs([n * n], 64)[0], 1024, 8)
+    via_fb = c_oracle.paillier_encrypt_with(fb, n_l, hs_l, ints_to_limbs(m, 32), ints_to_limbs(r, 16))
+    fb.close()
+    assert np.array_equal(via_fb, c_oracle.paillier_encrypt(n_l, hs_l, ints_to_limbs(m, 32), ints_to_limbs(r, 16)))
+
+
 def test_ifma_leg_on_iso_kat():
     """r^n mod n^2 of the reference's ISO/IEC 18033-6 vector (test/test_cryptography.cpp:99-241)."""
     if c_oracle.ifma_lib() is None:
