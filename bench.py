@@ -484,6 +484,10 @@ def decrypt_kernel(sk, count, nw, key_bits, busy_lanes=0):
     e = key_bits // 2
     if not split.value:
         return f"modexp_kernel<Geo<{lanes.value},{limbs.value}>>", algorithmic_mac32(key_bits, e)
+    if split.value == 3:       # a whole exponentiation per lane (csrc/hensel_lane.hpp): the useful count IS what it executes
+        l2 = limbs.value
+        nmul = (e + 4) // 5 + 30 + (2 * nw + e // 64 - 1) // (e // 64) + 2
+        return f"hensel_decrypt_lane_kernel<{l2}>", e * (l2 * (l2 + 1) // 2 + 3 * l2 * l2) + nmul * 5 * l2 * l2
     seq = split.value == 2
     l2 = (lanes.value if seq else lanes.value // 2) * limbs.value
     if _capi.lib().pgpu_get_secret_exponent_policy():          # sliding schedule of p-1: ~e/7 products, 32 odd powers

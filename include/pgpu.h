@@ -298,6 +298,7 @@ typedef enum pgpu_kernel_form {
   PGPU_FORM_FULL_WIDTH = 0,
   PGPU_FORM_PAIRED = 1,
   PGPU_FORM_SEQ = 2,
+  PGPU_FORM_LANE = 4,      /* a whole exponentiation per lane (hensel_lane.hpp: 1024-bit keys, >= 32768 ciphertexts) */
   PGPU_FORM_CU_CLAIM = 16
 } pgpu_kernel_form;
 int pgpu_timing_collect_ex(int* kinds, int* forms, double* ms, int max_entries);
@@ -313,8 +314,10 @@ int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, i
  * hensel_decrypt_kernel<*lanes / 2, *limbs> -- residues modulo p^2 / q^2 as pairs of half-width numbers (DESIGN.md
  * section 3; compiled for 1024- to 4096-bit keys; PGPU_HENSEL=0 turns it off); *split = 2: for ciphertexts of a
  * resident batch (pair rows), hensel_decrypt_seq_kernel<*lanes, *limbs> -- both halves of a pair in the same *lanes
- * lanes, launches that still put a wavefront on every SIMD that way (PGPU_SEQ_DECRYPT=0 turns it off); *split = 0:
- * the full-width modexp_kernel<Geo<*lanes, *limbs>>.  Host-side query. */
+ * lanes, launches that still put a wavefront on every SIMD that way (PGPU_SEQ_DECRYPT=0 turns it off); *split = 3 (round 4):
+ * hensel_decrypt_lane_kernel<*limbs> -- a whole exponentiation in ONE lane, *limbs limbs per half (1024-bit keys, launches of
+ * 32768 ciphertexts or more; PGPU_LANE_DECRYPT=0 turns it off); *split = 0: the full-width modexp_kernel<Geo<*lanes, *limbs>>.
+ * Host-side query. */
 int pgpu_decrypt_kernel_form(const pgpu_privkey* key, size_t count, int* split, int* lanes, int* limbs);
 /* ... when `busy_lanes` OTHER batch lanes of the GPU have work queued at launch time (round 4, the adaptive policy: a
  * launch that will share the chip anyway takes the sequential-halves form as soon as waves * (1 + busy_lanes) covers the

@@ -58,7 +58,7 @@ def hensel_parts():
         skip |= {22, 23, 24}
     if not build_ab():
         skip |= {15}
-    return [p for p in range(30) if p not in skip]
+    return [p for p in range(31) if p not in skip]
 
 
 def _objects():
@@ -86,6 +86,8 @@ def _objects():
         hdeps_k = [os.path.join(CSRC, f) for f in ("hensel.hpp", "hensel_q.hpp", "hensel_seq.hpp")]
         if part == 15:
             hdeps_k.append(os.path.join(CSRC, "hensel_ab.hpp"))
+        if part == 30:
+            hdeps_k.append(os.path.join(CSRC, "hensel_lane.hpp"))
         out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src] + hdeps_k + kdeps))
     for name in ("capi.cpp", "runtime.cpp", os.path.join("host", "bignum.cpp")):
         src = os.path.join(CSRC, name)

@@ -1581,6 +1581,26 @@ bool seq_form_pays(int H, int K, size_t count, int busy = 0) {
   const int pol = g_seq_policy.load();
   return pol == 2 || (pol == 3 && 2 * waves >= kSimds) || ((pol == 1 || pol == 4) && waves >= kSimds) || seq_adaptive(waves, busy);
 }
+// the one-lane-per-exponentiation form (csrc/hensel_lane.hpp) for a decrypt of `count` resident ciphertexts whose split
+// form has L2 limbs per half?  PGPU_LANE_DECRYPT: 0 never, 1 (default) launches that put a wavefront on every SIMD that
+// way (64 exponentiations per wavefront: 32768 ciphertexts), 2 whenever it is compiled (tests)
+std::atomic<int> g_lane_policy{[] {
+  const char* e = std::getenv("PGPU_LANE_DECRYPT");
+  return e ? std::max(0, std::min(2, std::atoi(e))) : 1;
+}()};
+bool lane_form_pays(int L2, size_t count) {
+  if (!pgpu::hensel_lane_has(L2)) return false;
+  const size_t waves = 2 * ((count + 63) / 64);
+  const int pol = g_lane_policy.load();
+  return pol == 2 || (pol == 1 && waves >= kSimds);
+}
+// the split form of the key whose limbs per half have a one-lane kernel, when a decrypt of `count` ciphertexts takes it
+const pgpu_privkey::HenselSet* lane_hset(const pgpu_privkey* key, size_t count) {
+  if (!hensel_enabled()) return nullptr;
+  for (const auto& f : key->hs)
+    if (lane_form_pays(f->H * f->K, count)) return f.get();
+  return nullptr;
+}
 int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m, size_t count,
                hipStream_t s, bool in_mont, const uint32_t* d_pair = nullptr, int in_pair_l2 = 0, int busy_lanes = 0) {
   const bool other_lane_busy = busy_lanes > 0;
@@ -1593,6 +1613,8 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
   const bool sliding = secret_policy() == PGPU_EXP_SLIDING && key->sched[0].dev.bytes;
   bool have_m = false;
   const pgpu_privkey::HenselSet* hset = pick_hensel(key, count);
+  if (d_pair && !sliding && hset)
+    if (const pgpu_privkey::HenselSet* ls = lane_hset(key, count)) hset = ls;
   if (d_pair && (!hset || hset->pair_l2 != in_pair_l2))
     return fail(PGPU_ERR_UNSUPPORTED, "decrypt: pair-row ciphertexts need the split-form kernel of this key size");
   if (hset) {
@@ -1658,9 +1680,16 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
                     (ab_policy() == 1 || ab_policy() == 3 || (ab_policy() == 2 && other_lane_busy));   // 3: always, four pairs per workgroup
     const size_t seq_ipw = 64 / (size_t)hset->H;
     const size_t seq_waves = 2 * ((count + seq_ipw - 1) / seq_ipw);
-    const bool seq = !ab && d_pair && !sliding && seq_form_pays(hset->H, hset->K, count, busy_lanes);
-    t.set_form(seq ? PGPU_FORM_SEQ : (ab ? PGPU_FORM_PAIRED | 64 : PGPU_FORM_PAIRED));
-    if (seq) {
+    const bool lanef = !ab && d_pair && !sliding && lane_form_pays(L2, count);
+    const bool seq = !lanef && !ab && d_pair && !sliding && seq_form_pays(hset->H, hset->K, count, busy_lanes);
+    t.set_form(lanef ? PGPU_FORM_LANE : seq ? PGPU_FORM_SEQ : (ab ? PGPU_FORM_PAIRED | 64 : PGPU_FORM_PAIRED));
+    if (lanef) {
+      const size_t lwaves = 2 * ((count + 63) / 64);
+      const unsigned lblocks = (unsigned)((lwaves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
+      RC_TRY(w.table.ensure((size_t)lblocks * pgpu::kWavesPerWG * 64 * entries * 2 * L2 * sizeof(uint32_t), s));
+      h.table = (uint32_t*)w.table.p;
+      if (!pgpu::launch_hensel_lane(L2, h, lblocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "one-lane decrypt kernel not compiled");
+    } else if (seq) {
       const unsigned sblocks = (unsigned)((seq_waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
       RC_TRY(w.table.ensure((size_t)sblocks * pgpu::kWavesPerWG * seq_ipw * entries * 2 * L2 * sizeof(uint32_t), s));
       h.table = (uint32_t*)w.table.p;
@@ -2121,6 +2150,13 @@ int pgpu_decrypt_kernel_form_ex(const pgpu_privkey* key, size_t count, int busy_
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_decrypt_kernel_form: bad argument");
   RC_TRY(check_gen(key->gen, "key"));
   if (const pgpu_privkey::HenselSet* f = pick_hensel(key, count)) {
+    if (pair_rows_enabled() && secret_policy() != PGPU_EXP_SLIDING && ab_policy() == 0)
+      if (const pgpu_privkey::HenselSet* ls = lane_hset(key, count)) {
+        *split = 3;
+        *lanes = 1;
+        *limbs = ls->H * ls->K;
+        return PGPU_OK;
+      }
     if (pair_rows_enabled() && secret_policy() != PGPU_EXP_SLIDING && ab_policy() == 0 && seq_form_pays(f->H, f->K, count, busy_lanes)) {
       *split = 2;
       *lanes = f->H;
@@ -2176,6 +2212,7 @@ void pgpu_debug_set_packed_decrypt(int on) { g_packed_decrypt.store(on != 0); }
 // tests / A-B measurements: hensel_seq.hpp (0 never, 1 by launch size, 2 whenever it applies).  Not part of the public header.
 void pgpu_debug_set_seq_decrypt(int policy) { g_seq_policy.store(policy < 0 ? 0 : (policy > 4 ? 4 : policy)); }
 int pgpu_debug_get_seq_decrypt(void) { return g_seq_policy.load(); }
+void pgpu_debug_set_lane_decrypt(int policy) { g_lane_policy.store(policy < 0 ? 0 : (policy > 2 ? 2 : policy)); }
 void pgpu_debug_set_adaptive(int enc_seq, int claim_busy) {
   g_adapt_enc_seq.store(enc_seq);
   g_adapt_claim_busy.store(claim_busy);

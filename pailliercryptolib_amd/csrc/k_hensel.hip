@@ -3,12 +3,15 @@
 // the two-wavefronts-per-SIMD build of the (2,19) decrypt form; 11-13: element-wise operations on pair rows).
 #include "hensel_seq.hpp"
 #include "launch.hpp"
+#if defined(PGPU_PART) && PGPU_PART == 30
+#include "hensel_lane.hpp"   // whole exponentiations in one lane (1024-bit keys, large batches)
+#endif
 #if defined(PGPU_PART) && PGPU_PART == 15
 #include "hensel_ab.hpp"   // the A/B-wavefront experiment: built only with PGPU_BUILD_AB=1
 #endif
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..29"
+#error "compile with -DPGPU_PART=0..30"
 #endif
 
 namespace pgpu {
@@ -202,6 +205,14 @@ bool launch_hensel_seq_part29(int G, int K, const HenselArgs& a, unsigned blocks
       if (once != hipSuccess) return false;
     }
     hipLaunchKernelGGL((hensel_decrypt_seq_kernel<2, 10>), dim3(blocks), dim3(kWGThreads), lds_pad, s, a);
+    return true;
+  }
+  return false;
+}
+#elif PGPU_PART == 30
+bool launch_hensel_lane_part30(int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
+  if (K == 20) {
+    hipLaunchKernelGGL((hensel_decrypt_lane_kernel<20>), dim3(blocks), dim3(kWGThreads), 0, s, a);
     return true;
   }
   return false;

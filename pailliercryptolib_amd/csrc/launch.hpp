@@ -164,6 +164,14 @@ inline bool launch_hensel_seq(int G, int K, const HenselArgs& a, unsigned blocks
          launch_hensel_seq_part29(G, K, a, blocks, s, lds_pad);
 }
 
+// CRT decrypt with a whole exponentiation per lane (hensel_lane.hpp; k_hensel.hip part 30): pair-row ciphertexts,
+// fixed-window scan; L2 = limbs per half of the key's split form: 20 (1024-bit keys)
+inline bool hensel_lane_has(int L2) { return L2 == 20; }
+bool launch_hensel_lane_part30(int L2, const HenselArgs& a, unsigned blocks, hipStream_t s);
+inline bool launch_hensel_lane(int L2, const HenselArgs& a, unsigned blocks, hipStream_t s) {
+  return launch_hensel_lane_part30(L2, a, blocks, s);
+}
+
 // per-element bases modulo n^2 in the same form (k_hensel.hip part 18): resident pair rows in and out, fixed window
 // (4,18): 2048-bit keys, (8,14): 3072 (part 26), (2,19): 1024 (part 28)
 inline bool hensel_modexp_seq_has(int G, int K) { return (G == 4 && K == 18) || (G == 8 && K == 14) || (G == 2 && K == 19); }

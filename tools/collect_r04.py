@@ -119,7 +119,13 @@ for s, d in [("gpurun_out/r04p/ipcl_api_bench.txt", "profiles/r04_ipcl_api_bench
     if os.path.exists(s):
         txt = [l for l in open(s).read().splitlines() if "amdgpu.ids" not in l]
         open(d, "w").write("\n".join(txt) + "\n")
-ks = [f"gpurun_out/r04p/keysizes_{c}.txt" for c in (16384, 65536)]
+if os.path.exists("gpurun_out/r04p/lane_decrypt.txt"):
+    with open("profiles/r04_lane_decrypt.txt", "w") as f:
+        f.write("# tools/run_r04_e.sh: CRT decrypt of 65536 ciphertexts under a 1024-bit key, one-lane kernel (csrc/hensel_lane.hpp, default from\n"
+                "# 32768 ciphertexts) against the sequential-halves kernel (PGPU_LANE_DECRYPT=0): rocprofv3 kernel stats and, in a pass of\n"
+                "# its own, PMC.  GRBM_GUI_ACTIVE / 8 XCDs / kernel time = the clock the chip held under the kernel.\n")
+        f.write("".join(l for l in open("gpurun_out/r04p/lane_decrypt.txt") if "amdgpu.ids" not in l and not l.startswith("+")))
+ks = [f"gpurun_out/r04p/keysizes_{c}.txt" for c in (16384, 65536, 131072)]
 if all(os.path.exists(f) for f in ks):
     with open("profiles/r04_keysizes_split_on_off.txt", "w") as f:
         f.write("# tools/bench_keysizes.py <count> (tools/profile_r04.sh): resident batches per key class, wall time of the second call incl.\n"

@@ -38,7 +38,8 @@ BENCH_SINGLE_DEVICE=1 python bench.py --gpus 8 --steps 10 --warmup 2 --no-cpu-ba
 BENCH_SINGLE_DEVICE=1 python bench.py --gpus 8 --config 4 --steps 3 --warmup 1 > $OUT/bench_c4_n8_pool_1dev.json 2>/dev/null
 BENCH_SINGLE_DEVICE=1 python bench.py --gpus 8 --config 5 --steps 8 > $OUT/bench_c5_n8_pool_1dev.json 2>/dev/null
 ./pailliercryptolib_amd/ipcl_api_bench > $OUT/ipcl_api_bench.txt 2>&1
-for c in 16384 65536; do python tools/bench_keysizes.py $c > $OUT/keysizes_$c.txt 2>&1; done
+for c in 16384 65536 131072; do python tools/bench_keysizes.py $c > $OUT/keysizes_$c.txt 2>&1; done
+bash tools/run_r04_e.sh > $OUT/lane_decrypt.txt 2>&1
 python tools/probe_lanes.py --lanes 1 2 3 4 --steps 40 > $OUT/lanes.txt 2>&1
 python tools/probe_trace.py 2 8 > $OUT/trace_2lanes.txt 2>&1
 python tools/probe_trace.py 4 20 > $OUT/trace_4lanes.txt 2>&1
