@@ -888,10 +888,34 @@ def extras(pa, L, B, pk, sk, n, p, q, hs, m_host, r_host, per_kind):
         out["masked_table_gather"] = {"what": "pgpu_set_table_gather_policy(1): CRT decrypt of the batch with every window-table "
                                               "entry read and selected (address stream independent of p-1 / q-1) vs indexed",
                                       "decrypt_ms_masked": round(tm * 1e3, 3), "decrypt_ms_indexed": round(ti * 1e3, 3)}
+        # the same policy on the DJN encrypt (round 4): hs^r over the small-window table, every entry of a window read and selected
+        hold4 = {}
+
+        def enc_once():
+            B.free(hold4.get("c"))
+            hold4["c"] = B.op(L.pgpu_batch_encrypt, pk._h, bm3, br3, 64 * pw)
+            _capi.check(L.pgpu_synchronize())
+        enc_once()
+        tei = best_of(enc_once, 5)
+        ref_c = B.down(hold4["c"])
+        _capi.check(L.pgpu_set_table_gather_policy(1))
+        enc_once(); enc_once()
+        tem = best_of(enc_once, 5)
+        same = bool(np.array_equal(B.down(hold4["c"]), ref_c))
+        _capi.check(L.pgpu_set_table_gather_policy(0))
+        B.free(hold4.get("c"))
+        if not same:
+            raise RuntimeError("masked fixed-base encrypt differs from the indexed one")
+        out["masked_fixed_base_encrypt"] = {"what": "pgpu_set_table_gather_policy(1) on the DJN encrypt of the batch: hs^r as 255 products "
+                                                    "over a 4-bit-window table, all 16 entries of a window read and the wanted one selected "
+                                                    "(address stream independent of r), vs 85 products addressed by the digits of r; "
+                                                    "call time incl. launch and synchronise, results identical",
+                                            "encrypt_ms_masked": round(tem * 1e3, 3), "encrypt_ms_indexed": round(tei * 1e3, 3)}
         B.free(hold3.get("o"), c3, bm3, br3)
     except Exception as e:                                  # noqa: BLE001
         _capi.check(L.pgpu_set_table_gather_policy(0))
-        out["masked_table_gather"] = {"error": str(e)[:300]}
+        out.setdefault("masked_table_gather", {"error": str(e)[:300]})
+        out.setdefault("masked_fixed_base_encrypt", {"error": str(e)[:300]})
     # (5) two batches in flight: consecutive steps alternate between two HIP streams (`_dev` entry points), so that the
     # encrypt launch of step i+1 and the decrypt launches of steps i / i+1 share the SIMDs -- how a pool entry with its
     # two worker lanes actually runs under load.  A lone wavefront on a SIMD issues every ~4.6 cycles, two every ~4.3

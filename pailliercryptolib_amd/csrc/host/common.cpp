@@ -269,7 +269,12 @@ std::vector<BigNumber> copy_texts(const std::vector<BigNumber>& v) {
     return v;
   }
   std::vector<BigNumber> out(v.size());
-  parallel_for(v.size(), kGrain, [&](std::size_t i) { out[i] = v[i]; });
+  parallel_chunks(v.size(), kGrain, [&](std::size_t lo, std::size_t hi) {
+    std::size_t limbs = 0;
+    for (std::size_t i = lo; i < hi; ++i) limbs += v[i].limbs64().size();
+    LimbBulkScope arena(limbs * 8 + (hi - lo) * 32);
+    for (std::size_t i = lo; i < hi; ++i) out[i] = v[i];
+  });
   return out;
 }
 
@@ -298,7 +303,11 @@ std::vector<BigNumber> unpack(const uint64_t* flat, std::size_t count, int words
     for (std::size_t i = 0; i < count; ++i) v[i] = BigNumber::fromLimbs64(flat + i * (size_t)words, (size_t)words);
     return v;
   }
-  parallel_for(count, kGrain, [&](std::size_t i) { v[i] = BigNumber::fromLimbs64(flat + i * (size_t)words, (size_t)words); });
+  // (each member of the team carves the limb blocks of its chunk out of an arena of its own)
+  parallel_chunks(count, kGrain, [&](std::size_t lo, std::size_t hi) {
+    LimbBulkScope arena(arena_hint(hi - lo, (std::size_t)words));
+    for (std::size_t i = lo; i < hi; ++i) v[i] = BigNumber::fromLimbs64(flat + i * (size_t)words, (size_t)words);
+  });
   return v;
 }
 std::vector<BigNumber> unpack(const std::vector<uint64_t>& flat, std::size_t count, int words) {
