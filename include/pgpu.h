@@ -256,7 +256,8 @@ int pgpu_batch_row_limbs(const pgpu_batch* b);
 /* Batch lanes: every GPU of the pool has pgpu_batch_lanes() (4) batch streams, so that many independent chains of
  * resident batches can be in flight at once (their kernels share the chip: a wavefront that is alone on a SIMD issues
  * ~8 % slower than two, and the sequential-halves kernels -- 11-17 % fewer instructions -- need 16384 ciphertexts in
- * flight to reach every SIMD).  Uploads and pgpu_batch_create take the calling thread's lane (default 0); every result
+ * flight to reach every SIMD).  Uploads and pgpu_batch_create take the calling thread's lane (the first thread of the
+ * process that uploads gets lane 0, further threads the next lanes round-robin; pgpu_set_batch_lane overrides); every result
  * inherits the lane of the operation's first operand; operands of another lane are ordered in by events.  What a launch
  * looks like depends on whether its neighbour lanes are busy when it is queued (pgpu_decrypt_kernel_form_ex). */
 int pgpu_set_batch_lane(int lane /* 0 .. pgpu_batch_lanes() - 1 */);

@@ -676,14 +676,24 @@ struct pgpu_batch {
 
 namespace {
 
-thread_local int t_batch_lane = 0;
+// The batch lane of the calling thread's uploads: set with pgpu_set_batch_lane, else handed out round-robin the first
+// time a thread uploads or creates a batch -- the first thread of the process gets lane 0, so single-threaded callers see
+// what they always saw, and the threads of a multi-threaded caller (the reference's own tests encrypt / decrypt from
+// four OpenMP threads, test_cryptography.cpp:45-57) land on different lanes: their chains overlap on the GPU and the
+// adaptive kernel-form policy places their launches side by side.
+std::atomic<int> g_next_thread_lane{0};
+thread_local int t_batch_lane = -1;
+int thread_batch_lane() {
+  if (t_batch_lane < 0) t_batch_lane = g_next_thread_lane.fetch_add(1) % rt::kBatchLanes;
+  return t_batch_lane;
+}
 int new_batch(size_t count, int words, std::unique_ptr<pgpu_batch>* out, int pair_l2 = 0, int lane = -1) {
   if (count == 0 || words <= 0) return fail(PGPU_ERR_INVALID_PARAM, "batch needs count > 0 and words > 0");
   std::unique_ptr<pgpu_batch> b(new pgpu_batch);
   b->count = count;
   b->words = words;
   b->gen = rt::pool_generation();
-  b->lane = lane < 0 ? t_batch_lane : (lane % rt::kBatchLanes);
+  b->lane = lane < 0 ? thread_batch_lane() : (lane % rt::kBatchLanes);
   b->replicated = count == 1 && rt::pool_size() > 1;
   b->ndev = b->replicated ? rt::pool_size() : rt::shard_devices(count);
   b->shard.resize((size_t)b->ndev);
