@@ -30,12 +30,15 @@ namespace detail {
 // (profiles/r03_api_stage_probe.txt).  A thread may therefore open a BULK SCOPE: while it is open, the limb blocks this
 // thread allocates are carved out of one arena with a bump pointer, and freed by a counter -- the arena returns to the
 // heap when its last block has died (so one surviving BigNumber of a batch keeps that batch's arena alive: a few MB).
+// Up to four retired arenas (64 KB - 64 MB each) are kept for the next scope instead of going back to the heap: their
+// pages are already mapped; limb_cache_trim() (terminateContext calls it) frees them.
 // Outside a scope, and when an arena is full, blocks come from malloc as before.  Every block carries a 16-byte header
 // that says where it came from, so any thread may free any block.
 void* limb_alloc(std::size_t bytes);
 void limb_free(void* p) noexcept;
 void limb_bulk_begin(std::size_t bytes_hint);
 void limb_bulk_end() noexcept;
+void limb_cache_trim() noexcept;
 struct LimbBulkScope {
   explicit LimbBulkScope(std::size_t bytes_hint) { limb_bulk_begin(bytes_hint); }
   ~LimbBulkScope() { limb_bulk_end(); }

@@ -648,6 +648,9 @@ struct pgpu_privkey {
     size_t side_words() const { return (size_t)H * K * (6 + 4 * (size_t)nchunks + 3 * (size_t)pchunks); }
   };
   std::vector<std::unique_ptr<HenselSet>> hs;
+  // constants of the pair rows of n^2 = (p*q)^2 -- what a public key over n holds as its pair form: word ciphertexts are
+  // brought into pair rows with it when the launch then takes a kernel that reads only those (decrypt_on)
+  std::shared_ptr<pgpu_pubkey::PubForm> conv_form;
 };
 
 // sharded device-resident batch
@@ -683,6 +686,8 @@ namespace {
 // adaptive kernel-form policy places their launches side by side.
 std::atomic<int> g_next_thread_lane{0};
 thread_local int t_batch_lane = -1;
+std::atomic<int> g_host_adapt{[] { const char* e = std::getenv("PGPU_HOST_ADAPT"); return e && std::atoi(e) != 0 ? 1 : 0; }()};
+bool host_adapt() { return g_host_adapt.load() != 0; }
 int thread_batch_lane() {
   if (t_batch_lane < 0) t_batch_lane = g_next_thread_lane.fetch_add(1) % rt::kBatchLanes;
   return t_batch_lane;
@@ -1611,6 +1616,8 @@ const pgpu_privkey::HenselSet* lane_hset(const pgpu_privkey* key, size_t count) 
     if (lane_form_pays(f->H * f->K, count)) return f.get();
   return nullptr;
 }
+int words_to_pair_on(rt::Device& d, const pgpu_pubkey::PubForm* f, const uint64_t* words, size_t stride, int nwords,
+                     bool src_mont, uint32_t* out, size_t count, hipStream_t s);
 int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m, size_t count,
                hipStream_t s, bool in_mont, const uint32_t* d_pair = nullptr, int in_pair_l2 = 0, int busy_lanes = 0) {
   const bool other_lane_busy = busy_lanes > 0;
@@ -1623,6 +1630,22 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
   const bool sliding = secret_policy() == PGPU_EXP_SLIDING && key->sched[0].dev.bytes;
   bool have_m = false;
   const pgpu_privkey::HenselSet* hset = pick_hensel(key, count);
+  // Word ciphertexts (host arrays, uploaded batches) become pair rows first when the launch then takes a kernel that reads
+  // only those: the one-lane form, the sequential-halves form by size, or -- beside busy neighbours -- the half-chip
+  // launch of the adaptive policy.  One pair_ops_kernel pass (a product per chunk), ~1 % of the exponentiation.
+  rt::DevMem conv_rows;
+  if (!d_pair && !sliding && hset && key->conv_form) {
+    const pgpu_privkey::HenselSet* cand = lane_hset(key, count);
+    if (!cand) cand = hset;
+    const int cl2 = key->conv_form->H * key->conv_form->K;
+    if (cand->pair_l2 == cl2 &&
+        (lane_form_pays(cand->H * cand->K, count) || seq_form_pays(cand->H, cand->K, count, busy_lanes))) {
+      RC_TRY(conv_rows.alloc(d, s, count * (size_t)2 * cl2 * sizeof(uint32_t)));
+      RC_TRY(words_to_pair_on(d, key->conv_form.get(), d_c, (size_t)2 * nw, 2 * nw, in_mont, (uint32_t*)conv_rows.p, count, s));
+      d_pair = (const uint32_t*)conv_rows.p;
+      in_pair_l2 = cl2;
+    }
+  }
   if (d_pair && !sliding && hset)
     if (const pgpu_privkey::HenselSet* ls = lane_hset(key, count)) hset = ls;
   if (d_pair && (!hset || hset->pair_l2 != in_pair_l2))
@@ -2221,6 +2244,10 @@ void pgpu_debug_set_packed_decrypt(int on) { g_packed_decrypt.store(on != 0); }
 // other batch lane is busy.  Not part of the public header.
 // tests / A-B measurements: hensel_seq.hpp (0 never, 1 by launch size, 2 whenever it applies).  Not part of the public header.
 void pgpu_debug_set_seq_decrypt(int policy) { g_seq_policy.store(policy < 0 ? 0 : (policy > 4 ? 4 : policy)); }
+int pgpu_debug_set_host_adapt(int on) {
+  const int was = g_host_adapt.exchange(on != 0 ? 1 : 0);
+  return was;
+}
 int pgpu_debug_get_seq_decrypt(void) { return g_seq_policy.load(); }
 void pgpu_debug_set_lane_decrypt(int policy) { g_lane_policy.store(policy < 0 ? 0 : (policy > 2 ? 2 : policy)); }
 void pgpu_debug_set_adaptive(int enc_seq, int claim_busy) {
@@ -2441,19 +2468,20 @@ namespace {
 // for n^2.  The way back to a full-width residue has constants of its own, so the forms need not match the geometry
 // of the key's n^2 context; Montgomery-form results carry that context's radix Rs (they mix with the full-width
 // kernels of resident batches).
-int build_hensel_pub_form(pgpu_pubkey* k, int H, int K) {
+// (n, n_words, the radix exponent of the n^2 context): all a form needs -- a PRIVATE key builds the same constants for its
+// n = p*q, to bring word ciphertexts into pair rows ahead of the kernels that take only those (make_conv_form)
+int make_pub_form(const BigNumber& n, int n_words, int nsq_rbits, int H, int K, std::shared_ptr<pgpu_pubkey::PubForm>* out) {
   const int L2 = H * K;
-  const BigNumber& n = k->n;
   const BigNumber N = n * n;
-  const int cw = std::min(k->n_words, n.BitSize() / 64);
+  const int cw = std::min(n_words, n.BitSize() / 64);
   if (cw <= 0) return PGPU_OK;
-  const int nch = (2 * k->n_words + cw - 1) / cw;
+  const int nch = (2 * n_words + cw - 1) / cw;
   std::shared_ptr<pgpu_pubkey::PubForm> f(new pgpu_pubkey::PubForm);
   f->H = H;
   f->K = K;
   f->chunk_words = cw;
   f->nchunks = nch;
-  f->n_words = k->n_words;
+  f->n_words = n_words;
   f->n = n;
   auto n0inv_of = [](const BigNumber& v) {
     uint32_t n0 = (uint32_t)(v.limbs64()[0] & pgpu::kLimbMask), inv = n0;
@@ -2483,7 +2511,7 @@ int build_hensel_pub_form(pgpu_pubkey* k, int H, int K) {
   const BigNumber Rm = R % P2, R2 = (Rm * Rm) % P2;
   put_pair(h.data() + 3 * L2, Rm);
   // (second set: bases that arrive as c*Rs mod n^2 -- resident ciphertexts)
-  const BigNumber Rs = pow2(k->nsq->geo.rbits());
+  const BigNumber Rs = pow2(nsq_rbits);
   const BigNumber R2m = (R2 * P2.InverseMul(Rs % P2)) % P2;
   for (int i = 0; i < nch; ++i) {
     const BigNumber sh = pow2(64 * cw * i) % P2;
@@ -2499,7 +2527,13 @@ int build_hensel_pub_form(pgpu_pubkey* k, int H, int K) {
   to_limbs29((((n * Rf) % N) * Rsn) % N, LF, g.data() + 2 * LF);
   to_limbs29((Rf * Rsn) % N, LF, g.data() + 3 * LF);
   RC_TRY(f->full.upload(g.data(), g.size() * sizeof(uint32_t), false));
-  k->hforms.push_back(std::move(f));
+  *out = std::move(f);
+  return PGPU_OK;
+}
+int build_hensel_pub_form(pgpu_pubkey* k, int H, int K) {
+  std::shared_ptr<pgpu_pubkey::PubForm> f;
+  RC_TRY(make_pub_form(k->n, k->n_words, k->nsq->geo.rbits(), H, K, &f));
+  if (f) k->hforms.push_back(std::move(f));
   return PGPU_OK;
 }
 int build_hensel_pub(pgpu_pubkey* k) {
@@ -2580,19 +2614,41 @@ int pgpu_paillier_encrypt(const pgpu_pubkey* key, const uint64_t* m, size_t m_st
   if (r_words <= 0 || r_stride < (size_t)r_words)
     return fail(PGPU_ERR_INVALID_PARAM, "random width/stride invalid");
   const size_t sub_min = (key->djn && fixed_base_window() > 0) ? kSubMinLight : kSubMinHeavy;
+  // PGPU_HOST_ADAPT=1 (default 0): callers of the host-array entry points count as users of their thread's batch lane
+  // (new_batch: thread_batch_lane), see each other -- and the resident batches of other lanes -- through the lane
+  // activity stamps, and their launches take the part-chip forms of the adaptive policy like those of resident batches.
+  // Measured r04 (tools/probe_two_callers.py, profiles/r04_two_callers.txt): it does NOT pay for synchronous callers.
+  // Two of them keep the GPU busy with full-chip kernels back to back already (2 x (0.82 + 4.58) ms per pair of calls,
+  // the copies of one under the kernels of the other: 5.45 ms per encrypt + decrypt); on half the chip each, a caller's
+  // half idles while its copies and host work run, and the pair of calls takes 6.0 ms.  The part-chip forms need an
+  // asynchronous feed -- resident batches on the batch lanes.
+  const int caller_lane = host_adapt() ? thread_batch_lane() : -1;
+  const pgpu_pubkey::PubForm* pf =
+      (key->djn && fixed_base_window() > 0 && 64 * m_words <= key->n.BitSize()) ? pair_form(key) : nullptr;
   int rc = run_sharded(count, sub_min, [=](rt::Lane& lane, size_t lo, size_t hi) -> int {
     rt::Device& d = *lane.dev;
     hipStream_t s = lane.stream;
     const size_t n = hi - lo;
-    rt::DevMem dm, dr, dc;
+    rt::DevMem dm, dr, dc, rows;
     RC_TRY(dm.alloc(d, s, n * m_stride * 8));
     RC_TRY(dr.alloc(d, s, n * r_stride * 8));
     RC_TRY(dc.alloc(d, s, n * (size_t)W * 8));
     RC_TRY(lane.h2d(dm.p, m + lo * m_stride, n * m_stride * 8, s));
     RC_TRY(lane.h2d(dr.p, r + lo * r_stride, n * r_stride * 8, s));
-    RC_TRY(encrypt_on(d, key, (const uint64_t*)dm.p, m_stride, m_words, (const uint64_t*)dr.p, r_stride, r_words,
-                      r_bits, (uint64_t*)dc.p, n, s, false, count));
-    return lane.d2h(c + lo * (size_t)W, dc.p, n * (size_t)W * 8, s);
+    const int busy = caller_lane >= 0 ? busy_other_lanes(d, caller_lane) : 0;
+    if (pf && busy > 0 && fb_encrypt_seq_pays(pf->H, pf->K, n, busy)) {
+      // the sequential-halves kernel leaves pair rows: one pair_ops_kernel pass brings them back to words
+      RC_TRY(rows.alloc(d, s, n * (size_t)2 * pf->H * pf->K * sizeof(uint32_t)));
+      RC_TRY(encrypt_on(d, key, (const uint64_t*)dm.p, m_stride, m_words, (const uint64_t*)dr.p, r_stride, r_words,
+                        r_bits, nullptr, n, s, true, count, (uint32_t*)rows.p, busy));
+      RC_TRY(pair_to_words_on(d, pf, (const uint32_t*)rows.p, (uint64_t*)dc.p, n, s));
+    } else {
+      RC_TRY(encrypt_on(d, key, (const uint64_t*)dm.p, m_stride, m_words, (const uint64_t*)dr.p, r_stride, r_words,
+                        r_bits, (uint64_t*)dc.p, n, s, false, count));
+    }
+    const int rcd = lane.d2h(c + lo * (size_t)W, dc.p, n * (size_t)W * 8, s);
+    if (caller_lane >= 0) (void)busy_other_lanes(d, caller_lane);   // (stamp: a long call stays visible until it ends)
+    return rcd;
   });
   if (rc == PGPU_OK && key->djn) {
     std::lock_guard<std::mutex> lk(key->mu);
@@ -2606,7 +2662,7 @@ namespace {
 // Constants of the split-form exponentiation (hensel.hpp) for both sides of the key.  A residue z modulo P^2 is
 // the pair (a, b) with z == a - P*b: a = z mod P, b = (P - z div P) mod P.
 // limbs per half of the pair rows a PUBLIC key over n would use (build_hensel_pub: its form of fewest lanes), 0: none
-int pair_l2_for_modulus(const BigNumber& n) {
+int pair_l2_for_modulus(const BigNumber& n, int* H_out = nullptr, int* K_out = nullptr) {
   const int need = n.BitSize() + 29 + 8, nsq_bits = 2 * n.BitSize();
   int l2 = 0;
   for (int H : {8, 4, 2})
@@ -2614,6 +2670,8 @@ int pair_l2_for_modulus(const BigNumber& n) {
       if ((pgpu::hensel_modexp_has(H, K) || pgpu::hensel_fb_has(H, K)) && pgpu::kLimbBits * H * K >= need &&
           2 * pgpu::kLimbBits * H * K >= nsq_bits + 8) {
         l2 = pgpu::pair_ops_has(H, K) ? H * K : 0;
+        if (H_out) *H_out = H;
+        if (K_out) *K_out = K;
         break;
       }
   return l2;
@@ -2711,6 +2769,11 @@ int build_hensel(pgpu_privkey* k, const BigNumber& p, const BigNumber& q, const 
         if (set->H) k->hs.push_back(std::move(set));
         break;
       }
+  if (!k->hs.empty() && k->hs.front()->pair_l2) {
+    int H = 0, K = 0;
+    const BigNumber n = p * q;
+    if (pair_l2_for_modulus(n, &H, &K)) RC_TRY(make_pub_form(n, k->n_words, k->nsq_rbits, H, K, &k->conv_form));
+  }
   return PGPU_OK;
 }
 }  // namespace
@@ -2853,6 +2916,7 @@ int pgpu_paillier_decrypt_crt(const pgpu_privkey* key, const uint64_t* c, uint64
   if (count == 0) return PGPU_OK;
   if (!c || !m) return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer");
   const int nw = key->n_words;
+  const int caller_lane = host_adapt() ? thread_batch_lane() : -1;   // (see pgpu_paillier_encrypt)
   return run_sharded(count, kSubMinHeavy, [=](rt::Lane& lane, size_t lo, size_t hi) -> int {
     rt::Device& d = *lane.dev;
     hipStream_t s = lane.stream;
@@ -2861,8 +2925,11 @@ int pgpu_paillier_decrypt_crt(const pgpu_privkey* key, const uint64_t* c, uint64
     RC_TRY(dc.alloc(d, s, n * (size_t)2 * nw * 8));
     RC_TRY(dm.alloc(d, s, n * (size_t)nw * 8));
     RC_TRY(lane.h2d(dc.p, c + lo * (size_t)2 * nw, n * (size_t)2 * nw * 8, s));
-    RC_TRY(decrypt_on(d, key, (const uint64_t*)dc.p, (uint64_t*)dm.p, n, s, false));
-    return lane.d2h(m + lo * (size_t)nw, dm.p, n * (size_t)nw * 8, s);
+    RC_TRY(decrypt_on(d, key, (const uint64_t*)dc.p, (uint64_t*)dm.p, n, s, false, nullptr, 0,
+                      caller_lane >= 0 ? busy_other_lanes(d, caller_lane) : 0));
+    const int rcd = lane.d2h(m + lo * (size_t)nw, dm.p, n * (size_t)nw * 8, s);
+    if (caller_lane >= 0) (void)busy_other_lanes(d, caller_lane);
+    return rcd;
   });
 }
 
@@ -3006,6 +3073,7 @@ int pgpu_batch_download(const pgpu_batch* b, uint64_t* host) {
         else RC_TRY(modmul_on(dev, *b->mont, pgpu::MM_BY_ONE, b->ptr(d), nullptr, 0, 0, (uint64_t*)plain[(size_t)d].p, hi - lo, s));
         src = plain[(size_t)d].p;
       }
+      HIP_TRY(rt::drain_before_copy(s));
       HIP_TRY(hipMemcpyAsync(host + lo * (size_t)b->words, src, bytes, hipMemcpyDeviceToHost, s));
     }
     for (int d = 0; d < nd; ++d) {
@@ -3031,6 +3099,7 @@ int pgpu_batch_download(const pgpu_batch* b, uint64_t* host) {
       else RC_TRY(modmul_on(dev, *b->mont, pgpu::MM_BY_ONE, b->ptr(0), nullptr, 0, 0, (uint64_t*)plain.p, b->count, s));
       src = plain.p;
     }
+    HIP_TRY(rt::drain_before_copy(s));
     HIP_TRY(hipMemcpyAsync(bn.p, src, bytes, hipMemcpyDeviceToHost, s));
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) return fail(PGPU_ERR_HIP, std::string("device -> host copy failed: ") + hipGetErrorString(e));
@@ -3135,8 +3204,9 @@ int pgpu_batch_decrypt_crt(const pgpu_privkey* key, const pgpu_batch* c, pgpu_ba
       const int busy = busy_other_lanes(dev, c->lane);
       RC_TRY(decrypt_on(dev, key, nullptr, out->ptr(d), hi - lo, dev.bs(c->lane), false, c->prow(d), c->pair_l2, busy));
     }
-    else
-      RC_TRY(decrypt_on(dev, key, c->ptr(d), out->ptr(d), hi - lo, dev.bs(c->lane), c->mont != nullptr));
+    else   // (word ciphertexts: decrypt_on converts them when the launch then takes a pair-row kernel)
+      RC_TRY(decrypt_on(dev, key, c->ptr(d), out->ptr(d), hi - lo, dev.bs(c->lane), c->mont != nullptr, nullptr, 0,
+                        busy_other_lanes(dev, c->lane)));
   }
   *m = out.release();
   return PGPU_OK;

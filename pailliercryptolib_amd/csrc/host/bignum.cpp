@@ -22,6 +22,7 @@ namespace {
 struct LimbArena {
   std::atomic<std::size_t> live;   // blocks handed out and not yet freed, + 1 while the scope that owns the arena is open
   std::size_t cap, used;           // bytes behind the header
+  std::size_t room;                // bytes the allocation really has behind the header (>= cap; a recycled arena keeps its size)
 };
 struct LimbHeader {                // in front of every block
   LimbArena* arena;                // null: the block came from malloc
@@ -31,10 +32,46 @@ static_assert(sizeof(LimbHeader) == 16, "blocks stay 16-byte aligned behind thei
 constexpr std::size_t kArenaHead = (sizeof(LimbArena) + 15) & ~(std::size_t)15;
 thread_local LimbArena* t_arena = nullptr;
 thread_local int t_bulk_depth = 0;
+// Retired arenas are kept for the next bulk scope: a fresh multi-megabyte allocation comes from mmap and pays a page
+// fault per 4 KB on first touch -- for the 8192 plaintexts of a decrypt call that was 2/3 of the unpacking time.  A
+// caller that drops one batch of results before (or while) it asks for the next gets the same pages back.
+constexpr int kArenaKeep = 4;
+constexpr std::size_t kArenaKeepMin = 64 << 10, kArenaKeepMax = 64 << 20;
+std::atomic_flag g_keep_lock = ATOMIC_FLAG_INIT;
+LimbArena* g_keep[kArenaKeep] = {};
+struct KeepGuard {
+  KeepGuard() noexcept { while (g_keep_lock.test_and_set(std::memory_order_acquire)) {} }
+  ~KeepGuard() { g_keep_lock.clear(std::memory_order_release); }
+};
 void arena_release(LimbArena* a) noexcept {
-  if (a->live.fetch_sub(1, std::memory_order_acq_rel) == 1) std::free(a);
+  if (a->live.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+  if (a->room >= kArenaKeepMin && a->room <= kArenaKeepMax) {
+    KeepGuard g;
+    for (LimbArena*& slot : g_keep)
+      if (!slot) { slot = a; return; }
+  }
+  std::free(a);
+}
+// a retired arena with room for `cap` bytes that is not more than four times too large
+LimbArena* arena_reuse(std::size_t cap) noexcept {
+  KeepGuard g;
+  LimbArena** best = nullptr;
+  for (LimbArena*& slot : g_keep)
+    if (slot && slot->room >= cap && slot->room / 4 <= cap && (!best || slot->room < (*best)->room)) best = &slot;
+  if (!best) return nullptr;
+  LimbArena* a = *best;
+  *best = nullptr;
+  return a;
 }
 }  // namespace
+
+void limb_cache_trim() noexcept {
+  KeepGuard g;
+  for (LimbArena*& slot : g_keep) {
+    std::free(slot);
+    slot = nullptr;
+  }
+}
 
 void* limb_alloc(std::size_t bytes) {
   const std::size_t need = sizeof(LimbHeader) + ((bytes + 15) & ~(std::size_t)15);
@@ -63,10 +100,14 @@ void limb_bulk_begin(std::size_t bytes_hint) {
   if (t_bulk_depth++ > 0) return;   // nested scopes share the outer arena
   if (bytes_hint < 4096) return;    // not worth an arena
   const std::size_t cap = (bytes_hint + 4095) & ~(std::size_t)4095;
-  LimbArena* a = static_cast<LimbArena*>(std::malloc(kArenaHead + cap));
-  if (!a) return;                   // no arena: blocks come from malloc
+  LimbArena* a = arena_reuse(cap);
+  if (!a) {
+    a = static_cast<LimbArena*>(std::malloc(kArenaHead + cap));
+    if (!a) return;                 // no arena: blocks come from malloc
+    a->room = cap;
+  }
   new (&a->live) std::atomic<std::size_t>(1);
-  a->cap = cap;
+  a->cap = a->room;
   a->used = 0;
   t_arena = a;
 }

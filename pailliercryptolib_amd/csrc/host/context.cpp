@@ -78,6 +78,7 @@ bool initializeContext(const std::string runtime_choice) {
 }
 
 bool terminateContext() {
+  detail::limb_cache_trim();       // retired limb arenas kept for reuse (bignum.h)
   detail::release_pinned_pool();   // idle staging blocks of the host layer (blocks still held by texts follow when those die)
   pgpu_shutdown();
   return true;

@@ -430,6 +430,7 @@ size_t stage_piece(size_t bytes) {
   const size_t part = ((bytes + pieces - 1) / pieces + 4095) & ~(size_t)4095;
   return std::min(kStageBytes, std::max<size_t>((size_t)512 << 10, part));
 }
+hipError_t wait_event(hipEvent_t ev) { return hipEventSynchronize(ev); }
 int ensure_stage(Lane& l) {
   for (int i = 0; i < 2; ++i) {
     if (!l.stage[i]) HIP_TRY(hipHostMalloc(&l.stage[i], kStageBytes, hipHostMallocDefault));
@@ -438,6 +439,18 @@ int ensure_stage(Lane& l) {
   return PGPU_OK;
 }
 }  // namespace
+
+// A device -> host copy is handed to the copy engine only once the kernels in front of it on its stream have run.
+// The engines work through their rings in order: a copy queued behind an unfinished kernel parks the ring on that
+// kernel's completion signal, and every copy queued after it -- of ANY stream -- waits there too.  Measured r04 with two
+// synchronous callers (tools/probe_two_callers.py, rocprofv3 --memory-copy-trace --hip-runtime-trace): one caller's
+// 24 us upload sat 0.9 ms behind the other's download (which was waiting for a 0.8 ms encrypt), 4.6 ms behind a decrypt;
+// the callers' kernels ended up strictly one after the other with the copies exposed in between (6.1 ms per encrypt +
+// decrypt instead of 5.4).  One host round trip (~10 us) per download.  PGPU_D2H_PRESYNC=0 turns it off.
+hipError_t drain_before_copy(hipStream_t s) {
+  static const bool on = [] { const char* e = std::getenv("PGPU_D2H_PRESYNC"); return !e || std::atoi(e) != 0; }();
+  return on ? hipStreamSynchronize(s) : hipSuccess;
+}
 
 // host -> device: chunk i+1 is packed into the other pinned buffer while chunk i is on the wire.  The copies
 // are ordered on `s` (the stream the consumer kernels run on); nothing is waited for at the end.
@@ -453,7 +466,7 @@ int Lane::h2d(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
   for (int i = 0; off < bytes; ++i) {
     const int b = i & 1;
     const size_t n = std::min(piece, bytes - off);
-    HIP_TRY(hipEventSynchronize(stage_ev[b]));   // the DMA that last used this buffer is done (no-op if never recorded)
+    HIP_TRY(wait_event(stage_ev[b]));   // the DMA that last used this buffer is done (no-op if never recorded)
     big_copy(stage[b], (const char*)h_src + off, n);
     HIP_TRY(hipMemcpyAsync((char*)d_dst + off, stage[b], n, hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(stage_ev[b], s));
@@ -464,6 +477,7 @@ int Lane::h2d(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
 
 // device -> host, ordered behind the work queued on `s`: chunk i+1 is on the wire while chunk i is unpacked
 int Lane::d2h(void* h_dst, const void* d_src, size_t bytes, hipStream_t s) {
+  HIP_TRY(drain_before_copy(s));
   if (bytes && host_is_pinned(h_dst, bytes)) {   // pinned target: one DMA, no unpacking copy
     HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s));
     hipError_t e = hipStreamSynchronize(s);
@@ -475,7 +489,7 @@ int Lane::d2h(void* h_dst, const void* d_src, size_t bytes, hipStream_t s) {
   const int chunks = (int)((bytes + piece - 1) / piece);
   auto issue = [&](int i) -> hipError_t {
     const size_t off = (size_t)i * piece, n = std::min(piece, bytes - off);
-    hipError_t r = hipEventSynchronize(stage_ev[i & 1]);
+    hipError_t r = wait_event(stage_ev[i & 1]);
     if (r == hipSuccess) r = hipMemcpyAsync(stage[i & 1], (const char*)d_src + off, n, hipMemcpyDeviceToHost, s);
     return r == hipSuccess ? hipEventRecord(stage_ev[i & 1], s) : r;
   };
@@ -483,7 +497,7 @@ int Lane::d2h(void* h_dst, const void* d_src, size_t bytes, hipStream_t s) {
   if (chunks > 0) e = issue(0);
   for (int i = 0; i < chunks && e == hipSuccess; ++i) {
     if (i + 1 < chunks) e = issue(i + 1);   // its buffer was unpacked in iteration i-1
-    if (e == hipSuccess) e = hipEventSynchronize(stage_ev[i & 1]);
+    if (e == hipSuccess) e = wait_event(stage_ev[i & 1]);
     if (e != hipSuccess) break;
     const size_t off = (size_t)i * piece, n = std::min(piece, bytes - off);
     big_copy((char*)h_dst + off, stage[i & 1], n);

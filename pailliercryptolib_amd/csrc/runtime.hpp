@@ -154,6 +154,9 @@ struct Device {
   int bind() const;   // hipSetDevice(ordinal) for the calling thread
 };
 
+// waits for the work queued on `s` before a device -> host copy is issued on it (runtime.cpp: why)
+hipError_t drain_before_copy(hipStream_t s);
+
 // RAII device allocation from a Device's allocator
 struct DevMem {
   Device* dev = nullptr;

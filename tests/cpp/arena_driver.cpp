@@ -67,6 +67,24 @@ int main() {
   bad += a != value(42, 20);
   a += 1u;
   bad += a != value(42, 20) + 1u;
+  // 5. retired arenas are recycled: a batch dropped before the next one is built hands its pages on; a survivor of the
+  //    old batch keeps ITS arena out of the cache (so nothing is overwritten under it); trimming the cache is harmless
+  const void* first = nullptr;
+  BigNumber survivor;
+  for (int round = 0; round < 6; ++round) {
+    std::vector<BigNumber> v(2000);
+    {
+      ipcl::detail::LimbBulkScope s(2000 * (32 * 8 + 32));
+      for (unsigned i = 0; i < 2000; ++i) v[i] = value(i + (unsigned)round, 32);
+    }
+    if (round == 0) first = v[0].limbs64().data();
+    if (round == 1) bad += v[0].limbs64().data() != first;     // round 0's arena died with its vector: same pages again
+    if (round == 2) survivor = std::move(v[7]);                // pins round 2's arena
+    if (round == 4) ipcl::detail::limb_cache_trim();
+    for (unsigned i = 0; i < 2000; ++i)
+      if (!(round == 2 && i == 7)) bad += v[i] != value(i + (unsigned)round, 32);
+    bad += round > 2 && survivor != value(7 + 2, 32);
+  }
   std::printf("%s %d\n", bad ? "FAIL" : "OK", bad);
   return bad ? 1 : 0;
 }

@@ -295,7 +295,7 @@ def test_sequential_halves_decrypt_kernel_is_bit_identical(engine, bits, count):
             assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, c)) == m
         finally:
             _capi.check(L.pgpu_set_table_gather_policy(0))
-            L.pgpu_debug_set_seq_decrypt(1)
+            L.pgpu_debug_set_seq_decrypt(4)                     # (back to the default: adaptive)
     finally:
         R.close()
 
@@ -338,7 +338,7 @@ def test_sequential_halves_ct_times_pt_is_bit_identical(engine, bits, ebits, cou
             assert R.down(R.op(L.pgpu_batch_ct_mul, pk._h, c, be, ebits)) == want
         finally:
             _capi.check(L.pgpu_set_table_gather_policy(0))
-            L.pgpu_debug_set_seq_decrypt(1)
+            L.pgpu_debug_set_seq_decrypt(4)                     # (back to the default: adaptive)
     finally:
         R.close()
 
@@ -378,7 +378,7 @@ def test_sequential_halves_ct_plus_ct_is_bit_identical(engine, bits, count):
             one = R.up([o2[0]], 2 * nw)
             assert R.down(R.op(L.pgpu_batch_ct_add, pk._h, c1, one)) == [a * o2[0] % nsq for a in o1]
         finally:
-            L.pgpu_debug_set_seq_decrypt(1)
+            L.pgpu_debug_set_seq_decrypt(4)                     # (back to the default: adaptive)
     finally:
         R.close()
 
@@ -414,6 +414,6 @@ def test_sequential_halves_djn_encrypt_is_bit_identical(engine, bits, count):
             assert R.down(c) == want
             assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, c)) == [v % n for v in m]
         finally:
-            L.pgpu_debug_set_seq_decrypt(1)
+            L.pgpu_debug_set_seq_decrypt(4)                     # (back to the default: adaptive)
     finally:
         R.close()

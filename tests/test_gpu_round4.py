@@ -320,3 +320,87 @@ def test_lane_decrypt_kernel_is_bit_identical(engine, count):
             L.pgpu_debug_set_lane_decrypt(1)
     finally:
         R.close()
+
+
+@pytest.mark.parametrize("bits,count", [(2048, 8192), (2048, 2100), (2048, 20000), (1024, 40000), (3072, 4100)])
+def test_host_array_callers_side_by_side(engine, bits, count):
+    """Two threads calling pgpu_paillier_encrypt / pgpu_paillier_decrypt_crt on host arrays of their own (the reference's
+    BM_Encrypt / BM_Decrypt shape, benchmark/bench_cryptography.cpp:24-63, from an OpenMP team): each sees the other
+    through the lane activity stamps (PGPU_HOST_ADAPT=1, switched on here), so the launches take the part-chip forms of the
+    adaptive policy -- word ciphertexts converted to pair rows on the way in, pair rows back to words on the way out; the
+    larger counts take the conversion by size alone (sequential-halves / one-lane decrypt of word ciphertexts).  Bit-identical with the same calls
+    issued alone under the fixed paired policy, and with the oracle (sampled)."""
+    import threading
+    from oracle import paillier_oracle as orc
+    from pailliercryptolib_amd import _capi
+    from pailliercryptolib_amd.limbs import ints_to_limbs, limbs_to_ints
+    L = _capi.lib()
+    p, q, hs = key_case(bits)
+    n = p * q
+    nw, pw = bits // 64, bits // 128
+    pk, sk = engine.PublicKey(n, bits, hs=hs), engine.PrivateKey(p, q)
+    opk = orc.PublicKey(n, bits)
+    opk.set_djn(hs)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    sets = []
+    for t in range(2):
+        rng = random.Random(bits * 7 + count + t)
+        m = ([0, 1, n - 1] + [rng.randrange(n) for _ in range(count)])[:count]
+        r = ([0, 1, (1 << (bits // 2)) - 1] + [rng.getrandbits(bits // 2) for _ in range(count)])[:count]
+        sets.append((m, r, ints_to_limbs(m, nw), ints_to_limbs(r, pw)))
+    # reference run: one caller, lone-caller forms only
+    L.pgpu_debug_set_seq_decrypt(1)
+    alone = []
+    try:
+        for m, r, ma, ra in sets:
+            c = np.empty((count, 2 * nw), dtype=np.uint64)
+            d = np.empty((count, nw), dtype=np.uint64)
+            _capi.check(L.pgpu_paillier_encrypt(pk._h, ptr(ma), nw, nw, ptr(ra), pw, pw, 64 * pw, ptr(c), count))
+            _capi.check(L.pgpu_paillier_decrypt_crt(sk._h, ptr(c), ptr(d), count))
+            alone.append((c, d))
+    finally:
+        L.pgpu_debug_set_seq_decrypt(4)                 # the default: adaptive
+    for (m, r, ma, ra), (c, d) in zip(sets, alone):
+        assert limbs_to_ints(d) == m
+        assert limbs_to_ints(c[:6]) == opk.encrypt(m[:6], r[:6])
+    _capi.check(L.pgpu_set_timing(1))
+    was = L.pgpu_debug_set_host_adapt(1)        # (PGPU_HOST_ADAPT: off by default -- it does not pay for synchronous callers)
+    outs = [[], []]
+    errs = []
+    bar = threading.Barrier(2)
+
+    def caller(t):
+        m, r, ma, ra = sets[t]
+        try:
+            bar.wait()
+            for _ in range(3):
+                c = np.empty((count, 2 * nw), dtype=np.uint64)
+                d = np.empty((count, nw), dtype=np.uint64)
+                _capi.check(L.pgpu_paillier_encrypt(pk._h, ptr(ma), nw, nw, ptr(ra), pw, pw, 64 * pw, ptr(c), count))
+                _capi.check(L.pgpu_paillier_decrypt_crt(sk._h, ptr(c), ptr(d), count))
+                outs[t].append((c, d))
+        except Exception as e:                              # noqa: BLE001
+            errs.append(repr(e))
+            try:
+                bar.abort()
+            except Exception:                               # noqa: BLE001
+                pass
+    th = [threading.Thread(target=caller, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    mx = 256
+    kinds, forms, ms = (ctypes.c_int * mx)(), (ctypes.c_int * mx)(), (ctypes.c_double * mx)()
+    got = L.pgpu_timing_collect_ex(kinds, forms, ms, mx)
+    L.pgpu_set_timing(0)
+    L.pgpu_debug_set_host_adapt(was)
+    assert not errs, errs
+    for t in range(2):
+        for c, d in outs[t]:
+            assert np.array_equal(c, alone[t][0])
+            assert np.array_equal(d, alone[t][1])
+    # (which forms ran depends on how the two threads met; with 2048-bit keys and a batch that fills half the chip the
+    # sequential-halves form must have been among them)
+    if bits == 2048 and count == 8192:
+        assert any(forms[i] & 2 for i in range(got)), [forms[i] for i in range(got)]
