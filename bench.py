@@ -1167,6 +1167,18 @@ def api_level():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     d["modexps_per_s"] = round(3 * BATCH / ((d["encrypt_us"] + d["decrypt_us"]) * 1e-6), 1)
+    # the same calls from several host threads at once (the reference's tests call the API from an OpenMP team,
+    # test_cryptography.cpp:45-57): each thread is synchronous, their calls overlap on the GPU
+    d["threads"] = {}
+    for t in (2, 4):
+        try:
+            r = subprocess.run([exe, "--threads", str(t), str(BATCH), "8"], capture_output=True, text=True, timeout=300)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+            j = json.loads(line)
+            d["threads"][str(t)] = {"us_per_encrypt_plus_decrypt": j["us_per_encrypt_plus_decrypt"], "modexps_per_s": j["modexps_per_s"],
+                                    "round_trip_ok": j["round_trip_ok"]}
+        except Exception as e:                              # noqa: BLE001
+            d["threads"][str(t)] = {"error": repr(e)[:200]}
     return d
 
 

@@ -686,6 +686,12 @@ namespace {
 // adaptive kernel-form policy places their launches side by side.
 std::atomic<int> g_next_thread_lane{0};
 thread_local int t_batch_lane = -1;
+// true once the thread has chosen a lane itself (pgpu_set_batch_lane): a caller that PIPELINES -- keeps several lanes fed
+// without waiting in between.  Only such callers enter the adaptive kernel-form policy (busy_other_lanes).  Threads on
+// the lanes handed out round-robin are synchronous API callers (upload, operation, download, wait): their lanes fall idle
+// for the host part of every call, and a part-chip launch beside an idle neighbour is the worst case of that policy
+// (measured r04, tests/cpp/ipcl_bench.cpp --threads 2: 11.8 ms per encrypt + decrypt against 7.2 with full-chip launches).
+thread_local bool t_lane_explicit = false;
 std::atomic<int> g_host_adapt{[] { const char* e = std::getenv("PGPU_HOST_ADAPT"); return e && std::atoi(e) != 0 ? 1 : 0; }()};
 bool host_adapt() { return g_host_adapt.load() != 0; }
 int thread_batch_lane() {
@@ -1541,7 +1547,8 @@ unsigned adaptive_cu_claim(size_t waves, int busy_lanes) {
 // in one mode: right after a synchronisation every lane is empty for a moment, and a policy that only looked at the
 // queues would start each burst with a full-chip launch that the next lane's half-chip launch then has to share CUs
 // with (measured: ~7 ms lost at the head of a 20-step run, 5.31 instead of 4.95 ms per step).  Also stamps `lane`.
-int busy_other_lanes(rt::Device& dev, int lane) {
+int busy_other_lanes(rt::Device& dev, int lane, bool force = false) {
+  if (!force && !t_lane_explicit) return 0;   // (synchronous callers on round-robin lanes: lone-caller forms, no stamp)
   static const int64_t window_ns = [] {
     const char* e = std::getenv("PGPU_LANE_ACTIVE_MS");
     return (int64_t)(e ? std::max(0, std::atoi(e)) : 50) * 1000000;
@@ -2075,7 +2082,8 @@ int pgpu_synchronize(void) {
     for (int k = 0; k < rt::kBatchLanes; ++k) HIP_TRY(hipStreamSynchronize(d.bs(k)));
     const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
     for (int k = 0; k < rt::kBatchLanes; ++k)
-      if (was_busy[k]) d.lane_fed_ns[k].store(now, std::memory_order_relaxed);
+      if (was_busy[k] && d.lane_fed_ns[k].load(std::memory_order_relaxed) != 0)   // (lanes of pipelining callers only)
+        d.lane_fed_ns[k].store(now, std::memory_order_relaxed);
     for (auto& lane : d.lanes) HIP_TRY(hipStreamSynchronize(lane->stream));
   }
   drain_parked();   // evicted per-modulus contexts (their hipFree waits for whatever still reads them)
@@ -2635,7 +2643,7 @@ int pgpu_paillier_encrypt(const pgpu_pubkey* key, const uint64_t* m, size_t m_st
     RC_TRY(dc.alloc(d, s, n * (size_t)W * 8));
     RC_TRY(lane.h2d(dm.p, m + lo * m_stride, n * m_stride * 8, s));
     RC_TRY(lane.h2d(dr.p, r + lo * r_stride, n * r_stride * 8, s));
-    const int busy = caller_lane >= 0 ? busy_other_lanes(d, caller_lane) : 0;
+    const int busy = caller_lane >= 0 ? busy_other_lanes(d, caller_lane, true) : 0;
     if (pf && busy > 0 && fb_encrypt_seq_pays(pf->H, pf->K, n, busy)) {
       // the sequential-halves kernel leaves pair rows: one pair_ops_kernel pass brings them back to words
       RC_TRY(rows.alloc(d, s, n * (size_t)2 * pf->H * pf->K * sizeof(uint32_t)));
@@ -2647,7 +2655,7 @@ int pgpu_paillier_encrypt(const pgpu_pubkey* key, const uint64_t* m, size_t m_st
                         r_bits, (uint64_t*)dc.p, n, s, false, count));
     }
     const int rcd = lane.d2h(c + lo * (size_t)W, dc.p, n * (size_t)W * 8, s);
-    if (caller_lane >= 0) (void)busy_other_lanes(d, caller_lane);   // (stamp: a long call stays visible until it ends)
+    if (caller_lane >= 0) (void)busy_other_lanes(d, caller_lane, true);   // (stamp: a long call stays visible until it ends)
     return rcd;
   });
   if (rc == PGPU_OK && key->djn) {
@@ -2926,9 +2934,9 @@ int pgpu_paillier_decrypt_crt(const pgpu_privkey* key, const uint64_t* c, uint64
     RC_TRY(dm.alloc(d, s, n * (size_t)nw * 8));
     RC_TRY(lane.h2d(dc.p, c + lo * (size_t)2 * nw, n * (size_t)2 * nw * 8, s));
     RC_TRY(decrypt_on(d, key, (const uint64_t*)dc.p, (uint64_t*)dm.p, n, s, false, nullptr, 0,
-                      caller_lane >= 0 ? busy_other_lanes(d, caller_lane) : 0));
+                      caller_lane >= 0 ? busy_other_lanes(d, caller_lane, true) : 0));
     const int rcd = lane.d2h(m + lo * (size_t)nw, dm.p, n * (size_t)nw * 8, s);
-    if (caller_lane >= 0) (void)busy_other_lanes(d, caller_lane);
+    if (caller_lane >= 0) (void)busy_other_lanes(d, caller_lane, true);
     return rcd;
   });
 }
@@ -3437,6 +3445,7 @@ int pgpu_batch_ct_mul(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_ba
 int pgpu_set_batch_lane(int lane) {
   if (lane < 0 || lane >= rt::kBatchLanes) return fail(PGPU_ERR_INVALID_PARAM, "batch lane out of range (pgpu_batch_lanes())");
   t_batch_lane = lane;
+  t_lane_explicit = true;
   return PGPU_OK;
 }
 int pgpu_batch_lane(const pgpu_batch* b) { return b ? b->lane : 0; }

@@ -2,6 +2,7 @@
 #include "ipcl/base_text.hpp"
 
 #include <algorithm>
+#include <cstdint>
 #include <mutex>
 
 #include "detail.hpp"
@@ -13,7 +14,29 @@ namespace ipcl {
 
 // ---- device-resident values ----
 namespace {
-std::mutex g_materialise_mu;  // lazy host/device copies are created under one lock (const methods)
+// Lazy host / device copies are created inside const methods, under a lock picked by the object's address out of a small
+// table.  (Round 3 had ONE lock for all texts: a thread materialising its results -- which waits for its kernels -- held
+// up every other thread's accessor for that long; four API threads ran no faster than one.)
+constexpr std::size_t kTextLocks = 64;
+std::mutex g_text_mu[kTextLocks];
+std::mutex& text_mu(const void* obj) {
+  const std::uintptr_t a = reinterpret_cast<std::uintptr_t>(obj);
+  return g_text_mu[((a >> 4) ^ (a >> 12)) % kTextLocks];
+}
+// both objects of an assignment (one lock when they share a slot; address order otherwise)
+struct PairLock {
+  std::mutex *a, *b;
+  PairLock(const void* x, const void* y) : a(&text_mu(x)), b(&text_mu(y)) {
+    if (a == b) b = nullptr;
+    else if (b < a) std::swap(a, b);
+    a->lock();
+    if (b) b->lock();
+  }
+  ~PairLock() {
+    if (b) b->unlock();
+    a->unlock();
+  }
+};
 }
 
 BaseText::BaseText(std::shared_ptr<detail::DeviceBatch> dev)
@@ -21,7 +44,7 @@ BaseText::BaseText(std::shared_ptr<detail::DeviceBatch> dev)
 
 // a text may be copied while another thread materialises its host values (const accessors download lazily)
 BaseText::BaseText(const BaseText& o) {
-  std::lock_guard<std::mutex> lk(g_materialise_mu);
+  std::lock_guard<std::mutex> lk(text_mu(&o));
   m_texts = detail::copy_texts(o.m_texts);
   m_size = o.m_size;
   m_dev = o.m_dev;
@@ -31,7 +54,7 @@ BaseText::BaseText(const BaseText& o) {
 
 BaseText& BaseText::operator=(const BaseText& o) {
   if (this == &o) return *this;
-  std::lock_guard<std::mutex> lk(g_materialise_mu);
+  PairLock lk(this, &o);
   m_texts = detail::copy_texts(o.m_texts);
   m_size = o.m_size;
   m_dev = o.m_dev;
@@ -65,7 +88,7 @@ bool BaseText::adoptValues(const std::vector<BigNumber>& v) {
 
 void BaseText::ensureHost() const {
   if (m_host_valid) return;
-  std::lock_guard<std::mutex> lk(g_materialise_mu);
+  std::lock_guard<std::mutex> lk(text_mu(this));
   if (m_host_valid) return;
   m_texts = m_dev->download();
   m_host_valid = true;
@@ -84,13 +107,13 @@ int BaseText::maxBitsHint() const {
 
 std::shared_ptr<detail::DeviceBatch> BaseText::deviceBatch(int words, const BigNumber* reduce_mod) const {
   {
-    std::lock_guard<std::mutex> lk(g_materialise_mu);
+    std::lock_guard<std::mutex> lk(text_mu(this));
     if (m_dev && m_dev->words == words) return m_dev;
   }
   ensureHost();
   if (detail::all_fit(m_texts, words)) {
     auto b = detail::DeviceBatch::upload(detail::pack(m_texts, words), m_size, words);
-    std::lock_guard<std::mutex> lk(g_materialise_mu);
+    std::lock_guard<std::mutex> lk(text_mu(this));
     m_dev = b;   // the device copy mirrors m_texts exactly: cache it
     return b;
   }
@@ -218,7 +241,7 @@ std::vector<BigNumber> BaseText::getTexts() const& {
 // on a temporary (`pk.encrypt(pt).getTexts()`): hand the values over instead of copying them a second time
 std::vector<BigNumber> BaseText::getTexts() && {
   ensureHost();
-  std::lock_guard<std::mutex> lk(g_materialise_mu);
+  std::lock_guard<std::mutex> lk(text_mu(this));
   std::vector<BigNumber> out = std::move(m_texts);
   m_texts.clear();
   if (m_dev) m_host_valid = false;   // the device copy is still there: a later accessor downloads again

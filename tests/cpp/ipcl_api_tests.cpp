@@ -15,6 +15,8 @@
 #include <random>
 #include <sstream>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "ipcl/ipcl.hpp"
@@ -313,6 +315,50 @@ TEST(eager_upload_texts_and_cached_randomness) {
   EXPECT_TRUE(!pe.isDeviceResident());
   ipcl::PublicKey pk3(n, 2048, true);
   EXPECT_EQ(sk.decrypt(pk3.encrypt(pones) * pe).getElement(17), BigNumber((unsigned int)6));
+}
+
+// Threads that share texts: const accessors materialise host values lazily under per-object locks (base_text.cpp), copies and
+// assignments between threads take both objects' locks; every thread also runs whole encrypt / decrypt calls of its own
+// (the reference's OpenMP tests, test_cryptography.cpp:45-57, call the API from four threads at once).
+TEST(threads_share_texts_and_run_side_by_side) {
+  BigNumber p(KAT_P), q(KAT_Q), n = p * q;
+  ipcl::PublicKey pk(n, 2048, true);
+  ipcl::PrivateKey sk(pk, p, q);
+  pk.setHS(BigNumber(KAT_BENCH_HS));
+  const size_t N = 600;
+  std::vector<BigNumber> m(N);
+  for (size_t i = 0; i < N; i++) m[i] = p - BigNumber((unsigned int)(i * 1024));
+  ipcl::PlainText pt(m);
+  ipcl::CipherText shared = pk.encrypt(pt);            // resident: no host values yet
+  ipcl::PlainText shared_pt = sk.decrypt(shared);      // resident as well
+  std::atomic<int> bad{0};
+  std::vector<std::thread> th;
+  for (int t = 0; t < 4; ++t)
+    th.emplace_back([&, t] {
+      for (int round = 0; round < 3; ++round) {
+        // lazy materialisation raced by four threads
+        if (shared_pt.getElement((size_t)(t * 7 + round)) != m[(size_t)(t * 7 + round)]) bad++;
+        ipcl::CipherText mine = shared;                  // copy while others read
+        ipcl::PlainText back = sk.decrypt(mine);
+        if (back.getElement(N - 1 - (size_t)t) != m[N - 1 - (size_t)t]) bad++;
+        ipcl::CipherText assigned;
+        assigned = mine;
+        if (assigned.getElement(0) != shared.getElement(0)) bad++;
+        // a whole call chain of its own, values of its own
+        std::vector<BigNumber> mm(N);
+        for (size_t i = 0; i < N; i++) mm[i] = q - BigNumber((unsigned int)(i * 3 + (size_t)t));
+        std::vector<BigNumber> c = pk.encrypt(ipcl::PlainText(mm)).getTexts();
+        std::vector<BigNumber> d = sk.decrypt(ipcl::CipherText(pk, c)).getTexts();
+        for (size_t i = 0; i < N; i++)
+          if (d[i] != mm[i]) { bad++; break; }
+      }
+    });
+  for (auto& x : th) x.join();
+  EXPECT_EQ(bad.load(), 0);
+  std::vector<BigNumber> all = shared_pt.getTexts();
+  bool same = all.size() == N;
+  for (size_t i = 0; same && i < N; i++) same = all[i] == m[i];
+  EXPECT_TRUE(same);
 }
 
 TEST(large_batch_marshalling) {

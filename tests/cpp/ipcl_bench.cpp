@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <functional>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "ipcl/ipcl.hpp"
@@ -55,8 +57,55 @@ static int json_mode(size_t dsize) {
   return ok ? 0 : 1;
 }
 
+// `--threads <T> <batch> [rounds]`: T host threads, each encrypting and decrypting vectors of its own through the API
+// (vector<BigNumber> in and out), side by side -- the shape of the reference's OpenMP tests (test_cryptography.cpp:45-57);
+// aggregate rate, one JSON line.
+static int threads_mode(int T, size_t dsize, int rounds) {
+  ipcl::initializeContext("default");
+  BigNumber P(KAT_P), Q(KAT_Q), n = P * Q;
+  ipcl::PublicKey pk(n, 2048, true);
+  ipcl::PrivateKey sk(pk, P, Q);
+  pk.setRandom(std::vector<BigNumber>(dsize, BigNumber(KAT_BENCH_R)));
+  pk.setHS(BigNumber(KAT_BENCH_HS));
+  std::vector<std::vector<BigNumber>> m((size_t)T, std::vector<BigNumber>(dsize));
+  for (int t = 0; t < T; ++t)
+    for (size_t i = 0; i < dsize; i++) m[(size_t)t][i] = P - BigNumber((unsigned int)(i * 1024 + (size_t)t));
+  std::vector<int> ok((size_t)T, 1);
+  std::atomic<int> ready{0}, go{0};
+  std::vector<std::thread> th;
+  std::chrono::steady_clock::time_point t0;
+  for (int t = 0; t < T; ++t)
+    th.emplace_back([&, t] {
+      std::vector<BigNumber> c, d;
+      for (int r = 0; r < rounds + 2; ++r) {
+        if (r == 2) {   // two untimed rounds (tables, workspaces, arenas), then all threads start together
+          ready.fetch_add(1);
+          while (!go.load()) std::this_thread::yield();
+        }
+        c = pk.encrypt(ipcl::PlainText(m[(size_t)t])).getTexts();
+        d = sk.decrypt(ipcl::CipherText(pk, c)).getTexts();
+      }
+      for (size_t i = 0; i < dsize; ++i) ok[(size_t)t] &= d[i] == m[(size_t)t][i];
+    });
+  while (ready.load() < T) std::this_thread::yield();
+  t0 = std::chrono::steady_clock::now();
+  go.store(1);
+  for (auto& x : th) x.join();
+  const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  bool all = true;
+  for (int v : ok) all = all && v;
+  std::printf("{\"what\": \"%d host threads, each ipcl::PublicKey::encrypt + PrivateKey::decrypt with vector<BigNumber> in and out, "
+              "batch %zu, %d rounds each\", \"threads\": %d, \"us_per_encrypt_plus_decrypt\": %.1f, \"modexps_per_s\": %.1f, "
+              "\"round_trip_ok\": %s}\n",
+              T, dsize, rounds, T, us / (rounds * T), 3.0 * dsize * rounds * T / (us * 1e-6), all ? "true" : "false");
+  ipcl::terminateContext();
+  return all ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
   if (argc > 2 && std::string(argv[1]) == "--json") return json_mode((size_t)std::atol(argv[2]));
+  if (argc > 3 && std::string(argv[1]) == "--threads")
+    return threads_mode(std::atoi(argv[2]), (size_t)std::atol(argv[3]), argc > 4 ? std::atoi(argv[4]) : 8);
   ipcl::initializeContext("default");
   BigNumber P(KAT_P), Q(KAT_Q), n = P * Q;
   std::vector<size_t> sizes = {16, 64, 128, 256, 512, 1024, 2048, 2100};   // bench_cryptography.cpp:12-19
