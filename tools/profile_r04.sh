@@ -43,4 +43,7 @@ bash tools/run_r04_e.sh > $OUT/lane_decrypt.txt 2>&1
 python tools/probe_lanes.py --lanes 1 2 3 4 --steps 40 > $OUT/lanes.txt 2>&1
 python tools/probe_trace.py 2 8 > $OUT/trace_2lanes.txt 2>&1
 python tools/probe_trace.py 4 20 > $OUT/trace_4lanes.txt 2>&1
+(for w in 1 0; do for v in pageable pinned; do for c in 1 2 4; do echo "# PGPU_D2H_PRESYNC=$w  python tools/probe_two_callers.py $v $c 8"; PGPU_D2H_PRESYNC=$w python tools/probe_two_callers.py $v $c 8 2>&1 | grep -v amdgpu.ids | head -$((c+1)); done; done; done
+ for v in pageable pinned; do echo "# PGPU_HOST_ADAPT=1  python tools/probe_two_callers.py $v 2 8"; PGPU_HOST_ADAPT=1 python tools/probe_two_callers.py $v 2 8 2>&1 | grep -v amdgpu.ids | head -3; done) > $OUT/two_callers.txt 2>&1
+(for t in 1 2 3 4; do ./pailliercryptolib_amd/ipcl_api_bench --threads $t 8192 8 2>&1 | grep -v amdgpu.ids; done) > $OUT/ipcl_api_threads.txt 2>&1
 ls $OUT
