@@ -258,8 +258,12 @@ int pgpu_batch_row_limbs(const pgpu_batch* b);
  * ~8 % slower than two, and the sequential-halves kernels -- 11-17 % fewer instructions -- need 16384 ciphertexts in
  * flight to reach every SIMD).  Uploads and pgpu_batch_create take the calling thread's lane (the first thread of the
  * process that uploads gets lane 0, further threads the next lanes round-robin; pgpu_set_batch_lane overrides); every result
- * inherits the lane of the operation's first operand; operands of another lane are ordered in by events.  What a launch
- * looks like depends on whether its neighbour lanes are busy when it is queued (pgpu_decrypt_kernel_form_ex). */
+ * inherits the lane of the operation's first operand; operands of another lane are ordered in by events.
+ * A thread that CHOOSES its lanes (pgpu_set_batch_lane) is taken to pipeline -- to keep several lanes fed without waiting in
+ * between: what its launches look like depends on whether the neighbour lanes are busy when they are queued (the adaptive
+ * policy, pgpu_decrypt_kernel_form_ex: part-chip launches side by side).  Threads on the round-robin lanes are synchronous
+ * API callers (upload, operation, download): their lanes idle during the host part of every call, so their launches keep
+ * the lone caller's full-chip forms and simply overlap one thread's copies and host work with another's kernels. */
 int pgpu_set_batch_lane(int lane /* 0 .. pgpu_batch_lanes() - 1 */);
 int pgpu_batch_lane(const pgpu_batch* b);
 int pgpu_batch_lanes(void);
