@@ -804,6 +804,12 @@ def extras(pa, L, B, pk, sk, n, p, q, hs, m_host, r_host, per_kind):
             out[key] = two_callers(L, pk, sk, m_host, r_host, variant)
         except Exception as e:                              # noqa: BLE001
             out[key] = {"error": repr(e)[:300]}
+    # (1d) ONE thread pipelining host-to-host steps over two (and four) batch lanes
+    for ln in (2, 4):
+        try:
+            out["end_to_end_pipelined" + ("" if ln == 2 else "_4_lanes")] = pipelined_e2e(L, pk, sk, m_host, r_host, lanes=ln)
+        except Exception as e:                              # noqa: BLE001
+            out["end_to_end_pipelined" + ("" if ln == 2 else "_4_lanes")] = {"error": repr(e)[:300]}
     time.sleep(0.15)   # (the callers' lanes stay marked active for 50 ms: the lone-caller measurements below start clean)
     # (2) the API-visible timing of the reference's own benchmark: ipcl::PublicKey::encrypt / PrivateKey::decrypt with
     # std::vector<BigNumber> in and out (benchmark/bench_cryptography.cpp:73-121)
@@ -1017,6 +1023,88 @@ def two_callers(L, pk, sk, m_host, r_host, variant, reps=6, ncall=2):
                     "of its own, %d rounds each; aggregate rate" % (variant, reps),
             "wall_ms": round(wall * 1e3, 3), "ms_per_encrypt_plus_decrypt": round(wall / (reps * ncall) * 1e3, 3),
             "modexps_per_s": round(3 * BATCH * reps * ncall / wall, 1)}
+
+
+def pipelined_e2e(L, pk, sk, m_host, r_host, lanes=2, steps=24):
+    """ONE host thread pipelining whole host-to-host steps over `lanes` batch lanes: per step the plaintexts and the
+    randomness are uploaded from the caller's (pinned) arrays, encrypted, decrypted and the result is downloaded into the
+    caller's array -- nothing resident between steps.  The thread never waits inside a step: uploads from pinned blocks
+    only queue their copy, the operations are asynchronous, pgpu_batch_download_async returns a ticket; a lane's ticket is
+    waited for when the lane comes round again.  (The reference's accelerator path has the same shape: HE-QAT submits
+    batches and polls for completions, ipcl/mod_exp.cpp:162-440.)"""
+    from pailliercryptolib_amd import _capi
+    nw, pw = m_host.shape[1], r_host.shape[1]
+    held = []
+
+    def pin(shape):
+        nbytes = int(np.prod(shape)) * 8
+        pp = ctypes.c_void_p()
+        _capi.check(L.pgpu_host_alloc(nbytes, ctypes.byref(pp)))
+        held.append(pp)
+        return np.frombuffer((ctypes.c_uint8 * nbytes).from_address(pp.value), dtype=np.uint64).reshape(shape)
+    slots = []
+    for _ in range(lanes):
+        a, b2, o = pin((BATCH, nw)), pin((BATCH, pw)), pin((BATCH, nw))
+        a[:], b2[:] = m_host, r_host
+        o[:] = 0
+        slots.append({"m": a, "r": b2, "out": o, "ticket": None, "live": []})
+
+    def retire(sl):
+        if sl["ticket"] is not None:
+            _capi.check(L.pgpu_ticket_wait(sl["ticket"]))
+            sl["ticket"] = None
+        for h in sl["live"]:
+            L.pgpu_batch_destroy(h)
+        sl["live"] = []
+
+    def step(i):
+        sl = slots[i % lanes]
+        retire(sl)                       # the lane's previous step has delivered: its buffers and batches are free
+        _capi.check(L.pgpu_set_batch_lane(i % lanes))
+        hs_ = []
+        for arr, words in ((sl["m"], nw), (sl["r"], pw)):
+            h = ctypes.c_void_p()
+            _capi.check(L.pgpu_batch_upload(ptr(arr), BATCH, words, words, ctypes.byref(h)))
+            hs_.append(h)
+        c = ctypes.c_void_p()
+        _capi.check(L.pgpu_batch_encrypt(pk._h, hs_[0], hs_[1], 64 * pw, ctypes.byref(c)))
+        o = ctypes.c_void_p()
+        _capi.check(L.pgpu_batch_decrypt_crt(sk._h, c, ctypes.byref(o)))
+        t = ctypes.c_void_p()
+        _capi.check(L.pgpu_batch_download_async(o, ptr(sl["out"]), ctypes.byref(t)))
+        sl["ticket"] = t
+        sl["live"] = hs_ + [c, o]
+    try:
+        for i in range(2 * lanes):
+            step(i)
+        for sl in slots:
+            retire(sl)
+        for sl in slots:
+            sl["out"][:] = 0
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        t_issue = time.perf_counter() - t0
+        for sl in slots:
+            retire(sl)
+        wall = time.perf_counter() - t0
+        ok = all(bool(np.array_equal(sl["out"], m_host)) for sl in slots)
+    finally:
+        _capi.check(L.pgpu_set_batch_lane(0))
+        for sl in slots:
+            try:
+                retire(sl)
+            except Exception:                               # noqa: BLE001
+                pass
+        for pp in held:
+            L.pgpu_host_free(pp)
+    if not ok:
+        raise RuntimeError("pipelined end-to-end: results differ")
+    return {"what": "ONE host thread, %d batch lanes: per step upload of m and r from pinned caller arrays, encrypt, CRT decrypt, "
+                    "asynchronous download into the caller's array (pgpu_batch_download_async); %d steps, nothing resident "
+                    "between steps" % (lanes, steps),
+            "ms_per_step": round(wall / steps * 1e3, 4), "modexps_per_s": round(3 * BATCH * steps / wall, 1),
+            "host_time_in_calls_ms_per_step": round(t_issue / steps * 1e3, 4)}
 
 
 def lanes_sweep(L, B, pk, sk, m_host, r_host, seconds=0.8):

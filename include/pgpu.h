@@ -244,6 +244,15 @@ typedef struct pgpu_batch pgpu_batch;
 int pgpu_batch_create(size_t count, int words, pgpu_batch** out);            /* uninitialised */
 int pgpu_batch_upload(const uint64_t* host, size_t count, int words, size_t stride, pgpu_batch** out);
 int pgpu_batch_download(const pgpu_batch* b, uint64_t* host /* [count][words] */);
+/* Download that does not hold the caller (round 4): returns at once with a ticket; a worker of the pool runs the conversion
+ * (if the batch is in a device-side domain) and queues the copy once the batch's kernels have finished -- never earlier, so
+ * that it cannot block the copy engine for other lanes.  pgpu_ticket_wait blocks until the data has arrived, returns the
+ * status of the download and frees the ticket.  `b` and `host` must stay alive until then.  With buffers from
+ * pgpu_host_alloc this is what lets ONE thread pipeline whole host-to-host steps over two lanes (bench.py:
+ * end_to_end_pipelined). */
+typedef struct pgpu_ticket pgpu_ticket;
+int pgpu_batch_download_async(const pgpu_batch* b, uint64_t* host /* [count][words] */, pgpu_ticket** out);
+int pgpu_ticket_wait(pgpu_ticket* t);
 void pgpu_batch_destroy(pgpu_batch* b);
 size_t pgpu_batch_count(const pgpu_batch* b);
 int pgpu_batch_words(const pgpu_batch* b);

@@ -3058,6 +3058,34 @@ int pgpu_batch_upload(const uint64_t* host, size_t count, int words, size_t stri
   return PGPU_OK;
 }
 
+namespace {
+// one task per shard on the pool's worker lanes: conversion kernel (if any), then the copy -- which Lane::d2h hands to the
+// copy engine only once the batch's kernels have run
+void download_tasks(rt::TaskGroup& tg, const pgpu_batch* b, uint64_t* host, int nd) {
+  for (int d = 0; d < nd; ++d) {
+    tg.run(rt::device(d), [=](rt::Lane& lane) -> int {
+      size_t lo, hi;
+      b->bounds(d, &lo, &hi);
+      rt::Device& dev = *lane.dev;
+      hipStream_t s = dev.bs(b->lane);
+      const size_t bytes = (hi - lo) * (size_t)b->words * 8;
+      if (b->pair_l2) {   // pair rows: the plain value materialises here
+        rt::DevMem plain;
+        RC_TRY(plain.alloc(dev, s, bytes));
+        rt::DeviceGuard g(dev.ordinal);
+        RC_TRY(pair_to_words_on(dev, b->pair_form.get(), b->prow(d), (uint64_t*)plain.p, hi - lo, s));
+        return lane.d2h(host + lo * (size_t)b->words, plain.p, bytes, s);
+      }
+      if (!b->mont) return lane.d2h(host + lo * (size_t)b->words, b->ptr(d), bytes, s);
+      rt::DevMem plain;   // leave the Montgomery domain on the way out
+      RC_TRY(plain.alloc(dev, s, bytes));
+      RC_TRY(modmul_on(dev, *b->mont, pgpu::MM_BY_ONE, b->ptr(d), nullptr, 0, 0, (uint64_t*)plain.p, hi - lo, s));
+      return lane.d2h(host + lo * (size_t)b->words, plain.p, bytes, s);
+    });
+  }
+}
+}  // namespace
+
 int pgpu_batch_download(const pgpu_batch* b, uint64_t* host) {
   RC_TRY(rt::check_ready());
   if (!b || !host) return fail(PGPU_ERR_INVALID_PARAM, "null pointer");
@@ -3115,28 +3143,32 @@ int pgpu_batch_download(const pgpu_batch* b, uint64_t* host) {
     return PGPU_OK;
   }
   rt::TaskGroup tg;
-  for (int d = 0; d < nd; ++d) {
-    tg.run(rt::device(d), [=](rt::Lane& lane) -> int {
-      size_t lo, hi;
-      b->bounds(d, &lo, &hi);
-      rt::Device& dev = *lane.dev;
-      hipStream_t s = dev.bs(b->lane);
-      const size_t bytes = (hi - lo) * (size_t)b->words * 8;
-      if (b->pair_l2) {   // pair rows: the plain value materialises here
-        rt::DevMem plain;
-        RC_TRY(plain.alloc(dev, s, bytes));
-        rt::DeviceGuard g(dev.ordinal);
-        RC_TRY(pair_to_words_on(dev, b->pair_form.get(), b->prow(d), (uint64_t*)plain.p, hi - lo, s));
-        return lane.d2h(host + lo * (size_t)b->words, plain.p, bytes, s);
-      }
-      if (!b->mont) return lane.d2h(host + lo * (size_t)b->words, b->ptr(d), bytes, s);
-      rt::DevMem plain;   // leave the Montgomery domain on the way out
-      RC_TRY(plain.alloc(dev, s, bytes));
-      RC_TRY(modmul_on(dev, *b->mont, pgpu::MM_BY_ONE, b->ptr(d), nullptr, 0, 0, (uint64_t*)plain.p, hi - lo, s));
-      return lane.d2h(host + lo * (size_t)b->words, plain.p, bytes, s);
-    });
-  }
+  download_tasks(tg, b, host, nd);
   return tg.wait();
+}
+
+// ---- downloads that do not hold the caller ----
+struct pgpu_ticket {
+  rt::TaskGroup tg;
+  uint64_t gen = 0;
+};
+
+int pgpu_batch_download_async(const pgpu_batch* b, uint64_t* host, pgpu_ticket** out) {
+  RC_TRY(rt::check_ready());
+  if (!b || !host || !out) return fail(PGPU_ERR_INVALID_PARAM, "null pointer");
+  RC_TRY(check_gen(b->gen, "batch"));
+  std::unique_ptr<pgpu_ticket> t(new pgpu_ticket);
+  t->gen = b->gen;
+  download_tasks(t->tg, b, host, b->replicated ? 1 : b->ndev);
+  *out = t.release();
+  return PGPU_OK;
+}
+
+int pgpu_ticket_wait(pgpu_ticket* t) {
+  if (!t) return fail(PGPU_ERR_INVALID_PARAM, "null ticket");
+  const int rc = t->tg.wait();
+  delete t;
+  return rc;
 }
 
 int pgpu_batch_encrypt(const pgpu_pubkey* key, const pgpu_batch* m, const pgpu_batch* r, int r_bits,

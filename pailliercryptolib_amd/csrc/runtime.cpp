@@ -619,7 +619,10 @@ int pool_init(const std::vector<int>& ordinals) {
       HIP_TRY(hipStreamCreateWithFlags(&d->bstreams[k], hipStreamNonBlocking));
       HIP_TRY(hipEventCreateWithFlags(&d->xlane_ev[k], hipEventDisableTiming));
     }
-    for (int l = 0; l < 2; ++l) {
+    // (worker lanes: host-array calls and asynchronous downloads run on them, each blocks its lane until its kernels are
+    //  done -- four, so that two pipelined downloads leave room for two synchronous callers; pinned staging buffers are
+    //  only allocated by a lane that ever moves pageable memory)
+    for (int l = 0; l < 4; ++l) {
       std::unique_ptr<Lane> lane(new Lane);
       lane->dev = d.get();
       lane->id = l;

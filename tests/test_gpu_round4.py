@@ -404,3 +404,67 @@ def test_host_array_callers_side_by_side(engine, bits, count):
     # sequential-halves form must have been among them)
     if bits == 2048 and count == 8192:
         assert any(forms[i] & 2 for i in range(got)), [forms[i] for i in range(got)]
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_async_download_tickets(engine, pinned):
+    """pgpu_batch_download_async / pgpu_ticket_wait: the download runs on a worker of the pool after the batch's kernels, the
+    caller goes on queueing work on other lanes meanwhile.  Batches in every representation (plain words, Montgomery words
+    or pair rows from encrypt, decrypt results), ragged sizes, pinned and pageable targets; equal to the synchronous
+    download, and decrypt results equal to the plaintexts."""
+    from pailliercryptolib_amd import _capi
+    from pailliercryptolib_amd.limbs import ints_to_limbs
+    L = _capi.lib()
+    p, q, hs = key_case(2048)
+    n = p * q
+    nw, pw = 32, 16
+    pk, sk = engine.PublicKey(n, 2048, hs=hs), engine.PrivateKey(p, q)
+    rng = random.Random(77)
+    held, live, tickets = [], [], []
+
+    def target(rows, words):
+        if not pinned:
+            return np.zeros((rows, words), dtype=np.uint64)
+        pp = ctypes.c_void_p()
+        _capi.check(L.pgpu_host_alloc(rows * words * 8, ctypes.byref(pp)))
+        held.append(pp)
+        a = np.frombuffer((ctypes.c_uint8 * (rows * words * 8)).from_address(pp.value), dtype=np.uint64).reshape(rows, words)
+        a[:] = 0
+        return a
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+
+    def op(fn, *a):
+        h = ctypes.c_void_p()
+        _capi.check(fn(*a, ctypes.byref(h)))
+        live.append(h)
+        return h
+    try:
+        jobs = []
+        for lane, count in enumerate((37, 2100, 8192, 513)):
+            _capi.check(L.pgpu_set_batch_lane(lane))
+            m = ints_to_limbs([rng.randrange(n) for _ in range(count)], nw)
+            r = ints_to_limbs([rng.getrandbits(1024) for _ in range(count)], pw)
+            bm = op(L.pgpu_batch_upload, ptr(m), count, nw, nw)
+            br = op(L.pgpu_batch_upload, ptr(r), count, pw, pw)
+            c = op(L.pgpu_batch_encrypt, pk._h, bm, br, 1024)
+            d = op(L.pgpu_batch_decrypt_crt, sk._h, c)
+            for b, words, want in ((bm, nw, m), (c, 2 * nw, None), (d, nw, m)):
+                out = target(count, words)
+                t = ctypes.c_void_p()
+                _capi.check(L.pgpu_batch_download_async(b, ptr(out), ctypes.byref(t)))
+                jobs.append((t, b, out, words, want))
+        _capi.check(L.pgpu_set_batch_lane(0))
+        for t, b, out, words, want in jobs:
+            _capi.check(L.pgpu_ticket_wait(t))
+            ref = np.empty_like(out)
+            _capi.check(L.pgpu_batch_download(b, ptr(ref)))
+            assert np.array_equal(out, ref)
+            if want is not None:
+                assert np.array_equal(out, want)
+        assert L.pgpu_batch_download_async(None, None, None) != 0      # null arguments are refused, no ticket is made
+    finally:
+        L.pgpu_set_batch_lane(0)
+        for h in live:
+            L.pgpu_batch_destroy(h)
+        for pp in held:
+            L.pgpu_host_free(pp)
