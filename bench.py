@@ -276,7 +276,7 @@ def run_pool(args):
     result = headline(args, N, elapsed, per_kind, nw, pw,
                       f"in-process device pool x{N} (batch sharded; key images: {L.pgpu_pool_transport().decode()})",
                       decrypt_kernel(sk, BATCH, nw, KEY_BITS),
-                      encrypt_kernel(pk, BATCH, nw, KEY_BITS, fb["window"] or int(os.environ.get("PGPU_FB_WINDOW", "12"))), fb)
+                      encrypt_kernel(pk, BATCH, nw, KEY_BITS, fb["window"] or int(os.environ.get("PGPU_FB_WINDOW", "13"))), fb)
     result["config"]["secret_exponent_policy"] = ["fixed-window", "sliding"][L.pgpu_get_secret_exponent_policy()]
     result["config"]["batches_in_flight_per_gpu"] = nfl
     result["config"]["resident_ciphertext_form"] = ("pair rows (%d limbs)" % L.pgpu_batch_row_limbs(state["c"])
@@ -628,7 +628,7 @@ def headline(args, world, elapsed, per_kind, nw, pw, parallelism, dec_kernel=Non
         pmc = json.load(open(pmc_path))
     # encrypt leg: with fixed-base tables the kernel EXECUTES far fewer multiplications than the
     # canonical square-and-multiply count, so its honest ALU fraction uses the executed count
-    fbw = int(os.environ.get("PGPU_FB_WINDOW", "12"))
+    fbw = int(os.environ.get("PGPU_FB_WINDOW", "13"))
     s4096 = 2 * KEY_BITS // 32
     if fixed_base:
         nmul = (KEY_BITS // 2 + fbw - 1) // fbw + 1            # nwin-1 table products + g^m + exit
@@ -1326,7 +1326,7 @@ def run_config45(args, pa, L, B, N):
         exec_dec = dec_exec * 2 * shard
         useful_dec = decrypt_useful_mac32(nw, bits) * 2 * shard
         fb4 = fixed_base_info(L, pk)
-        enc_name, enc_per_elt, enc_note = encrypt_kernel(pk, shard, nw, bits, fb4["window"] or 12)
+        enc_name, enc_per_elt, enc_note = encrypt_kernel(pk, shard, nw, bits, fb4["window"] or 13)
         enc_ms = float(np.mean(per[K_FB]))
         pmc = {}
         pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
@@ -1597,7 +1597,7 @@ def run_ranks(args, world):
         result = headline(args, world, elapsed, per_kind, nw, pw,
                           f"one process per GPU x{world} (torch.distributed {backend}; key broadcast only)",
                           decrypt_kernel(sk, BATCH, nw, KEY_BITS),
-                      encrypt_kernel(pk, BATCH, nw, KEY_BITS, int(os.environ.get("PGPU_FB_WINDOW", "12"))))
+                      encrypt_kernel(pk, BATCH, nw, KEY_BITS, int(os.environ.get("PGPU_FB_WINDOW", "13"))))
         result["config"]["secret_exponent_policy"] = ["fixed-window", "sliding"][L.pgpu_get_secret_exponent_policy()]
         result["config"]["batches_in_flight_per_gpu"] = nfl
         result["config"]["resident_ciphertext_form"] = ("pair rows (%d limbs)" % row_limbs) if row_limbs else "Montgomery-form words"

@@ -161,10 +161,12 @@ int pgpu_paillier_encrypt_dev(const pgpu_pubkey* key, const uint64_t* d_m, size_
 
 /* DJN keys: hs is a key constant, so hs^r runs as a fixed-base product over a per-key table of
  * hs^(d*2^(w*i)) (built on the GPU at the first encrypt, no squarings afterwards).  w = 0 selects
- * the generic square-and-multiply kernel instead; default 12 (env PGPU_FB_WINDOW): 86 table products
- * for a 1024-bit r, 203 MB of table per 2048-bit key (w = 10: 103 products, 61 MB; measured on the
- * bench batch: 1.19 ms vs 1.41 ms).  Unless a window was set explicitly, a key starts with w = 8 (13 MB,
- * built in ~2 ms) and switches to the default after its first 4096 elements.  Results are identical. */
+ * the generic square-and-multiply kernel instead; default 13 (env PGPU_FB_WINDOW, 0..14): 79 table products
+ * for a 1024-bit r, 373 MB of table per 2048-bit key and GPU, built in 73 ms (w = 12: 86 products, 203 MB, 40 ms -- the
+ * default until round 4; w = 10: 103 products, 61 MB; encrypt launch of the bench batch 0.775 / 0.835 / 1.19 ms).  The
+ * table budgets (pgpu_set_fixed_base_budget) narrow the window until the table fits.  Unless a window was set
+ * explicitly, a key starts with w = 8 (13 MB, built in ~2 ms) and switches to the default after its first 4096
+ * elements.  Results are identical. */
 int pgpu_set_fixed_base_window(int w);
 /* Table memory is bounded (round 3): per key and GPU by max_bytes_per_key (default 512 MiB, env
  * PGPU_FB_KEY_MAX_BYTES: the window narrows until the table fits), per GPU over ALL keys by max_bytes_per_device

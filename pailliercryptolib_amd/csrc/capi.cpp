@@ -388,14 +388,18 @@ int make_schedule(const BigNumber& e, int w, ExpSchedule* out, bool secret) {
 
 // window width of the fixed-base table for the DJN obfuscator; PGPU_FB_WINDOW=0 selects the
 // generic (per-instance table, square-and-multiply) kernel instead.
+constexpr int kFbMaxW = 14;        // (the kernels take any width; the table budgets narrow it -- fb_fit_window)
+// 13 since round 4: 79 products for a 1024-bit r instead of 86 (encrypt launch of the bench 0.835 -> 0.775 ms, step +1 %),
+// 373 MB of table per 2048-bit key and GPU instead of 203 MB, built in 73 ms instead of 40
+constexpr int kFbDefaultW = 13;
 constexpr int kFbMaskedMaxW = 5;   // tables of windows up to this width belong to the masked product (kept beside the indexed table)
 std::atomic<int> g_fb_window{-1};
 std::atomic<bool> g_fb_window_explicit{false};   // set through the environment or pgpu_set_fixed_base_window
 int fixed_base_window() {
   if (g_fb_window.load() < 0) {
     const char* e = std::getenv("PGPU_FB_WINDOW");
-    int v = e ? std::atoi(e) : 12;
-    g_fb_window.store((v < 0 || v > 12) ? 12 : v);
+    int v = e ? std::atoi(e) : kFbDefaultW;
+    g_fb_window.store((v < 0 || v > kFbMaxW) ? kFbDefaultW : v);
     if (e) g_fb_window_explicit.store(true);
   }
   return g_fb_window.load();
@@ -2217,7 +2221,7 @@ int pgpu_decrypt_kernel_form_ex(const pgpu_privkey* key, size_t count, int busy_
 }
 
 int pgpu_set_fixed_base_window(int w) {
-  if (w < 0 || w > 12) return fail(PGPU_ERR_INVALID_PARAM, "fixed-base window must be 0..12");
+  if (w < 0 || w > kFbMaxW) return fail(PGPU_ERR_INVALID_PARAM, "fixed-base window must be 0..14");
   g_fb_window.store(w);
   g_fb_window_explicit.store(true);
   return PGPU_OK;

@@ -214,7 +214,7 @@ def test_split_form_djn_encrypt_equals_full_width(engine, hensel, fbw):
         for h in (bm, br, c, d):
             L.pgpu_batch_destroy(h)
     finally:
-        _capi.check(L.pgpu_set_fixed_base_window(12))
+        _capi.check(L.pgpu_set_fixed_base_window(13))
 
 
 @pytest.mark.parametrize("count", [37, 4200])

@@ -75,7 +75,7 @@ def test_djn_encrypt_generic_vs_fixed_base(engine, kat, fbw):
         assert pk.encrypt(m, r) == want                      # ... and regrown for the 2047-bit R_BN
         assert pk.encrypt(m[:2], r[:2]) == want[:2]          # r in {0, 1}
     finally:
-        _capi.check(_capi.lib().pgpu_set_fixed_base_window(12))   # the library default
+        _capi.check(_capi.lib().pgpu_set_fixed_base_window(13))   # the library default
 
 
 def test_seeded_fixtures(engine):
