@@ -17,6 +17,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <ostream>
+#include <cstring>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -59,6 +60,112 @@ struct LimbAllocator {
   template <class U>
   bool operator!=(const LimbAllocator<U>&) const noexcept { return false; }
 };
+// The limb container of BigNumber: the subset of std::vector<uint64_t> the arithmetic uses, over limb_alloc / limb_free, plus
+// ONE thing a vector cannot do: take over limbs that already lie in a block of the limb allocator (adopt).  Results of
+// a GPU call arrive by DMA in a pinned block laid out as such blocks (16-byte header, row, header, row, ...); their
+// BigNumbers point into it instead of copying 2-4 MB out of it (csrc/host/common.cpp: DeviceBatch::download).
+class LimbVec {
+ public:
+  using value_type = uint64_t;
+  using size_type = std::size_t;
+  using iterator = uint64_t*;
+  using const_iterator = const uint64_t*;
+  LimbVec() noexcept = default;
+  explicit LimbVec(std::size_t n, uint64_t v = 0) { grow_to(n); for (std::size_t i = 0; i < n; ++i) p_[i] = v; n_ = n; }
+  LimbVec(const LimbVec& o) { if (o.n_) { grow_to(o.n_); std::memcpy(p_, o.p_, o.n_ * sizeof(uint64_t)); n_ = o.n_; } }
+  LimbVec(LimbVec&& o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+  LimbVec& operator=(const LimbVec& o) {
+    if (this != &o) {
+      if (o.n_ > cap_) { release(); grow_to(o.n_); }
+      if (o.n_) std::memcpy(p_, o.p_, o.n_ * sizeof(uint64_t));
+      n_ = o.n_;
+    }
+    return *this;
+  }
+  LimbVec& operator=(LimbVec&& o) noexcept {
+    if (this != &o) {
+      release();
+      p_ = o.p_; n_ = o.n_; cap_ = o.cap_;
+      o.p_ = nullptr; o.n_ = o.cap_ = 0;
+    }
+    return *this;
+  }
+  ~LimbVec() { release(); }
+  // limbs[0 .. n) lie in a limb-allocator block of room for cap limbs (header in front, see limb_block_adopt)
+  static LimbVec adopt(uint64_t* limbs, std::size_t n, std::size_t cap) noexcept {
+    LimbVec v;
+    v.p_ = limbs; v.n_ = n; v.cap_ = cap;
+    return v;
+  }
+  std::size_t size() const noexcept { return n_; }
+  std::size_t capacity() const noexcept { return cap_; }
+  bool empty() const noexcept { return n_ == 0; }
+  uint64_t* data() noexcept { return p_; }
+  const uint64_t* data() const noexcept { return p_; }
+  uint64_t& operator[](std::size_t i) noexcept { return p_[i]; }
+  const uint64_t& operator[](std::size_t i) const noexcept { return p_[i]; }
+  uint64_t& back() noexcept { return p_[n_ - 1]; }
+  const uint64_t& back() const noexcept { return p_[n_ - 1]; }
+  iterator begin() noexcept { return p_; }
+  iterator end() noexcept { return p_ + n_; }
+  const_iterator begin() const noexcept { return p_; }
+  const_iterator end() const noexcept { return p_ + n_; }
+  void clear() noexcept { n_ = 0; }
+  void pop_back() noexcept { --n_; }
+  void push_back(uint64_t v) { if (n_ == cap_) reserve(cap_ ? 2 * cap_ : 4); p_[n_++] = v; }
+  void reserve(std::size_t n) {
+    if (n <= cap_) return;
+    uint64_t* q = static_cast<uint64_t*>(limb_alloc(n * sizeof(uint64_t)));
+    if (n_) std::memcpy(q, p_, n_ * sizeof(uint64_t));
+    limb_free(p_);
+    p_ = q; cap_ = n;
+  }
+  void resize(std::size_t n) {            // (new limbs are zero)
+    reserve(n);
+    for (std::size_t i = n_; i < n; ++i) p_[i] = 0;
+    n_ = n;
+  }
+  void assign(std::size_t n, uint64_t v) {
+    if (n > cap_) { release(); grow_to(n); }
+    for (std::size_t i = 0; i < n; ++i) p_[i] = v;
+    n_ = n;
+  }
+  template <class It>
+  void assign(It first, It last) {
+    const std::size_t n = (std::size_t)(last - first);
+    if (n > cap_) { release(); grow_to(n); }
+    for (std::size_t i = 0; i < n; ++i) p_[i] = (uint64_t)first[i];
+    n_ = n;
+  }
+  void swap(LimbVec& o) noexcept { std::swap(p_, o.p_); std::swap(n_, o.n_); std::swap(cap_, o.cap_); }
+  // (ordering and equality as std::vector's: lexicographic over the limbs -- a map key in mod_exp.cpp)
+  friend bool operator==(const LimbVec& a, const LimbVec& b) noexcept {
+    return a.n_ == b.n_ && (a.n_ == 0 || std::memcmp(a.p_, b.p_, a.n_ * sizeof(uint64_t)) == 0);
+  }
+  friend bool operator!=(const LimbVec& a, const LimbVec& b) noexcept { return !(a == b); }
+  friend bool operator<(const LimbVec& a, const LimbVec& b) noexcept {
+    const std::size_t n = a.n_ < b.n_ ? a.n_ : b.n_;
+    for (std::size_t i = 0; i < n; ++i)
+      if (a.p_[i] != b.p_[i]) return a.p_[i] < b.p_[i];
+    return a.n_ < b.n_;
+  }
+
+ private:
+  uint64_t* p_ = nullptr;
+  std::size_t n_ = 0, cap_ = 0;
+  void grow_to(std::size_t n) { p_ = static_cast<uint64_t*>(limb_alloc(n * sizeof(uint64_t))); cap_ = n; }   // (p_ is null)
+  void release() noexcept { limb_free(p_); p_ = nullptr; n_ = cap_ = 0; }
+};
+
+// Blocks that live in caller-provided memory (a pinned result block): `ctrl` (64 bytes, 16-aligned) becomes the control
+// structure of an arena that owns no memory itself; limb_block_adopt stamps the 16 bytes in front of `limbs` as the header
+// of a block of that arena; when the last block has been freed and the opener has closed, release(cookie) runs (once, on
+// whichever thread frees last).  limb_free / LimbVec treat such blocks like any other.
+struct LimbArenaExt;
+LimbArenaExt* limb_arena_open(void* ctrl, void (*release)(void*), void* cookie) noexcept;
+void limb_block_adopt(LimbArenaExt* a, uint64_t* limbs) noexcept;
+void limb_blocks_adopt(LimbArenaExt* a, uint64_t* first, std::size_t stride_limbs, std::size_t count) noexcept;   // rows of a batch
+void limb_arena_close(LimbArenaExt* a) noexcept;
 }  // namespace detail
 }  // namespace ipcl
 
@@ -71,7 +178,7 @@ typedef enum { IppsBigNumNEG = 0, IppsBigNumPOS = 1 } IppsBigNumSGN;
 
 class BigNumber {
  public:
-  using Limbs = std::vector<uint64_t, ipcl::detail::LimbAllocator<uint64_t>>;
+  using Limbs = ipcl::detail::LimbVec;
   BigNumber(Ipp32u value = 0);
   BigNumber(Ipp32s value);
   BigNumber(const Ipp32u* pData, int length = 1, IppsBigNumSGN sgn = IppsBigNumPOS);
@@ -152,6 +259,9 @@ class BigNumber {
   // Returns false if the magnitude does not fit.
   bool toLimbs64(uint64_t* out, std::size_t nlimbs) const;
   static BigNumber fromLimbs64(const uint64_t* limbs, std::size_t nlimbs);
+  // the same without a copy: limbs[0 .. nlimbs) lie in a block of the limb allocator with room for nlimbs
+  // (ipcl::detail::limb_block_adopt has stamped its header); leading zero limbs are trimmed
+  static BigNumber adoptLimbs64(uint64_t* limbs, std::size_t nlimbs);
   const Limbs& limbs64() const { return m_mag; }
   bool isNegative() const { return m_neg; }
   bool isZero() const { return m_mag.empty(); }

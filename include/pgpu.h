@@ -252,6 +252,10 @@ int pgpu_batch_download(const pgpu_batch* b, uint64_t* host /* [count][words] */
  * status of the download and frees the ticket.  `b` and `host` must stay alive until then.  With buffers from
  * pgpu_host_alloc this is what lets ONE thread pipeline whole host-to-host steps over two lanes (bench.py:
  * end_to_end_pipelined). */
+/* Download with the rows `host_stride` words apart (the words between rows are left alone): lets a host layer lay results
+ * out with room for its own per-row headers and use them in place (the ipcl:: layer's BigNumbers point into the pinned
+ * block).  Pinned targets, one-GPU pools, plain or pair-row batches; otherwise PGPU_ERR_UNSUPPORTED. */
+int pgpu_batch_download_strided(const pgpu_batch* b, uint64_t* host, size_t host_stride_words);
 typedef struct pgpu_ticket pgpu_ticket;
 int pgpu_batch_download_async(const pgpu_batch* b, uint64_t* host /* [count][words] */, pgpu_ticket** out);
 int pgpu_ticket_wait(pgpu_ticket* t);

@@ -30,7 +30,7 @@ SYMBOLS = [
     "pgpu_batch_ct_add", "pgpu_batch_ct_add_plain", "pgpu_batch_ct_mul",
     "pgpu_rccl_note", "pgpu_replication_stats", "pgpu_debug_corrupt_next_replica",
     "pgpu_set_fixed_base_budget", "pgpu_fixed_base_stats", "pgpu_pubkey_fixed_base_info",
-    "pgpu_batch_row_limbs", "pgpu_set_batch_lane", "pgpu_batch_lane", "pgpu_batch_download_async", "pgpu_ticket_wait",
+    "pgpu_batch_row_limbs", "pgpu_set_batch_lane", "pgpu_batch_lane", "pgpu_batch_download_async", "pgpu_ticket_wait", "pgpu_batch_download_strided",
     "pgpu_set_table_gather_policy", "pgpu_get_table_gather_policy",
     "pgpu_build_features", "pgpu_batch_lanes", "pgpu_timing_collect_ex", "pgpu_decrypt_kernel_form_ex",
     "pgpu_encrypt_kernel_form_ex", "pgpu_host_alloc", "pgpu_host_free", "pgpu_host_wait",
@@ -125,6 +125,7 @@ def lib():
     L.pgpu_batch_download.argtypes = [c_void_p, c_void_p]; L.pgpu_batch_download.restype = c_int
     L.pgpu_batch_download_async.argtypes = [c_void_p, c_void_p, POINTER(c_void_p)]; L.pgpu_batch_download_async.restype = c_int
     L.pgpu_ticket_wait.argtypes = [c_void_p]; L.pgpu_ticket_wait.restype = c_int
+    L.pgpu_batch_download_strided.argtypes = [c_void_p, c_void_p, c_size_t]; L.pgpu_batch_download_strided.restype = c_int
     L.pgpu_batch_destroy.argtypes = [c_void_p]; L.pgpu_batch_destroy.restype = None
     L.pgpu_batch_count.argtypes = [c_void_p]; L.pgpu_batch_count.restype = c_size_t
     L.pgpu_batch_words.argtypes = [c_void_p]; L.pgpu_batch_words.restype = c_int

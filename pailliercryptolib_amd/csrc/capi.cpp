@@ -1872,14 +1872,14 @@ int words_to_pair_on(rt::Device& d, const pgpu_pubkey::PubForm* f, const uint64_
 }
 // one shard: pair rows -> canonical plain words
 int pair_to_words_on(rt::Device& d, const pgpu_pubkey::PubForm* f, const uint32_t* rows, uint64_t* out, size_t count,
-                     hipStream_t s) {
+                     hipStream_t s, size_t out_stride = 0) {
   pgpu::PairOpsArgs a{};
   a.ctx = hensel_pub_view(f, d.index);
   a.full = hensel_full_view(nullptr, f, d.index, false);
   a.op = pgpu::PO_TO_WORDS;
   a.a = rows;
   a.out_words = out;
-  a.out_stride = (size_t)2 * f->n_words;
+  a.out_stride = out_stride ? out_stride : (size_t)2 * f->n_words;
   a.count = count;
   return pair_op_launch(d, f, a, s, PGPU_KERNEL_MODMUL);
 }
@@ -3149,6 +3149,36 @@ int pgpu_batch_download(const pgpu_batch* b, uint64_t* host) {
   rt::TaskGroup tg;
   download_tasks(tg, b, host, nd);
   return tg.wait();
+}
+
+// Rows land `host_stride` words apart (host_stride >= words; the words in between are not written): the ipcl:: layer lays
+// results out as blocks of its limb allocator -- a 16-byte header in front of every row -- so that the BigNumbers point
+// into the pinned block instead of copying out of it.  Pinned targets (pgpu_host_alloc) and one-GPU pools only; plain and
+// pair-row batches (others: PGPU_ERR_UNSUPPORTED, the caller takes pgpu_batch_download).
+int pgpu_batch_download_strided(const pgpu_batch* b, uint64_t* host, size_t host_stride) {
+  RC_TRY(rt::check_ready());
+  if (!b || !host) return fail(PGPU_ERR_INVALID_PARAM, "null pointer");
+  RC_TRY(check_gen(b->gen, "batch"));
+  if (host_stride < (size_t)b->words) return fail(PGPU_ERR_INVALID_PARAM, "download stride narrower than the rows");
+  const size_t span = ((b->count - 1) * host_stride + (size_t)b->words) * 8;
+  if ((b->replicated ? 1 : b->ndev) != 1 || (b->mont && !b->pair_l2) || !rt::host_is_pinned(host, span))
+    return fail(PGPU_ERR_UNSUPPORTED, "strided download: pinned target, one GPU, plain or pair-row batch");
+  rt::Device& dev = rt::device(0);
+  rt::DeviceGuard g(dev.ordinal);
+  hipStream_t s = dev.bs(b->lane);
+  rt::DevMem tmp;
+  RC_TRY(tmp.alloc(dev, s, span));
+  if (b->pair_l2) {
+    RC_TRY(pair_to_words_on(dev, b->pair_form.get(), b->prow(0), (uint64_t*)tmp.p, b->count, s, host_stride));
+  } else {
+    HIP_TRY(hipMemcpy2DAsync(tmp.p, host_stride * 8, b->ptr(0), (size_t)b->words * 8, (size_t)b->words * 8, b->count,
+                             hipMemcpyDeviceToDevice, s));
+  }
+  HIP_TRY(rt::drain_before_copy(s));
+  HIP_TRY(hipMemcpyAsync(host, tmp.p, span, hipMemcpyDeviceToHost, s));
+  hipError_t e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return fail(PGPU_ERR_HIP, std::string("device -> host copy failed: ") + hipGetErrorString(e));
+  return PGPU_OK;
 }
 
 // ---- downloads that do not hold the caller ----

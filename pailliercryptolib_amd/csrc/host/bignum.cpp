@@ -23,7 +23,10 @@ struct LimbArena {
   std::atomic<std::size_t> live;   // blocks handed out and not yet freed, + 1 while the scope that owns the arena is open
   std::size_t cap, used;           // bytes behind the header
   std::size_t room;                // bytes the allocation really has behind the header (>= cap; a recycled arena keeps its size)
+  void (*release)(void*);          // non-null: the arena lives in caller memory (limb_arena_open); called instead of free
+  void* cookie;
 };
+static_assert(sizeof(LimbArena) <= 64, "limb_arena_open: the control structure fits the 64 bytes callers reserve");
 struct LimbHeader {                // in front of every block
   LimbArena* arena;                // null: the block came from malloc
   std::size_t pad;
@@ -45,6 +48,12 @@ struct KeepGuard {
 };
 void arena_release(LimbArena* a) noexcept {
   if (a->live.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+  if (a->release) {                // caller memory: hand it back (the control structure dies with it)
+    void (*fn)(void*) = a->release;
+    void* ck = a->cookie;
+    fn(ck);
+    return;
+  }
   if (a->room >= kArenaKeepMin && a->room <= kArenaKeepMax) {
     KeepGuard g;
     for (LimbArena*& slot : g_keep)
@@ -106,11 +115,39 @@ void limb_bulk_begin(std::size_t bytes_hint) {
     if (!a) return;                 // no arena: blocks come from malloc
     a->room = cap;
   }
+  a->release = nullptr;
+  a->cookie = nullptr;
   new (&a->live) std::atomic<std::size_t>(1);
   a->cap = a->room;
   a->used = 0;
   t_arena = a;
 }
+
+struct LimbArenaExt : LimbArena {};
+
+LimbArenaExt* limb_arena_open(void* ctrl, void (*release)(void*), void* cookie) noexcept {
+  LimbArena* a = static_cast<LimbArena*>(ctrl);
+  new (&a->live) std::atomic<std::size_t>(1);   // the opener's reference (limb_arena_close drops it)
+  a->cap = a->used = a->room = 0;
+  a->release = release;
+  a->cookie = cookie;
+  return static_cast<LimbArenaExt*>(a);
+}
+void limb_block_adopt(LimbArenaExt* a, uint64_t* limbs) noexcept {
+  LimbHeader* h = reinterpret_cast<LimbHeader*>(limbs) - 1;
+  h->arena = a;
+  h->pad = 0;
+  a->live.fetch_add(1, std::memory_order_relaxed);
+}
+void limb_blocks_adopt(LimbArenaExt* a, uint64_t* first, std::size_t stride_limbs, std::size_t count) noexcept {
+  a->live.fetch_add(count, std::memory_order_relaxed);   // (one atomic for the batch; the headers are plain stores)
+  for (std::size_t i = 0; i < count; ++i) {
+    LimbHeader* h = reinterpret_cast<LimbHeader*>(first + i * stride_limbs) - 1;
+    h->arena = a;
+    h->pad = 0;
+  }
+}
+void limb_arena_close(LimbArenaExt* a) noexcept { arena_release(a); }
 
 void limb_bulk_end() noexcept {
   if (--t_bulk_depth > 0) return;
@@ -605,6 +642,14 @@ BigNumber BigNumber::fromLimbs64(const uint64_t* limbs, std::size_t nlimbs) {
   BigNumber r;
   r.m_mag.assign(limbs, limbs + nlimbs);
   r.trim();
+  return r;
+}
+
+BigNumber BigNumber::adoptLimbs64(uint64_t* limbs, std::size_t nlimbs) {
+  std::size_t n = nlimbs;
+  while (n > 0 && limbs[n - 1] == 0) --n;
+  BigNumber r;
+  r.m_mag = Limbs::adopt(limbs, n, nlimbs);   // (a zero keeps the block too: it goes back with the value)
   return r;
 }
 

@@ -418,8 +418,56 @@ std::shared_ptr<DeviceBatch> DeviceBatch::upload_values(const std::vector<BigNum
   return b;
 }
 
+namespace {
+// Results used in place: the pinned block is laid out as blocks of the limb allocator -- 64 bytes of arena control, then
+// per value a 16-byte header and its row -- the rows arrive by ONE strided download, and the BigNumbers adopt them
+// (bignum.h: LimbVec::adopt).  Nobody copies 2-4 MB out of the block; it returns to the pool when the last value that
+// points into it has died.  Pinned memory a caller may hold that way is capped (beyond it: the copying path below);
+// IPCL_ADOPT_RESULTS=0 turns it off.
+constexpr std::size_t kAdoptCtrlWords = 8, kAdoptHeaderWords = 2;
+constexpr std::size_t kAdoptCapBytes = (std::size_t)512 << 20;
+std::atomic<std::size_t> g_adopted_bytes{0};
+bool adopt_enabled() {
+  static const bool on = [] { const char* e = std::getenv("IPCL_ADOPT_RESULTS"); return !e || std::atoi(e) != 0; }();
+  return on;
+}
+struct AdoptCookie {
+  std::shared_ptr<PinnedBlock> blk;
+  std::size_t bytes;
+};
+void adopt_release(void* ck) {
+  AdoptCookie* c = static_cast<AdoptCookie*>(ck);
+  g_adopted_bytes.fetch_sub(c->bytes, std::memory_order_relaxed);
+  delete c;   // (the block goes back to the pool, or to the driver when the pool is gone)
+}
+bool download_adopting(pgpu_batch* h, std::size_t count, int words, std::vector<BigNumber>* out) {
+  const std::size_t stride = (std::size_t)words + kAdoptHeaderWords;
+  const std::size_t bytes = (kAdoptCtrlWords + count * stride) * 8;
+  if (!adopt_enabled() || g_adopted_bytes.load(std::memory_order_relaxed) + bytes > kAdoptCapBytes) return false;
+  std::shared_ptr<PinnedBlock> blk = PinnedBlock::acquire(bytes);
+  if (!blk) return false;
+  uint64_t* rows = blk->p + kAdoptCtrlWords + kAdoptHeaderWords;   // row i at rows + i * stride, its header in front
+  if (pgpu_batch_download_strided(h, rows, stride) != PGPU_OK) return false;   // (not this kind of batch / pool)
+  AdoptCookie* ck = new AdoptCookie{blk, blk->bytes};
+  g_adopted_bytes.fetch_add(ck->bytes, std::memory_order_relaxed);
+  LimbArenaExt* arena = limb_arena_open(blk->p, adopt_release, ck);
+  blk.reset();
+  std::vector<BigNumber> v;
+  v.reserve(count);
+  limb_blocks_adopt(arena, rows, stride, count);
+  for (std::size_t i = 0; i < count; ++i) v.push_back(BigNumber::adoptLimbs64(rows + i * stride, (std::size_t)words));
+  limb_arena_close(arena);
+  *out = std::move(v);
+  return true;
+}
+}  // namespace
+
 std::vector<BigNumber> DeviceBatch::download() const {
   const std::size_t bytes = count * (size_t)words * 8;
+  if (bytes >= kEagerUploadBytes) {
+    std::vector<BigNumber> v;
+    if (download_adopting(h, count, words, &v)) return v;
+  }
   // the results land in a pinned block (one DMA, no unpacking copy) and become BigNumbers whose limbs share one arena
   if (std::shared_ptr<PinnedBlock> blk = bytes >= kEagerUploadBytes ? PinnedBlock::acquire(bytes) : nullptr) {
     IPCL_GPU_CHECK(pgpu_batch_download(h, blk->p), "device download");

@@ -85,6 +85,51 @@ int main() {
       if (!(round == 2 && i == 7)) bad += v[i] != value(i + (unsigned)round, 32);
     bad += round > 2 && survivor != value(7 + 2, 32);
   }
+  // 6. values that ADOPT rows of a caller buffer (results used in place): 64 bytes of arena control, then per value a
+  //    16-byte header and its row; the release hook runs once, after the last value that points into the buffer has died
+  //    (or grown out of it), whatever thread that happens on
+  {
+    static std::atomic<int> released{0};
+    const size_t rows = 300, words = 32, stride = words + 2;
+    std::vector<uint64_t>* backing = new std::vector<uint64_t>(8 + rows * stride, 0xdeadbeefdeadbeefull);
+    uint64_t* base = backing->data();
+    for (size_t i = 0; i < rows; ++i)
+      for (size_t k = 0; k < words; ++k)
+        base[8 + 2 + i * stride + k] = (i == 5) ? 0 : (k < 1 + i % words ? 0x9e3779b97f4a7c15ull * (i + 1) + k : 0);   // ragged, one zero
+    ipcl::detail::LimbArenaExt* ar = ipcl::detail::limb_arena_open(base, [](void* ck) {
+      released++;
+      delete static_cast<std::vector<uint64_t>*>(ck);
+    }, backing);
+    std::vector<BigNumber> v(rows);
+    for (size_t i = 0; i < rows; ++i) {
+      uint64_t* row = base + 8 + 2 + i * stride;
+      ipcl::detail::limb_block_adopt(ar, row);
+      v[i] = BigNumber::adoptLimbs64(row, words);
+    }
+    ipcl::detail::limb_arena_close(ar);
+    bad += released.load() != 0;
+    for (size_t i = 0; i < rows; ++i) {
+      std::vector<uint64_t> w(words, 0);
+      for (size_t k = 0; k < words; ++k) w[k] = (i == 5) ? 0 : (k < 1 + i % words ? 0x9e3779b97f4a7c15ull * (i + 1) + k : 0);
+      bad += v[i] != BigNumber::fromLimbs64(w.data(), words);
+      bad += v[i].limbs64().size() != (i == 5 ? 0u : 1 + i % words);
+      bad += (i != 5) && v[i].limbs64().data() != base + 8 + 2 + i * stride;     // in place, not copied
+    }
+    BigNumber copy = v[7];                                   // a copy owns limbs of its own
+    bad += copy.limbs64().data() == v[7].limbs64().data();
+    BigNumber grown = std::move(v[8]);                       // a move keeps the row ...
+    bad += grown.limbs64().data() != base + 8 + 2 + 8 * stride;
+    for (int k = 0; k < 40; ++k) grown = grown * grown % (v[9] + 12345u) + v[10];   // ... arithmetic leaves it behind
+    bad += grown.isZero();
+    std::vector<std::thread> th2;
+    for (int t = 0; t < 3; ++t)
+      th2.emplace_back([&, t] {
+        for (size_t i = (size_t)t; i < rows; i += 3) v[i] = BigNumber();
+      });
+    for (auto& x : th2) x.join();
+    bad += released.load() != 1;                             // every row has been given back: the buffer is gone
+    bad += copy.isZero();                                    // (the copy outlives the buffer)
+  }
   std::printf("%s %d\n", bad ? "FAIL" : "OK", bad);
   return bad ? 1 : 0;
 }

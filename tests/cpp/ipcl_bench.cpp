@@ -49,7 +49,7 @@ static int json_mode(size_t dsize) {
   // resident chaining (the texts never become BigNumbers in between): encrypt -> CT+CT -> decrypt -> first element
   ipcl::PlainText pt(m);
   ipcl::CipherText ct2 = pk.encrypt(pt);
-  const double chain = best_us([&] { (void)sk.decrypt(pk.encrypt(pt) + ct2).getElement(0); }, 3);
+  const double chain = best_us([&] { (void)sk.decrypt(pk.encrypt(pt) + ct2).getElement(0); }, 8);   // (the first calls after new texts run slow)
   std::printf("{\"what\": \"ipcl::PublicKey::encrypt / PrivateKey::decrypt, vector<BigNumber> in and out, batch %zu\", "
               "\"encrypt_us\": %.1f, \"decrypt_us\": %.1f, \"chain_enc_add_dec_us\": %.1f, \"round_trip_ok\": %s}\n",
               dsize, enc, dec, chain, ok ? "true" : "false");
