@@ -46,20 +46,6 @@ struct LimbBulkScope {
   LimbBulkScope(const LimbBulkScope&) = delete;
   LimbBulkScope& operator=(const LimbBulkScope&) = delete;
 };
-template <class T>
-struct LimbAllocator {
-  using value_type = T;
-  using is_always_equal = std::true_type;
-  LimbAllocator() noexcept = default;
-  template <class U>
-  LimbAllocator(const LimbAllocator<U>&) noexcept {}
-  T* allocate(std::size_t n) { return static_cast<T*>(limb_alloc(n * sizeof(T))); }
-  void deallocate(T* p, std::size_t) noexcept { limb_free(p); }
-  template <class U>
-  bool operator==(const LimbAllocator<U>&) const noexcept { return true; }
-  template <class U>
-  bool operator!=(const LimbAllocator<U>&) const noexcept { return false; }
-};
 // The limb container of BigNumber: the subset of std::vector<uint64_t> the arithmetic uses, over limb_alloc / limb_free, plus
 // ONE thing a vector cannot do: take over limbs that already lie in a block of the limb allocator (adopt).  Results of
 // a GPU call arrive by DMA in a pinned block laid out as such blocks (16-byte header, row, header, row, ...); their

@@ -13,7 +13,7 @@
 
 typedef unsigned __int128 u128;
 
-// ---- limb storage (bignum.h: LimbAllocator) ----
+// ---- limb storage (bignum.h: limb_alloc / LimbVec / LimbBulkScope) ----
 #include <atomic>
 #include <new>
 namespace ipcl {

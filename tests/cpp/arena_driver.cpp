@@ -1,4 +1,4 @@
-// Test driver for the limb storage of the host BigNumber (include/ipcl/bignum.h: LimbAllocator, LimbBulkScope): blocks
+// Test driver for the limb storage of the host BigNumber (include/ipcl/bignum.h: LimbVec, LimbBulkScope): blocks
 // carved out of an arena inside a bulk scope, freed in any order and from any thread, mixed with heap blocks.
 #include <atomic>
 #include <cstdio>
