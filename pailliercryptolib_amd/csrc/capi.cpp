@@ -1932,6 +1932,7 @@ int as_word_batch(const pgpu_batch* a, const pgpu_batch** out, std::unique_ptr<p
 // fn(lane, lo, hi) handles elements [lo, hi) on lane.dev; sub_min: smallest sub-batch worth its own task
 template <class F>
 int run_sharded(size_t count, size_t sub_min, F fn) {
+  rt::note_caller();
   const int D = rt::shard_devices(count);
   rt::TaskGroup tg;
   for (int d = 0; d < D; ++d) {
@@ -2999,6 +3000,7 @@ int pgpu_batch_is_montgomery(const pgpu_batch* b) { return b && (b->mont || b->p
 
 int pgpu_batch_upload(const uint64_t* host, size_t count, int words, size_t stride, pgpu_batch** out) {
   RC_TRY(rt::check_ready());
+  rt::note_caller();
   if (!host || !out) return fail(PGPU_ERR_INVALID_PARAM, "null pointer");
   if (words <= 0 || stride < (size_t)words) return fail(PGPU_ERR_INVALID_PARAM, "stride smaller than the row width");
   std::unique_ptr<pgpu_batch> b;
@@ -3065,9 +3067,10 @@ int pgpu_batch_upload(const uint64_t* host, size_t count, int words, size_t stri
 namespace {
 // one task per shard on the pool's worker lanes: conversion kernel (if any), then the copy -- which Lane::d2h hands to the
 // copy engine only once the batch's kernels have run
-void download_tasks(rt::TaskGroup& tg, const pgpu_batch* b, uint64_t* host, int nd) {
+void download_tasks(rt::TaskGroup& tg, const pgpu_batch* b, uint64_t* host, int nd, bool async = false) {
   for (int d = 0; d < nd; ++d) {
     tg.run(rt::device(d), [=](rt::Lane& lane) -> int {
+      struct Force { bool on; Force(bool o) : on(o) { if (on) rt::force_presync(true); } ~Force() { if (on) rt::force_presync(false); } } force(async);
       size_t lo, hi;
       b->bounds(d, &lo, &hi);
       rt::Device& dev = *lane.dev;
@@ -3092,6 +3095,7 @@ void download_tasks(rt::TaskGroup& tg, const pgpu_batch* b, uint64_t* host, int 
 
 int pgpu_batch_download(const pgpu_batch* b, uint64_t* host) {
   RC_TRY(rt::check_ready());
+  rt::note_caller();
   if (!b || !host) return fail(PGPU_ERR_INVALID_PARAM, "null pointer");
   RC_TRY(check_gen(b->gen, "batch"));
   const int nd = b->replicated ? 1 : b->ndev;
@@ -3157,6 +3161,7 @@ int pgpu_batch_download(const pgpu_batch* b, uint64_t* host) {
 // pair-row batches (others: PGPU_ERR_UNSUPPORTED, the caller takes pgpu_batch_download).
 int pgpu_batch_download_strided(const pgpu_batch* b, uint64_t* host, size_t host_stride) {
   RC_TRY(rt::check_ready());
+  rt::note_caller();
   if (!b || !host) return fail(PGPU_ERR_INVALID_PARAM, "null pointer");
   RC_TRY(check_gen(b->gen, "batch"));
   if (host_stride < (size_t)b->words) return fail(PGPU_ERR_INVALID_PARAM, "download stride narrower than the rows");
@@ -3193,7 +3198,7 @@ int pgpu_batch_download_async(const pgpu_batch* b, uint64_t* host, pgpu_ticket**
   RC_TRY(check_gen(b->gen, "batch"));
   std::unique_ptr<pgpu_ticket> t(new pgpu_ticket);
   t->gen = b->gen;
-  download_tasks(t->tg, b, host, b->replicated ? 1 : b->ndev);
+  download_tasks(t->tg, b, host, b->replicated ? 1 : b->ndev, true);
   *out = t.release();
   return PGPU_OK;
 }

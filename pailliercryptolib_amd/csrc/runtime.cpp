@@ -5,6 +5,8 @@
 #include <rccl/rccl.h>   // types only: the library is dlopen'ed (replicate over xGMI), never linked
 
 #include <algorithm>
+#include <functional>
+#include <chrono>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -447,9 +449,33 @@ int ensure_stage(Lane& l) {
 // 24 us upload sat 0.9 ms behind the other's download (which was waiting for a 0.8 ms encrypt), 4.6 ms behind a decrypt;
 // the callers' kernels ended up strictly one after the other with the copies exposed in between (6.1 ms per encrypt +
 // decrypt instead of 5.4).  One host round trip (~10 us) per download.  PGPU_D2H_PRESYNC=0 turns it off.
+// The wait costs a lone caller one more host round trip per download (Add_CTCT(16) at the ipcl:: API 57 -> 67 us) and buys
+// it nothing -- its own copies are in order anyway.  So it is taken only while more than one host thread has been calling
+// into the transfer entry points (note_caller: another thread within the last 50 ms), and by the asynchronous downloads
+// (their point is that the SAME thread keeps other lanes busy meanwhile).  PGPU_D2H_PRESYNC: 0 never, 1 (default) as
+// described, 2 always.
+namespace {
+std::atomic<uint64_t> g_last_caller{0};
+std::atomic<int64_t> g_other_caller_ns{0};
+thread_local bool t_force_presync = false;
+int64_t now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+void note_caller() {
+  static thread_local const uint64_t me = std::hash<std::thread::id>()(std::this_thread::get_id()) | 1;
+  const uint64_t prev = g_last_caller.exchange(me, std::memory_order_relaxed);
+  if (prev != me && prev != 0) g_other_caller_ns.store(now_ns(), std::memory_order_relaxed);
+}
+void force_presync(bool on) { t_force_presync = on; }
 hipError_t drain_before_copy(hipStream_t s) {
-  static const bool on = [] { const char* e = std::getenv("PGPU_D2H_PRESYNC"); return !e || std::atoi(e) != 0; }();
-  return on ? hipStreamSynchronize(s) : hipSuccess;
+  static const int mode = [] { const char* e = std::getenv("PGPU_D2H_PRESYNC"); return e ? std::atoi(e) : 1; }();
+  if (mode <= 0) return hipSuccess;
+  if (mode == 1 && !t_force_presync) {
+    const int64_t other = g_other_caller_ns.load(std::memory_order_relaxed);
+    if (other == 0 || now_ns() - other > 50 * 1000000ll) return hipSuccess;
+  }
+  return hipStreamSynchronize(s);
 }
 
 // host -> device: chunk i+1 is packed into the other pinned buffer while chunk i is on the wire.  The copies

@@ -156,6 +156,8 @@ struct Device {
 
 // waits for the work queued on `s` before a device -> host copy is issued on it (runtime.cpp: why)
 hipError_t drain_before_copy(hipStream_t s);
+void note_caller();             // called by the transfer entry points on the CALLING thread (multi-caller detection)
+void force_presync(bool on);    // the calling (worker) thread's downloads always wait first (asynchronous downloads)
 
 // RAII device allocation from a Device's allocator
 struct DevMem {
