@@ -679,6 +679,19 @@ struct pgpu_batch {
     if (replicated) { *lo = 0; *hi = count; }
     else rt::shard_bounds(count, ndev, d, lo, hi);
   }
+  // Cross-lane use (lane_acquire / lane_release): per device ONE event that says "produced" -- recorded on the batch's lane
+  // the first time another lane consumes it, never again (batches are immutable), so later consumers wait on an event
+  // that has long completed -- and per consuming lane an event recorded behind its latest reader.  The batch's own lane
+  // waits for the readers only when the batch DIES (before its memory returns to that lane's allocator), not after every
+  // use: operands shared between lanes -- a cached randomness batch, a ciphertext several threads read -- no longer chain
+  // the lanes to each other (round 4: four API threads sharing injected randomness ran their kernels two at a time).
+  struct XLane {
+    hipEvent_t ready = nullptr;
+    hipEvent_t reader[rt::kBatchLanes] = {};
+  };
+  mutable std::mutex xmu;
+  mutable std::vector<XLane> xlane;    // [device], sized on first cross-lane use
+  ~pgpu_batch();
 };
 
 namespace {
@@ -743,19 +756,29 @@ int same_layout(const pgpu_batch* a, const pgpu_batch* b) {
 // the operation's first operand.  An operand of the OTHER lane is ordered in before the launch (its producer has to be
 // done) and its lane is ordered behind the launch afterwards (its memory may be recycled by that lane's allocator only
 // after this reader is done).
-std::mutex g_xlane_mu;
 int lane_acquire(rt::Device& dev, const pgpu_batch* x, int lane) {
   if (!x || x->lane == lane) return PGPU_OK;
-  std::lock_guard<std::mutex> lk(g_xlane_mu);
-  HIP_TRY(hipEventRecord(dev.xlane_ev[x->lane], dev.bs(x->lane)));
-  HIP_TRY(hipStreamWaitEvent(dev.bs(lane), dev.xlane_ev[x->lane], 0));
+  hipEvent_t ready;
+  {
+    std::lock_guard<std::mutex> lk(x->xmu);
+    if (x->xlane.size() < (size_t)rt::pool_size()) x->xlane.resize((size_t)rt::pool_size());
+    pgpu_batch::XLane& xl = x->xlane[(size_t)dev.index];
+    if (!xl.ready) {
+      HIP_TRY(hipEventCreateWithFlags(&xl.ready, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(xl.ready, dev.bs(x->lane)));   // everything queued on its lane so far: its producer among it
+    }
+    ready = xl.ready;
+  }
+  HIP_TRY(hipStreamWaitEvent(dev.bs(lane), ready, 0));
   return PGPU_OK;
 }
 int lane_release(rt::Device& dev, const pgpu_batch* x, int lane) {
   if (!x || x->lane == lane) return PGPU_OK;
-  std::lock_guard<std::mutex> lk(g_xlane_mu);
-  HIP_TRY(hipEventRecord(dev.xlane_ev[lane], dev.bs(lane)));
-  HIP_TRY(hipStreamWaitEvent(dev.bs(x->lane), dev.xlane_ev[lane], 0));
+  std::lock_guard<std::mutex> lk(x->xmu);
+  if (x->xlane.size() < (size_t)rt::pool_size()) x->xlane.resize((size_t)rt::pool_size());
+  hipEvent_t& ev = x->xlane[(size_t)dev.index].reader[lane % rt::kBatchLanes];
+  if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ev, dev.bs(lane)));   // (the batch's lane waits for it when the batch dies: ~pgpu_batch)
   return PGPU_OK;
 }
 
@@ -770,6 +793,23 @@ int lanes_order(const pgpu_batch* x, int lane, bool acquire) {
   return PGPU_OK;
 }
 
+}  // namespace
+pgpu_batch::~pgpu_batch() {
+  const bool live = gen == rt::pool_generation() && rt::initialized();
+  for (size_t d = 0; d < xlane.size(); ++d) {
+    XLane& xl = xlane[d];
+    const bool dev_ok = live && (int)d < rt::pool_size();
+    std::unique_ptr<rt::DeviceGuard> g(dev_ok ? new rt::DeviceGuard(rt::device((int)d).ordinal) : nullptr);
+    for (hipEvent_t ev : xl.reader)
+      if (ev) {
+        if (dev_ok) (void)hipStreamWaitEvent(rt::device((int)d).bs(lane), ev, 0);   // readers first, then the memory goes back
+        (void)hipEventDestroy(ev);
+      }
+    if (xl.ready) (void)hipEventDestroy(xl.ready);
+  }
+  if (!xlane.empty()) (void)hipGetLastError();
+}
+namespace {
 // ---- launch helpers on one device ----
 int modmul_on(rt::Device& d, const ModCtx& ctx, int mode, const uint64_t* a, const uint64_t* b, size_t b_stride,
               int b_words, uint64_t* out, size_t count, hipStream_t s, int view_flags = VF_NONE) {

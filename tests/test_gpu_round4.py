@@ -468,3 +468,43 @@ def test_async_download_tickets(engine, pinned):
             L.pgpu_batch_destroy(h)
         for pp in held:
             L.pgpu_host_free(pp)
+
+
+def test_shared_operand_across_lanes_and_early_destroy(engine):
+    """An operand shared by operations on other lanes (the ipcl:: layer's cached randomness, a ciphertext several threads
+    add to): consumers wait on the operand's one 'produced' event, its own lane waits for the readers only when the operand
+    is destroyed.  Here the operand is destroyed right after the readers were queued and its lane immediately reuses the
+    memory for new uploads: every reader still saw the operand (CT+CT against the oracle's product), many rounds."""
+    from oracle import paillier_oracle as orc
+    from pailliercryptolib_amd import _capi
+    L = _capi.lib()
+    p, q, hs = key_case(2048)
+    n = p * q
+    nsq = n * n
+    pk, sk = engine.PublicKey(n, 2048, hs=hs), engine.PrivateKey(p, q)
+    rng = random.Random(4242)
+    count = 3000
+    R = Res()
+    try:
+        for rnd in range(6):
+            xs = [rng.randrange(nsq) for _ in range(count)]
+            _capi.check(L.pgpu_set_batch_lane(0))
+            shared = R.up(xs, 64)                                   # lane 0
+            outs = []
+            for lane in (1, 2, 3):
+                _capi.check(L.pgpu_set_batch_lane(lane))
+                ys = [rng.randrange(nsq) for _ in range(count)]
+                by = R.up(ys, 64)                                   # lane `lane`
+                outs.append((ys, R.op(L.pgpu_batch_ct_add, pk._h, by, shared)))   # result on `lane`, reads lane 0's batch
+            L.pgpu_batch_destroy(shared)                            # readers are merely queued
+            R.live.remove(shared)
+            _capi.check(L.pgpu_set_batch_lane(0))
+            junk = [R.up([rng.randrange(nsq) for _ in range(count)], 64) for _ in range(3)]   # lane 0 recycles the memory
+            for ys, o in outs:
+                got = R.down(o)
+                idx = [0, 1, count // 2, count - 1] + [rng.randrange(count) for _ in range(12)]
+                assert [got[i] for i in idx] == [xs[i] * ys[i] % nsq for i in idx]
+            assert len(junk) == 3
+    finally:
+        L.pgpu_set_batch_lane(0)
+        R.close()
