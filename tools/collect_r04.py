@@ -133,6 +133,8 @@ if os.path.exists("gpurun_out/r04p/ipcl_api_threads.txt"):
         f.write("# pailliercryptolib_amd/ipcl_api_bench --threads T 8192 8 (tests/cpp/ipcl_bench.cpp): T host threads, each\n"
                 "# ipcl::PublicKey::encrypt + PrivateKey::decrypt with vector<BigNumber> in and out (the benchmark key: 2047-bit injected r)\n")
         f.write("".join(l for l in open("gpurun_out/r04p/ipcl_api_threads.txt") if not l.startswith("+")))
+if os.path.exists("gpurun_out/r04p/ipcl_api_threads_small.txt"):
+    shutil.copy("gpurun_out/r04p/ipcl_api_threads_small.txt", "profiles/r04_ipcl_api_threads_small.txt")
 if os.path.exists("gpurun_out/r04p/lane_decrypt.txt"):
     with open("profiles/r04_lane_decrypt.txt", "w") as f:
         f.write("# tools/run_r04_e.sh: CRT decrypt of 65536 ciphertexts under a 1024-bit key, one-lane kernel (csrc/hensel_lane.hpp, default from\n"

@@ -46,4 +46,5 @@ python tools/probe_trace.py 4 20 > $OUT/trace_4lanes.txt 2>&1
 (for w in 1 0; do for v in pageable pinned; do for c in 1 2 4; do echo "# PGPU_D2H_PRESYNC=$w  python tools/probe_two_callers.py $v $c 8"; PGPU_D2H_PRESYNC=$w python tools/probe_two_callers.py $v $c 8 2>&1 | grep -v amdgpu.ids | head -$((c+1)); done; done; done
  for v in pageable pinned; do echo "# PGPU_HOST_ADAPT=1  python tools/probe_two_callers.py $v 2 8"; PGPU_HOST_ADAPT=1 python tools/probe_two_callers.py $v 2 8 2>&1 | grep -v amdgpu.ids | head -3; done) > $OUT/two_callers.txt 2>&1
 (for t in 1 2 3 4; do ./pailliercryptolib_amd/ipcl_api_bench --threads $t 8192 8 2>&1 | grep -v amdgpu.ids; done) > $OUT/ipcl_api_threads.txt 2>&1
+(echo "# small batches, T host threads (each encrypt + decrypt through the ipcl:: API, vector in / out), 400 rounds: tests/cpp/ipcl_bench.cpp --threads T n 400"; for n in 64 700 2048; do for t in 1 2 4 8; do ./pailliercryptolib_amd/ipcl_api_bench --threads $t $n 400 2>&1 | grep -v amdgpu.ids; done; done) > $OUT/ipcl_api_threads_small.txt
 ls $OUT
