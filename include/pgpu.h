@@ -319,6 +319,7 @@ typedef enum pgpu_kernel_form {
   PGPU_FORM_PAIRED = 1,
   PGPU_FORM_SEQ = 2,
   PGPU_FORM_LANE = 4,      /* a whole exponentiation per lane (hensel_lane.hpp: 1024-bit keys, >= 32768 ciphertexts) */
+  PGPU_FORM_PS = 8,        /* with PGPU_FORM_LANE: by product scanning (hensel_ps.hpp: 2048-bit keys; round 5) */
   PGPU_FORM_CU_CLAIM = 16
 } pgpu_kernel_form;
 int pgpu_timing_collect_ex(int* kinds, int* forms, double* ms, int max_entries);
@@ -336,7 +337,10 @@ int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, i
  * resident batch (pair rows), hensel_decrypt_seq_kernel<*lanes, *limbs> -- both halves of a pair in the same *lanes
  * lanes, launches that still put a wavefront on every SIMD that way (PGPU_SEQ_DECRYPT=0 turns it off); *split = 3 (round 4):
  * hensel_decrypt_lane_kernel<*limbs> -- a whole exponentiation in ONE lane, *limbs limbs per half (1024-bit keys, launches of
- * 32768 ciphertexts or more; PGPU_LANE_DECRYPT=0 turns it off); *split = 0: the full-width modexp_kernel<Geo<*lanes, *limbs>>.
+ * 32768 ciphertexts or more; PGPU_LANE_DECRYPT=0 turns it off); *split = 4 (round 5): hensel_decrypt_ps_kernel<*limbs, 28>
+ * -- a whole exponentiation in one lane by product scanning, *limbs limbs of 28 bits per half (2048-bit keys; launches of
+ * 32768 ciphertexts or more, or smaller ones that cover the SIMDs together with busy neighbour lanes: 8192 beside three;
+ * PGPU_PS_DECRYPT=0 turns it off); *split = 0: the full-width modexp_kernel<Geo<*lanes, *limbs>>.
  * Host-side query. */
 int pgpu_decrypt_kernel_form(const pgpu_privkey* key, size_t count, int* split, int* lanes, int* limbs);
 /* ... when `busy_lanes` OTHER batch lanes of the GPU have work queued at launch time (round 4, the adaptive policy: a

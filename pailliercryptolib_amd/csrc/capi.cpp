@@ -73,17 +73,20 @@ const GeoInfo* pick_geo(int in_words, int mod_bits, bool unit_q = false) {
   return fit;
 }
 
-void to_limbs29(const BigNumber& v, int L, uint32_t* out) {
+// v as L limbs of lb bits (the kernels' 29; hensel_ps.hpp: 28 for the 2048-bit key class)
+void to_limbs(const BigNumber& v, int L, uint32_t* out, int lb) {
   const BigNumber::Limbs& w = v.limbs64();
+  const uint32_t mask = (1u << lb) - 1;
   for (int i = 0; i < L; ++i) {
-    int bit = i * pgpu::kLimbBits;
+    int bit = i * lb;
     size_t word = (size_t)bit >> 6;
     int sh = bit & 63;
     uint64_t x = word < w.size() ? w[word] >> sh : 0;
-    if (sh > 64 - pgpu::kLimbBits && word + 1 < w.size()) x |= w[word + 1] << (64 - sh);
-    out[i] = (uint32_t)x & pgpu::kLimbMask;
+    if (sh > 64 - lb && word + 1 < w.size()) x |= w[word + 1] << (64 - sh);
+    out[i] = (uint32_t)x & mask;
   }
 }
+void to_limbs29(const BigNumber& v, int L, uint32_t* out) { to_limbs(v, L, out, pgpu::kLimbBits); }
 
 BigNumber pow2(int bits) {
   std::vector<uint64_t> w((size_t)bits / 64 + 1, 0);
@@ -649,9 +652,13 @@ struct pgpu_privkey {
                                 //           | pairs pconv[pchunks] | pcb[pchunks] (L2 limbs each): entry from pair rows
     uint32_t n0inv[2] = {0, 0};
     int pair_l2 = 0, pchunk_limbs = 0, pchunks = 0;   // pair rows of this key's n^2 domain (0: none)
+    int lb = pgpu::kLimbBits;   // bits per limb of the constants (the pair ROWS are 29-bit limbs whatever this says)
     size_t side_words() const { return (size_t)H * K * (6 + 4 * (size_t)nchunks + 3 * (size_t)pchunks); }
   };
   std::vector<std::unique_ptr<HenselSet>> hs;
+  // the constants of hensel_decrypt_ps_kernel (hensel_ps.hpp: one lane per exponentiation, product scanning): H = 1,
+  // K limbs of lb bits per half (2048-bit keys: 38 x 28); null: no such kernel for this key size
+  std::unique_ptr<HenselSet> hs_ps;
   // constants of the pair rows of n^2 = (p*q)^2 -- what a public key over n holds as its pair form: word ciphertexts are
   // brought into pair rows with it when the launch then takes a kernel that reads only those (decrypt_on)
   std::shared_ptr<pgpu_pubkey::PubForm> conv_form;
@@ -1667,6 +1674,21 @@ const pgpu_privkey::HenselSet* lane_hset(const pgpu_privkey* key, size_t count) 
     if (lane_form_pays(f->H * f->K, count)) return f.get();
   return nullptr;
 }
+// the one-lane product-scanning form (csrc/hensel_ps.hpp; 2048-bit keys) for a decrypt of `count` resident ciphertexts?
+// 64 exponentiations per wavefront: 8192 ciphertexts are 256 wavefronts -- a quarter of the SIMDs.  PGPU_PS_DECRYPT:
+// 0 never; 1 (default) launches that put a wavefront on every SIMD that way (32768 ciphertexts), or -- adaptive, like the
+// sequential-halves form -- do so together with the busy neighbour lanes: waves * (1 + busy) >= SIMDs (16384 ciphertexts
+// beside one busy lane, 8192 beside three); 2 whenever it is compiled (tests)
+std::atomic<int> g_ps_policy{[] {
+  const char* e = std::getenv("PGPU_PS_DECRYPT");
+  return e ? std::max(0, std::min(2, std::atoi(e))) : 1;
+}()};
+bool ps_form_pays(const pgpu_privkey* key, size_t count, int busy) {
+  if (!key->hs_ps || !hensel_enabled()) return false;
+  const size_t waves = 2 * ((count + 63) / 64);
+  const int pol = g_ps_policy.load();
+  return pol == 2 || (pol == 1 && (waves >= kSimds || seq_adaptive(waves, busy)));
+}
 int words_to_pair_on(rt::Device& d, const pgpu_pubkey::PubForm* f, const uint64_t* words, size_t stride, int nwords,
                      bool src_mont, uint32_t* out, size_t count, hipStream_t s);
 int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m, size_t count,
@@ -1690,7 +1712,8 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
     if (!cand) cand = hset;
     const int cl2 = key->conv_form->H * key->conv_form->K;
     if (cand->pair_l2 == cl2 &&
-        (lane_form_pays(cand->H * cand->K, count) || seq_form_pays(cand->H, cand->K, count, busy_lanes))) {
+        (lane_form_pays(cand->H * cand->K, count) || seq_form_pays(cand->H, cand->K, count, busy_lanes) ||
+         ps_form_pays(key, count, busy_lanes))) {
       RC_TRY(conv_rows.alloc(d, s, count * (size_t)2 * cl2 * sizeof(uint32_t)));
       RC_TRY(words_to_pair_on(d, key->conv_form.get(), d_c, (size_t)2 * nw, 2 * nw, in_mont, (uint32_t*)conv_rows.p, count, s));
       d_pair = (const uint32_t*)conv_rows.p;
@@ -1699,6 +1722,9 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
   }
   if (d_pair && !sliding && hset)
     if (const pgpu_privkey::HenselSet* ls = lane_hset(key, count)) hset = ls;
+  const bool psf = d_pair && !sliding && hset && ab_policy() == 0 && ps_form_pays(key, count, busy_lanes) &&
+                   key->hs_ps->pair_l2 == in_pair_l2;
+  if (psf) hset = key->hs_ps.get();
   if (d_pair && (!hset || hset->pair_l2 != in_pair_l2))
     return fail(PGPU_ERR_UNSUPPORTED, "decrypt: pair-row ciphertexts need the split-form kernel of this key size");
   if (hset) {
@@ -1764,10 +1790,21 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
                     (ab_policy() == 1 || ab_policy() == 3 || (ab_policy() == 2 && other_lane_busy));   // 3: always, four pairs per workgroup
     const size_t seq_ipw = 64 / (size_t)hset->H;
     const size_t seq_waves = 2 * ((count + seq_ipw - 1) / seq_ipw);
-    const bool lanef = !ab && d_pair && !sliding && lane_form_pays(L2, count);
-    const bool seq = !lanef && !ab && d_pair && !sliding && seq_form_pays(hset->H, hset->K, count, busy_lanes);
-    t.set_form(lanef ? PGPU_FORM_LANE : seq ? PGPU_FORM_SEQ : (ab ? PGPU_FORM_PAIRED | 64 : PGPU_FORM_PAIRED));
-    if (lanef) {
+    const bool lanef = !psf && !ab && d_pair && !sliding && lane_form_pays(L2, count);
+    const bool seq = !psf && !lanef && !ab && d_pair && !sliding && seq_form_pays(hset->H, hset->K, count, busy_lanes);
+    t.set_form(psf ? PGPU_FORM_LANE | PGPU_FORM_PS : lanef ? PGPU_FORM_LANE : seq ? PGPU_FORM_SEQ : (ab ? PGPU_FORM_PAIRED | 64 : PGPU_FORM_PAIRED));
+    if (psf) {
+      const size_t lwaves = 2 * ((count + 63) / 64);
+      const unsigned lblocks = (unsigned)((lwaves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
+      RC_TRY(w.table.ensure((size_t)lblocks * pgpu::kWavesPerWG * pgpu::hensel_ps_table_words(hset->K, entries) * sizeof(uint32_t), s));
+      h.table = (uint32_t*)w.table.p;
+      // a part-chip launch beside busy neighbour lanes claims whole CUs (one workgroup per CU: the launches of the lanes
+      // spread over the chip, one wavefront per SIMD each)
+      const unsigned lds_pad = adaptive_cu_claim(lwaves, busy_lanes);
+      if (lds_pad) t.set_form(PGPU_FORM_LANE | PGPU_FORM_PS | PGPU_FORM_CU_CLAIM);
+      if (!pgpu::launch_hensel_ps(hset->K, hset->lb, h, lblocks, s, lds_pad))
+        return fail(PGPU_ERR_UNSUPPORTED, "one-lane product-scanning decrypt kernel not compiled");
+    } else if (lanef) {
       const size_t lwaves = 2 * ((count + 63) / 64);
       const unsigned lblocks = (unsigned)((lwaves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
       RC_TRY(w.table.ensure((size_t)lblocks * pgpu::kWavesPerWG * 64 * entries * 2 * L2 * sizeof(uint32_t), s));
@@ -2236,6 +2273,13 @@ int pgpu_decrypt_kernel_form_ex(const pgpu_privkey* key, size_t count, int busy_
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_decrypt_kernel_form: bad argument");
   RC_TRY(check_gen(key->gen, "key"));
   if (const pgpu_privkey::HenselSet* f = pick_hensel(key, count)) {
+    if (pair_rows_enabled() && secret_policy() != PGPU_EXP_SLIDING && ab_policy() == 0 && ps_form_pays(key, count, busy_lanes) &&
+        key->hs_ps->pair_l2 == f->pair_l2) {
+      *split = 4;
+      *lanes = 1;
+      *limbs = key->hs_ps->K;
+      return PGPU_OK;
+    }
     if (pair_rows_enabled() && secret_policy() != PGPU_EXP_SLIDING && ab_policy() == 0)
       if (const pgpu_privkey::HenselSet* ls = lane_hset(key, count)) {
         *split = 3;
@@ -2303,6 +2347,9 @@ int pgpu_debug_set_host_adapt(int on) {
 }
 int pgpu_debug_get_seq_decrypt(void) { return g_seq_policy.load(); }
 void pgpu_debug_set_lane_decrypt(int policy) { g_lane_policy.store(policy < 0 ? 0 : (policy > 2 ? 2 : policy)); }
+// tests / A-B measurements: hensel_ps.hpp (0 never, 1 by launch size and neighbour lanes, 2 whenever it is compiled)
+void pgpu_debug_set_ps_decrypt(int policy) { g_ps_policy.store(policy < 0 ? 0 : (policy > 2 ? 2 : policy)); }
+int pgpu_debug_get_ps_decrypt(void) { return g_ps_policy.load(); }
 void pgpu_debug_set_adaptive(int enc_seq, int claim_busy) {
   g_adapt_enc_seq.store(enc_seq);
   g_adapt_claim_busy.store(claim_busy);
@@ -2731,25 +2778,31 @@ int pair_l2_for_modulus(const BigNumber& n, int* H_out = nullptr, int* K_out = n
 }
 
 int build_hensel_set(pgpu_privkey* k, pgpu_privkey::HenselSet* hs, int H, int K, const BigNumber& p,
-                     const BigNumber& q, const BigNumber& hp, const BigNumber& hq) {
+                     const BigNumber& q, const BigNumber& hp, const BigNumber& hq, int lb = pgpu::kLimbBits) {
+  // lb: bits per limb of the constants (R = 2^(lb*L2), P = prime * (-prime^-1 mod 2^lb)); the pair rows this set reads are
+  // rows of 29-bit limbs in any case
   const int L2 = H * K;
+  const uint32_t lmask = (1u << lb) - 1;
+  auto to_limbs29 = [lb](const BigNumber& v, int L, uint32_t* out) { to_limbs(v, L, out, lb); };   // (shadows the 29-bit one)
+  hs->lb = lb;
   const int bits_lo = std::min(p.BitSize(), q.BitSize());
   // a ciphertext enters in chunks z < 2^(64*cw) <= 2P (P >= prime > 2^(bits-1))
   const int cw = std::min(k->pq_words, bits_lo / 64);
   if (cw <= 0) return PGPU_OK;   // (leaves hs->H == 0: no split form for this key)
   const int ct_words = 2 * k->n_words;
   const int nch = (ct_words + cw - 1) / cw;
-  const BigNumber R = pow2(L2 * pgpu::kLimbBits);
+  const BigNumber R = pow2(L2 * lb);
   hs->H = H;
   hs->K = K;
   hs->chunk_words = cw;
   hs->nchunks = nch;
   // entry from pair rows of the n^2 domain: the a part in chunks of at most L2 limbs (so that a chunk fits the lanes of
-  // one half), evenly sized
+  // one half), evenly sized; with narrower limbs: as many 29-bit row limbs as fit a half with two bits to spare
   const BigNumber nmod = p * q;
   hs->pair_l2 = pair_l2_for_modulus(nmod);
   if (hs->pair_l2) {
-    hs->pchunks = (hs->pair_l2 + L2 - 1) / L2;
+    const int fit = lb == pgpu::kLimbBits ? L2 : (L2 * lb - 2) / pgpu::kLimbBits;
+    hs->pchunks = (hs->pair_l2 + fit - 1) / fit;
     hs->pchunk_limbs = (hs->pair_l2 + hs->pchunks - 1) / hs->pchunks;
   }
   uint32_t kn = 0;   // Pn = n * kn == -1 mod 2^29
@@ -2762,9 +2815,9 @@ int build_hensel_set(pgpu_privkey* k, pgpu_privkey::HenselSet* hs, int H, int K,
   std::vector<uint32_t> h(2 * side_words, 0);
   for (int sd = 0; sd < 2; ++sd) {
     const BigNumber& pr = sd ? q : p;
-    uint32_t n0 = (uint32_t)(pr.limbs64()[0] & pgpu::kLimbMask), inv = n0;
+    uint32_t n0 = (uint32_t)(pr.limbs64()[0] & lmask), inv = n0;
     for (int i = 0; i < 5; ++i) inv *= 2u - n0 * inv;
-    const uint32_t n0inv = (0u - inv) & pgpu::kLimbMask;
+    const uint32_t n0inv = (0u - inv) & lmask;
     const BigNumber P = pr * BigNumber((Ipp32u)n0inv);
     const BigNumber P2 = P * P;
     uint32_t* b = h.data() + sd * side_words;
@@ -2826,6 +2879,18 @@ int build_hensel(pgpu_privkey* k, const BigNumber& p, const BigNumber& q, const 
     int H = 0, K = 0;
     const BigNumber n = p * q;
     if (pair_l2_for_modulus(n, &H, &K)) RC_TRY(make_pub_form(n, k->n_words, k->nsq_rbits, H, K, &k->conv_form));
+  }
+  // one lane per exponentiation, product scanning (hensel_ps.hpp): K limbs of lb bits per half, R = 2^(lb*K) >= 256 * P,
+  // P = prime * k < 2^(bits + lb).  Reads pair rows only.
+  if (!k->hs.empty() && k->hs.front()->pair_l2) {
+    const int bits = std::max(p.BitSize(), q.BitSize());
+    for (int lb : {28})
+      for (int K = 1; K <= 40 && !k->hs_ps; ++K)
+        if (pgpu::hensel_ps_has(K, lb) && lb * K >= bits + lb + 8 && lb * (K - 1) < bits + lb + 8) {
+          std::unique_ptr<pgpu_privkey::HenselSet> set(new pgpu_privkey::HenselSet);
+          RC_TRY(build_hensel_set(k, set.get(), 1, K, p, q, hp, hq, lb));
+          if (set->H && set->pair_l2) k->hs_ps = std::move(set);
+        }
   }
   return PGPU_OK;
 }

@@ -6,12 +6,15 @@
 #if defined(PGPU_PART) && PGPU_PART == 30
 #include "hensel_lane.hpp"   // whole exponentiations in one lane (1024-bit keys, large batches)
 #endif
+#if defined(PGPU_PART) && PGPU_PART == 31
+#include "hensel_ps.hpp"     // whole exponentiations in one lane by product scanning (2048-bit keys; round 5)
+#endif
 #if defined(PGPU_PART) && PGPU_PART == 15
 #include "hensel_ab.hpp"   // the A/B-wavefront experiment: built only with PGPU_BUILD_AB=1
 #endif
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..30"
+#error "compile with -DPGPU_PART=0..31"
 #endif
 
 namespace pgpu {
@@ -217,6 +220,21 @@ bool launch_hensel_lane_part30(int K, const HenselArgs& a, unsigned blocks, hipS
   }
   return false;
 }
+#elif PGPU_PART == 31
+// lds_pad: whole-CU claim (launch_hensel_seq); one_per_simd: the launch runs one wavefront per SIMD by construction
+bool launch_hensel_ps_part31(int K, int lb, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad) {
+  if (K == 38 && lb == 28) {
+    if (lds_pad) {
+      static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_ps_kernel<38, 28, 2>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (once != hipSuccess) return false;
+    }
+    hipLaunchKernelGGL((hensel_decrypt_ps_kernel<38, 28, 2>), dim3(blocks), dim3(kWGThreads), lds_pad, s, a);
+    return true;
+  }
+  return false;
+}
+size_t hensel_ps_table_words(int K, size_t entries) { return K == 38 ? ps_table_words<38>(entries) : 0; }
 #elif PGPU_PART == 15
 bool launch_hensel_ab_part15(int K, int pairs_per_wg, const HenselArgs& a, unsigned blocks, hipStream_t s) {
   if (K == 19 && pairs_per_wg == 2) {

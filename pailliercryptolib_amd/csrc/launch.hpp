@@ -172,6 +172,15 @@ inline bool launch_hensel_lane(int L2, const HenselArgs& a, unsigned blocks, hip
   return launch_hensel_lane_part30(L2, a, blocks, s);
 }
 
+// CRT decrypt with a whole exponentiation per lane by product scanning (hensel_ps.hpp; k_hensel.hip part 31): pair-row
+// ciphertexts, fixed-window scan, constants in limbs of `lb` bits: K = 38 limbs of 28 bits (2048-bit keys)
+inline bool hensel_ps_has(int K, int lb) { return K == 38 && lb == 28; }
+bool launch_hensel_ps_part31(int K, int lb, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
+inline bool launch_hensel_ps(int K, int lb, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad = 0) {
+  return launch_hensel_ps_part31(K, lb, a, blocks, s, lds_pad);
+}
+size_t hensel_ps_table_words(int K, size_t entries);   // 32-bit words of window table per wavefront
+
 // per-element bases modulo n^2 in the same form (k_hensel.hip part 18): resident pair rows in and out, fixed window
 // (4,18): 2048-bit keys, (8,14): 3072 (part 26), (2,19): 1024 (part 28)
 inline bool hensel_modexp_seq_has(int G, int K) { return (G == 4 && K == 18) || (G == 8 && K == 14) || (G == 2 && K == 19); }
