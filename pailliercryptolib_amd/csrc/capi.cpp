@@ -1447,7 +1447,12 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
       if (seq) {
         // a part-chip launch beside busy neighbour lanes claims whole CUs, like the decrypt it feeds (decrypt_on)
         const size_t seq_waves = (count + ipw - 1) / ipw;
-        const unsigned lds_pad = adaptive_cu_claim(seq_waves, busy_lanes);
+        // beside ONE busy lane: one workgroup per CU, half the chip each (round 4).  Beside two or three (round 5): the
+        // workgroup owns 80 000 bytes in all -- two of them share a CU (two wavefronts per SIMD on a quarter of the chip),
+        // but none fits beside a neighbour's decrypt workgroup (84 000 bytes claimed): an encrypt wavefront that shares a
+        // SIMD with an older decrypt wavefront only gets the issue slots that one leaves (measured: 0.8 -> 10 ms)
+        unsigned lds_pad = adaptive_cu_claim(seq_waves, busy_lanes);
+        if (lds_pad && busy_lanes >= 2) lds_pad = pgpu::kLdsTotalFlag | 80000u;
         if (lds_pad) t.set_form(PGPU_FORM_SEQ | PGPU_FORM_CU_CLAIM);
         if (!pgpu::launch_hensel_fb_encrypt_seq(form->H, form->K, f, blocks, s, lds_pad))
           return fail(PGPU_ERR_UNSUPPORTED, "sequential-halves fixed-base kernel not compiled");
@@ -1582,7 +1587,7 @@ int seq_policy_by_size() {
 // chip -- the step goes 4.92 -> 4.87 ms; with three the paired full-chip encrypt hides better under the neighbours'
 // decrypts, 4.72 against 4.87 ms; without the claim its 512 wavefronts stack onto a neighbour's CUs: 0.79 -> 1.7 ms), and
 // up to how many busy neighbours a part-chip launch claims whole CUs
-std::atomic<int> g_adapt_enc_seq{[] { const char* e = std::getenv("PGPU_ADAPT_ENC_SEQ"); return e ? std::atoi(e) : 1; }()};
+std::atomic<int> g_adapt_enc_seq{[] { const char* e = std::getenv("PGPU_ADAPT_ENC_SEQ"); return e ? std::atoi(e) : 3; }()};
 std::atomic<int> g_adapt_claim_busy{[] { const char* e = std::getenv("PGPU_ADAPT_CLAIM_BUSY"); return e ? std::atoi(e) : 3; }()};
 // with `busy` other batch lanes at work, does a launch of `waves` wavefronts of a sequential-halves form fill its share?
 bool seq_adaptive(size_t waves, int busy) {

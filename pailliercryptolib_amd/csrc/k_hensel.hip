@@ -144,14 +144,26 @@ bool launch_pair_mul_seq_part19(int G, int K, const PairOpsArgs& a, unsigned blo
 #elif PGPU_PART == 20
 bool launch_hensel_fb_encrypt_seq_part20(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad) {
   if (G == 4 && K == 18) {
-    if (lds_pad) {   // (whole-CU claim of a part-chip launch beside a busy neighbour lane, as launch_hensel_seq)
-      // (the kernel's own ~45 KB of LDS + the 84 000-byte claim fit a CU's 160 KB once, not twice; a 128 KB allowance
+    // lds_pad: whole-CU claim of a part-chip launch beside busy neighbour lanes, as launch_hensel_seq.  With
+    // kLdsTotalFlag set the rest of the value is what the workgroup shall own IN ALL (its own LDS included): the claim
+    // that lets two of these workgroups share a CU but keeps them off the CUs of a neighbour lane's decrypt
+    unsigned dyn = lds_pad;
+    if (lds_pad & kLdsTotalFlag) {
+      static const unsigned own = [] {
+        hipFuncAttributes fa{};
+        return hipFuncGetAttributes(&fa, (const void*)hensel_fb_encrypt_seq_kernel<4, 18>) == hipSuccess ? (unsigned)fa.sharedSizeBytes : 0u;
+      }();
+      const unsigned total = lds_pad & ~kLdsTotalFlag;
+      dyn = own && total > own ? total - own : 0;
+    }
+    if (dyn) {
+      // (the kernel's own ~57 KB of LDS + the 84 000-byte claim fit a CU's 160 KB once, not twice; a 128 KB allowance
       // on top of the static part would exceed the CU and the attribute call fails)
       static const hipError_t once = hipFuncSetAttribute((const void*)hensel_fb_encrypt_seq_kernel<4, 18>,
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
       if (once != hipSuccess) return false;
     }
-    hipLaunchKernelGGL((hensel_fb_encrypt_seq_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), lds_pad, s, a);
+    hipLaunchKernelGGL((hensel_fb_encrypt_seq_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), dyn, s, a);
     return true;
   }
   return false;
@@ -224,12 +236,16 @@ bool launch_hensel_lane_part30(int K, const HenselArgs& a, unsigned blocks, hipS
 // lds_pad: whole-CU claim (launch_hensel_seq); one_per_simd: the launch runs one wavefront per SIMD by construction
 bool launch_hensel_ps_part31(int K, int lb, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad) {
   if (K == 38 && lb == 28) {
-    if (lds_pad) {
+    // lds_pad asks for that many bytes of LDS per workgroup in all (more than half a CU's: one workgroup per CU); the
+    // kernel's own parking area (40 KB) counts towards it
+    constexpr unsigned kStatic = sizeof(uint4) * kWavesPerWG * ((38 + 3) / 4) * kWave;
+    const unsigned dyn = lds_pad > kStatic ? lds_pad - kStatic : 0;
+    if (dyn) {
       static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_ps_kernel<38, 28, 2>,
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
       if (once != hipSuccess) return false;
     }
-    hipLaunchKernelGGL((hensel_decrypt_ps_kernel<38, 28, 2>), dim3(blocks), dim3(kWGThreads), lds_pad, s, a);
+    hipLaunchKernelGGL((hensel_decrypt_ps_kernel<38, 28, 2>), dim3(blocks), dim3(kWGThreads), dyn, s, a);
     return true;
   }
   return false;

@@ -205,7 +205,9 @@ inline bool hensel_fb_encrypt_seq_has(int G, int K) { return (G == 4 && K == 18)
 bool launch_hensel_fb_encrypt_seq_part28(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
 bool launch_hensel_fb_encrypt_seq_part20(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
 bool launch_hensel_fb_encrypt_seq_part21(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s);
-// lds_pad: whole-CU claim (see launch_hensel_seq); honoured by the (4,18) form, the one the adaptive policy uses part-chip
+// lds_pad: whole-CU claim (see launch_hensel_seq); honoured by the (4,18) form, the one the adaptive policy uses part-chip.
+// kLdsTotalFlag | bytes: the workgroup owns `bytes` of LDS in all (its static part included)
+constexpr unsigned kLdsTotalFlag = 0x80000000u;
 inline bool launch_hensel_fb_encrypt_seq(int G, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad = 0) {
   return launch_hensel_fb_encrypt_seq_part20(G, K, a, blocks, s, lds_pad) || launch_hensel_fb_encrypt_seq_part21(G, K, a, blocks, s) ||
          launch_hensel_fb_encrypt_seq_part28(G, K, a, blocks, s);

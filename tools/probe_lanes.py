@@ -16,6 +16,7 @@ ap.add_argument("--count", type=int, default=8192)
 ap.add_argument("--lanes", type=int, nargs="*", default=[1, 2, 3, 4])
 ap.add_argument("--enc-seq", type=int, default=None)
 ap.add_argument("--claim-busy", type=int, default=None)
+ap.add_argument("--ps", type=int, default=None, help="PGPU_PS_DECRYPT policy (hensel_ps.hpp): 0 never, 1 adaptive, 2 always")
 args = ap.parse_args()
 pa.initialize(0)
 L = _capi.lib()
@@ -23,7 +24,9 @@ if args.policy is not None:
     L.pgpu_debug_set_seq_decrypt(args.policy)
 if args.enc_seq is not None or args.claim_busy is not None:
     L.pgpu_debug_set_adaptive(args.enc_seq or 0, 3 if args.claim_busy is None else args.claim_busy)
-print("enc_seq", args.enc_seq, "claim_busy", args.claim_busy)
+if args.ps is not None:
+    L.pgpu_debug_set_ps_decrypt(args.ps)
+print("ps policy", args.ps, "enc_seq", args.enc_seq, "claim_busy", args.claim_busy)
 k = json.load(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "iso_kat.json")))
 p, q, hs = int(k["p"], 16), int(k["q"], 16), int(k["bench_hs"], 16)
 n = p * q
