@@ -120,11 +120,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
                     help="2: BASELINE configs[1]+[2] (default, the headline); 4 / 5: configs[3] / configs[4]")
-    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
+    ap.add_argument("--in-flight", type=int, default=4, choices=[1, 2, 3, 4],
                     help="resident batches in flight per GPU: consecutive steps rotate over that many of the library's "
-                         "four batch lanes (default 2: each lane then owns half the chip, and a 20-step run is as fast as a "
-                         "long one; 4 sustains ~4 %% more over seconds but needs ~10 steps to fall out of lock-step: "
-                         "batches_in_flight_sweep in the line)")
+                         "four batch lanes (default 4 since round 5: each lane then owns a QUARTER of the chip -- the decrypt "
+                         "runs the one-lane product-scanning kernel, 256 wavefronts on 64 CUs, the encrypt two workgroups per "
+                         "CU on the same quarter; 2: each lane owns half the chip with the sequential-halves kernels, the "
+                         "round-4 headline: batches_in_flight_sweep in the line has every k)")
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="length of the sustained-rate run behind the timed region (N = 1; 0 skips it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -200,6 +201,14 @@ def run_pool(args):
         if torch is not None and torch.cuda.is_available():
             torch.cuda.synchronize()
 
+    # Priming (set-up, like the key's tables): two untimed steps on every batch lane, so that each lane has run the kernel
+    # forms of the steady state once -- the adaptive policy picks a lane's form from what its neighbours are doing, and the
+    # very first launches of a process see idle neighbours -- and owns its window-table workspace (a first launch in a new
+    # form is a hipMallocAsync of ~170 MB: milliseconds of host time).  Then the W warm-up steps of the contract.
+    priming = 2 * nfl if nfl > 1 else 0
+    for _ in range(priming):
+        step()
+    sync_all()
     for _ in range(max(args.warmup, nfl)):
         step()
     sync_all()
@@ -216,7 +225,8 @@ def run_pool(args):
     t_issue = time.perf_counter() - t0          # the calling thread has queued every launch of the timed region
     sync_all()
     elapsed = time.perf_counter() - t0
-    timed_forms = collect_forms(L, 8 * args.steps + 64)
+    timed_trace = collect_trace(L, 8 * args.steps + 64)
+    timed_forms = [(k, f, ms) for k, f, ms, _, _ in timed_trace]
     single_ms = None
     if nfl == 1:
         per_kind = forms_to_kinds(timed_forms)
@@ -279,6 +289,7 @@ def run_pool(args):
                       encrypt_kernel(pk, BATCH, nw, KEY_BITS, fb["window"] or int(os.environ.get("PGPU_FB_WINDOW", "13"))), fb)
     result["config"]["secret_exponent_policy"] = ["fixed-window", "sliding"][L.pgpu_get_secret_exponent_policy()]
     result["config"]["batches_in_flight_per_gpu"] = nfl
+    result["config"]["lane_priming_steps"] = priming
     result["config"]["resident_ciphertext_form"] = ("pair rows (%d limbs)" % L.pgpu_batch_row_limbs(state["c"])
                                                     if L.pgpu_batch_row_limbs(state["c"]) else "Montgomery-form words")
     r = result["roofline"]
@@ -288,6 +299,12 @@ def run_pool(args):
                         "lane idling through another's products); executed - useful = slots the paired kernel spends on "
                         "products nobody needs")
     result["kernel_forms_in_timed_region"] = forms_summary(timed_forms)
+    if N == 1 and len(timed_trace) <= 400:
+        kn = {K_MODEXP: "dec", K_CRT: "crt", K_FB: "enc"}
+        result["timed_region_trace"] = {
+            "what": "every launch of the timed region on GPU 0: [batch lane, kernel, form bits, start ms, duration ms] from the "
+                    "library's HIP events (pgpu_timing_collect_trace); start is relative to the first launch",
+            "launches": [[ln, kn.get(k, k), f, round(st, 3), round(ms, 3)] for k, f, ms, ln, st in timed_trace]}
     result["host_issue_ms_per_step"] = round(t_issue / args.steps * 1e3, 4)
     result["host_issue_note"] = ("time the ONE calling thread spends queueing a step's launches over the %d pool entries (3 launches "
                                  "+ allocations per GPU and step); %.1f %% of a step" % (N, 100 * t_issue / elapsed))
@@ -309,10 +326,15 @@ def run_pool(args):
         if dec_timed:
             top = max({f for f, _ in dec_timed}, key=lambda f: sum(1 for g, _ in dec_timed if g == f))
             ms_top = float(np.mean([ms for f, ms in dec_timed if f == top]))
-            name, per_exp = decrypt_kernel(sk, BATCH, nw, KEY_BITS, 1 if top & 2 else 0)
+            name, per_exp = decrypt_kernel(sk, BATCH, nw, KEY_BITS, busy_for_form(top))
             # CU claim: 128 workgroups on 128 of the 256 CUs -- with TWO lanes a launch holds its half from its first
-            # wavefront to its last; with more lanes a launch also waits for a free half inside its event span
-            share = 0.5 if (top == 18 and nfl == 2) else None
+            # wavefront to its last; with more lanes a launch also waits for a free half inside its event span.  The one-lane
+            # product-scanning kernel is 64 workgroups: with FOUR lanes each launch holds a quarter of the chip
+            share = 0.5 if (top == 18 and nfl == 2) else (0.25 if (top == 28 and nfl == 4) else None)
+            if top & 8:
+                r["useful_mac32_per_launch"] = per_exp * 2 * BATCH
+                r["useful_note"] = ("the one-lane product-scanning kernel executes only products the split form needs (and takes "
+                                    "q*n_0 of every reduction column as a shift): executed = useful")
             r["kernel"] = (f"{name} ({FORM_NAMES.get(top, top)}; CRT-decrypt leg: {2 * BATCH} half-width modexps per launch; "
                            f"{sum(1 for g, _ in dec_timed if g == top)} of the {len(dec_timed)} decrypt launches of the timed region)")
             r["executed_mac32_per_launch"] = per_exp * 2 * BATCH
@@ -334,8 +356,9 @@ def run_pool(args):
                 r["frac"] = sig(per_exp * 2 * BATCH / (ms_top * 1e-3) / 1e12 / (PEAK_TMAC32 * share))
                 r["frac_useful"] = sig(r["useful_mac32_per_launch"] / (ms_top * 1e-3) / 1e12 / (PEAK_TMAC32 * share))
                 r["frac_basis"] = ("EXECUTED multiply-accumulates per launch / HIP-event duration of the launch / (peak x chip_share): "
-                                   "the launch holds 128 of the 256 CUs (one workgroup per CU by its LDS claim) while the neighbour "
-                                   "lane's launches use the rest; whole-chip accounting of the same leg: roofline.measured_in_flight")
+                                   "the launch holds %d of the 256 CUs (one workgroup per CU by its LDS claim) while the neighbour "
+                                   "lanes' launches use the rest; whole-chip accounting of the same leg: roofline.measured_in_flight"
+                                   % int(256 * share))
             elif "decrypt_leg" in measured:
                 r["achieved"] = sig(measured["decrypt_leg"]["executed_mac32"] / (measured["decrypt_leg"]["wall_ms"] * 1e-3) / 1e12, 3)
                 r["frac"] = measured["decrypt_leg"]["frac_executed"]
@@ -347,6 +370,26 @@ def run_pool(args):
                 r[kk] = sig(r["canonical_mac32_per_launch"] / (ms_top * 1e-3) / 1e12 / (PEAK_TMAC32 * (share or 1.0))) if share else None
     if "decrypt_leg" in measured:
         r["measured_in_flight"] = measured["decrypt_leg"]
+        r["chip_ms_per_launch"] = measured["decrypt_leg"]["ms_per_launch"]
+        r["chip_ms_note"] = ("chip time one 8192-ciphertext decrypt costs under the overlap of the timed region (decrypt-only run on "
+                             "the same lanes: wall / launches); kernel_ms is the HIP-event span of ONE launch on its share of the chip")
+    # executed multiply-accumulates of ALL kernels of a step / ms_per_step / peak: the utilisation of the whole step, by
+    # the forms that ran in the timed region
+    try:
+        enc_timed = [f for k, f, _ in timed_forms if k == K_FB]
+        enc_top = max(set(enc_timed), key=enc_timed.count) if enc_timed else 0
+        dec_timed2 = [f for k, f, _ in timed_forms if k == K_MODEXP]
+        dec_top = max(set(dec_timed2), key=dec_timed2.count) if dec_timed2 else 0
+        enc_nm, enc_per_elt, _ = encrypt_kernel(pk, BATCH, nw, KEY_BITS, fb["window"] or 13, 1 if enc_top & 2 else 0)
+        dec_per_exp = decrypt_kernel(sk, BATCH, nw, KEY_BITS, busy_for_form(dec_top))[1]
+        step_exec = dec_per_exp * 2 * BATCH + enc_per_elt * BATCH
+        r["step_executed_mac32"] = step_exec
+        r["step_executed_frac"] = sig(step_exec / (elapsed / args.steps / N) / 1e12 / PEAK_TMAC32)
+        r["step_executed_note"] = ("executed multiply-accumulates of the decrypt (%s) and encrypt (%s) launches of one step / "
+                                   "ms_per_step / peak; the CRT kernel's are not counted" % (FORM_NAMES.get(dec_top, dec_top), enc_nm))
+    except Exception as e:                                  # noqa: BLE001
+        r["step_executed_frac"] = None
+        r["step_executed_note"] = repr(e)[:200]
     if "sustained" in measured:
         result["sustained"] = measured["sustained"]
     result["pool"] = per_gpu
@@ -356,6 +399,15 @@ def run_pool(args):
             result.update(extras(pa, L, B, pk, sk, n, p, q, hs, m_host, r_host, per_kind))
         except Exception as e:                              # noqa: BLE001
             result["extras_error"] = repr(e)[:400]
+        # the API-visible call (SURVEY 8d's timed region: H2D + kernels + D2H inside the call) next to the resident value
+        av = {k: result[k] for k in ("end_to_end", "end_to_end_pinned", "end_to_end_two_callers", "end_to_end_two_callers_pinned",
+                                     "end_to_end_pipelined", "end_to_end_pipelined_4_lanes", "api_level") if k in result}
+        if av:
+            av["what"] = ("co-headline: the same step as a caller sees it -- inputs in host memory before the call, results in host "
+                          "memory after it.  end_to_end*: the C-ABI host-pointer entry points (one synchronous caller / two / one "
+                          "thread pipelining over the batch lanes); api_level: ipcl::PublicKey::encrypt + PrivateKey::decrypt with "
+                          "std::vector<BigNumber> in and out.  `value` is the device-resident rate")
+            result["api_visible"] = av
     if N == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(n, p, q, hs, m_host, r_host)
@@ -368,7 +420,22 @@ def run_pool(args):
     print(json.dumps(result), flush=True)              # the ONE JSON line, last thing on stdout
 
 
-FORM_NAMES = {0: "full-width", 1: "paired", 2: "sequential-halves", 18: "sequential-halves+cu-claim", 65: "a/b-wavefronts"}
+FORM_NAMES = {0: "full-width", 1: "paired", 2: "sequential-halves", 18: "sequential-halves+cu-claim", 65: "a/b-wavefronts",
+              4: "one-lane", 12: "one-lane product-scanning", 28: "one-lane product-scanning+cu-claim"}
+
+
+def busy_for_form(form):
+    """the busy_lanes argument under which pgpu_decrypt_kernel_form_ex names the kernel a recorded form bit pattern ran"""
+    return 3 if form & 8 else (1 if form & 2 else 0)
+
+
+def collect_trace(L, cap):
+    """[(kind, form, ms, lane, start_ms)] of the recorded launches of pool entry 0, in launch order: the library's own
+    kernel trace (HIP events on the launch streams; start relative to the first recorded launch)"""
+    kinds, forms, lanes = (ctypes.c_int * cap)(), (ctypes.c_int * cap)(), (ctypes.c_int * cap)()
+    start, dur = (ctypes.c_double * cap)(), (ctypes.c_double * cap)()
+    n = L.pgpu_timing_collect_trace(kinds, forms, lanes, start, dur, cap)
+    return [(kinds[i], forms[i], dur[i], lanes[i], start[i]) for i in range(n)]
 
 
 def collect_forms(L, cap):
@@ -423,10 +490,11 @@ def decrypt_leg_in_flight(L, B, sk, cts, nfl, nw, launches_per_lane=6):
             L.pgpu_batch_destroy(o)
     dec = [(f, ms) for kind, f, ms in rec if kind == K_MODEXP]
     executed = 0
+    useful = 0
     for f, _ in dec:
-        busy = 1 if f & 2 else 0
-        executed += decrypt_kernel(sk, BATCH, nw, KEY_BITS, busy)[1] * 2 * BATCH
-    useful = decrypt_useful_mac32(nw, KEY_BITS) * 2 * BATCH * len(dec)
+        ex = decrypt_kernel(sk, BATCH, nw, KEY_BITS, busy_for_form(f))[1] * 2 * BATCH
+        executed += ex
+        useful += ex if f & 8 else decrypt_useful_mac32(nw, KEY_BITS) * 2 * BATCH
     per_launch = wall / max(1, len(dec))
     return {"what": "decrypt-only steps (exponentiation + CRT kernel) on the %d batch lanes of the timed region, %d launches; "
                     "wall time / launches = chip time per 8192-ciphertext decrypt under that overlap" % (nfl, len(dec)),
@@ -493,6 +561,14 @@ def decrypt_kernel(sk, count, nw, key_bits, busy_lanes=0):
     e = key_bits // 2
     if not split.value:
         return f"modexp_kernel<Geo<{lanes.value},{limbs.value}>>", algorithmic_mac32(key_bits, e)
+    if split.value == 4:       # a whole exponentiation per lane by product scanning (csrc/hensel_ps.hpp): per squaring
+        # a*a with its symmetry, 2ab, and two reductions of L2 (L2 - 1) products (q*n_0 is a shift); a general product
+        # 3 L2^2 + 2 L2 (L2 - 1); the entry runs one single and one pair product per chunk, the exit the same
+        l2 = limbs.value
+        red = l2 * (l2 - 1)
+        nmul = (e + 4) // 5 + 30 + 2 + 1
+        return (f"hensel_decrypt_ps_kernel<{l2},28>", e * (l2 * (l2 + 1) // 2 + l2 * l2 + 2 * red) + nmul * (3 * l2 * l2 + 2 * red)
+                + 3 * (l2 * l2 + red))
     if split.value == 3:       # a whole exponentiation per lane (csrc/hensel_lane.hpp): the useful count IS what it executes
         l2 = limbs.value
         nmul = (e + 4) // 5 + 30 + (2 * nw + e // 64 - 1) // (e // 64) + 2
@@ -570,7 +646,7 @@ def modexp_n2_kernel(pk, count, per_element_exponents=False):
     return f"modexp_kernel<Geo<{lanes.value},{limbs.value}>>"
 
 
-def encrypt_kernel(pk, count, nw, key_bits, fbw):
+def encrypt_kernel(pk, count, nw, key_bits, fbw, busy_lanes=0):
     """(name, executed MAC32 per element, note) of the fixed-base DJN encrypt kernel: full-width products (2 s^2 + s,
     s = 4096/32) or pair products of the split form (6 L2^2 limb products each issued; 5 L2^2 with both halves of a
     residue in the same lanes), plus the exit: onto a pair row two half-width products (4 L2^2), back to full-width words
@@ -578,7 +654,7 @@ def encrypt_kernel(pk, count, nw, key_bits, fbw):
     from pailliercryptolib_amd import _capi
     L = _capi.lib()
     split, lanes, limbs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    _capi.check(L.pgpu_encrypt_kernel_form(pk._h, nw, count, ctypes.byref(split), ctypes.byref(lanes), ctypes.byref(limbs)))
+    _capi.check(L.pgpu_encrypt_kernel_form_ex(pk._h, nw, count, busy_lanes, ctypes.byref(split), ctypes.byref(lanes), ctypes.byref(limbs)))
     nprod = (key_bits // 2 + fbw - 1) // fbw - 1           # table products
     s = 2 * key_bits // 32
     if not split.value:
@@ -925,7 +1001,7 @@ def extras(pa, L, B, pk, sk, n, p, q, hs, m_host, r_host, per_kind):
             raise RuntimeError("masked fixed-base encrypt differs from the indexed one")
         out["masked_fixed_base_encrypt"] = {"what": "pgpu_set_table_gather_policy(1) on the DJN encrypt of the batch: hs^r as 255 products "
                                                     "over a 4-bit-window table, all 16 entries of a window read and the wanted one selected "
-                                                    "(address stream independent of r), vs 85 products addressed by the digits of r; "
+                                                    "(address stream independent of r), vs 78 products (w = 13) addressed by the digits of r; "
                                                     "call time incl. launch and synchronise, results identical",
                                             "encrypt_ms_masked": round(tem * 1e3, 3), "encrypt_ms_indexed": round(tei * 1e3, 3)}
         B.free(hold3.get("o"), c3, bm3, br3)
@@ -1556,6 +1632,9 @@ def run_ranks(args, world):
         dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(2 * nfl if nfl > 1 else 0):      # priming, as in run_pool: every lane reaches its steady-state forms
+        step()
+    sync_all()
     for _ in range(max(args.warmup, nfl)):
         step()
     sync_all()
@@ -1605,8 +1684,9 @@ def run_ranks(args, world):
         result["config"]["batches_in_flight_per_gpu"] = nfl
         result["config"]["resident_ciphertext_form"] = ("pair rows (%d limbs)" % row_limbs) if row_limbs else "Montgomery-form words"
         if nfl == 2:
-            result["config"]["workload"] += ("; TWO batches in flight per GPU: consecutive steps alternate between the "
-                                             "library's two batch lanes (streams), exactly K steps timed")
+            result["config"]["workload"] += ("; %d batches in flight per GPU: consecutive steps rotate over %d of the "
+                                             "library's batch lanes (streams), exactly K steps timed" % (nfl, nfl))
+            result["config"]["lane_priming_steps"] = 2 * nfl
         print(json.dumps(result), flush=True)
     B.free(*state["c"], *state["out"], *[h for pair in sets for h in pair])
     dist.barrier()
@@ -1704,7 +1784,7 @@ def cpu_baseline(n, p, q, hs, m_host, r_host):
     return {"value": legs[best]["value"], "unit": "modexps/s", "cores": threads, "kind": "port",
             "encrypt_like_for_like": best == "ifma_fixed_base",
             "encrypt_note": "legs.ifma_fixed_base computes hs^r as the GPU step does -- a fixed-base product over a per-key table "
-                            "built outside the timed region (CPU: w = 8, 127 products; GPU: w = 12, 85 products); the other legs "
+                            "built outside the timed region (CPU: w = 8, 127 products; GPU: w = 13, 78 products); the other legs "
                             "square-and-multiply it (1259 products per element) as the reference's ippMBModExp does",
             "sample": f"{legs[best]['elements']} elements (the same batch, from its start, repeated if shorter than the "
                       f"time target), encrypt + CRT decrypt "

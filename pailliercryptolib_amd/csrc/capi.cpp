@@ -1788,8 +1788,8 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
     h.count = count;
     const size_t waves = 2 * ((count + ipw - 1) / ipw);
     const unsigned blocks = (unsigned)((waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
-    RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * ipw * entries * 2 * L2 * sizeof(uint32_t), s));
-    h.table = (uint32_t*)w.table.p;
+    // (the window-table workspace is sized by the form that runs: one allocation per launch at most -- a growing
+    // workspace is a hipMallocAsync of a few hundred MB, milliseconds of host time when the pool has to go to the driver)
     TimerScope t(d, s, PGPU_KERNEL_MODEXP);
     const bool ab = d_pair && !sliding && hset->H == 2 && pgpu::hensel_ab_has(hset->K) && count >= 2048 &&
                     (ab_policy() == 1 || ab_policy() == 3 || (ab_policy() == 2 && other_lane_busy));   // 3: always, four pairs per workgroup
@@ -1840,8 +1840,12 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
       RC_TRY(w.table.ensure((size_t)ab_blocks * ppw * 32 * entries * 2 * L2 * sizeof(uint32_t), s));
       h.table = (uint32_t*)w.table.p;
       if (!pgpu::launch_hensel_ab(hset->K, ppw, h, ab_blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "A/B decrypt kernel not compiled");
-    } else if (!pgpu::launch_hensel(hset->H, hset->K, waves > kSimds || g_packed_decrypt.load(), h, blocks, s))
-      return fail(PGPU_ERR_UNSUPPORTED, "split-form kernel not compiled");
+    } else {
+      RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * ipw * entries * 2 * L2 * sizeof(uint32_t), s));
+      h.table = (uint32_t*)w.table.p;
+      if (!pgpu::launch_hensel(hset->H, hset->K, waves > kSimds || g_packed_decrypt.load(), h, blocks, s))
+        return fail(PGPU_ERR_UNSUPPORTED, "split-form kernel not compiled");
+    }
     HIP_TRY(hipGetLastError());
     t.stop();
     have_m = true;
