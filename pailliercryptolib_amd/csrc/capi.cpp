@@ -1900,7 +1900,10 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
   c.out_words = nw;
   c.count = count;
   TimerScope tc(d, s, PGPU_KERNEL_CRT);
-  if (!pgpu::launch_crt(key->geo_crt.G, key->geo_crt.K, c, blocks_for(count, key->geo_crt), s))
+  // beside two or three busy neighbour lanes (each lane owns a quarter of the chip) the recombination stays on the CUs its
+  // decrypt has just left: 80 000 bytes per workgroup, as the encrypt of that mode (encrypt_on)
+  const unsigned crt_claim = (busy_lanes >= 2 && adaptive_cu_claim(1, busy_lanes)) ? 80000u : 0u;
+  if (!pgpu::launch_crt(key->geo_crt.G, key->geo_crt.K, c, blocks_for(count, key->geo_crt), s, crt_claim))
     return fail(PGPU_ERR_UNSUPPORTED, "crt kernel geometry not compiled");
   HIP_TRY(hipGetLastError());
   tc.stop();

@@ -29,6 +29,12 @@
 
 #include "hensel.hpp"
 
+// which multiply-accumulate chains are pinned to the carry of the column below (ps_mac_pinned): 0 none, 1 the q*n chain of
+// symmetric columns (default), 2 every chain (A/B, tools/build_variant.py)
+#ifndef PGPU_PS_PIN
+#define PGPU_PS_PIN 1
+#endif
+
 namespace pgpu {
 
 template <int LB>
@@ -53,6 +59,14 @@ __device__ __forceinline__ uint32_t ps_uniform(uint32_t v) { return (uint32_t)__
 
 // acc += x * y  (one v_mad_u64_u32)
 __device__ __forceinline__ void ps_mac(uint64_t& acc, uint32_t x, uint32_t y) { acc += (uint64_t)x * y; }
+// ... as a link of a chain the optimiser must leave in this order: the (empty) second use of the partial sum keeps the
+// sum of the column from being re-associated.  Left alone the compiler builds every chain from zero and adds the carry of
+// the column below last -- right for latency, but one 64-bit add more per column; a column that has a second chain anyway
+// (the cross products of a squaring, joined by the shift-and-add that doubles them) pins the first one to the carry.
+__device__ __forceinline__ void ps_mac_pinned(uint64_t& acc, uint32_t x, uint32_t y) {
+  acc += (uint64_t)x * y;
+  asm volatile("" ::"v"(acc));
+}
 
 // One Montgomery product by product scanning, everything in this lane:
 //   r = (x1*y1 [+ x2*y2] [+ qio as a number]) * R^-1 mod n      (lazy; canonical limbs in and out)
@@ -82,7 +96,8 @@ __device__ __forceinline__ void ps_montmul(uint32_t (&r)[K], const uint32_t (&x1
       if constexpr (ihi > ilo) {
         ps_static_for<ihi - ilo>([&](auto ic) __attribute__((always_inline)) {
           constexpr int i = ilo + decltype(ic)::value;
-          ps_mac(acc, q[i], (UNITQ && col - i == 1) ? n1p : n[col - i]);
+          if constexpr (PGPU_PS_PIN == 2 || (PGPU_PS_PIN == 1 && SYM)) ps_mac_pinned(acc, q[i], (UNITQ && col - i == 1) ? n1p : n[col - i]);
+          else ps_mac(acc, q[i], (UNITQ && col - i == 1) ? n1p : n[col - i]);
         });
       }
     }
@@ -104,8 +119,13 @@ __device__ __forceinline__ void ps_montmul(uint32_t (&r)[K], const uint32_t (&x1
       constexpr int ihi = col < K ? col + 1 : K;
       ps_static_for<ihi - ilo>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = ilo + decltype(ic)::value;
-        ps_mac(acc, x1[i], y1[col - i]);
-        if constexpr (NP == 2) ps_mac(acc, x2[i], y2[col - i]);
+        if constexpr (PGPU_PS_PIN == 2) {
+          ps_mac_pinned(acc, x1[i], y1[col - i]);
+          if constexpr (NP == 2) ps_mac_pinned(acc, x2[i], y2[col - i]);
+        } else {
+          ps_mac(acc, x1[i], y1[col - i]);
+          if constexpr (NP == 2) ps_mac(acc, x2[i], y2[col - i]);
+        }
       });
     }
     if constexpr (col < K) {

@@ -18,8 +18,25 @@ bool launch_modmul(int G, int K, const ModmulArgs& a, unsigned blocks, hipStream
   PGPU_FOR_GEOS(PGPU_ONE_MODMUL)
   return false;
 }
-#define PGPU_ONE_CRT(g, k) PGPU_ONE(crt_kernel, g, k)
-bool launch_crt(int G, int K, const CrtArgs& a, unsigned blocks, hipStream_t s) {
+// lds_total: bytes of LDS a workgroup shall own in all (0: what it needs) -- the claim that keeps the recombination of a
+// batch lane on the CUs its decrypt has just left instead of squeezed beside the neighbour lanes' decrypt wavefronts
+// (capi.cpp: decrypt_on; launch_hensel_fb_encrypt_seq has the same claim)
+#define PGPU_ONE_CRT(g, k)                                                                                        \
+  if (G == g && K == k) {                                                                                         \
+    unsigned dyn = 0;                                                                                             \
+    if (lds_total) {                                                                                              \
+      static const unsigned own = [] {                                                                            \
+        hipFuncAttributes fa{};                                                                                   \
+        return hipFuncGetAttributes(&fa, (const void*)crt_kernel<Geo<g, k>>) == hipSuccess ? (unsigned)fa.sharedSizeBytes : ~0u; \
+      }();                                                                                                        \
+      static const hipError_t once = hipFuncSetAttribute((const void*)crt_kernel<Geo<g, k>>,                      \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);  \
+      if (own != ~0u && once == hipSuccess && lds_total > own) dyn = lds_total - own;                             \
+    }                                                                                                             \
+    hipLaunchKernelGGL((crt_kernel<Geo<g, k>>), dim3(blocks), dim3(kWGThreads), dyn, s, a);                       \
+    return true;                                                                                                  \
+  }
+bool launch_crt(int G, int K, const CrtArgs& a, unsigned blocks, hipStream_t s, unsigned lds_total) {
   PGPU_FOR_GEOS(PGPU_ONE_CRT)
   return false;
 }

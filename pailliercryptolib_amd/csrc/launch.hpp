@@ -214,7 +214,7 @@ inline bool launch_hensel_fb_encrypt_seq(int G, int K, const HenselFbArgs& a, un
 }
 
 bool launch_modmul(int G, int K, const ModmulArgs& a, unsigned blocks, hipStream_t s);
-bool launch_crt(int G, int K, const CrtArgs& a, unsigned blocks, hipStream_t s);
+bool launch_crt(int G, int K, const CrtArgs& a, unsigned blocks, hipStream_t s, unsigned lds_total = 0);
 bool launch_fb_build(int G, int K, const FixedBaseBuildArgs& a, unsigned blocks, hipStream_t s);
 bool launch_fb_encrypt(int G, int K, const FixedBaseArgs& a, unsigned blocks, hipStream_t s);
 
