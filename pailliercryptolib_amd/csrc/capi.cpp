@@ -1603,8 +1603,15 @@ unsigned adaptive_cu_claim(size_t waves, int busy_lanes) {
 // in one mode: right after a synchronisation every lane is empty for a moment, and a policy that only looked at the
 // queues would start each burst with a full-chip launch that the next lane's half-chip launch then has to share CUs
 // with (measured: ~7 ms lost at the head of a 20-step run, 5.31 instead of 4.95 ms per step).  Also stamps `lane`.
+// PGPU_RR_ADAPT = k > 0 (round 5; default 3): threads on ROUND-ROBIN lanes (synchronous callers of the ipcl:: API side by
+// side) enter the adaptive policy as well, but only when at least k other lanes are active -- with all four lanes busy each
+// caller's launches take a quarter of the chip (the one-lane decrypt, 17 ms per encrypt + decrypt instead of 5.4 on the whole
+// chip, four of them side by side), which pays although every caller's quarter idles through its copies and host work;
+// with one busy neighbour (half-chip forms) it does not (r04: 11.8 against 7.2 ms per pair).  0: lone-caller forms always.
+std::atomic<int> g_rr_adapt{[] { const char* e = std::getenv("PGPU_RR_ADAPT"); return e ? std::max(0, std::atoi(e)) : 3; }()};
 int busy_other_lanes(rt::Device& dev, int lane, bool force = false) {
-  if (!force && !t_lane_explicit) return 0;   // (synchronous callers on round-robin lanes: lone-caller forms, no stamp)
+  const int rr_min = (!force && !t_lane_explicit) ? g_rr_adapt.load() : 1;
+  if (rr_min <= 0) return 0;   // (synchronous callers on round-robin lanes: lone-caller forms, no stamp)
   static const int64_t window_ns = [] {
     const char* e = std::getenv("PGPU_LANE_ACTIVE_MS");
     return (int64_t)(e ? std::max(0, std::atoi(e)) : 50) * 1000000;
@@ -1618,7 +1625,7 @@ int busy_other_lanes(rt::Device& dev, int lane, bool force = false) {
     if ((fed != 0 && now - fed < window_ns) || hipStreamQuery(dev.bs(k)) == hipErrorNotReady) ++busy;
   }
   (void)hipGetLastError();
-  return busy;
+  return busy >= rr_min ? busy : 0;
 }
 std::atomic<int> g_ab_policy{[] {
   const char* e = std::getenv("PGPU_AB_DECRYPT");
@@ -2362,6 +2369,8 @@ void pgpu_debug_set_lane_decrypt(int policy) { g_lane_policy.store(policy < 0 ? 
 // tests / A-B measurements: hensel_ps.hpp (0 never, 1 by launch size and neighbour lanes, 2 whenever it is compiled)
 void pgpu_debug_set_ps_decrypt(int policy) { g_ps_policy.store(policy < 0 ? 0 : (policy > 2 ? 2 : policy)); }
 int pgpu_debug_get_ps_decrypt(void) { return g_ps_policy.load(); }
+// tests / A-B measurements: from how many active neighbour lanes on threads on round-robin lanes take the adaptive forms (0 never)
+int pgpu_debug_set_rr_adapt(int min_busy) { return g_rr_adapt.exchange(min_busy < 0 ? 0 : min_busy); }
 void pgpu_debug_set_adaptive(int enc_seq, int claim_busy) {
   g_adapt_enc_seq.store(enc_seq);
   g_adapt_claim_busy.store(claim_busy);

@@ -102,11 +102,11 @@ bool PGPU_PO_NAME(int H, int K, const PairOpsArgs& a, unsigned blocks, hipStream
 #elif PGPU_PART == 16
 bool launch_hensel_seq_part16(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad) {
   if (G == 4 && K == 14) {
-    if (lds_pad) {
-      static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_seq_kernel<4, 14>,
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      if (once != hipSuccess) return false;
-    }
+    // (set at the FIRST launch of the kernel, whatever that launch asks for: a thread that changes the attribute while
+    // another thread launches the same function races inside the HIP runtime -- seen as a segfault with four API threads)
+    static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_seq_kernel<4, 14>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (lds_pad && once != hipSuccess) return false;
     hipLaunchKernelGGL((hensel_decrypt_seq_kernel<4, 14>), dim3(blocks), dim3(kWGThreads), lds_pad, s, a);
     return true;
   }
@@ -115,11 +115,11 @@ bool launch_hensel_seq_part16(int G, int K, const HenselArgs& a, unsigned blocks
 #elif PGPU_PART == 17
 bool launch_hensel_seq_part17(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad) {
   if (G == 2 && K == 19) {
-    if (lds_pad) {
-      static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_seq_kernel<2, 19>,
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      if (once != hipSuccess) return false;
-    }
+    // (set at the FIRST launch of the kernel, whatever that launch asks for: a thread that changes the attribute while
+    // another thread launches the same function races inside the HIP runtime -- seen as a segfault with four API threads)
+    static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_seq_kernel<2, 19>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (lds_pad && once != hipSuccess) return false;
     hipLaunchKernelGGL((hensel_decrypt_seq_kernel<2, 19>), dim3(blocks), dim3(kWGThreads), lds_pad, s, a);
     return true;
   }
@@ -148,21 +148,20 @@ bool launch_hensel_fb_encrypt_seq_part20(int G, int K, const HenselFbArgs& a, un
     // kLdsTotalFlag set the rest of the value is what the workgroup shall own IN ALL (its own LDS included): the claim
     // that lets two of these workgroups share a CU but keeps them off the CUs of a neighbour lane's decrypt
     unsigned dyn = lds_pad;
+    static const unsigned own = [] {
+      hipFuncAttributes fa{};
+      return hipFuncGetAttributes(&fa, (const void*)hensel_fb_encrypt_seq_kernel<4, 18>) == hipSuccess ? (unsigned)fa.sharedSizeBytes : 0u;
+    }();
     if (lds_pad & kLdsTotalFlag) {
-      static const unsigned own = [] {
-        hipFuncAttributes fa{};
-        return hipFuncGetAttributes(&fa, (const void*)hensel_fb_encrypt_seq_kernel<4, 18>) == hipSuccess ? (unsigned)fa.sharedSizeBytes : 0u;
-      }();
       const unsigned total = lds_pad & ~kLdsTotalFlag;
       dyn = own && total > own ? total - own : 0;
     }
-    if (dyn) {
-      // (the kernel's own ~57 KB of LDS + the 84 000-byte claim fit a CU's 160 KB once, not twice; a 128 KB allowance
-      // on top of the static part would exceed the CU and the attribute call fails)
-      static const hipError_t once = hipFuncSetAttribute((const void*)hensel_fb_encrypt_seq_kernel<4, 18>,
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      if (once != hipSuccess) return false;
-    }
+    // (the kernel's own ~57 KB of LDS + the 84 000-byte claim fit a CU's 160 KB once, not twice; a 128 KB allowance
+    // on top of the static part would exceed the CU and the attribute call fails.  Set at the first launch, whatever it
+    // asks for: see launch_hensel_seq_part16)
+    static const hipError_t once = hipFuncSetAttribute((const void*)hensel_fb_encrypt_seq_kernel<4, 18>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (dyn && once != hipSuccess) return false;
     hipLaunchKernelGGL((hensel_fb_encrypt_seq_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), dyn, s, a);
     return true;
   }
@@ -214,11 +213,11 @@ bool launch_hensel_fb_encrypt_seq_part28(int G, int K, const HenselFbArgs& a, un
 #elif PGPU_PART == 29
 bool launch_hensel_seq_part29(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad) {
   if (G == 2 && K == 10) {
-    if (lds_pad) {
-      static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_seq_kernel<2, 10>,
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      if (once != hipSuccess) return false;
-    }
+    // (set at the FIRST launch of the kernel, whatever that launch asks for: a thread that changes the attribute while
+    // another thread launches the same function races inside the HIP runtime -- seen as a segfault with four API threads)
+    static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_seq_kernel<2, 10>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (lds_pad && once != hipSuccess) return false;
     hipLaunchKernelGGL((hensel_decrypt_seq_kernel<2, 10>), dim3(blocks), dim3(kWGThreads), lds_pad, s, a);
     return true;
   }
@@ -240,11 +239,9 @@ bool launch_hensel_ps_part31(int K, int lb, const HenselArgs& a, unsigned blocks
     // kernel's own parking area (40 KB) counts towards it
     constexpr unsigned kStatic = sizeof(uint4) * kWavesPerWG * ((38 + 3) / 4) * kWave;
     const unsigned dyn = lds_pad > kStatic ? lds_pad - kStatic : 0;
-    if (dyn) {
-      static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_ps_kernel<38, 28, 2>,
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      if (once != hipSuccess) return false;
-    }
+    static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_ps_kernel<38, 28, 2>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // (first launch: see part 16)
+    if (dyn && once != hipSuccess) return false;
     hipLaunchKernelGGL((hensel_decrypt_ps_kernel<38, 28, 2>), dim3(blocks), dim3(kWGThreads), dyn, s, a);
     return true;
   }

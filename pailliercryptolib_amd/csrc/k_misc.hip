@@ -23,16 +23,16 @@ bool launch_modmul(int G, int K, const ModmulArgs& a, unsigned blocks, hipStream
 // (capi.cpp: decrypt_on; launch_hensel_fb_encrypt_seq has the same claim)
 #define PGPU_ONE_CRT(g, k)                                                                                        \
   if (G == g && K == k) {                                                                                         \
+    /* (both at the FIRST launch of the instantiation, whatever it asks for: changing a function's attributes while  \
+       another thread launches it races inside the HIP runtime) */                                                  \
+    static const unsigned own = [] {                                                                              \
+      hipFuncAttributes fa{};                                                                                     \
+      return hipFuncGetAttributes(&fa, (const void*)crt_kernel<Geo<g, k>>) == hipSuccess ? (unsigned)fa.sharedSizeBytes : ~0u; \
+    }();                                                                                                          \
+    static const hipError_t once = hipFuncSetAttribute((const void*)crt_kernel<Geo<g, k>>,                        \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);    \
     unsigned dyn = 0;                                                                                             \
-    if (lds_total) {                                                                                              \
-      static const unsigned own = [] {                                                                            \
-        hipFuncAttributes fa{};                                                                                   \
-        return hipFuncGetAttributes(&fa, (const void*)crt_kernel<Geo<g, k>>) == hipSuccess ? (unsigned)fa.sharedSizeBytes : ~0u; \
-      }();                                                                                                        \
-      static const hipError_t once = hipFuncSetAttribute((const void*)crt_kernel<Geo<g, k>>,                      \
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);  \
-      if (own != ~0u && once == hipSuccess && lds_total > own) dyn = lds_total - own;                             \
-    }                                                                                                             \
+    if (lds_total && own != ~0u && once == hipSuccess && lds_total > own) dyn = lds_total - own;                  \
     hipLaunchKernelGGL((crt_kernel<Geo<g, k>>), dim3(blocks), dim3(kWGThreads), dyn, s, a);                       \
     return true;                                                                                                  \
   }
