@@ -88,6 +88,9 @@ class BaseText {
   // device copy with exactly `words` 64-bit limbs per element (uploaded and cached on demand);
   // values that are negative / too wide are reduced mod *reduce_mod (else: error)
   std::shared_ptr<detail::DeviceBatch> deviceBatch(int words, const BigNumber* reduce_mod = nullptr) const;
+  // the values as an operand no wider than max_words: the resident copy when it fits (no host round trip), otherwise a
+  // batch of the values reduced modulo *reduce_mod (over-wide plaintexts: (n*m + 1) % n^2 only depends on m mod n)
+  std::shared_ptr<detail::DeviceBatch> operandBatch(int max_words, const BigNumber* reduce_mod) const;
   int maxBitsHint() const;      // exact for host values, 64*words for device-only values
 
   friend class PublicKey;

@@ -252,10 +252,16 @@ int pgpu_batch_download(const pgpu_batch* b, uint64_t* host /* [count][words] */
  * status of the download and frees the ticket.  `b` and `host` must stay alive until then.  With buffers from
  * pgpu_host_alloc this is what lets ONE thread pipeline whole host-to-host steps over two lanes (bench.py:
  * end_to_end_pipelined). */
-/* Download with the rows `host_stride` words apart (the words between rows are left alone): lets a host layer lay results
- * out with room for its own per-row headers and use them in place (the ipcl:: layer's BigNumbers point into the pinned
- * block).  Pinned targets, one-GPU pools, plain or pair-row batches; otherwise PGPU_ERR_UNSUPPORTED. */
+/* Download with the rows `host_stride` words apart (the words between rows are overwritten with ZEROS -- write per-row
+ * headers after the call): lets a host layer lay results out with room for its own per-row headers and use them in place
+ * (the ipcl:: layer's BigNumbers point into the pinned block).  Pinned targets, one-GPU pools, plain or pair-row batches;
+ * otherwise PGPU_ERR_UNSUPPORTED. */
 int pgpu_batch_download_strided(const pgpu_batch* b, uint64_t* host, size_t host_stride_words);
+/* 1: the batch belongs to the device pool that is up now; 0: its pool has been shut down (pgpu_shutdown, also followed by
+ * a new pgpu_init*): every operation refuses it, only pgpu_batch_destroy takes it.  Lets a host layer that caches device
+ * copies of caller data (the ipcl:: layer: injected randomness, texts uploaded at construction) fall back to its host
+ * copy instead of failing. */
+int pgpu_batch_is_current(const pgpu_batch* b);
 typedef struct pgpu_ticket pgpu_ticket;
 int pgpu_batch_download_async(const pgpu_batch* b, uint64_t* host /* [count][words] */, pgpu_ticket** out);
 int pgpu_ticket_wait(pgpu_ticket* t);

@@ -32,7 +32,7 @@ SYMBOLS = [
     "pgpu_set_fixed_base_budget", "pgpu_fixed_base_stats", "pgpu_pubkey_fixed_base_info",
     "pgpu_batch_row_limbs", "pgpu_set_batch_lane", "pgpu_batch_lane", "pgpu_batch_download_async", "pgpu_ticket_wait", "pgpu_batch_download_strided",
     "pgpu_set_table_gather_policy", "pgpu_get_table_gather_policy",
-    "pgpu_build_features", "pgpu_batch_lanes", "pgpu_timing_collect_ex", "pgpu_decrypt_kernel_form_ex",
+    "pgpu_build_features", "pgpu_batch_is_current", "pgpu_batch_lanes", "pgpu_timing_collect_ex", "pgpu_decrypt_kernel_form_ex",
     "pgpu_encrypt_kernel_form_ex", "pgpu_host_alloc", "pgpu_host_free", "pgpu_host_wait",
     "pgpu_timing_collect_trace",
 ]

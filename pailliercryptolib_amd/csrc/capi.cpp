@@ -3281,7 +3281,9 @@ int pgpu_batch_download(const pgpu_batch* b, uint64_t* host) {
   return tg.wait();
 }
 
-// Rows land `host_stride` words apart (host_stride >= words; the words in between are not written): the ipcl:: layer lays
+// Rows land `host_stride` words apart (host_stride >= words; the words in between are OVERWRITTEN WITH ZEROS: the rows
+// travel as one linear copy of a device image whose gaps are cleared first -- a caller's own headers between the rows must
+// be written after the call, and no stale device memory reaches the host): the ipcl:: layer lays
 // results out as blocks of its limb allocator -- a 16-byte header in front of every row -- so that the BigNumbers point
 // into the pinned block instead of copying out of it.  Pinned targets (pgpu_host_alloc) and one-GPU pools only; plain and
 // pair-row batches (others: PGPU_ERR_UNSUPPORTED, the caller takes pgpu_batch_download).
@@ -3299,6 +3301,7 @@ int pgpu_batch_download_strided(const pgpu_batch* b, uint64_t* host, size_t host
   hipStream_t s = dev.bs(b->lane);
   rt::DevMem tmp;
   RC_TRY(tmp.alloc(dev, s, span));
+  if (host_stride > (size_t)b->words) HIP_TRY(hipMemsetAsync(tmp.p, 0, span, s));   // (the gaps: recycled device memory otherwise)
   if (b->pair_l2) {
     RC_TRY(pair_to_words_on(dev, b->pair_form.get(), b->prow(0), (uint64_t*)tmp.p, b->count, s, host_stride));
   } else {
@@ -3646,6 +3649,7 @@ int pgpu_set_batch_lane(int lane) {
   return PGPU_OK;
 }
 int pgpu_batch_lane(const pgpu_batch* b) { return b ? b->lane : 0; }
+int pgpu_batch_is_current(const pgpu_batch* b) { return b && rt::pool_size() > 0 && b->gen == rt::pool_generation() ? 1 : 0; }
 int pgpu_batch_lanes(void) { return rt::kBatchLanes; }
 int pgpu_batch_row_limbs(const pgpu_batch* b) { return b ? 2 * b->pair_l2 : 0; }
 

@@ -130,6 +130,16 @@ std::shared_ptr<detail::DeviceBatch> BaseText::deviceBatch(int words, const BigN
   return detail::DeviceBatch::upload(detail::pack(red, rw), m_size, rw);  // not cached
 }
 
+std::shared_ptr<detail::DeviceBatch> BaseText::operandBatch(int max_words, const BigNumber* reduce_mod) const {
+  if (!m_host_valid) {
+    std::lock_guard<std::mutex> lk(text_mu(this));
+    if (m_dev && m_dev->words <= max_words) return m_dev;
+  }
+  // (a text adopted onto the device at construction keeps the width of its widest value: wider than the operation takes,
+  // it comes back to the host once and is reduced like any other over-wide input)
+  return deviceBatch(std::min(max_words, detail::words_for_bits(maxBitsHint())), reduce_mod);
+}
+
 BaseText::BaseText(const uint32_t& n) : m_texts(1, BigNumber((Ipp32u)n)), m_size(1) {}
 
 BaseText::BaseText(const std::vector<uint32_t>& n_v) {

@@ -52,10 +52,8 @@ CipherText CipherText::operator+(const PlainText& other) const {
   const BigNumber& nsq = *(m_pk->getNSQ());
   const int W = detail::words_for_bits(nsq.BitSize());
   // g^m only depends on m mod n: reduce plaintexts that are negative or wider than n^2
-  const int mw = other.isDeviceResident() ? other.m_dev->words
-                                          : std::min(W, detail::words_for_bits(other.maxBitsHint()));
   auto da = deviceBatch(W, &nsq);
-  auto dm = other.isDeviceResident() ? other.m_dev : other.deviceBatch(mw, m_pk->getN().get());
+  auto dm = other.operandBatch(W, m_pk->getN().get());
   pgpu_batch* o = nullptr;
   IPCL_GPU_CHECK(pgpu_batch_ct_add_plain(m_pk->device()->h, da->h, dm->h, &o), "CT + PT");
   return CipherText(m_pk, detail::DeviceBatch::adopt(o));

@@ -447,10 +447,20 @@ bool download_adopting(pgpu_batch* h, std::size_t count, int words, std::vector<
   if (!adopt_enabled() || g_adopted_bytes.load(std::memory_order_relaxed) + bytes > kAdoptCapBytes) return false;
   std::shared_ptr<PinnedBlock> blk = PinnedBlock::acquire(bytes);
   if (!blk) return false;
+  // what is charged against the cap is what is checked: the block's size CLASS (up to twice the request), taken with one
+  // fetch_add and given back when the cap would be passed (a load followed by a later add let racing threads overshoot).
+  // Retention: one surviving BigNumber keeps its whole pinned block alive ("Results used in place")
+  const std::size_t charge = blk->bytes;
+  if (g_adopted_bytes.fetch_add(charge, std::memory_order_relaxed) + charge > kAdoptCapBytes) {
+    g_adopted_bytes.fetch_sub(charge, std::memory_order_relaxed);
+    return false;
+  }
   uint64_t* rows = blk->p + kAdoptCtrlWords + kAdoptHeaderWords;   // row i at rows + i * stride, its header in front
-  if (pgpu_batch_download_strided(h, rows, stride) != PGPU_OK) return false;   // (not this kind of batch / pool)
-  AdoptCookie* ck = new AdoptCookie{blk, blk->bytes};
-  g_adopted_bytes.fetch_add(ck->bytes, std::memory_order_relaxed);
+  if (pgpu_batch_download_strided(h, rows, stride) != PGPU_OK) {   // (not this kind of batch / pool)
+    g_adopted_bytes.fetch_sub(charge, std::memory_order_relaxed);
+    return false;
+  }
+  AdoptCookie* ck = new AdoptCookie{blk, charge};
   LimbArenaExt* arena = limb_arena_open(blk->p, adopt_release, ck);
   blk.reset();
   std::vector<BigNumber> v;
@@ -465,6 +475,12 @@ bool download_adopting(pgpu_batch* h, std::size_t count, int words, std::vector<
 
 std::vector<BigNumber> DeviceBatch::download() const {
   const std::size_t bytes = count * (size_t)words * 8;
+  // a batch whose pool is gone (terminateContext, also followed by a new context): values a caller handed in and that
+  // went to the GPU at construction are still in the pinned block the upload read -- the caller gets its own input back
+  if (src && !pgpu_batch_is_current(h)) {
+    (void)pgpu_host_wait(src->p);
+    return unpack(src->p, count, words);
+  }
   if (bytes >= kAdoptMinBytes) {   // (below: the copying path is as fast -- Add_CTCT(2048) 141 against 175 us)
     std::vector<BigNumber> v;
     if (download_adopting(h, count, words, &v)) return v;

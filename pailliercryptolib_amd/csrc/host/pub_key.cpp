@@ -198,8 +198,7 @@ CipherText PublicKey::encrypt(const PlainText& pt, bool make_secure) const {
     // reads, without a BigNumber per element in between
     auto dev = device();
     const int nw = detail::words_for_bits(m_n->BitSize());
-    const int mw = pt.isDeviceResident() ? 0 : std::min(2 * nw, detail::words_for_bits(pt.maxBitsHint()));
-    std::shared_ptr<detail::DeviceBatch> dm = pt.isDeviceResident() ? pt.m_dev : pt.deviceBatch(mw, m_n.get());
+    std::shared_ptr<detail::DeviceBatch> dm = pt.operandBatch(2 * nw, m_n.get());
     const int rw = detail::words_for_bits(m_randbits);
     std::vector<uint64_t> flat(sz * (std::size_t)rw);
     detail::fill_random(flat.data(), flat.size() * sizeof(uint64_t));
@@ -223,10 +222,9 @@ CipherText PublicKey::encrypt(const PlainText& pt, bool make_secure) const {
   const int nw = detail::words_for_bits(m_n->BitSize());
   // injected randomness that has been through here before: its device copy feeds this encrypt as well
   std::shared_ptr<InjectedRandom> cached = m_testv ? std::atomic_load(&m_r_dev) : nullptr;
-  if (cached && cached->from == m_r && cached->dev->count == sz) {
+  if (cached && cached->from == m_r && cached->dev->count == sz && pgpu_batch_is_current(cached->dev->h)) {   // (a pool restart drops it: re-upload below)
     auto dev = device();
-    const int mw = pt.isDeviceResident() ? 0 : std::min(2 * nw, detail::words_for_bits(pt.maxBitsHint()));
-    std::shared_ptr<detail::DeviceBatch> dm = pt.isDeviceResident() ? pt.m_dev : pt.deviceBatch(mw, m_n.get());
+    std::shared_ptr<detail::DeviceBatch> dm = pt.operandBatch(2 * nw, m_n.get());
     pgpu_batch* c = nullptr;
     IPCL_GPU_CHECK(pgpu_batch_encrypt(dev->h, dm->h, cached->dev->h, cached->bits, &c), "encrypt");
     return CipherText(*this, detail::DeviceBatch::adopt(c));
@@ -248,8 +246,7 @@ CipherText PublicKey::encrypt(const PlainText& pt, bool make_secure) const {
   const std::vector<BigNumber>& r = *rp;
   auto dev = device();
   // (n*m+1) % n^2 only depends on m mod n: reduce plaintexts that are negative or wider than n^2
-  const int mw = pt.isDeviceResident() ? 0 : std::min(2 * nw, detail::words_for_bits(pt.maxBitsHint()));
-  std::shared_ptr<detail::DeviceBatch> dm = pt.isDeviceResident() ? pt.m_dev : pt.deviceBatch(mw, m_n.get());
+  std::shared_ptr<detail::DeviceBatch> dm = pt.operandBatch(2 * nw, m_n.get());
   const int rbits = detail::max_bits(r);
   const int rw = detail::words_for_bits(rbits);
   auto dr = detail::DeviceBatch::upload_values(r, rw);

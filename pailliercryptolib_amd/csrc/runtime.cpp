@@ -347,7 +347,16 @@ void big_copy(void* dst, const void* src, size_t n) {
 namespace {
 struct HostBlock {
   size_t bytes = 0;
-  std::vector<hipEvent_t> last_read;   // [pool device]: behind the last upload that reads the block (null: none)
+  // one event per (pool device, stream) that ever uploaded from the block, recorded behind that stream's LATEST copy: a
+  // caller that feeds several batch lanes from one block (the documented one-thread pipeline) has copies pending on
+  // several streams at once, and an earlier copy queued behind another lane's kernels may not have read the block yet
+  // when the last-recorded stream is done -- pgpu_host_wait / pgpu_host_free wait for every one of them
+  struct Read {
+    int dev;
+    hipStream_t stream;
+    hipEvent_t ev;
+  };
+  std::vector<Read> last_read;
 };
 std::mutex g_host_mu;
 std::map<uintptr_t, HostBlock>& g_host_blocks = *new std::map<uintptr_t, HostBlock>();
@@ -379,7 +388,7 @@ int host_wait(const void* p) {
     std::lock_guard<std::mutex> lk(g_host_mu);
     auto it = host_lookup(p, 1);
     if (it == g_host_blocks.end()) return PGPU_OK;   // not ours: nothing is ever pending on it
-    evs = it->second.last_read;
+    for (const auto& r : it->second.last_read) evs.push_back(r.ev);
   }
   for (hipEvent_t e : evs)
     if (e) HIP_TRY(hipEventSynchronize(e));
@@ -397,8 +406,8 @@ void host_free(void* p) {
     b = it->second;
     g_host_blocks.erase(it);
   }
-  for (hipEvent_t e : b.last_read)
-    if (e) (void)hipEventDestroy(e);
+  for (const auto& r : b.last_read)
+    if (r.ev) (void)hipEventDestroy(r.ev);
   (void)hipHostFree(p);
 }
 
@@ -411,14 +420,20 @@ void host_note_read(const void* p, size_t bytes, int dev, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_host_mu);
   auto it = host_lookup(p, bytes);
   if (it == g_host_blocks.end() || dev < 0) return;
-  auto& ev = it->second.last_read;
-  if (ev.size() <= (size_t)dev) ev.resize((size_t)dev + 1, nullptr);
-  if (!ev[(size_t)dev] && hipEventCreateWithFlags(&ev[(size_t)dev], hipEventDisableTiming) != hipSuccess) {
-    ev[(size_t)dev] = nullptr;
+  auto& reads = it->second.last_read;
+  for (auto& r : reads)
+    if (r.dev == dev && r.stream == s) {
+      (void)hipEventRecord(r.ev, s);
+      return;
+    }
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
     (void)hipStreamSynchronize(s);   // no event to remember the copy by: wait for it here
     return;
   }
-  (void)hipEventRecord(ev[(size_t)dev], s);
+  (void)hipEventRecord(ev, s);
+  reads.push_back({dev, s, ev});
 }
 
 namespace {
@@ -724,8 +739,8 @@ void pool_shutdown() {
     // devices have drained above, and the next pool may number its entries differently)
     std::lock_guard<std::mutex> hl(g_host_mu);
     for (auto& kv : g_host_blocks) {
-      for (hipEvent_t e : kv.second.last_read)
-        if (e) (void)hipEventDestroy(e);
+      for (const auto& r : kv.second.last_read)
+        if (r.ev) (void)hipEventDestroy(r.ev);
       kv.second.last_read.clear();
     }
   }

@@ -236,6 +236,28 @@ TEST(negative_and_wide_plaintexts) {
   pk.setRandom(std::vector<BigNumber>(vals.size(), BigNumber(KAT_R0)));
   std::vector<BigNumber> got2 = sk.decrypt(pk.encrypt(pt)).getTexts();
   for (size_t i = 0; i < vals.size() && i < got2.size(); ++i) EXPECT_EQ(got2[i], vals[i] % (P * Q));
+  // a LARGE batch of non-negative values with some wider than n^2: the text is adopted onto the device at construction
+  // (base_text.cpp: adoptValues keeps the width of the widest value) -- encrypt and CT + PT must still reduce them mod n
+  // like the reference's (n*m + 1) % n^2 (pub_key.cpp:88-89), not refuse the over-wide resident rows
+  {
+    const size_t big = 700;
+    std::vector<BigNumber> wide, wwant;
+    for (size_t i = 0; i < big; ++i) {
+      BigNumber v = (i % 7 == 3) ? n * n * n + BigNumber((Ipp32u)(i + 1)) : BigNumber((Ipp32u)(1000 + i));
+      wide.push_back(v);
+      wwant.push_back(v % n);
+    }
+    ipcl::PlainText wpt(wide);
+    std::vector<BigNumber> wgot = key.priv_key.decrypt(key.pub_key.encrypt(wpt)).getTexts();
+    EXPECT_EQ(wgot.size(), big);
+    for (size_t i = 0; i < big && i < wgot.size(); ++i) EXPECT_EQ(wgot[i], wwant[i]);
+    std::vector<BigNumber> base(big, BigNumber(5u));
+    ipcl::CipherText cb = key.pub_key.encrypt(ipcl::PlainText(base));
+    std::vector<BigNumber> wsum = key.priv_key.decrypt(cb + wpt).getTexts();
+    EXPECT_EQ(wsum.size(), big);
+    for (size_t i = 0; i < big && i < wsum.size(); ++i) EXPECT_EQ(wsum[i], (wwant[i] + BigNumber(5u)) % n);
+    EXPECT_EQ(wpt.getElement(3), wide[3]);      // the text still holds what the caller handed in
+  }
   // getTexts() on a temporary moves the values out; on an lvalue it copies and the text stays usable
   ipcl::PlainText keep(a);
   std::vector<BigNumber> c1 = keep.getTexts(), c2 = keep.getTexts();
@@ -654,6 +676,39 @@ TEST(keygen_non_djn_and_3072_bit) {
   EXPECT_EQ(k3.pub_key.getN()->BitSize(), 3072);
   ipcl::PlainText d3 = k3.priv_key.decrypt(k3.pub_key.encrypt(ipcl::PlainText(a)));
   for (size_t i = 0; i < a.size(); i++) EXPECT_EQ(d3.getElementVec(i)[0], a[i]);
+}
+
+// Round 5: a device pool restart under live objects.  Texts that went to the GPU when they were built around host values,
+// and the cached device copy of injected randomness, must not depend on the pool they were uploaded to: the caller gets
+// its own input back, and encrypt re-uploads (reference: containers own their BigNumbers, base_text.cpp:10-40).
+// (last test: it restarts the context)
+TEST(zz_context_restart_keeps_caller_values) {
+  BigNumber p(KAT_P), q(KAT_Q), n = p * q;
+  ipcl::PublicKey pk(n, 2048, true);
+  pk.setHS(BigNumber(KAT_BENCH_HS));
+  ipcl::PrivateKey sk(pk, p, q);
+  const size_t cnt = 700;
+  std::vector<BigNumber> vals, rnd;
+  for (size_t i = 0; i < cnt; ++i) {
+    vals.push_back((n - BigNumber((Ipp32u)(i + 1))) % n);     // full-width values: 700 x 256 B, adopted at construction
+    rnd.push_back(BigNumber(KAT_R0));
+  }
+  pk.setRandom(rnd);
+  ipcl::PlainText pt(vals);
+  ipcl::CipherText c0 = pk.encrypt(pt);                        // (caches the device copy of the randomness)
+  std::vector<BigNumber> c0v = c0.getTexts();
+  ipcl::PlainText kept(vals);                                  // device-only until somebody asks
+  ipcl::terminateContext();
+  EXPECT_TRUE(kept.getTexts() == vals);                        // from the pinned block its upload read
+  ipcl::initializeContext("default");
+  ipcl::PublicKey pk2(n, 2048, true);
+  pk2.setHS(BigNumber(KAT_BENCH_HS));
+  ipcl::PrivateKey sk2(pk2, p, q);
+  pk2.setRandom(rnd);
+  std::vector<BigNumber> d = sk2.decrypt(pk2.encrypt(ipcl::PlainText(kept.getTexts()))).getTexts();
+  EXPECT_EQ(d.size(), cnt);
+  for (size_t i = 0; i < cnt && i < d.size(); i += 97) EXPECT_EQ(d[i], vals[i]);
+  EXPECT_TRUE(pk2.encrypt(ipcl::PlainText(vals)).getTexts() == c0v);   // same key, same randomness: same ciphertexts
 }
 
 int main(int argc, char** argv) {
