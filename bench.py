@@ -262,6 +262,36 @@ def run_pool(args):
                                      "what": "the same steps back to back for about %.0f s behind the timed region (the boxes "
                                              "hold a lower clock over seconds than over the 0.1 s of a 20-step run)" % args.sustain_seconds}
 
+        # the same step with constant-address table access (pgpu_set_table_gather_policy(1)): every window-table / fixed-base
+        # table candidate is read and the wanted one selected, as the reference's mbx_exp_mb8 gathers (mod_exp.cpp:508-516)
+        if not args.no_extras:
+            try:
+                _capi.check(L.pgpu_set_table_gather_policy(1))
+                state["i"] = 0
+                for _ in range(2 * nfl):
+                    step()
+                sync_all()
+                kh = 6 * nfl
+                t3 = time.perf_counter()
+                for _ in range(kh):
+                    step()
+                sync_all()
+                dth = time.perf_counter() - t3
+                okh = all(bool(np.array_equal(B.down(o), m_host)) for o in state["out"])
+                measured["hardened"] = {"steps": kh, "ms_per_step": round(dth / kh * 1e3, 4), "modexps_per_s": round(3 * BATCH * N * kh / dth, 1),
+                                        "round_trip_ok": okh,
+                                        "what": "the resident step of the headline with secret_table_access = masked: decrypt window tables "
+                                                "(32 entries) and the DJN fixed-base product (255 products over 16-entry windows instead of "
+                                                "78 indexed ones) read every candidate and select; same lanes, same batch"}
+            except Exception as e:                          # noqa: BLE001
+                measured["hardened"] = {"error": repr(e)[:300]}
+            finally:
+                _capi.check(L.pgpu_set_table_gather_policy(0))
+                state["i"] = 0
+                for _ in range(nfl):       # (the checked results below are those of the default policy)
+                    step()
+                sync_all()
+
     # ---- correctness of what was timed: full-size round trip + oracle spot checks ----
     ok = all(bool(np.array_equal(B.down(o), m_host)) for o in state["out"])
     all_c, all_out = state["c"], state["out"]
@@ -392,6 +422,13 @@ def run_pool(args):
         r["step_executed_note"] = repr(e)[:200]
     if "sustained" in measured:
         result["sustained"] = measured["sustained"]
+    if "hardened" in measured:
+        result["hardened"] = measured["hardened"]
+    result["config"]["secret_table_access"] = "masked" if L.pgpu_get_table_gather_policy() else "indexed"
+    result["config"]["secret_table_access_note"] = ("indexed: window-table / fixed-base-table ADDRESSES follow the digits of p-1, q-1 and of the "
+                                                    "encryption randomness r (include/pgpu.h, SIDE CHANNELS); masked "
+                                                    "(pgpu_set_table_gather_policy(1)): every candidate read, one selected -- the `hardened` block "
+                                                    "has that step")
     result["pool"] = per_gpu
     # side measurements must never sink the contract line: a failure is reported inside it
     if N == 1 and not args.no_extras:

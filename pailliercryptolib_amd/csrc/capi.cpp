@@ -407,6 +407,18 @@ int fixed_base_window() {
   }
   return g_fb_window.load();
 }
+// window of the CRT-decrypt exponentiation under the masked table gather (round 5): every one of the 2^w entries of an
+// exponentiation's table is read at every window product, so the table is what the launch streams -- 9.7 KB per
+// exponentiation at w = 5, 32 entries x 235 products; four batches in flight (636 MB of tables) fall out of the 256 MB
+// Infinity Cache and the one-lane decrypt went from 14.5 to 37 ms.  w = 3: 8 entries x 348 products, a third of the bytes,
+// the tables of four batches fit the cache again, 11 % more products.  PGPU_MASKED_DEC_WINDOW: 1..5.
+int masked_decrypt_window() {
+  static const int w = [] {
+    const char* e = std::getenv("PGPU_MASKED_DEC_WINDOW");
+    return e ? std::max(1, std::min(5, std::atoi(e))) : 3;
+  }();
+  return w;
+}
 // window of the MASKED fixed-base product (every entry of a window is read and selected): small on purpose
 int masked_fb_window() {
   static const int w = [] {
@@ -1785,7 +1797,7 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
       h.window = key->sched[0].w;
       entries = (size_t)1 << (h.window - 1);
     } else {
-      h.window = pick_window(h.exp_bits);
+      h.window = g_ct_gather.load() ? std::min(masked_decrypt_window(), pick_window(h.exp_bits)) : pick_window(h.exp_bits);
       entries = (size_t)1 << h.window;
     }
     h.ct_gather = g_ct_gather.load();

@@ -318,18 +318,24 @@ __device__ __forceinline__ void ps_table_load(uint32_t (&a)[K], uint32_t (&b)[K]
     ps_park_load<K>(b, tw + ps_table_row<K>(idx, 1));
     return;
   }
+  // (every lane of the wavefront wants the SAME entry -- one side of the key, one exponent -- so the selection is a
+  // v_cndmask_b32 under a wave-uniform condition per limb: half the instructions of an and / or pair.  Two entries per
+  // trip: their loads are in flight together)
 #pragma unroll
   for (int j = 0; j < K; ++j) a[j] = b[j] = 0;
 #pragma unroll 1
-  for (int e = 0; e < tsize; ++e) {
-    uint32_t ta[K], tb[K];
+  for (int e = 0; e < tsize; e += 2) {
+    uint32_t ta[K], tb[K], ua[K], ub[K];
+    const int e1 = e + 1 < tsize ? e + 1 : e;
     ps_park_load<K>(ta, tw + ps_table_row<K>(e, 0));
     ps_park_load<K>(tb, tw + ps_table_row<K>(e, 1));
-    const uint32_t k = 0u - (uint32_t)(e == idx);
+    ps_park_load<K>(ua, tw + ps_table_row<K>(e1, 0));
+    ps_park_load<K>(ub, tw + ps_table_row<K>(e1, 1));
+    const bool s0 = e == idx, s1 = e1 == idx;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      a[j] |= ta[j] & k;
-      b[j] |= tb[j] & k;
+      a[j] = s0 ? ta[j] : (s1 ? ua[j] : a[j]);
+      b[j] = s0 ? tb[j] : (s1 ? ub[j] : b[j]);
     }
   }
 }

@@ -557,9 +557,10 @@ __device__ __forceinline__ void load_table_entry(uint32_t (&dst)[K], const uint3
       t0[j] = tbl[(size_t)e * stride + j];
       t1[j] = tbl[(size_t)e1 * stride + j];
     }
-    const uint32_t k0 = 0u - (uint32_t)(e == idx), k1 = 0u - (uint32_t)(e1 == idx);
+    // (one v_cndmask_b32 per limb and candidate -- round 4 masked and or-ed: three to four instructions per limb and pair)
+    const bool s0 = e == idx, s1 = e1 == idx;
 #pragma unroll
-    for (int j = 0; j < K; ++j) dst[j] |= (t0[j] & k0) | (t1[j] & k1);
+    for (int j = 0; j < K; ++j) dst[j] = s0 ? t0[j] : (s1 ? t1[j] : dst[j]);
   }
 }
 

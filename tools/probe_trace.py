@@ -1,5 +1,5 @@
 """Kernel timeline of a short burst of resident steps on k batch lanes, from the library's own HIP events
-(pgpu_timing_collect_trace).  usage: python tools/probe_trace.py [lanes] [steps]   (tools/, diagnostics only)"""
+(pgpu_timing_collect_trace).  usage: python tools/probe_trace.py [lanes] [steps] [masked gather 0/1]   (tools/, diagnostics only)"""
 import ctypes, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -7,8 +7,11 @@ import pailliercryptolib_amd as pa
 from pailliercryptolib_amd import _capi
 nl = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+gather = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 pa.initialize(0)
 L = _capi.lib()
+if gather:
+    _capi.check(L.pgpu_set_table_gather_policy(1))
 k = json.load(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "iso_kat.json")))
 p, q, hs = int(k["p"], 16), int(k["q"], 16), int(k["bench_hs"], 16)
 n = p * q
