@@ -370,12 +370,16 @@ def run_pool(args):
             r["executed_mac32_per_launch"] = per_exp * 2 * BATCH
             r["kernel_ms"] = round(ms_top, 3)
             r["kernel_ms_basis"] = "mean HIP-event duration of those launches INSIDE the timed region (rocprofv3 kernel-trace agrees)"
-            if top & 2:
+            if top & 10:
                 pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
                 pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
-                if pmc.get("seq_decrypt_hbm_bytes_per_launch"):
-                    r["traffic"] = pmc["seq_decrypt_hbm_bytes_per_launch"]
-                    r["traffic_source"] = pmc_source(pmc, "seq_decrypt_kernel")
+                pk_ = "ps_decrypt" if top & 8 else "seq_decrypt"
+                if pmc.get(pk_ + "_hbm_bytes_per_launch"):
+                    r["traffic"] = pmc[pk_ + "_hbm_bytes_per_launch"]
+                    r["traffic_source"] = pmc_source(pmc, pk_ + "_kernel")
+                else:
+                    r["traffic"] = None
+                    r["traffic_source"] = None
             if share:
                 r["chip_share"] = share
                 # achieved / peak = frac holds for the line's three fields: the launch's rate scaled to the whole chip
