@@ -69,7 +69,7 @@ def _objects():
     hip = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + _switches() + inc
     host = ["g++", "-O2", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + _switches() + inc
     kdeps = [os.path.join(CSRC, f) for f in ("kernels.hpp", "mont_core.hpp", "kargs.hpp", "launch.hpp")]
-    hdeps = [os.path.join(CSRC, f) for f in ("kargs.hpp", "launch.hpp", "runtime.hpp")]
+    hdeps = [os.path.join(CSRC, f) for f in ("kargs.hpp", "launch.hpp", "runtime.hpp", "policy.hpp")]
     hdeps += [os.path.join(ROOT, "include", "pgpu.h"), os.path.join(ROOT, "include", "ipcl", "bignum.h"),
               os.path.join(ROOT, "include", "ipcl", "utils", "serialize.hpp")]
     obj = os.path.join(HERE, "build")
@@ -91,7 +91,7 @@ def _objects():
         if part == 31:
             hdeps_k.append(os.path.join(CSRC, "hensel_ps.hpp"))
         out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src] + hdeps_k + kdeps))
-    for name in ("capi.cpp", "runtime.cpp", os.path.join("host", "bignum.cpp")):
+    for name in ("capi.cpp", "policy.cpp", "runtime.cpp", os.path.join("host", "bignum.cpp")):
         src = os.path.join(CSRC, name)
         o = os.path.join(obj, os.path.basename(name).replace(".cpp", ".o"))
         out.append((o, host + ["-c", src, "-o", o], [src] + hdeps))

@@ -23,10 +23,25 @@
 #include "ipcl/bignum.h"
 #include "kargs.hpp"
 #include "launch.hpp"
+#include "policy.hpp"
 #include "runtime.hpp"
 
 namespace rt = pgpu::rt;
 using rt::fail;
+// the kernel-form policy (policy.cpp: pure host logic, unit-tested on the CPU)
+namespace policy = pgpu::policy;
+using pgpu::policy::ab_policy;
+using pgpu::policy::adaptive_cu_claim;
+using pgpu::policy::fb_encrypt_seq_pays;
+using pgpu::policy::kSimds;
+using pgpu::policy::lane_form_pays;
+using pgpu::policy::masked_decrypt_window;
+using pgpu::policy::modexp_seq_form_pays;
+using pgpu::policy::pair_mul_seq_pays;
+using pgpu::policy::pick_window;
+using pgpu::policy::seq_adaptive;
+using pgpu::policy::seq_form_pays;
+using pgpu::policy::seq_policy_by_size;
 
 namespace {
 
@@ -323,24 +338,6 @@ int secret_policy() {
   return p;
 }
 
-// fixed-window width: the w in 1..5 that minimises (2^w - 2) table multiplications +
-// ceil(e/w) window multiplications (w = 5 for e >= ~240 bits).
-int pick_window(int exp_bits) {
-  // PGPU_FIXED_WINDOW=w: A/B measurements of the window width (what an LDS-resident table, which
-  // holds 8 entries per exponentiation at most, would have to beat)
-  static const int forced = [] {
-    const char* e = std::getenv("PGPU_FIXED_WINDOW");
-    return e ? std::max(1, std::min(5, std::atoi(e))) : 0;
-  }();
-  if (forced) return forced;
-  int best = 1;
-  long best_cost = 1L << 60;
-  for (int w = 1; w <= 5; ++w) {
-    long cost = ((1L << w) - 2) + (exp_bits + w - 1) / w;
-    if (cost < best_cost) { best_cost = cost; best = w; }
-  }
-  return best;
-}
 
 // Sliding-window schedule of an exponent the host knows: odd powers base^(2i+1), i < 2^(w-1);
 // step = (nsq << 6) | (idx + 1) -- nsq squarings then * base^(2 idx + 1) (idx + 1 == 0: squarings only);
@@ -407,18 +404,6 @@ int fixed_base_window() {
   }
   return g_fb_window.load();
 }
-// window of the CRT-decrypt exponentiation under the masked table gather (round 5): every one of the 2^w entries of an
-// exponentiation's table is read at every window product, so the table is what the launch streams -- 9.7 KB per
-// exponentiation at w = 5, 32 entries x 235 products; four batches in flight (636 MB of tables) fall out of the 256 MB
-// Infinity Cache and the one-lane decrypt went from 14.5 to 37 ms.  w = 3: 8 entries x 348 products, a third of the bytes,
-// the tables of four batches fit the cache again, 11 % more products.  PGPU_MASKED_DEC_WINDOW: 1..5.
-int masked_decrypt_window() {
-  static const int w = [] {
-    const char* e = std::getenv("PGPU_MASKED_DEC_WINDOW");
-    return e ? std::max(1, std::min(5, std::atoi(e))) : 3;
-  }();
-  return w;
-}
 // window of the MASKED fixed-base product (every entry of a window is read and selected): small on purpose
 int masked_fb_window() {
   static const int w = [] {
@@ -471,7 +456,6 @@ unsigned blocks_for(size_t count, const GeoInfo& g) {
 // multiplication (2048-bit class: (16,5), 1190 instructions instead of 1590 for (8,9); 3072-bit class: (16,7)
 // for (8,14), same L and therefore the same context).  Used while the 16-lane split still fits one wavefront
 // per SIMD; (16,5) has L = 80, so it needs its own Montgomery context.
-constexpr size_t kSimds = 256 * 4;
 GeoInfo latency_geo(const GeoInfo& geo) {
   static const bool allow = [] { const char* e = std::getenv("PGPU_LATENCY_GEO"); return !e || std::atoi(e) != 0; }();
   if (!allow) return geo;
@@ -1301,9 +1285,6 @@ const pgpu_pubkey::PubForm* split_modexp_form(const pgpu_pubkey* key, size_t cou
   const size_t ipw = 64 / (2 * (size_t)last->H);
   return (count + ipw - 1) / ipw > max_waves ? nullptr : last;
 }
-bool modexp_seq_form_pays(int H, int K, size_t count);
-bool fb_encrypt_seq_pays(int H, int K, size_t count, int busy = 0);
-unsigned adaptive_cu_claim(size_t waves, int busy_lanes);
 int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::PubForm* form, const uint64_t* d_base, size_t base_stride,
                     int base_words, bool base_mont, const uint64_t* d_exp, size_t exp_stride, int exp_words,
                     int exp_bits, const SchedRef* sched, int final_mul, const uint64_t* d_m, size_t m_stride,
@@ -1566,63 +1547,13 @@ const pgpu_privkey::HenselSet* pick_hensel(const pgpu_privkey* key, size_t count
 }
 
 // fused CRT decrypt on one device; in_mont: ciphertexts arrive in the Montgomery domain of n^2
-// PGPU_AB_DECRYPT: 0 (default) = never, 1 = whenever it applies, 2 = when the GPU's other batch lane is busy at launch time.
-// hensel_ab.hpp: the two halves of a residue in different wavefronts -- 12.5 % fewer VALU instructions per launch (PMC),
-// but measured (profiles/r03_ab_decrypt.txt): alone its longer half sets the pace (5.41 vs 4.59 ms), and with two batches
-// in flight the gain depends on which wavefronts the dispatcher pairs on a SIMD (A+B: good, B+B: none) -- +1.6 % on
-// average.  Kept as an experiment, bit-identical, off by default.
-// PGPU_SEQ_DECRYPT: 0 = never, 1 (default) = for launches that put at least one wavefront of that form on every SIMD
-// (16384 ciphertexts under a 2048-bit key, 8192 under a 3072-bit key), 2 = whenever it applies.  hensel_seq.hpp: both halves of a residue in the same lanes, one after the other -- 10-13 %
-// fewer instructions per exponentiation on half the lanes.
-std::atomic<int> g_seq_policy{[] {
-  const char* e = std::getenv("PGPU_SEQ_DECRYPT");
-  return e ? std::max(0, std::min(4, std::atoi(e))) : 4;
-}()};
-// (3: the round-3 opt-in mode for two batch lanes that are both kept busy -- a CRT decrypt also takes the form when it
-// fills HALF the chip, its workgroups claiming more than half a CU's LDS so that the two lanes' launches spread over all
-// CUs; every other operation as under 1.
-//  4 (default since round 4): ADAPTIVE -- by launch size as under 1, and a launch that would leave SIMDs empty in this
-// form takes it all the same when the GPU's OTHER batch lanes have work queued at launch time, i.e. when this launch
-// will share the chip anyway: with b busy neighbours it needs waves * (1 + b) >= SIMDs.  One busy neighbour: the
-// launch claims the LDS that keeps a second workgroup off its CUs (two half-chip launches side by side, as under 3);
-// two or more: no claim (two workgroups per CU, the launches of four lanes fill every SIMD twice).  A lone caller
-// -- nothing queued beside it -- keeps the full-chip paired kernels.  The probe is a hipStreamQuery per lane: what it
-// costs when it is wrong is bounded by one launch (a neighbour that drains early leaves a half-chip launch to
-// finish alone: 8.1 instead of 4.6 ms for 8192 ciphertexts).)
-int seq_policy_by_size() {
-  const int p = g_seq_policy.load();
-  return (p == 3 || p == 4) ? 1 : p;
-}
-// tuning knobs of the adaptive policy (tools/probe_lanes.py; pgpu_debug_set_adaptive / PGPU_ADAPT_ENC_SEQ,
-// PGPU_ADAPT_CLAIM_BUSY): up to how many busy neighbours the DJN encrypt follows the decrypt into the sequential-halves
-// form with a CU claim (measured r04, profiles/r04_lanes.txt: with ONE busy neighbour -- two lanes, each owning half the
-// chip -- the step goes 4.92 -> 4.87 ms; with three the paired full-chip encrypt hides better under the neighbours'
-// decrypts, 4.72 against 4.87 ms; without the claim its 512 wavefronts stack onto a neighbour's CUs: 0.79 -> 1.7 ms), and
-// up to how many busy neighbours a part-chip launch claims whole CUs
-std::atomic<int> g_adapt_enc_seq{[] { const char* e = std::getenv("PGPU_ADAPT_ENC_SEQ"); return e ? std::atoi(e) : 3; }()};
-std::atomic<int> g_adapt_claim_busy{[] { const char* e = std::getenv("PGPU_ADAPT_CLAIM_BUSY"); return e ? std::atoi(e) : 3; }()};
-// with `busy` other batch lanes at work, does a launch of `waves` wavefronts of a sequential-halves form fill its share?
-bool seq_adaptive(size_t waves, int busy) {
-  return g_seq_policy.load() == 4 && busy >= 1 && waves * (size_t)(1 + busy) >= kSimds;
-}
-// LDS bytes a part-chip launch of a sequential-halves form claims beyond its needs under the adaptive policy (more than
-// half a CU's LDS: one workgroup per CU, so that the launches of neighbour lanes spread over the chip); 0: no claim
-unsigned adaptive_cu_claim(size_t waves, int busy_lanes) {
-  return (g_seq_policy.load() == 4 && waves < kSimds && busy_lanes >= 1 && busy_lanes <= g_adapt_claim_busy.load()) ? 84000u : 0u;
-}
 // Batch lanes of `dev` other than `lane` that are ACTIVE: work queued right now, or fed within the last few tens of
 // milliseconds (PGPU_LANE_ACTIVE_MS, default 50).  The second clause is what keeps a caller that rotates over the lanes
 // in one mode: right after a synchronisation every lane is empty for a moment, and a policy that only looked at the
 // queues would start each burst with a full-chip launch that the next lane's half-chip launch then has to share CUs
 // with (measured: ~7 ms lost at the head of a 20-step run, 5.31 instead of 4.95 ms per step).  Also stamps `lane`.
-// PGPU_RR_ADAPT = k > 0 (round 5; default 3): threads on ROUND-ROBIN lanes (synchronous callers of the ipcl:: API side by
-// side) enter the adaptive policy as well, but only when at least k other lanes are active -- with all four lanes busy each
-// caller's launches take a quarter of the chip (the one-lane decrypt, 17 ms per encrypt + decrypt instead of 5.4 on the whole
-// chip, four of them side by side), which pays although every caller's quarter idles through its copies and host work;
-// with one busy neighbour (half-chip forms) it does not (r04: 11.8 against 7.2 ms per pair).  0: lone-caller forms always.
-std::atomic<int> g_rr_adapt{[] { const char* e = std::getenv("PGPU_RR_ADAPT"); return e ? std::max(0, std::atoi(e)) : 3; }()};
 int busy_other_lanes(rt::Device& dev, int lane, bool force = false) {
-  const int rr_min = (!force && !t_lane_explicit) ? g_rr_adapt.load() : 1;
+  const int rr_min = (!force && !t_lane_explicit) ? policy::rr_adapt() : 1;
   if (rr_min <= 0) return 0;   // (synchronous callers on round-robin lanes: lone-caller forms, no stamp)
   static const int64_t window_ns = [] {
     const char* e = std::getenv("PGPU_LANE_ACTIVE_MS");
@@ -1639,58 +1570,7 @@ int busy_other_lanes(rt::Device& dev, int lane, bool force = false) {
   (void)hipGetLastError();
   return busy >= rr_min ? busy : 0;
 }
-std::atomic<int> g_ab_policy{[] {
-  const char* e = std::getenv("PGPU_AB_DECRYPT");
-  return e ? std::max(0, std::min(3, std::atoi(e))) : 0;
-}()};
-int ab_policy() { return g_ab_policy.load(); }
 
-bool fb_encrypt_seq_pays(int H, int K, size_t count, int busy) {
-  if (!pgpu::hensel_fb_encrypt_seq_has(H, K)) return false;
-  const size_t ipw = 64 / (size_t)H;
-  const size_t waves = (count + ipw - 1) / ipw;
-  const int pol = seq_policy_by_size();
-  // (adaptive: beside busy neighbour lanes the form of half the wavefronts -- and a sixth fewer multiply-accumulates --
-  // also for launches that would not fill the chip alone; 4-lane groups only, see below for the others)
-  if (H == 4 && busy <= g_adapt_enc_seq.load() && seq_adaptive(waves, busy)) return true;
-  // (2-lane groups, 1024-bit keys: measured equal or behind the paired kernel at 65536 elements -- 1.04 against 1.02 ms,
-  // 0.96 against 0.92 ms: 19 limbs per lane and the LDS staging leave no register room -- so only when forced)
-  if (H == 2 && pol != 2) return false;
-  // (8-lane groups pay two DPP moves per row broadcast: alone on a SIMD the form is 2 % behind the paired kernel --
-  // 3072-bit keys, 8192 elements: 3.60 against 3.52 ms -- and 7 % ahead with two wavefronts per SIMD: 6.2 against 6.7 ms)
-  return pol == 2 || (pol == 1 && waves >= (H >= 8 ? 2 : 1) * kSimds);
-}
-bool modexp_seq_form_pays(int H, int K, size_t count) {
-  if (!pgpu::hensel_modexp_seq_has(H, K)) return false;
-  const size_t ipw = 64 / (size_t)H;
-  const size_t waves = (count + ipw - 1) / ipw;
-  const int pol = seq_policy_by_size();
-  // (2-lane groups, 1024-bit keys: measured equal or behind the paired kernel at 65536 elements -- 1.04 against 1.02 ms,
-  // 0.96 against 0.92 ms: 19 limbs per lane and the LDS staging leave no register room -- so only when forced)
-  if (H == 2 && pol != 2) return false;
-  return pol == 2 || (pol == 1 && waves >= (H >= 8 ? 2 : 1) * kSimds);   // (8-lane groups: see fb_encrypt_seq_pays)
-}
-// the sequential-halves form (csrc/hensel_seq.hpp) for a decrypt of `count` resident ciphertexts in form (H, K)?
-bool seq_form_pays(int H, int K, size_t count, int busy = 0) {
-  if (!pgpu::hensel_seq_has(H, K)) return false;
-  const size_t ipw = 64 / (size_t)H;
-  const size_t waves = 2 * ((count + ipw - 1) / ipw);
-  const int pol = g_seq_policy.load();
-  return pol == 2 || (pol == 3 && 2 * waves >= kSimds) || ((pol == 1 || pol == 4) && waves >= kSimds) || seq_adaptive(waves, busy);
-}
-// the one-lane-per-exponentiation form (csrc/hensel_lane.hpp) for a decrypt of `count` resident ciphertexts whose split
-// form has L2 limbs per half?  PGPU_LANE_DECRYPT: 0 never, 1 (default) launches that put a wavefront on every SIMD that
-// way (64 exponentiations per wavefront: 32768 ciphertexts), 2 whenever it is compiled (tests)
-std::atomic<int> g_lane_policy{[] {
-  const char* e = std::getenv("PGPU_LANE_DECRYPT");
-  return e ? std::max(0, std::min(2, std::atoi(e))) : 1;
-}()};
-bool lane_form_pays(int L2, size_t count) {
-  if (!pgpu::hensel_lane_has(L2)) return false;
-  const size_t waves = 2 * ((count + 63) / 64);
-  const int pol = g_lane_policy.load();
-  return pol == 2 || (pol == 1 && waves >= kSimds);
-}
 // the split form of the key whose limbs per half have a one-lane kernel, when a decrypt of `count` ciphertexts takes it
 const pgpu_privkey::HenselSet* lane_hset(const pgpu_privkey* key, size_t count) {
   if (!hensel_enabled()) return nullptr;
@@ -1698,20 +1578,9 @@ const pgpu_privkey::HenselSet* lane_hset(const pgpu_privkey* key, size_t count) 
     if (lane_form_pays(f->H * f->K, count)) return f.get();
   return nullptr;
 }
-// the one-lane product-scanning form (csrc/hensel_ps.hpp; 2048-bit keys) for a decrypt of `count` resident ciphertexts?
-// 64 exponentiations per wavefront: 8192 ciphertexts are 256 wavefronts -- a quarter of the SIMDs.  PGPU_PS_DECRYPT:
-// 0 never; 1 (default) launches that put a wavefront on every SIMD that way (32768 ciphertexts), or -- adaptive, like the
-// sequential-halves form -- do so together with the busy neighbour lanes: waves * (1 + busy) >= SIMDs (16384 ciphertexts
-// beside one busy lane, 8192 beside three); 2 whenever it is compiled (tests)
-std::atomic<int> g_ps_policy{[] {
-  const char* e = std::getenv("PGPU_PS_DECRYPT");
-  return e ? std::max(0, std::min(2, std::atoi(e))) : 1;
-}()};
+// the one-lane product-scanning form (csrc/hensel_ps.hpp) for a decrypt of `count` resident ciphertexts under this key?
 bool ps_form_pays(const pgpu_privkey* key, size_t count, int busy) {
-  if (!key->hs_ps || !hensel_enabled()) return false;
-  const size_t waves = 2 * ((count + 63) / 64);
-  const int pol = g_ps_policy.load();
-  return pol == 2 || (pol == 1 && (waves >= kSimds || seq_adaptive(waves, busy)));
+  return key->hs_ps && hensel_enabled() && policy::ps_form_pays(count, busy);
 }
 int words_to_pair_on(rt::Device& d, const pgpu_pubkey::PubForm* f, const uint64_t* words, size_t stride, int nwords,
                      bool src_mont, uint32_t* out, size_t count, hipStream_t s);
@@ -1843,9 +1712,9 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
         return e ? atoi(e) : -1;
       }();
       // a launch that covers less than the chip leaves the other CUs to the neighbour lane's launch (policy 3)
-      const int pol = g_seq_policy.load();
+      const int pol = policy::seq_policy();
       const unsigned lds_pad = env_pad >= 0 ? (unsigned)env_pad
-                               : (seq_waves < kSimds && (pol == 3 || (pol == 4 && busy_lanes >= 1 && busy_lanes <= g_adapt_claim_busy.load())) ? 84000u : 0u);
+                               : (seq_waves < kSimds && (pol == 3 || (pol == 4 && busy_lanes >= 1 && busy_lanes <= policy::adapt_claim_busy())) ? 84000u : 0u);
       if (lds_pad) t.set_form(PGPU_FORM_SEQ | PGPU_FORM_CU_CLAIM);
       if (!pgpu::launch_hensel_seq(hset->H, hset->K, h, sblocks, s, lds_pad))
         return fail(PGPU_ERR_UNSUPPORTED, "sequential-halves decrypt kernel not compiled");
@@ -1940,13 +1809,6 @@ const pgpu_pubkey::PubForm* pair_op_form(const pgpu_pubkey* key, const pgpu_pubk
       return alt.get();
   }
   return f;
-}
-bool pair_mul_seq_pays(int H, int K, size_t count) {
-  if (!pgpu::pair_mul_seq_has(H, K)) return false;
-  const size_t ipw = 64 / (size_t)H;
-  const size_t waves = (count + ipw - 1) / ipw;
-  const int pol = seq_policy_by_size();
-  return pol == 2 || (pol == 1 && waves >= (H >= 8 ? 2 : 1) * kSimds);   // (8-lane groups: see fb_encrypt_seq_pays)
 }
 int pair_op_launch(rt::Device& d, const pgpu_pubkey::PubForm* f, pgpu::PairOpsArgs& a, hipStream_t s, int kind) {
   // CT + CT of launches that still put a wavefront on every SIMD with half the lanes per element: both halves of a
@@ -2371,23 +2233,20 @@ void pgpu_debug_set_packed_decrypt(int on) { g_packed_decrypt.store(on != 0); }
 // tests / A-B measurements: the A/B-wavefront decrypt kernel (hensel_ab.hpp): 0 never, 1 whenever it applies, 2 when the
 // other batch lane is busy.  Not part of the public header.
 // tests / A-B measurements: hensel_seq.hpp (0 never, 1 by launch size, 2 whenever it applies).  Not part of the public header.
-void pgpu_debug_set_seq_decrypt(int policy) { g_seq_policy.store(policy < 0 ? 0 : (policy > 4 ? 4 : policy)); }
+void pgpu_debug_set_seq_decrypt(int policy) { pgpu::policy::set_seq_policy(policy); }
 int pgpu_debug_set_host_adapt(int on) {
   const int was = g_host_adapt.exchange(on != 0 ? 1 : 0);
   return was;
 }
-int pgpu_debug_get_seq_decrypt(void) { return g_seq_policy.load(); }
-void pgpu_debug_set_lane_decrypt(int policy) { g_lane_policy.store(policy < 0 ? 0 : (policy > 2 ? 2 : policy)); }
+int pgpu_debug_get_seq_decrypt(void) { return pgpu::policy::seq_policy(); }
+void pgpu_debug_set_lane_decrypt(int policy) { pgpu::policy::set_lane_policy(policy); }
 // tests / A-B measurements: hensel_ps.hpp (0 never, 1 by launch size and neighbour lanes, 2 whenever it is compiled)
-void pgpu_debug_set_ps_decrypt(int policy) { g_ps_policy.store(policy < 0 ? 0 : (policy > 2 ? 2 : policy)); }
-int pgpu_debug_get_ps_decrypt(void) { return g_ps_policy.load(); }
+void pgpu_debug_set_ps_decrypt(int policy) { pgpu::policy::set_ps_policy(policy); }
+int pgpu_debug_get_ps_decrypt(void) { return pgpu::policy::ps_policy(); }
 // tests / A-B measurements: from how many active neighbour lanes on threads on round-robin lanes take the adaptive forms (0 never)
-int pgpu_debug_set_rr_adapt(int min_busy) { return g_rr_adapt.exchange(min_busy < 0 ? 0 : min_busy); }
-void pgpu_debug_set_adaptive(int enc_seq, int claim_busy) {
-  g_adapt_enc_seq.store(enc_seq);
-  g_adapt_claim_busy.store(claim_busy);
-}
-void pgpu_debug_set_ab_decrypt(int policy) { g_ab_policy.store(policy < 0 ? 0 : (policy > 3 ? 3 : policy)); }
+int pgpu_debug_set_rr_adapt(int min_busy) { return pgpu::policy::set_rr_adapt(min_busy); }
+void pgpu_debug_set_adaptive(int enc_seq, int claim_busy) { pgpu::policy::set_adaptive(enc_seq, claim_busy); }
+void pgpu_debug_set_ab_decrypt(int policy) { pgpu::policy::set_ab_policy(policy); }
 
 int pgpu_set_timing(int enabled) {
   g_timing.store(enabled != 0);

@@ -1,0 +1,64 @@
+// pailliercryptolib_amd -- the kernel-FORM policy of the host runtime: which form of a split-form kernel a launch takes,
+// from its size and from what the GPU's other batch lanes are doing.  Pure host logic (sizes x busy lanes -> form, LDS
+// claim, window): no device, no HIP call -- tests/cpp/policy_tests.cpp checks it on the CPU.  The measurements behind
+// every threshold are in DESIGN.md sections 3-4; the environment knobs are read once.
+//
+// The forms (include/pgpu.h: pgpu_kernel_form; reference: the operations of ipcl/pri_key.cpp:114-146, pub_key.cpp:51-129,
+// ciphertext.cpp:135-162 all funnel into one exponentiation primitive, which is what takes these forms here):
+//   paired        hensel.hpp      the two halves of a residue in neighbouring lanes -- most lanes per residue: a lone caller
+//   sequential    hensel_seq.hpp  both halves in the same lanes -- half the wavefronts: launches that still cover the SIMDs,
+//                                 alone or together with one busy neighbour lane (each launch then claims half the chip)
+//   one-lane      hensel_lane.hpp / hensel_ps.hpp   a whole exponentiation per lane -- a quarter of the wavefronts again:
+//                                 large launches, or 8192-ciphertext launches beside three busy lanes (a quarter chip each)
+#ifndef PAILLIERCRYPTOLIB_AMD_CSRC_POLICY_HPP_
+#define PAILLIERCRYPTOLIB_AMD_CSRC_POLICY_HPP_
+
+#include <stddef.h>
+
+namespace pgpu {
+namespace policy {
+
+constexpr size_t kSimds = 256 * 4;   // MI355X: 256 CUs x 4 SIMDs; a launch of fewer wavefronts leaves SIMDs empty
+
+// ---- knobs (environment at start-up; the setters are what pgpu_debug_set_* and the tests use) ----
+int seq_policy();            // PGPU_SEQ_DECRYPT: 0 never, 1 by launch size, 2 always, 3 two-lane mode (r03), 4 adaptive (default)
+void set_seq_policy(int p);
+int lane_policy();           // PGPU_LANE_DECRYPT (hensel_lane.hpp): 0 never, 1 by launch size (default), 2 always
+void set_lane_policy(int p);
+int ps_policy();             // PGPU_PS_DECRYPT (hensel_ps.hpp): 0 never, 1 by launch size / neighbour lanes (default), 2 always
+void set_ps_policy(int p);
+int ab_policy();             // PGPU_AB_DECRYPT (hensel_ab.hpp, an experiment): 0 never (default) .. 3
+void set_ab_policy(int p);
+int adapt_enc_seq();         // PGPU_ADAPT_ENC_SEQ: up to how many busy neighbours the DJN encrypt takes the part-chip form (3)
+int adapt_claim_busy();      // PGPU_ADAPT_CLAIM_BUSY: up to how many busy neighbours a part-chip launch claims whole CUs (3)
+void set_adaptive(int enc_seq, int claim_busy);
+int rr_adapt();              // PGPU_RR_ADAPT: from how many active neighbours on threads on round-robin lanes adapt (3; 0 never)
+int set_rr_adapt(int min_busy);   // returns the previous value
+
+// ---- decisions ----
+// the by-size part of the sequential-halves policy (modes 3 and 4 decide by size like mode 1, plus their extras)
+int seq_policy_by_size();
+// with `busy` other batch lanes at work, does a launch of `waves` wavefronts of a part-chip form fill its share of the chip?
+bool seq_adaptive(size_t waves, int busy);
+// LDS bytes a part-chip launch claims beyond its needs under the adaptive policy (more than half a CU's LDS: one workgroup
+// per CU, so that the launches of neighbour lanes spread over the chip); 0: no claim
+unsigned adaptive_cu_claim(size_t waves, int busy_lanes);
+// CRT decrypt of `count` resident ciphertexts in split form (H, K): the sequential-halves kernel?
+bool seq_form_pays(int H, int K, size_t count, int busy = 0);
+// ... the one-lane kernel of hensel_lane.hpp (L2 limbs per half)?
+bool lane_form_pays(int L2, size_t count);
+// ... the one-lane product-scanning kernel of hensel_ps.hpp (the key must have its constant set)?
+bool ps_form_pays(size_t count, int busy);
+// DJN encrypt onto pair rows / CT x PT / CT + CT of `count` elements in form (H, K): the sequential-halves kernels?
+bool fb_encrypt_seq_pays(int H, int K, size_t count, int busy = 0);
+bool modexp_seq_form_pays(int H, int K, size_t count);
+bool pair_mul_seq_pays(int H, int K, size_t count);
+// fixed window of a per-element / secret exponent of exp_bits bits: the w in 1..5 with the fewest products
+int pick_window(int exp_bits);
+// ... under the masked table gather (every entry of the table read at every window product: small on purpose)
+int masked_decrypt_window();
+
+}  // namespace policy
+}  // namespace pgpu
+
+#endif  // PAILLIERCRYPTOLIB_AMD_CSRC_POLICY_HPP_

@@ -1,0 +1,84 @@
+// CPU unit test of the kernel-form policy (pailliercryptolib_amd/csrc/policy.cpp): sizes x busy lanes -> form, LDS claim,
+// window.  Pure host logic -- built with g++ from policy.cpp alone, no device, no HIP call.  The expectations are the
+// thresholds DESIGN.md sections 3-4 document for the MI355X (1024 SIMDs); the operations they steer are the reference's
+// PrivateKey::decryptCRT (ipcl/pri_key.cpp:114-146), PublicKey::encrypt (pub_key.cpp:99-129) and the CipherText
+// operators (ciphertext.cpp:135-162).
+#include <cstdio>
+
+#include "policy.hpp"
+
+namespace pol = pgpu::policy;
+static int g_failed = 0, g_checks = 0;
+#define CHECK(cond)                                                        \
+  do {                                                                     \
+    ++g_checks;                                                            \
+    if (!(cond)) {                                                         \
+      ++g_failed;                                                          \
+      std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond);          \
+    }                                                                      \
+  } while (0)
+
+int main() {
+  // ---- defaults: adaptive (4), one-lane forms by size / neighbours (1), experiment off ----
+  CHECK(pol::seq_policy() == 4 && pol::lane_policy() == 1 && pol::ps_policy() == 1 && pol::ab_policy() == 0);
+  CHECK(pol::seq_policy_by_size() == 1);
+  // CRT decrypt, 2048-bit keys, split form (2,19): 32 ciphertexts per sequential-halves wavefront and side
+  CHECK(!pol::seq_form_pays(2, 19, 8192, 0));      // 512 wavefronts: a lone caller keeps the paired kernel
+  CHECK(pol::seq_form_pays(2, 19, 8192, 1));       // beside one busy lane: two half-chip launches
+  CHECK(pol::seq_form_pays(2, 19, 16384, 0));      // 1024 wavefronts: by size
+  CHECK(!pol::seq_form_pays(2, 19, 4096, 1));      // 256 x 2 < 1024
+  CHECK(pol::seq_form_pays(2, 19, 4096, 3));
+  CHECK(!pol::seq_form_pays(3, 19, 1 << 20, 3));   // not a compiled form
+  CHECK(pol::seq_form_pays(4, 14, 8192, 0));       // 3072-bit keys: 16 per wavefront -> 1024 wavefronts
+  // the one-lane product-scanning kernel: 64 exponentiations per wavefront
+  CHECK(!pol::ps_form_pays(8192, 0) && !pol::ps_form_pays(8192, 1) && !pol::ps_form_pays(8192, 2));
+  CHECK(pol::ps_form_pays(8192, 3));               // four lanes: a quarter of the chip each
+  CHECK(pol::ps_form_pays(16384, 1) && !pol::ps_form_pays(16384, 0));
+  CHECK(pol::ps_form_pays(32768, 0));              // covers the SIMDs alone
+  CHECK(!pol::ps_form_pays(1, 3) && !pol::ps_form_pays(8191 - 64, 3));   // 254 wavefronts x 4 < 1024
+  // the operand-scanning one-lane kernel exists for 20-limb halves (1024-bit keys)
+  CHECK(pol::lane_form_pays(20, 32768) && !pol::lane_form_pays(20, 32767 - 63) && !pol::lane_form_pays(38, 1 << 20));
+  // whole-CU claims of part-chip launches
+  CHECK(pol::adaptive_cu_claim(512, 1) == 84000u && pol::adaptive_cu_claim(256, 3) == 84000u);
+  CHECK(pol::adaptive_cu_claim(512, 0) == 0u && pol::adaptive_cu_claim(1024, 1) == 0u && pol::adaptive_cu_claim(256, 4) == 0u);
+  // DJN encrypt onto pair rows, form (4,18): 16 elements per sequential-halves wavefront
+  CHECK(!pol::fb_encrypt_seq_pays(4, 18, 8192, 0));
+  CHECK(pol::fb_encrypt_seq_pays(4, 18, 8192, 1) && pol::fb_encrypt_seq_pays(4, 18, 8192, 3));
+  CHECK(pol::fb_encrypt_seq_pays(4, 18, 16384, 0));
+  CHECK(!pol::fb_encrypt_seq_pays(2, 19, 1 << 20, 0));     // 2-lane groups: measured behind the paired kernel
+  CHECK(!pol::fb_encrypt_seq_pays(8, 14, 16384 - 8, 0));
+  CHECK(pol::fb_encrypt_seq_pays(8, 14, 16384, 0));        // 8-lane groups: from two wavefronts per SIMD (8 per wavefront)
+  // CT x PT and CT + CT
+  CHECK(pol::modexp_seq_form_pays(4, 18, 1 << 20) && !pol::modexp_seq_form_pays(4, 18, 8192));
+  CHECK(pol::pair_mul_seq_pays(4, 18, 1 << 20) && !pol::pair_mul_seq_pays(4, 18, 16383 - 16));
+  // windows
+  CHECK(pol::pick_window(1024) == 5 && pol::pick_window(512) == 5 && pol::pick_window(33) == 3 && pol::pick_window(1) == 1);
+  CHECK(pol::masked_decrypt_window() == 3);
+  // ---- knobs ----
+  pol::set_adaptive(1, 3);                                  // the round-4 encrypt rule: part-chip beside ONE neighbour only
+  CHECK(pol::fb_encrypt_seq_pays(4, 18, 8192, 1) && !pol::fb_encrypt_seq_pays(4, 18, 8192, 3));
+  pol::set_adaptive(3, 1);
+  CHECK(pol::adaptive_cu_claim(256, 3) == 0u && pol::adaptive_cu_claim(512, 1) == 84000u);
+  pol::set_adaptive(3, 3);
+  pol::set_seq_policy(1);                                   // by size only: no adaptive forms, no claims
+  CHECK(!pol::seq_form_pays(2, 19, 8192, 1) && pol::seq_form_pays(2, 19, 16384, 1) && pol::adaptive_cu_claim(512, 1) == 0u);
+  CHECK(!pol::ps_form_pays(8192, 3) && pol::ps_form_pays(32768, 0));
+  pol::set_seq_policy(3);                                   // round 3: half-chip launches take the form
+  CHECK(pol::seq_form_pays(2, 19, 8192, 0) && !pol::seq_form_pays(2, 19, 4096, 0));
+  pol::set_seq_policy(0);
+  CHECK(!pol::seq_form_pays(2, 19, 1 << 20, 3) && !pol::modexp_seq_form_pays(4, 18, 1 << 20));
+  pol::set_seq_policy(2);
+  CHECK(pol::seq_form_pays(2, 19, 1, 0) && pol::fb_encrypt_seq_pays(2, 19, 1, 0));
+  pol::set_seq_policy(4);
+  pol::set_ps_policy(2);
+  CHECK(pol::ps_form_pays(1, 0));
+  pol::set_ps_policy(0);
+  CHECK(!pol::ps_form_pays(1 << 20, 3));
+  pol::set_ps_policy(1);
+  pol::set_lane_policy(2);
+  CHECK(pol::lane_form_pays(20, 1) && !pol::lane_form_pays(19, 1));
+  pol::set_lane_policy(1);
+  CHECK(pol::set_rr_adapt(0) == 3 && pol::rr_adapt() == 0 && pol::set_rr_adapt(3) == 0);
+  std::printf("%d checks, %d failed\n", g_checks, g_failed);
+  return g_failed ? 1 : 0;
+}
