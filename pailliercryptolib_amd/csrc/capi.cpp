@@ -1445,7 +1445,7 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
         // but none fits beside a neighbour's decrypt workgroup (84 000 bytes claimed): an encrypt wavefront that shares a
         // SIMD with an older decrypt wavefront only gets the issue slots that one leaves (measured: 0.8 -> 10 ms)
         unsigned lds_pad = adaptive_cu_claim(seq_waves, busy_lanes);
-        if (lds_pad && busy_lanes >= 2) lds_pad = pgpu::kLdsTotalFlag | 80000u;
+        if (lds_pad && busy_lanes >= 3) lds_pad = pgpu::kLdsTotalFlag | 80000u;
         if (lds_pad) t.set_form(PGPU_FORM_SEQ | PGPU_FORM_CU_CLAIM);
         if (!pgpu::launch_hensel_fb_encrypt_seq(form->H, form->K, f, blocks, s, lds_pad))
           return fail(PGPU_ERR_UNSUPPORTED, "sequential-halves fixed-base kernel not compiled");
@@ -1788,9 +1788,10 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
   c.out_words = nw;
   c.count = count;
   TimerScope tc(d, s, PGPU_KERNEL_CRT);
-  // beside two or three busy neighbour lanes (each lane owns a quarter of the chip) the recombination stays on the CUs its
-  // decrypt has just left: 80 000 bytes per workgroup, as the encrypt of that mode (encrypt_on)
-  const unsigned crt_claim = (busy_lanes >= 2 && adaptive_cu_claim(1, busy_lanes)) ? 80000u : 0u;
+  // beside three busy neighbour lanes (each lane owns a quarter of the chip) the recombination stays on the CUs its
+  // decrypt has just left: 80 000 bytes per workgroup, as the encrypt of that mode (encrypt_on) -- 0.23 -> 0.07 ms.  Not
+  // beside two: their half-chip decrypts hold every CU and the launch would wait for one (1.6 ms)
+  const unsigned crt_claim = (busy_lanes >= 3 && adaptive_cu_claim(1, busy_lanes)) ? 80000u : 0u;
   if (!pgpu::launch_crt(key->geo_crt.G, key->geo_crt.K, c, blocks_for(count, key->geo_crt), s, crt_claim))
     return fail(PGPU_ERR_UNSUPPORTED, "crt kernel geometry not compiled");
   HIP_TRY(hipGetLastError());

@@ -92,7 +92,10 @@ bool fb_encrypt_seq_pays(int H, int K, size_t count, int busy) {
   const int pol = seq_policy_by_size();
   // (adaptive: beside busy neighbour lanes the form of half the wavefronts -- and a sixth fewer multiply-accumulates --
   // also for launches that would not fill the chip alone; 4-lane groups only, see below for the others)
-  if (H == 4 && busy <= g_adapt_enc_seq.load() && seq_adaptive(waves, busy)) return true;
+  // beside ONE neighbour (half the chip each) and beside THREE (a quarter each: the lane's own CUs between its one-lane
+  // decrypts); beside two the lanes' sequential-halves decrypts hold every CU and the paired full-chip encrypt squeezes
+  // in better than a launch that waits for whole CUs (k = 3 of the lane sweep: 4.9-5.1 against 5.2 ms per step)
+  if (H == 4 && busy != 2 && busy <= g_adapt_enc_seq.load() && seq_adaptive(waves, busy)) return true;
   // (2-lane groups, 1024-bit keys: measured equal or behind the paired kernel at 65536 elements -- 1.04 against 1.02 ms,
   // 0.96 against 0.92 ms: 19 limbs per lane and the LDS staging leave no register room -- so only when forced)
   if (H == 2 && pol != 2) return false;

@@ -44,6 +44,7 @@ int main() {
   // DJN encrypt onto pair rows, form (4,18): 16 elements per sequential-halves wavefront
   CHECK(!pol::fb_encrypt_seq_pays(4, 18, 8192, 0));
   CHECK(pol::fb_encrypt_seq_pays(4, 18, 8192, 1) && pol::fb_encrypt_seq_pays(4, 18, 8192, 3));
+  CHECK(!pol::fb_encrypt_seq_pays(4, 18, 8192, 2));        // beside two: the paired full-chip kernel
   CHECK(pol::fb_encrypt_seq_pays(4, 18, 16384, 0));
   CHECK(!pol::fb_encrypt_seq_pays(2, 19, 1 << 20, 0));     // 2-lane groups: measured behind the paired kernel
   CHECK(!pol::fb_encrypt_seq_pays(8, 14, 16384 - 8, 0));

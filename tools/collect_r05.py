@@ -51,7 +51,7 @@ for tag, label in (("f1", ""), ("f2", "_two_in_flight"), ("f4", "_four_in_flight
         for fn in glob.glob(f"{src}/{d}/*/*_counter_collection.csv"):
             for r in csv.DictReader(open(fn)):
                 s = short(r["Kernel_Name"])
-                if not s or int(r["Grid_Size"]) < 64 * 500:
+                if not s or int(r["Grid_Size"]) < 64 * 250:
                     continue
                 agg[s][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 meta[s] = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
