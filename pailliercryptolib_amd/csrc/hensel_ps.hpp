@@ -429,8 +429,11 @@ __global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_ps_kernel(Hen
     }
     ps_table_store<K>(tw, 0, oa, ob);
   }
+  // (the base comes back from entry 1 for every product, like the entries of the main loop: held in registers across
+  // the loop it cost 92 scratch accesses per product)
 #pragma unroll 1
   for (int e = 2; e < tsize; ++e) {
+    ps_table_load<K>(ma, mb, tw, 1, tsize, false);
     ps_pairmul<K, LB, true>(a, b, ma, mb, n, n1p, 0, slot);
     ps_table_store<K>(tw, e, a, b);
   }

@@ -61,3 +61,21 @@ def test_ps_decrypt_kernel_is_bit_identical(engine, count):
             L.pgpu_debug_set_ps_decrypt(1)
     finally:
         R.close()
+
+
+def test_four_api_threads_take_the_quarter_chip_forms(engine):
+    """Four host threads calling ipcl::PublicKey::encrypt / PrivateKey::decrypt on vectors of 8192 side by side (the
+    reference's BM_Encrypt / BM_Decrypt shape from an OpenMP team, benchmark/bench_cryptography.cpp:24-63): their
+    round-robin lanes see three active neighbours, so the launches take the quarter-chip forms (one-lane decrypt with a CU
+    claim, encrypt and CRT kernel with the 80 000-byte claim) from four launching threads at once -- the configuration in
+    which changing a kernel's attributes beside another thread's launch crashed inside the HIP runtime.  Every thread's
+    round trip must hold, several times over."""
+    import json
+    import subprocess
+    from pailliercryptolib_amd import build
+    exe = build.build_api_bench()
+    for _ in range(3):
+        r = subprocess.run([exe, "--threads", "4", "8192", "3"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        assert json.loads(line)["round_trip_ok"] is True
