@@ -94,7 +94,8 @@ def _objects():
     for name in ("capi.cpp", "policy.cpp", "runtime.cpp", os.path.join("host", "bignum.cpp")):
         src = os.path.join(CSRC, name)
         o = os.path.join(obj, os.path.basename(name).replace(".cpp", ".o"))
-        out.append((o, host + ["-c", src, "-o", o], [src] + hdeps))
+        extra = [os.path.join(CSRC, f) for f in ("capi_keys.inc", "capi_batches.inc", "capi_timing.inc")] if name == "capi.cpp" else []
+        out.append((o, host + ["-c", src, "-o", o], [src] + hdeps + extra))
     return out
 
 

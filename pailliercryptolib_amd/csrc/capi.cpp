@@ -2249,53 +2249,7 @@ int pgpu_debug_set_rr_adapt(int min_busy) { return pgpu::policy::set_rr_adapt(mi
 void pgpu_debug_set_adaptive(int enc_seq, int claim_busy) { pgpu::policy::set_adaptive(enc_seq, claim_busy); }
 void pgpu_debug_set_ab_decrypt(int policy) { pgpu::policy::set_ab_policy(policy); }
 
-int pgpu_set_timing(int enabled) {
-  g_timing.store(enabled != 0);
-  return PGPU_OK;
-}
-
-int pgpu_timing_collect_ex(int* kinds, int* forms, double* ms, int max_entries);
-int pgpu_timing_collect_trace(int* kinds, int* forms, int* lanes, double* start_ms, double* ms, int max_entries);
-int pgpu_timing_collect(int* kinds, double* ms, int max_entries) { return pgpu_timing_collect_ex(kinds, nullptr, ms, max_entries); }
-int pgpu_timing_collect_ex(int* kinds, int* forms, double* ms, int max_entries) {
-  return pgpu_timing_collect_trace(kinds, forms, nullptr, nullptr, ms, max_entries);
-}
-int pgpu_timing_collect_trace(int* kinds, int* forms, int* lanes, double* start_ms, double* ms, int max_entries) {
-  if (!rt::initialized()) return 0;
-  rt::Device& d = rt::current();
-  rt::DeviceGuard g(d.ordinal);
-  std::vector<rt::TimedLaunch> rec;
-  {
-    std::lock_guard<std::mutex> lk(d.mu);
-    rec.swap(d.timed);
-  }
-  int n = 0;
-  for (auto& t : rec) {
-    float v = 0;
-    if (hipEventSynchronize(t.e1) == hipSuccess && hipEventElapsedTime(&v, t.e0, t.e1) == hipSuccess &&
-        n < max_entries && kinds && ms) {
-      kinds[n] = t.kind;
-      if (forms) forms[n] = t.form;
-      if (lanes) {
-        lanes[n] = -1;
-        for (int k = 0; k < rt::kBatchLanes; ++k)
-          if (t.stream == d.bs(k)) lanes[n] = k;
-      }
-      if (start_ms) {   // start of this launch relative to the start of the first launch of the record
-        float off = 0;
-        start_ms[n] = (hipEventElapsedTime(&off, rec.front().e0, t.e0) == hipSuccess) ? off : -1.0;
-      }
-      ms[n] = v;
-      ++n;
-    }
-  }
-  std::lock_guard<std::mutex> lk(d.mu);
-  for (auto& t : rec) {
-    d.event_pool.push_back(t.e0);
-    d.event_pool.push_back(t.e1);
-  }
-  return n;
-}
+#include "capi_timing.inc"   // pgpu_set_timing, pgpu_timing_collect*
 
 // ===================== device buffers (current pool entry) =====================
 // Blocks handed out here are used on the default stream and on caller streams: their free list is the one of
@@ -2454,125 +2408,7 @@ int pgpu_modmul(const uint64_t* a, const uint64_t* b, size_t b_stride, const uin
   });
 }
 
-// ===================== Paillier public key / encrypt =====================
-namespace {
-// Constants of the split forms of n^2 (hensel.hpp) for DJN encrypt, r^n and CT x PT: per lane count the smallest
-// compiled form (fixed-base or generic kernel) with enough limbs for n*k and a full-width twin Geo<2H,K> wide enough
-// for n^2.  The way back to a full-width residue has constants of its own, so the forms need not match the geometry
-// of the key's n^2 context; Montgomery-form results carry that context's radix Rs (they mix with the full-width
-// kernels of resident batches).
-// (n, n_words, the radix exponent of the n^2 context): all a form needs -- a PRIVATE key builds the same constants for its
-// n = p*q, to bring word ciphertexts into pair rows ahead of the kernels that take only those (make_conv_form)
-int make_pub_form(const BigNumber& n, int n_words, int nsq_rbits, int H, int K, std::shared_ptr<pgpu_pubkey::PubForm>* out) {
-  const int L2 = H * K;
-  const BigNumber N = n * n;
-  const int cw = std::min(n_words, n.BitSize() / 64);
-  if (cw <= 0) return PGPU_OK;
-  const int nch = (2 * n_words + cw - 1) / cw;
-  std::shared_ptr<pgpu_pubkey::PubForm> f(new pgpu_pubkey::PubForm);
-  f->H = H;
-  f->K = K;
-  f->chunk_words = cw;
-  f->nchunks = nch;
-  f->n_words = n_words;
-  f->n = n;
-  auto n0inv_of = [](const BigNumber& v) {
-    uint32_t n0 = (uint32_t)(v.limbs64()[0] & pgpu::kLimbMask), inv = n0;
-    for (int i = 0; i < 5; ++i) inv *= 2u - n0 * inv;
-    return (0u - inv) & pgpu::kLimbMask;
-  };
-  f->n0inv = n0inv_of(n);
-  f->n0inv_full = n0inv_of(N);
-  const BigNumber P = n * BigNumber((Ipp32u)f->n0inv), P2 = P * P;
-  const BigNumber R = pow2(L2 * pgpu::kLimbBits);
-  std::vector<uint32_t> h((size_t)L2 * (6 + 4 * (size_t)nch), 0);
-  auto put_pair = [&](uint32_t* dst, const BigNumber& z) {
-    const BigNumber zr = z % P2;
-    const BigNumber q = zr / P;
-    to_limbs29(zr % P, L2, dst);
-    to_limbs29(q.isZero() ? q : P - q, L2, dst + L2);
-  };
-  to_limbs29(P, L2, h.data());
-  to_limbs29(n, L2, h.data() + L2);
-  {
-    // gm = (-k^-1 mod n) * R^2 mod n  (kargs.hpp HenselPubDev::gm; hensel.hpp pair_times_gm)
-    const BigNumber kinv = n.InverseMul(BigNumber((Ipp32u)f->n0inv) % n);
-    const BigNumber Rn = R % n;
-    to_limbs29((((n - kinv) % n) * ((Rn * Rn) % n)) % n, L2, h.data() + (size_t)L2 * (5 + 4 * (size_t)nch));
-  }
-  to_limbs29((R % n) * BigNumber((Ipp32u)f->n0inv) % n, L2, h.data() + 2 * L2);
-  const BigNumber Rm = R % P2, R2 = (Rm * Rm) % P2;
-  put_pair(h.data() + 3 * L2, Rm);
-  // (second set: bases that arrive as c*Rs mod n^2 -- resident ciphertexts)
-  const BigNumber Rs = pow2(nsq_rbits);
-  const BigNumber R2m = (R2 * P2.InverseMul(Rs % P2)) % P2;
-  for (int i = 0; i < nch; ++i) {
-    const BigNumber sh = pow2(64 * cw * i) % P2;
-    put_pair(h.data() + 5 * L2 + (size_t)i * 2 * L2, (R2 * sh) % P2);
-    put_pair(h.data() + 5 * L2 + (size_t)(nch + i) * 2 * L2, (R2m * sh) % P2);
-  }
-  RC_TRY(f->pub.upload(h.data(), h.size() * sizeof(uint32_t), false));
-  const int LF = 2 * L2;
-  const BigNumber Rf = pow2(LF * pgpu::kLimbBits) % N, Rsn = Rs % N;
-  std::vector<uint32_t> g((size_t)4 * LF, 0);
-  to_limbs29(N, LF, g.data());
-  to_limbs29((n * Rf) % N, LF, g.data() + LF);
-  to_limbs29((((n * Rf) % N) * Rsn) % N, LF, g.data() + 2 * LF);
-  to_limbs29((Rf * Rsn) % N, LF, g.data() + 3 * LF);
-  RC_TRY(f->full.upload(g.data(), g.size() * sizeof(uint32_t), false));
-  *out = std::move(f);
-  return PGPU_OK;
-}
-int build_hensel_pub_form(pgpu_pubkey* k, int H, int K) {
-  std::shared_ptr<pgpu_pubkey::PubForm> f;
-  RC_TRY(make_pub_form(k->n, k->n_words, k->nsq->geo.rbits(), H, K, &f));
-  if (f) k->hforms.push_back(std::move(f));
-  return PGPU_OK;
-}
-int build_hensel_pub(pgpu_pubkey* k) {
-  const int need = k->n.BitSize() + 29 + 8;
-  const int nsq_bits = 2 * k->n.BitSize();
-  for (int H : {8, 4, 2})
-    for (int K = 1; K <= 19; ++K)
-      if ((pgpu::hensel_modexp_has(H, K) || pgpu::hensel_fb_has(H, K)) && pgpu::kLimbBits * H * K >= need &&
-          2 * pgpu::kLimbBits * H * K >= nsq_bits + 8) {
-        RC_TRY(build_hensel_pub_form(k, H, K));
-        break;
-      }
-  return PGPU_OK;
-}
-}  // namespace
-
-int pgpu_pubkey_create(const uint64_t* n, int n_words, const uint64_t* hs_or_null,
-                       pgpu_pubkey** out) {
-  RC_TRY(rt::check_ready());
-  if (!n || n_words <= 0 || !out) return fail(PGPU_ERR_INVALID_PARAM, "null key material");
-  std::unique_ptr<pgpu_pubkey> k(new pgpu_pubkey);
-  k->gen = rt::pool_generation();
-  k->n_words = n_words;
-  k->n = BigNumber::fromLimbs64(n, (size_t)n_words);
-  if (!k->n.IsOdd()) return fail(PGPU_ERR_EVEN_MODULUS, "n must be odd");
-  BigNumber nsq = k->n * k->n;
-  const GeoInfo* geo = pick_geo(2 * n_words, nsq.BitSize(), true);
-  if (!geo) return fail(PGPU_ERR_UNSUPPORTED, "key wider than the compiled kernel geometries");
-  CtxExtras ex;
-  ex.nr_n = &k->n;
-  ex.unit_q = true;
-  RC_TRY(build_modctx(nsq, 2 * n_words, *geo, ex, &k->nsq));
-  if (hs_or_null) {
-    k->djn = true;
-    RC_TRY(k->d_hs.upload(hs_or_null, (size_t)2 * n_words * 8, false));
-  }
-  RC_TRY(k->d_n.upload(n, (size_t)n_words * 8, false));
-  if (sliding_enabled()) RC_TRY(make_schedule(k->n, pick_sliding_window(k->n.BitSize()), &k->sched_n, false));
-  k->fb.resize((size_t)rt::pool_size());
-  k->fbh.resize((size_t)rt::pool_size());
-  RC_TRY(build_hensel_pub(k.get()));
-  *out = k.release();
-  return PGPU_OK;
-}
-
-void pgpu_pubkey_destroy(pgpu_pubkey* key) { delete key; }
+#include "capi_keys.inc"   // pgpu_pubkey_create, pgpu_privkey_create and their constants
 
 int pgpu_paillier_encrypt_dev(const pgpu_pubkey* key, const uint64_t* d_m, size_t m_stride,
                               int m_words, const uint64_t* d_r, size_t r_stride, int r_words,
@@ -2650,262 +2486,6 @@ int pgpu_paillier_encrypt(const pgpu_pubkey* key, const uint64_t* m, size_t m_st
   return rc;
 }
 
-// ===================== Paillier private key / CRT decrypt =====================
-namespace {
-// Constants of the split-form exponentiation (hensel.hpp) for both sides of the key.  A residue z modulo P^2 is
-// the pair (a, b) with z == a - P*b: a = z mod P, b = (P - z div P) mod P.
-// limbs per half of the pair rows a PUBLIC key over n would use (build_hensel_pub: its form of fewest lanes), 0: none
-int pair_l2_for_modulus(const BigNumber& n, int* H_out = nullptr, int* K_out = nullptr) {
-  const int need = n.BitSize() + 29 + 8, nsq_bits = 2 * n.BitSize();
-  int l2 = 0;
-  for (int H : {8, 4, 2})
-    for (int K = 1; K <= 19; ++K)
-      if ((pgpu::hensel_modexp_has(H, K) || pgpu::hensel_fb_has(H, K)) && pgpu::kLimbBits * H * K >= need &&
-          2 * pgpu::kLimbBits * H * K >= nsq_bits + 8) {
-        l2 = pgpu::pair_ops_has(H, K) ? H * K : 0;
-        if (H_out) *H_out = H;
-        if (K_out) *K_out = K;
-        break;
-      }
-  return l2;
-}
-
-int build_hensel_set(pgpu_privkey* k, pgpu_privkey::HenselSet* hs, int H, int K, const BigNumber& p,
-                     const BigNumber& q, const BigNumber& hp, const BigNumber& hq, int lb = pgpu::kLimbBits) {
-  // lb: bits per limb of the constants (R = 2^(lb*L2), P = prime * (-prime^-1 mod 2^lb)); the pair rows this set reads are
-  // rows of 29-bit limbs in any case
-  const int L2 = H * K;
-  const uint32_t lmask = (1u << lb) - 1;
-  auto to_limbs29 = [lb](const BigNumber& v, int L, uint32_t* out) { to_limbs(v, L, out, lb); };   // (shadows the 29-bit one)
-  hs->lb = lb;
-  const int bits_lo = std::min(p.BitSize(), q.BitSize());
-  // a ciphertext enters in chunks z < 2^(64*cw) <= 2P (P >= prime > 2^(bits-1))
-  const int cw = std::min(k->pq_words, bits_lo / 64);
-  if (cw <= 0) return PGPU_OK;   // (leaves hs->H == 0: no split form for this key)
-  const int ct_words = 2 * k->n_words;
-  const int nch = (ct_words + cw - 1) / cw;
-  const BigNumber R = pow2(L2 * lb);
-  hs->H = H;
-  hs->K = K;
-  hs->chunk_words = cw;
-  hs->nchunks = nch;
-  // entry from pair rows of the n^2 domain: the a part in chunks of at most L2 limbs (so that a chunk fits the lanes of
-  // one half), evenly sized; with narrower limbs: as many 29-bit row limbs as fit a half with two bits to spare
-  const BigNumber nmod = p * q;
-  hs->pair_l2 = pair_l2_for_modulus(nmod);
-  if (hs->pair_l2) {
-    const int fit = lb == pgpu::kLimbBits ? L2 : (L2 * lb - 2) / pgpu::kLimbBits;
-    hs->pchunks = (hs->pair_l2 + fit - 1) / fit;
-    hs->pchunk_limbs = (hs->pair_l2 + hs->pchunks - 1) / hs->pchunks;
-  }
-  uint32_t kn = 0;   // Pn = n * kn == -1 mod 2^29
-  {
-    uint32_t n0 = (uint32_t)(nmod.limbs64()[0] & pgpu::kLimbMask), inv = n0;
-    for (int i = 0; i < 5; ++i) inv *= 2u - n0 * inv;
-    kn = (0u - inv) & pgpu::kLimbMask;
-  }
-  const size_t side_words = hs->side_words();
-  std::vector<uint32_t> h(2 * side_words, 0);
-  for (int sd = 0; sd < 2; ++sd) {
-    const BigNumber& pr = sd ? q : p;
-    uint32_t n0 = (uint32_t)(pr.limbs64()[0] & lmask), inv = n0;
-    for (int i = 0; i < 5; ++i) inv *= 2u - n0 * inv;
-    const uint32_t n0inv = (0u - inv) & lmask;
-    const BigNumber P = pr * BigNumber((Ipp32u)n0inv);
-    const BigNumber P2 = P * P;
-    uint32_t* b = h.data() + sd * side_words;
-    auto put_pair = [&](uint32_t* dst, const BigNumber& z) {
-      const BigNumber zr = z % P2;
-      const BigNumber f = zr / P;
-      to_limbs29(zr % P, L2, dst);
-      to_limbs29(f.isZero() ? f : P - f, L2, dst + L2);
-    };
-    to_limbs29(P, L2, b);
-    to_limbs29(pr, L2, b + L2);
-    to_limbs29(sd ? hq : hp, L2, b + 2 * L2);
-    to_limbs29((R % pr) * BigNumber((Ipp32u)n0inv) % pr, L2, b + 3 * L2);   // P = prime * (-prime^-1 mod 2^29)
-    const BigNumber Rm = R % P2, R2 = (Rm * Rm) % P2;
-    put_pair(b + 4 * L2, Rm);
-    const BigNumber R2m = (R2 * P2.InverseMul(pow2(k->nsq_rbits) % P2)) % P2;   // cancels the R of the n^2 context
-    for (int i = 0; i < nch; ++i) {
-      const BigNumber sh = pow2(64 * cw * i) % P2;
-      put_pair(b + 6 * L2 + (size_t)i * 2 * L2, (R2 * sh) % P2);
-      put_pair(b + 6 * L2 + (size_t)(nch + i) * 2 * L2, (R2m * sh) % P2);
-    }
-    if (hs->pair_l2) {
-      // c*Rn == a - Pn*b (mod n^2), Pn = n*kn = pr * (n/pr) * kn.  Modulo pr^2:  c*Rn == a - P*(kappa*b) with
-      // kappa = (n/pr) * kn * k^-1 mod pr  (P = pr*k; P*y only depends on y mod pr).  The pair of c*R is that times R/Rn.
-      const BigNumber Rn = pow2(hs->pair_l2 * pgpu::kLimbBits);
-      const BigNumber R2n = (R2 * P2.InverseMul(Rn % P2)) % P2;            // R^2 * Rn^-1 mod P^2
-      const BigNumber other = sd ? p : q;
-      const BigNumber kinv = pr.InverseMul(BigNumber((Ipp32u)n0inv) % pr);   // k^-1 mod pr
-      const BigNumber kappa = (((other % pr) * (BigNumber((Ipp32u)kn) % pr)) % pr * kinv) % pr;
-      const BigNumber Rp = R % pr;
-      const BigNumber r2n_p = (((Rp * Rp) % pr) * pr.InverseMul(Rn % pr)) % pr;   // R^2 * Rn^-1 mod pr
-      uint32_t* pc = b + (size_t)L2 * (6 + 4 * (size_t)nch);
-      uint32_t* pb = pc + (size_t)hs->pchunks * 2 * L2;
-      for (int i = 0; i < hs->pchunks; ++i) {
-        const BigNumber sh = pow2(pgpu::kLimbBits * hs->pchunk_limbs * i);
-        put_pair(pc + (size_t)i * 2 * L2, (R2n * (sh % P2)) % P2);
-        to_limbs29((((kappa * (sh % pr)) % pr) * r2n_p) % pr, L2, pb + (size_t)i * L2);
-      }
-    }
-    hs->n0inv[sd] = n0inv;
-  }
-  const int rc = hs->blob.upload(h.data(), h.size() * sizeof(uint32_t), true);
-  secure_wipe(h.data(), h.size() * sizeof(h[0]));
-  return rc;
-}
-int build_hensel(pgpu_privkey* k, const BigNumber& p, const BigNumber& q, const BigNumber& hp, const BigNumber& hq) {
-  // R = 2^(29*H*K) >= 256 * P, P = prime * k < 2^(bits + 29): per lane count the smallest compiled form with
-  // enough limbs
-  const int need = std::max(p.BitSize(), q.BitSize()) + 29 + 8;
-  for (int H : {8, 4, 2})
-    for (int K = 1; K <= 19; ++K)
-      if (pgpu::hensel_has(H, K) && pgpu::kLimbBits * H * K >= need) {
-        std::unique_ptr<pgpu_privkey::HenselSet> set(new pgpu_privkey::HenselSet);
-        RC_TRY(build_hensel_set(k, set.get(), H, K, p, q, hp, hq));
-        if (set->H) k->hs.push_back(std::move(set));
-        break;
-      }
-  if (!k->hs.empty() && k->hs.front()->pair_l2) {
-    int H = 0, K = 0;
-    const BigNumber n = p * q;
-    if (pair_l2_for_modulus(n, &H, &K)) RC_TRY(make_pub_form(n, k->n_words, k->nsq_rbits, H, K, &k->conv_form));
-  }
-  // one lane per exponentiation, product scanning (hensel_ps.hpp): K limbs of lb bits per half, R = 2^(lb*K) >= 256 * P,
-  // P = prime * k < 2^(bits + lb).  Reads pair rows only.
-  if (!k->hs.empty() && k->hs.front()->pair_l2) {
-    const int bits = std::max(p.BitSize(), q.BitSize());
-    for (int lb : {28})
-      for (int K = 1; K <= 40 && !k->hs_ps; ++K)
-        if (pgpu::hensel_ps_has(K, lb) && lb * K >= bits + lb + 8 && lb * (K - 1) < bits + lb + 8) {
-          std::unique_ptr<pgpu_privkey::HenselSet> set(new pgpu_privkey::HenselSet);
-          RC_TRY(build_hensel_set(k, set.get(), 1, K, p, q, hp, hq, lb));
-          if (set->H && set->pair_l2) k->hs_ps = std::move(set);
-        }
-  }
-  return PGPU_OK;
-}
-}  // namespace
-
-int pgpu_privkey_create(const uint64_t* p_in, const uint64_t* q_in, int pq_words,
-                        pgpu_privkey** out) {
-  RC_TRY(rt::check_ready());
-  if (!p_in || !q_in || pq_words <= 0 || !out) return fail(PGPU_ERR_INVALID_PARAM, "null key material");
-  BigNumber p = BigNumber::fromLimbs64(p_in, (size_t)pq_words);
-  BigNumber q = BigNumber::fromLimbs64(q_in, (size_t)pq_words);
-  if (q < p) std::swap(p, q);  // pri_key.cpp:19-22
-  if (p == q) return fail(PGPU_ERR_NOT_INVERTIBLE, "PrivateKey: p and q are same");
-  if (!p.IsOdd() || !q.IsOdd() || p <= BigNumber::Two())
-    return fail(PGPU_ERR_EVEN_MODULUS, "p and q must be odd primes");
-  std::unique_ptr<pgpu_privkey> k(new pgpu_privkey);
-  k->gen = rt::pool_generation();
-  const BigNumber n = p * q;
-  const int nw = (n.BitSize() + 63) / 64;  // words of n; p^2, q^2 rows use the same width
-  k->n_words = nw;
-  k->pq_words = pq_words;
-  const BigNumber psq = p * p, qsq = q * q;
-  const BigNumber pm1 = p - 1, qm1 = q - 1;
-  if (psq.BitSize() > 64 * nw || qsq.BitSize() > 64 * nw)
-    return fail(PGPU_ERR_INVALID_PARAM, "p and q differ too much in size");
-  // hp = L_p(g^(p-1) mod p^2)^-1 mod p   (computeHfun, pri_key.cpp:159-167).  The reference's g is always
-  // n + 1 (pub_key.cpp:17, pri_key.cpp:47) and n^2 == 0 mod p^2, so the binomial series stops after two terms:
-  //   g^(p-1) = 1 + (p-1)*n  (mod p^2)   =>   L_p(.) = ((p-1)*n mod p^2) / p = (p-1)*q mod p
-  // -- the same value without an exponentiation.
-  BigNumber hp, hq;
-  try {
-    hp = p.InverseMul((pm1 * q) % p);
-    hq = q.InverseMul((qm1 * p) % q);
-  } catch (const std::exception& e) {
-    return fail(PGPU_ERR_NOT_INVERTIBLE, std::string("PrivateKey precompute: ") + e.what());
-  }
-  // half-width exponentiation contexts: inputs are 2*nw-word ciphertexts reduced on load
-  const int sq_bits = std::max(psq.BitSize(), qsq.BitSize());
-  const GeoInfo* ge = pick_geo(nw, sq_bits, true);
-  if (!ge) return fail(PGPU_ERR_UNSUPPORTED, "key wider than the compiled kernel geometries");
-  k->geo_exp = *ge;
-  // Montgomery-form ciphertexts carry the R of the n^2 context (pgpu_pubkey_create picks it the same way)
-  const BigNumber nsq = n * n;
-  const GeoInfo* gn = pick_geo(2 * nw, nsq.BitSize(), true);
-  if (!gn) return fail(PGPU_ERR_UNSUPPORTED, "key wider than the compiled kernel geometries");
-  k->nsq_rbits = gn->rbits();
-  CtxExtras exp_p, exp_q;
-  exp_p.want_r2s = exp_q.want_r2s = true;
-  exp_p.unit_q = exp_q.unit_q = true;
-  exp_p.secret = exp_q.secret = true;
-  exp_p.mont_src_rbits = exp_q.mont_src_rbits = k->nsq_rbits;
-  exp_p.fc = &hp;
-  exp_q.fc = &hq;
-  // both sides of a launch share one instruction stream: unit quotient digits only if BOTH moduli leave room
-  // (p^2 can be a bit shorter than q^2 and straddle the threshold on its own)
-  exp_p.force_unit = exp_q.force_unit = unit_fits(*ge, sq_bits) ? 1 : 0;
-  RC_TRY(build_modctx(psq, nw, *ge, exp_p, &k->p2));
-  RC_TRY(build_modctx(qsq, nw, *ge, exp_q, &k->q2));
-  k->geo_lat = latency_geo(*ge);
-  if (k->geo_lat.L() == ge->L()) {
-    k->p2l = k->p2;
-    k->q2l = k->q2;
-  } else {
-    exp_p.force_unit = exp_q.force_unit = unit_fits(k->geo_lat, sq_bits) ? 1 : 0;
-    RC_TRY(build_modctx(psq, nw, k->geo_lat, exp_p, &k->p2l));
-    RC_TRY(build_modctx(qsq, nw, k->geo_lat, exp_q, &k->q2l));
-  }
-  std::vector<uint64_t> exps((size_t)2 * pq_words, 0);
-  pm1.toLimbs64(exps.data(), pq_words);
-  qm1.toLimbs64(exps.data() + pq_words, pq_words);
-  RC_TRY(k->d_exps.upload(exps.data(), exps.size() * 8, true));
-  secure_wipe(exps.data(), exps.size() * sizeof(exps[0]));
-  k->exp_bits = std::max(pm1.BitSize(), qm1.BitSize());
-  {
-    const int sw = pick_sliding_window(k->exp_bits);
-    RC_TRY(make_schedule(pm1, sw, &k->sched[0], true));
-    RC_TRY(make_schedule(qm1, sw, &k->sched[1], true));
-  }
-
-  RC_TRY(build_hensel(k.get(), p, q, hp, hq));
-
-  // recombination: auxiliary modulus M = 2^(29*(L-1)) - 1 must exceed n (exact u*p product)
-  const GeoInfo* gc = nullptr;
-  for (const GeoInfo& gg : kGeos)
-    if (!(gg.G == 4 && gg.K == 10) && pgpu::kLimbBits * (gg.L() - 1) >= n.BitSize() + 2 && gg.rbits() >= 64 * nw) {
-      gc = &gg;
-      break;
-    }
-  if (!gc) return fail(PGPU_ERR_UNSUPPORTED, "key wider than the compiled kernel geometries");
-  k->geo_crt = *gc;
-  const int Lc = gc->L();
-  const BigNumber M = pow2(pgpu::kLimbBits * (Lc - 1)) - 1;
-  if (M.gcd(p) != BigNumber::One() || M.gcd(q) != BigNumber::One())
-    return fail(PGPU_ERR_NOT_INVERTIBLE, "auxiliary modulus shares a factor with the key");
-  const int mwM = (M.BitSize() + 63) / 64;
-  CtxExtras sec;
-  sec.secret = true;
-  RC_TRY(build_modctx(M, mwM, *gc, CtxExtras(), &k->cM));
-  RC_TRY(build_modctx(q, nw, *gc, sec, &k->cQ));
-  const BigNumber Rc = pow2(gc->rbits());
-  const BigNumber pinv_q = q.InverseMul(p);  // p^-1 mod q (pri_key.cpp:27)
-  std::vector<uint32_t> c32((size_t)4 * Lc);
-  to_limbs29((M.InverseMul(p) * Rc) % M, Lc, c32.data());
-  to_limbs29((M.InverseMul(q) * Rc) % M, Lc, c32.data() + Lc);
-  to_limbs29((pinv_q * Rc) % q, Lc, c32.data() + 2 * Lc);
-  to_limbs29((p * Rc) % M, Lc, c32.data() + 3 * Lc);
-  RC_TRY(k->d_crt32.upload(c32.data(), c32.size() * 4, true));
-  secure_wipe(c32.data(), c32.size() * sizeof(c32[0]));
-  const int pad = gc->w64() + 1;  // rows padded so word helpers can run over W64 words
-  std::vector<uint64_t> c64((size_t)5 * pad, 0);
-  hp.toLimbs64(c64.data(), pad);
-  hq.toLimbs64(c64.data() + pad, pad);
-  psq.toLimbs64(c64.data() + 2 * pad, pad);
-  qsq.toLimbs64(c64.data() + 3 * pad, pad);
-  q.toLimbs64(c64.data() + 4 * pad, pad);
-  RC_TRY(k->d_crt64.upload(c64.data(), c64.size() * 8, true));
-  secure_wipe(c64.data(), c64.size() * sizeof(c64[0]));
-  *out = k.release();
-  return PGPU_OK;
-}
-
-void pgpu_privkey_destroy(pgpu_privkey* key) { delete key; }
 
 int pgpu_paillier_decrypt_crt_dev(const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m,
                                   size_t count, void* hip_stream) {
@@ -2944,586 +2524,7 @@ int pgpu_paillier_decrypt_crt(const pgpu_privkey* key, const uint64_t* c, uint64
   });
 }
 
-// ===================== sharded device-resident batches =====================
-namespace {
-// per-thread pinned bounce buffer for small uploads / downloads issued from the calling thread itself
-constexpr size_t kBounceBytes = (size_t)256 << 10;
-struct Bounce {
-  void* p = nullptr;
-  hipEvent_t ev = nullptr;
-  bool pending = false;      // an upload still reads the buffer
-  uint64_t gen = 0;
-  int ready() {
-    if (p && gen != rt::pool_generation()) {   // the pool this buffer's event belongs to is gone
-      if (ev) (void)hipEventDestroy(ev);
-      ev = nullptr;
-      pending = false;
-    }
-    if (!p) HIP_TRY(hipHostMalloc(&p, kBounceBytes, hipHostMallocPortable));
-    if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    gen = rt::pool_generation();
-    if (pending) {
-      HIP_TRY(hipEventSynchronize(ev));
-      pending = false;
-    }
-    return PGPU_OK;
-  }
-  ~Bounce() {
-    // (a thread that ends while the pool is up gives its buffer back; at process exit the HIP runtime may already be
-    // shutting down, so nothing is touched then and the driver reclaims the memory)
-    if (!rt::initialized() || gen != rt::pool_generation()) return;
-    if (ev) (void)hipEventDestroy(ev);
-    if (p) (void)hipHostFree(p);
-  }
-};
-Bounce& bounce() {
-  thread_local Bounce b;
-  return b;
-}
-}  // namespace
-
-int pgpu_batch_create(size_t count, int words, pgpu_batch** out) {
-  RC_TRY(rt::check_ready());
-  if (!out) return fail(PGPU_ERR_INVALID_PARAM, "null output pointer");
-  std::unique_ptr<pgpu_batch> b;
-  RC_TRY(new_batch(count, words, &b));
-  *out = b.release();
-  return PGPU_OK;
-}
-
-void pgpu_batch_destroy(pgpu_batch* b) { delete b; }
-size_t pgpu_batch_count(const pgpu_batch* b) { return b ? b->count : 0; }
-int pgpu_batch_words(const pgpu_batch* b) { return b ? b->words : 0; }
-int pgpu_batch_is_montgomery(const pgpu_batch* b) { return b && (b->mont || b->pair_l2) ? 1 : 0; }   // any device-side domain
-
-int pgpu_batch_upload(const uint64_t* host, size_t count, int words, size_t stride, pgpu_batch** out) {
-  RC_TRY(rt::check_ready());
-  rt::note_caller();
-  if (!host || !out) return fail(PGPU_ERR_INVALID_PARAM, "null pointer");
-  if (words <= 0 || stride < (size_t)words) return fail(PGPU_ERR_INVALID_PARAM, "stride smaller than the row width");
-  std::unique_ptr<pgpu_batch> b;
-  RC_TRY(new_batch(count, words, &b));
-  pgpu_batch* bp = b.get();
-  if (stride == (size_t)words && rt::host_is_pinned(host, count * (size_t)words * 8)) {
-    // a buffer from pgpu_host_alloc is the DMA source itself: one copy per shard, queued from the calling thread on the
-    // batch lane, NOT waited for (pgpu_host_wait / pgpu_host_free do, include/pgpu.h)
-    for (int d = 0; d < bp->ndev; ++d) {
-      size_t lo, hi;
-      bp->bounds(d, &lo, &hi);
-      rt::Device& dev = rt::device(d);
-      rt::DeviceGuard g(dev.ordinal);
-      hipStream_t s = dev.bs(bp->lane);
-      const uint64_t* src = host + lo * (size_t)words;
-      const size_t bytes = (hi - lo) * (size_t)words * 8;
-      HIP_TRY(hipMemcpyAsync(bp->ptr(d), src, bytes, hipMemcpyHostToDevice, s));
-      rt::host_note_read(src, bytes, dev.index, s);
-    }
-    *out = b.release();
-    return PGPU_OK;
-  }
-  if (bp->ndev == 1 && stride == (size_t)words && count * (size_t)words * 8 <= kBounceBytes) {
-    // small transfer: through the calling thread's own pinned bounce buffer -- no hand-over to a worker lane (a thread
-    // wake-up costs more than the copy: Add_CTCT(16) at the ipcl:: API is 60 us of which the GPU works 10)
-    rt::Device& dev = rt::device(0);
-    rt::DeviceGuard g(dev.ordinal);
-    Bounce& bn = bounce();
-    RC_TRY(bn.ready());
-    const size_t bytes = count * (size_t)words * 8;
-    std::memcpy(bn.p, host, bytes);
-    hipStream_t s = dev.bs(bp->lane);
-    HIP_TRY(hipMemcpyAsync(bp->ptr(0), bn.p, bytes, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipEventRecord(bn.ev, s));
-    bn.pending = true;
-    *out = b.release();
-    return PGPU_OK;
-  }
-  rt::TaskGroup tg;
-  for (int d = 0; d < bp->ndev; ++d) {
-    tg.run(rt::device(d), [=](rt::Lane& lane) -> int {
-      size_t lo, hi;
-      bp->bounds(d, &lo, &hi);
-      hipStream_t s = lane.dev->bs(bp->lane);
-      if (stride == (size_t)words) {
-        RC_TRY(lane.h2d(bp->ptr(d), host + lo * (size_t)words, (hi - lo) * (size_t)words * 8, s));
-      } else {   // rows padded to a wider stride on the host: the device batch is dense
-        std::vector<uint64_t> dense((hi - lo) * (size_t)words);
-        for (size_t i = lo; i < hi; ++i)
-          std::memcpy(dense.data() + (i - lo) * (size_t)words, host + i * stride, (size_t)words * 8);
-        RC_TRY(lane.h2d(bp->ptr(d), dense.data(), dense.size() * 8, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        return PGPU_OK;
-      }
-      HIP_TRY(hipStreamSynchronize(s));   // the caller may reuse `host` as soon as we return
-      return PGPU_OK;
-    });
-  }
-  RC_TRY(tg.wait());
-  *out = b.release();
-  return PGPU_OK;
-}
-
-namespace {
-// one task per shard on the pool's worker lanes: conversion kernel (if any), then the copy -- which Lane::d2h hands to the
-// copy engine only once the batch's kernels have run
-void download_tasks(rt::TaskGroup& tg, const pgpu_batch* b, uint64_t* host, int nd, bool async = false) {
-  for (int d = 0; d < nd; ++d) {
-    tg.run(rt::device(d), [=](rt::Lane& lane) -> int {
-      struct Force { bool on; Force(bool o) : on(o) { if (on) rt::force_presync(true); } ~Force() { if (on) rt::force_presync(false); } } force(async);
-      size_t lo, hi;
-      b->bounds(d, &lo, &hi);
-      rt::Device& dev = *lane.dev;
-      hipStream_t s = dev.bs(b->lane);
-      const size_t bytes = (hi - lo) * (size_t)b->words * 8;
-      if (b->pair_l2) {   // pair rows: the plain value materialises here
-        rt::DevMem plain;
-        RC_TRY(plain.alloc(dev, s, bytes));
-        rt::DeviceGuard g(dev.ordinal);
-        RC_TRY(pair_to_words_on(dev, b->pair_form.get(), b->prow(d), (uint64_t*)plain.p, hi - lo, s));
-        return lane.d2h(host + lo * (size_t)b->words, plain.p, bytes, s);
-      }
-      if (!b->mont) return lane.d2h(host + lo * (size_t)b->words, b->ptr(d), bytes, s);
-      rt::DevMem plain;   // leave the Montgomery domain on the way out
-      RC_TRY(plain.alloc(dev, s, bytes));
-      RC_TRY(modmul_on(dev, *b->mont, pgpu::MM_BY_ONE, b->ptr(d), nullptr, 0, 0, (uint64_t*)plain.p, hi - lo, s));
-      return lane.d2h(host + lo * (size_t)b->words, plain.p, bytes, s);
-    });
-  }
-}
-}  // namespace
-
-int pgpu_batch_download(const pgpu_batch* b, uint64_t* host) {
-  RC_TRY(rt::check_ready());
-  rt::note_caller();
-  if (!b || !host) return fail(PGPU_ERR_INVALID_PARAM, "null pointer");
-  RC_TRY(check_gen(b->gen, "batch"));
-  const int nd = b->replicated ? 1 : b->ndev;
-  if (rt::host_is_pinned(host, b->count * (size_t)b->words * 8)) {
-    // pinned target (pgpu_host_alloc): conversion kernel (if any) and ONE DMA per shard, queued from the calling thread;
-    // then the shards are waited for
-    std::vector<rt::DevMem> plain((size_t)nd);
-    for (int d = 0; d < nd; ++d) {
-      size_t lo, hi;
-      b->bounds(d, &lo, &hi);
-      rt::Device& dev = rt::device(d);
-      rt::DeviceGuard g(dev.ordinal);
-      hipStream_t s = dev.bs(b->lane);
-      const size_t bytes = (hi - lo) * (size_t)b->words * 8;
-      const void* src = b->ptr(d);
-      if (b->pair_l2 || b->mont) {
-        RC_TRY(plain[(size_t)d].alloc(dev, s, bytes));
-        if (b->pair_l2) RC_TRY(pair_to_words_on(dev, b->pair_form.get(), b->prow(d), (uint64_t*)plain[(size_t)d].p, hi - lo, s));
-        else RC_TRY(modmul_on(dev, *b->mont, pgpu::MM_BY_ONE, b->ptr(d), nullptr, 0, 0, (uint64_t*)plain[(size_t)d].p, hi - lo, s));
-        src = plain[(size_t)d].p;
-      }
-      HIP_TRY(rt::drain_before_copy(s));
-      HIP_TRY(hipMemcpyAsync(host + lo * (size_t)b->words, src, bytes, hipMemcpyDeviceToHost, s));
-    }
-    for (int d = 0; d < nd; ++d) {
-      rt::Device& dev = rt::device(d);
-      rt::DeviceGuard g(dev.ordinal);
-      hipError_t e = hipStreamSynchronize(dev.bs(b->lane));
-      if (e != hipSuccess) return fail(PGPU_ERR_HIP, std::string("device -> host copy failed: ") + hipGetErrorString(e));
-    }
-    return PGPU_OK;
-  }
-  if (nd == 1 && b->count * (size_t)b->words * 8 <= kBounceBytes) {   // small transfer: the calling thread's bounce buffer
-    rt::Device& dev = rt::device(0);
-    rt::DeviceGuard g(dev.ordinal);
-    Bounce& bn = bounce();
-    RC_TRY(bn.ready());
-    hipStream_t s = dev.bs(b->lane);
-    const size_t bytes = b->count * (size_t)b->words * 8;
-    rt::DevMem plain;
-    const void* src = b->ptr(0);
-    if (b->pair_l2 || b->mont) {
-      RC_TRY(plain.alloc(dev, s, bytes));
-      if (b->pair_l2) RC_TRY(pair_to_words_on(dev, b->pair_form.get(), b->prow(0), (uint64_t*)plain.p, b->count, s));
-      else RC_TRY(modmul_on(dev, *b->mont, pgpu::MM_BY_ONE, b->ptr(0), nullptr, 0, 0, (uint64_t*)plain.p, b->count, s));
-      src = plain.p;
-    }
-    HIP_TRY(rt::drain_before_copy(s));
-    HIP_TRY(hipMemcpyAsync(bn.p, src, bytes, hipMemcpyDeviceToHost, s));
-    hipError_t e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return fail(PGPU_ERR_HIP, std::string("device -> host copy failed: ") + hipGetErrorString(e));
-    std::memcpy(host, bn.p, bytes);
-    return PGPU_OK;
-  }
-  rt::TaskGroup tg;
-  download_tasks(tg, b, host, nd);
-  return tg.wait();
-}
-
-// Rows land `host_stride` words apart (host_stride >= words; the words in between are OVERWRITTEN WITH ZEROS: the rows
-// travel as one linear copy of a device image whose gaps are cleared first -- a caller's own headers between the rows must
-// be written after the call, and no stale device memory reaches the host): the ipcl:: layer lays
-// results out as blocks of its limb allocator -- a 16-byte header in front of every row -- so that the BigNumbers point
-// into the pinned block instead of copying out of it.  Pinned targets (pgpu_host_alloc) and one-GPU pools only; plain and
-// pair-row batches (others: PGPU_ERR_UNSUPPORTED, the caller takes pgpu_batch_download).
-int pgpu_batch_download_strided(const pgpu_batch* b, uint64_t* host, size_t host_stride) {
-  RC_TRY(rt::check_ready());
-  rt::note_caller();
-  if (!b || !host) return fail(PGPU_ERR_INVALID_PARAM, "null pointer");
-  RC_TRY(check_gen(b->gen, "batch"));
-  if (host_stride < (size_t)b->words) return fail(PGPU_ERR_INVALID_PARAM, "download stride narrower than the rows");
-  const size_t span = ((b->count - 1) * host_stride + (size_t)b->words) * 8;
-  if ((b->replicated ? 1 : b->ndev) != 1 || (b->mont && !b->pair_l2) || !rt::host_is_pinned(host, span))
-    return fail(PGPU_ERR_UNSUPPORTED, "strided download: pinned target, one GPU, plain or pair-row batch");
-  rt::Device& dev = rt::device(0);
-  rt::DeviceGuard g(dev.ordinal);
-  hipStream_t s = dev.bs(b->lane);
-  rt::DevMem tmp;
-  RC_TRY(tmp.alloc(dev, s, span));
-  if (host_stride > (size_t)b->words) HIP_TRY(hipMemsetAsync(tmp.p, 0, span, s));   // (the gaps: recycled device memory otherwise)
-  if (b->pair_l2) {
-    RC_TRY(pair_to_words_on(dev, b->pair_form.get(), b->prow(0), (uint64_t*)tmp.p, b->count, s, host_stride));
-  } else {
-    HIP_TRY(hipMemcpy2DAsync(tmp.p, host_stride * 8, b->ptr(0), (size_t)b->words * 8, (size_t)b->words * 8, b->count,
-                             hipMemcpyDeviceToDevice, s));
-  }
-  HIP_TRY(rt::drain_before_copy(s));
-  HIP_TRY(hipMemcpyAsync(host, tmp.p, span, hipMemcpyDeviceToHost, s));
-  hipError_t e = hipStreamSynchronize(s);
-  if (e != hipSuccess) return fail(PGPU_ERR_HIP, std::string("device -> host copy failed: ") + hipGetErrorString(e));
-  return PGPU_OK;
-}
-
-// ---- downloads that do not hold the caller ----
-struct pgpu_ticket {
-  rt::TaskGroup tg;
-  uint64_t gen = 0;
-};
-
-int pgpu_batch_download_async(const pgpu_batch* b, uint64_t* host, pgpu_ticket** out) {
-  RC_TRY(rt::check_ready());
-  if (!b || !host || !out) return fail(PGPU_ERR_INVALID_PARAM, "null pointer");
-  RC_TRY(check_gen(b->gen, "batch"));
-  std::unique_ptr<pgpu_ticket> t(new pgpu_ticket);
-  t->gen = b->gen;
-  download_tasks(t->tg, b, host, b->replicated ? 1 : b->ndev, true);
-  *out = t.release();
-  return PGPU_OK;
-}
-
-int pgpu_ticket_wait(pgpu_ticket* t) {
-  if (!t) return fail(PGPU_ERR_INVALID_PARAM, "null ticket");
-  const int rc = t->tg.wait();
-  delete t;
-  return rc;
-}
-
-int pgpu_batch_encrypt(const pgpu_pubkey* key, const pgpu_batch* m, const pgpu_batch* r, int r_bits,
-                       pgpu_batch** c) {
-  RC_TRY(rt::check_ready());
-  if (!key || !m || !r || !c) return fail(PGPU_ERR_INVALID_PARAM, "null argument");
-  RC_TRY(check_gen(key->gen, "key"));
-  RC_TRY(check_gen(m->gen, "batch"));
-  RC_TRY(check_gen(r->gen, "batch"));
-  if (m->count != r->count) return fail(PGPU_ERR_INVALID_PARAM, "modExp: input vector size error");
-  if (m->mont || r->mont) return fail(PGPU_ERR_INVALID_PARAM, "encrypt: operands must be plain batches");
-  if (m->pair_l2 || r->pair_l2) return fail(PGPU_ERR_INVALID_PARAM, "encrypt: operands must be plain batches");
-  RC_TRY(same_layout(m, r));
-  // Keys with a split form keep their resident ciphertexts as PAIR ROWS (kargs.hpp) whenever the obfuscator runs
-  // through a split-form kernel: DJN with a fixed-base table, or r^n.  Plaintext rows wider than n take the full-width
-  // kernels and leave Montgomery-form words, as in round 2; consumers convert on the way in.
-  const int l2 = (pair_form(key) && 64 * m->words <= key->n.BitSize() && (!key->djn || fixed_base_window() > 0) &&
-                  (key->djn || r->words <= 2 * key->n_words))
-                     ? pair_l2(key) : 0;
-  std::unique_ptr<pgpu_batch> out;
-  RC_TRY(new_batch(m->count, 2 * key->n_words, &out, l2, m->lane));
-  if (l2) out->pair_form = pair_form_shared(key);
-  else out->mont = key->nsq;
-  for (int d = 0; d < out->ndev; ++d) {
-    size_t lo, hi;
-    out->bounds(d, &lo, &hi);
-    rt::Device& dev = rt::device(d);
-    rt::DeviceGuard g(dev.ordinal);
-    RC_TRY(lane_acquire(dev, r, m->lane));
-    RC_TRY(encrypt_on(dev, key, m->ptr(d), (size_t)m->words, m->words, r->ptr(d), (size_t)r->words, r->words, r_bits,
-                      l2 ? nullptr : out->ptr(d), hi - lo, dev.bs(m->lane), true, m->count, l2 ? out->prow(d) : nullptr,
-                      l2 ? busy_other_lanes(dev, m->lane) : 0));
-    RC_TRY(lane_release(dev, r, m->lane));
-  }
-  if (key->djn) {
-    std::lock_guard<std::mutex> lk(key->mu);
-    key->fb_elems += m->count;
-  }
-  *c = out.release();
-  return PGPU_OK;
-}
-
-int pgpu_batch_decrypt_crt(const pgpu_privkey* key, const pgpu_batch* c, pgpu_batch** m) {
-  RC_TRY(rt::check_ready());
-  if (!key || !c || !m) return fail(PGPU_ERR_INVALID_PARAM, "null argument");
-  RC_TRY(check_gen(key->gen, "key"));
-  RC_TRY(check_gen(c->gen, "batch"));
-  if (c->words != 2 * key->n_words) return fail(PGPU_ERR_INVALID_PARAM, "decrypt: ciphertext width mismatch");
-  if (c->mont && c->mont->geo.rbits() != key->nsq_rbits)
-    return fail(PGPU_ERR_INVALID_PARAM, "decrypt: ciphertext batch belongs to a different key size");
-  // pair rows enter the split-form kernel as they are; when this launch would not take it (PGPU_HENSEL=0, a key class
-  // without the form) they become plain words first
-  std::unique_ptr<pgpu_batch> tmp;
-  if (c->pair_l2) {
-    size_t lo0, hi0;
-    c->bounds(0, &lo0, &hi0);
-    const pgpu_privkey::HenselSet* hset = pick_hensel(key, hi0 - lo0);
-    if (!hset || hset->pair_l2 != c->pair_l2) {
-      const pgpu_batch* cw = nullptr;
-      RC_TRY(as_word_batch(c, &cw, &tmp));
-      c = cw;
-    }
-  }
-  std::unique_ptr<pgpu_batch> out;
-  RC_TRY(new_batch(c->count, key->n_words, &out, 0, c->lane));
-  for (int d = 0; d < out->ndev; ++d) {
-    size_t lo, hi;
-    out->bounds(d, &lo, &hi);
-    rt::Device& dev = rt::device(d);
-    rt::DeviceGuard g(dev.ordinal);
-    if (c->pair_l2) {
-      // are the GPU's other batch lanes busy right now?  Then this launch will share the chip with theirs
-      const int busy = busy_other_lanes(dev, c->lane);
-      RC_TRY(decrypt_on(dev, key, nullptr, out->ptr(d), hi - lo, dev.bs(c->lane), false, c->prow(d), c->pair_l2, busy));
-    }
-    else   // (word ciphertexts: decrypt_on converts them when the launch then takes a pair-row kernel)
-      RC_TRY(decrypt_on(dev, key, c->ptr(d), out->ptr(d), hi - lo, dev.bs(c->lane), c->mont != nullptr, nullptr, 0,
-                        busy_other_lanes(dev, c->lane)));
-  }
-  *m = out.release();
-  return PGPU_OK;
-}
-
-// brings a plain ciphertext batch into the key's Montgomery domain (fresh batch), shard by shard
-static int to_montgomery(const pgpu_pubkey* key, const pgpu_batch* a, std::unique_ptr<pgpu_batch>* out) {
-  std::unique_ptr<pgpu_batch> t;
-  RC_TRY(new_batch(a->count, a->words, &t, 0, a->lane));
-  t->mont = key->nsq;
-  for (int d = 0; d < t->ndev; ++d) {
-    size_t lo, hi;
-    t->bounds(d, &lo, &hi);
-    rt::Device& dev = rt::device(d);
-    rt::DeviceGuard g(dev.ordinal);
-    RC_TRY(modmul_on(dev, *key->nsq, pgpu::MM_BY_R2, a->ptr(d), nullptr, 0, 0, t->ptr(d), hi - lo, dev.bs(a->lane)));
-  }
-  *out = std::move(t);
-  return PGPU_OK;
-}
-
-int pgpu_batch_ct_add(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_batch* b, pgpu_batch** out) {
-  RC_TRY(rt::check_ready());
-  if (!key || !a || !b || !out) return fail(PGPU_ERR_INVALID_PARAM, "null argument");
-  RC_TRY(check_gen(key->gen, "key"));
-  RC_TRY(check_gen(a->gen, "batch"));
-  RC_TRY(check_gen(b->gen, "batch"));
-  const int W = 2 * key->n_words;
-  if (a->words != W || b->words != W) return fail(PGPU_ERR_INVALID_PARAM, "CT + CT error: width mismatch");
-  if (b->count != a->count && b->count != 1) return fail(PGPU_ERR_INVALID_PARAM, "CT + CT error: Size mismatch!");
-  if (!same_domain(a->mont, key->nsq) || !same_domain(b->mont, key->nsq))
-    return fail(PGPU_ERR_INVALID_PARAM, "CT + CT error: 2 different public keys detected!");
-  RC_TRY(same_layout(a, b));
-  std::unique_ptr<pgpu_batch> ta, tb;
-  if (const pgpu_pubkey::PubForm* f = pair_form(key)) {
-    // pair rows: ONE pair product per element (5 instead of 8 s^2 limb products, no word <-> limb conversion)
-    RC_TRY(as_pair_batch(key, a, &a, &ta));
-    RC_TRY(as_pair_batch(key, b, &b, &tb));
-    const int l2 = f->H * f->K;
-    std::unique_ptr<pgpu_batch> o;
-    RC_TRY(new_batch(a->count, W, &o, l2, a->lane));
-    o->pair_form = pair_form_shared(key);
-    RC_TRY(lanes_order(b, a->lane, true));
-  const bool bcast = b->count == 1 && a->count != 1;
-    for (int d = 0; d < o->ndev; ++d) {
-      size_t lo, hi;
-      o->bounds(d, &lo, &hi);
-      rt::Device& dev = rt::device(d);
-      rt::DeviceGuard g(dev.ordinal);
-      pgpu::PairOpsArgs pa{};
-      const pgpu_pubkey::PubForm* lf = pair_op_form(key, f, hi - lo);
-      pa.ctx = hensel_pub_view(lf, dev.index);
-      pa.op = pgpu::PO_MUL;
-      pa.a = a->prow(d);
-      pa.b = b->prow(b->replicated ? d : (bcast ? 0 : d));
-      pa.b_stride = bcast ? 0 : (size_t)2 * l2;
-      pa.out = o->prow(d);
-      pa.count = hi - lo;
-      RC_TRY(pair_op_launch(dev, lf, pa, dev.bs(a->lane), PGPU_KERNEL_MODMUL));
-    }
-    RC_TRY(lanes_order(b, a->lane, false));
-    *out = o.release();
-    return PGPU_OK;
-  }
-  if (a->pair_l2 || b->pair_l2) return fail(PGPU_ERR_INVALID_PARAM, "CT + CT error: 2 different public keys detected!");
-  // both operands in the Montgomery domain -> ONE product per element, result stays there
-  if (!a->mont) {
-    RC_TRY(to_montgomery(key, a, &ta));
-    a = ta.get();
-  }
-  if (!b->mont) {
-    RC_TRY(to_montgomery(key, b, &tb));
-    b = tb.get();
-  }
-  std::unique_ptr<pgpu_batch> o;
-  RC_TRY(new_batch(a->count, W, &o, 0, a->lane));
-  o->mont = key->nsq;
-  RC_TRY(lanes_order(b, a->lane, true));
-  const bool bcast = b->count == 1 && a->count != 1;
-  for (int d = 0; d < o->ndev; ++d) {
-    size_t lo, hi;
-    o->bounds(d, &lo, &hi);
-    rt::Device& dev = rt::device(d);
-    rt::DeviceGuard g(dev.ordinal);
-    RC_TRY(modmul_on(dev, *key->nsq, pgpu::MM_SINGLE, a->ptr(d), b->ptr(b->replicated ? d : (bcast ? 0 : d)),
-                     bcast ? 0 : (size_t)W, 0, o->ptr(d), hi - lo, dev.bs(a->lane)));
-  }
-  RC_TRY(lanes_order(b, a->lane, false));
-  *out = o.release();
-  return PGPU_OK;
-}
-
-int pgpu_batch_ct_add_plain(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_batch* m, pgpu_batch** out) {
-  RC_TRY(rt::check_ready());
-  if (!key || !a || !m || !out) return fail(PGPU_ERR_INVALID_PARAM, "null argument");
-  RC_TRY(check_gen(key->gen, "key"));
-  RC_TRY(check_gen(a->gen, "batch"));
-  RC_TRY(check_gen(m->gen, "batch"));
-  const int W = 2 * key->n_words;
-  if (a->words != W || m->words > W) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: width mismatch");
-  if (m->count != a->count && m->count != 1) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: Size mismatch!");
-  if (!same_domain(a->mont, key->nsq)) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: batch belongs to a different key");
-  if (m->mont || m->pair_l2) return fail(PGPU_ERR_INVALID_PARAM, "CT + PT error: plaintext batch in Montgomery form");
-  RC_TRY(same_layout(a, m));
-  std::unique_ptr<pgpu_batch> ta;
-  const pgpu_pubkey::PubForm* pf = pair_form(key);
-  if (pf && 64 * m->words <= key->n.BitSize()) {
-    // pair rows: c * (1 + n*m) only changes the b half -- two half-width products (hensel.hpp: pair_times_gm)
-    RC_TRY(as_pair_batch(key, a, &a, &ta));
-    const int l2 = pf->H * pf->K;
-    std::unique_ptr<pgpu_batch> o;
-    RC_TRY(new_batch(a->count, W, &o, l2, a->lane));
-    o->pair_form = pair_form_shared(key);
-    RC_TRY(lanes_order(m, a->lane, true));
-  const bool bcast = m->count == 1 && a->count != 1;
-    for (int d = 0; d < o->ndev; ++d) {
-      size_t lo, hi;
-      o->bounds(d, &lo, &hi);
-      rt::Device& dev = rt::device(d);
-      rt::DeviceGuard g(dev.ordinal);
-      pgpu::PairOpsArgs pa{};
-      const pgpu_pubkey::PubForm* lf = pair_op_form(key, pf, hi - lo);
-      pa.ctx = hensel_pub_view(lf, dev.index);
-      pa.op = pgpu::PO_TIMES_GM;
-      pa.a = a->prow(d);
-      pa.words = m->ptr(m->replicated ? d : (bcast ? 0 : d));
-      pa.words_stride = bcast ? 0 : (size_t)m->words;
-      pa.nwords = m->words;
-      pa.out = o->prow(d);
-      pa.count = hi - lo;
-      RC_TRY(pair_op_launch(dev, lf, pa, dev.bs(a->lane), PGPU_KERNEL_MODMUL));
-    }
-    RC_TRY(lanes_order(m, a->lane, false));
-    *out = o.release();
-    return PGPU_OK;
-  }
-  if (a->pair_l2) {   // plaintext rows wider than n: the full-width kernel, on plain words
-    const pgpu_batch* aw = nullptr;
-    RC_TRY(as_word_batch(a, &aw, &ta));
-    a = aw;
-  }
-  std::unique_ptr<pgpu_batch> o;
-  RC_TRY(new_batch(a->count, W, &o, 0, a->lane));
-  o->mont = a->mont ? key->nsq : nullptr;   // the product keeps the form of the ciphertext
-  RC_TRY(lanes_order(m, a->lane, true));
-  const bool bcast = m->count == 1 && a->count != 1;
-  for (int d = 0; d < o->ndev; ++d) {
-    size_t lo, hi;
-    o->bounds(d, &lo, &hi);
-    rt::Device& dev = rt::device(d);
-    rt::DeviceGuard g(dev.ordinal);
-    RC_TRY(modmul_on(dev, *key->nsq, pgpu::MM_GM, a->ptr(d), m->ptr(m->replicated ? d : (bcast ? 0 : d)),
-                     bcast ? 0 : (size_t)m->words, m->words, o->ptr(d), hi - lo, dev.bs(a->lane), VF_GM_MONT));
-  }
-  RC_TRY(lanes_order(m, a->lane, false));
-  *out = o.release();
-  return PGPU_OK;
-}
-
-int pgpu_batch_ct_mul(const pgpu_pubkey* key, const pgpu_batch* a, const pgpu_batch* e, int e_bits,
-                      pgpu_batch** out) {
-  RC_TRY(rt::check_ready());
-  if (!key || !a || !e || !out) return fail(PGPU_ERR_INVALID_PARAM, "null argument");
-  RC_TRY(check_gen(key->gen, "key"));
-  RC_TRY(check_gen(a->gen, "batch"));
-  RC_TRY(check_gen(e->gen, "batch"));
-  const int W = 2 * key->n_words;
-  if (a->words != W) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: width mismatch");
-  if (e->count != a->count && e->count != 1) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: Size mismatch!");
-  if (e->mont) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: exponent batch in Montgomery form");
-  if (!same_domain(a->mont, key->nsq)) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: batch belongs to a different key");
-  if (e_bits < 0 || e_bits > 64 * e->words) return fail(PGPU_ERR_INVALID_PARAM, "exp_bits/exp_words inconsistent");
-  if (e->pair_l2) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: exponent batch in Montgomery form");
-  RC_TRY(same_layout(a, e));
-  RC_TRY(lanes_order(e, a->lane, true));
-  const bool bcast = e->count == 1 && a->count != 1;
-  std::unique_ptr<pgpu_batch> ta;
-  if (const pgpu_pubkey::PubForm* pf = pair_form(key)) {
-    // pair rows in, pair rows out: the split-form kernel starts from the row as it is and stores its result as it is.
-    // Forms of the same limb count share the rows (2048-bit keys: (8,9) for small batches, (4,18) beyond).
-    const int l2 = pf->H * pf->K;
-    RC_TRY(as_pair_batch(key, a, &a, &ta));
-    std::unique_ptr<pgpu_batch> o;
-    RC_TRY(new_batch(a->count, W, &o, l2, a->lane));
-    o->pair_form = pair_form_shared(key);
-    for (int d = 0; d < o->ndev; ++d) {
-      size_t lo, hi;
-      o->bounds(d, &lo, &hi);
-      rt::Device& dev = rt::device(d);
-      rt::DeviceGuard g(dev.ordinal);
-      const pgpu_pubkey::PubForm* form = split_modexp_form(key, hi - lo);
-      if (!form || form->H * form->K != l2) form = pf;
-      if (!pgpu::hensel_modexp_has(form->H, form->K)) return fail(PGPU_ERR_UNSUPPORTED, "split-form modexp kernel not compiled");
-      RC_TRY(modexp_split_on(dev, key, form, nullptr, 0, W, false, e->ptr(e->replicated ? d : (bcast ? 0 : d)),
-                             bcast ? 0 : (size_t)e->words, e->words, e_bits, nullptr, pgpu::FM_UNIT, nullptr, 0, 0, nullptr,
-                             false, hi - lo, dev.bs(a->lane), a->prow(d), (size_t)2 * l2, o->prow(d)));
-    }
-    RC_TRY(lanes_order(e, a->lane, false));
-    *out = o.release();
-    return PGPU_OK;
-  }
-  if (a->pair_l2) return fail(PGPU_ERR_INVALID_PARAM, "CT * PT error: batch belongs to a different key");
-  std::unique_ptr<pgpu_batch> o;
-  RC_TRY(new_batch(a->count, W, &o, 0, a->lane));
-  o->mont = key->nsq;
-  std::vector<uint64_t> mod((size_t)W);
-  key->nsq->N.toLimbs64(mod.data(), mod.size());
-  for (int d = 0; d < o->ndev; ++d) {
-    size_t lo, hi;
-    o->bounds(d, &lo, &hi);
-    rt::Device& dev = rt::device(d);
-    rt::DeviceGuard g(dev.ordinal);
-    if (const pgpu_pubkey::PubForm* form = split_modexp_form(key, hi - lo)) {
-      RC_TRY(modexp_split_on(dev, key, form, a->ptr(d), (size_t)W, W, a->mont != nullptr,
-                             e->ptr(e->replicated ? d : (bcast ? 0 : d)), bcast ? 0 : (size_t)e->words, e->words, e_bits,
-                             nullptr, pgpu::FM_UNIT, nullptr, 0, 0, o->ptr(d), true, hi - lo, dev.bs(a->lane)));
-      continue;
-    }
-    RC_TRY(modexp_on(dev, a->ptr(d), (size_t)W, e->ptr(e->replicated ? d : (bcast ? 0 : d)),
-                     bcast ? 0 : (size_t)e->words, e->words, e_bits, mod.data(), W, o->ptr(d), hi - lo, dev.bs(a->lane),
-                     nullptr, a->mont != nullptr, true, key->nsq));
-  }
-  RC_TRY(lanes_order(e, a->lane, false));
-  *out = o.release();
-  return PGPU_OK;
-}
-
-int pgpu_set_batch_lane(int lane) {
-  if (lane < 0 || lane >= rt::kBatchLanes) return fail(PGPU_ERR_INVALID_PARAM, "batch lane out of range (pgpu_batch_lanes())");
-  t_batch_lane = lane;
-  t_lane_explicit = true;
-  return PGPU_OK;
-}
-int pgpu_batch_lane(const pgpu_batch* b) { return b ? b->lane : 0; }
-int pgpu_batch_is_current(const pgpu_batch* b) { return b && rt::pool_size() > 0 && b->gen == rt::pool_generation() ? 1 : 0; }
-int pgpu_batch_lanes(void) { return rt::kBatchLanes; }
-int pgpu_batch_row_limbs(const pgpu_batch* b) { return b ? 2 * b->pair_l2 : 0; }
+#include "capi_batches.inc"   // pgpu_batch_*
 
 // ---- diagnostics of the pool's self-checks and table budget ----
 int pgpu_replication_stats(uint64_t* images_verified, uint64_t* copies_repaired) {
