@@ -15,10 +15,12 @@ How N GPUs are driven:
     streams per GPU, key images replicated by one RCCL broadcast over xGMI); the global batch of N x 8192
     elements is a sharded resident pgpu_batch, a step enqueues one launch per GPU.  This is also the N = 1 path.
   * under torch.distributed.run (WORLD_SIZE set): one process per GPU, backend nccl == RCCL; every rank
-    processes its own 8192-element batch through the `_dev` entry points; the only collective is the broadcast
+    runs the same resident step on its own GPU (a one-entry pool); the only collective is the broadcast
     of the key material from rank 0.
 Both are weak scaling (8192 elements per GPU per step); timing = barrier/synchronise on both sides of exactly K
-steps, MAX over ranks.  `--config 4|5` runs BASELINE.json configs[3] / configs[4] instead: a FIXED total batch
+steps, MAX over ranks.  Consecutive steps rotate over the library's four batch lanes (--in-flight, default 4 since round 5:
+four independent batches of 8192 in flight per GPU, each lane's launches on a quarter of the chip -- csrc/policy.cpp); every
+step is a whole encrypt + decrypt of one batch, and every lane's results are checked after the timed region.  `--config 4|5` runs BASELINE.json configs[3] / configs[4] instead: a FIXED total batch
 (65536 x 3072-bit encrypt+decrypt; 1 M x 2048-bit CT+CT and CT x PT) sharded over the N GPUs (strong scaling).
 """
 import argparse
