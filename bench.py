@@ -426,6 +426,22 @@ def run_pool(args):
     except Exception as e:                                  # noqa: BLE001
         r["step_executed_frac"] = None
         r["step_executed_note"] = repr(e)[:200]
+    if N == 1 and not args.no_extras:
+        try:
+            dec_forms = [f for k, f, _ in timed_forms if k == K_MODEXP]
+            top_f = max(set(dec_forms), key=dec_forms.count) if dec_forms else 0
+            kname = "hensel_decrypt_ps_kernel" if top_f & 8 else ("hensel_decrypt_seq_kernel" if top_f & 2 else "hensel_decrypt_kernel")
+            t_pmc = time.perf_counter()
+            tr = traffic_in_run(kname, nfl, 64 * 200)
+            if tr:
+                r["traffic"] = tr["bytes"]
+                r["traffic_source"] = {"how": "measured in THIS run: the step replayed by tools/pmc_step.py under rocprofv3 --pmc FETCH_SIZE and "
+                                              "--pmc WRITE_SIZE (a pass of its own each, counters only); bytes per launch = (2 * FETCH_SIZE + "
+                                              "WRITE_SIZE) * 1024, the x2 on FETCH per MI355X_MICROARCH.md (HBM)",
+                                       "measured_on_kernel": kname, "launches_averaged": tr["launches_averaged"],
+                                       "raw_bytes": tr["raw_bytes"], "seconds": round(time.perf_counter() - t_pmc, 1)}
+        except Exception as e:                              # noqa: BLE001
+            r["traffic_in_run_error"] = repr(e)[:200]
     if "sustained" in measured:
         result["sustained"] = measured["sustained"]
     if "hardened" in measured:
@@ -836,6 +852,43 @@ def headline(args, world, elapsed, per_kind, nw, pw, parallelism, dec_kernel=Non
     }
 
 
+def traffic_in_run(kernel_substr, lanes, min_grid):
+    """HBM bytes per launch of the kernel whose name contains kernel_substr, MEASURED in this run: the headline step replayed
+    by tools/pmc_step.py under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, one pass each (counters only, no trace
+    domain), bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 averaged over the full-size launches -- the x2 on FETCH per
+    MI355X_MICROARCH.md (HBM): gfx950 tallies wide reads at half their size.  None when rocprofv3 is not on PATH, the
+    passes fail or take too long (the committed constant of profiles/pmc_summary.json stays in the line then)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe or os.environ.get("BENCH_NO_PMC") == "1":
+        return None
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        try:
+            subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+                            os.path.join(ROOT, "tools", "pmc_step.py"), str(lanes), "8"],
+                           cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
+            got = []
+            for fn in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+                for row in csv.DictReader(open(fn)):
+                    if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter and int(row["Grid_Size"]) >= min_grid:
+                        got.append(float(row["Counter_Value"]))
+            if not got:
+                return None
+            vals[counter] = (sum(got) / len(got), len(got))
+        except Exception:                                   # noqa: BLE001
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"bytes": (2 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024,
+            "raw_bytes": (vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024, "launches_averaged": vals["FETCH_SIZE"][1]}
+
+
 def pmc_source(pmc, kernel_key):
     """where a `traffic` figure comes from: PMC counters cannot be read inside bench.py (rocprofv3 owns them), so the
     number is the per-launch average of a committed rocprofv3 --pmc pass (its own run, no trace domains) of THIS command
@@ -843,7 +896,8 @@ def pmc_source(pmc, kernel_key):
     if not pmc:
         return None
     return {"file": "profiles/pmc_summary.json", "measured_on_kernel": pmc.get(kernel_key), "how": pmc.get("source"),
-            "build": pmc.get("build"), "note": "constant read from the committed summary, not measured in this run"}
+            "build": pmc.get("build"), "collected": pmc.get("collected"),
+            "note": "constant read from the committed summary (its build and collection date named here), not measured in this run"}
 
 
 def best_of(fn, reps):
