@@ -282,9 +282,10 @@ def run_pool(args):
                 okh = all(bool(np.array_equal(B.down(o), m_host)) for o in state["out"])
                 measured["hardened"] = {"steps": kh, "ms_per_step": round(dth / kh * 1e3, 4), "modexps_per_s": round(3 * BATCH * N * kh / dth, 1),
                                         "round_trip_ok": okh,
-                                        "what": "the resident step of the headline with secret_table_access = masked: decrypt window tables "
-                                                "(32 entries) and the DJN fixed-base product (255 products over 16-entry windows instead of "
-                                                "78 indexed ones) read every candidate and select; same lanes, same batch"}
+                                        "what": "the resident step of the headline with secret_table_access = masked: the decrypt window tables "
+                                                "(3-bit windows under this policy: 8 entries, 348 products instead of 32 entries, 235) and the DJN "
+                                                "fixed-base product (255 products over 16-entry windows instead of 78 indexed ones) read every "
+                                                "candidate and select; same lanes, same batch"}
             except Exception as e:                          # noqa: BLE001
                 measured["hardened"] = {"error": repr(e)[:300]}
             finally:
