@@ -58,7 +58,7 @@ def hensel_parts():
         skip |= {22, 23, 24}
     if not build_ab():
         skip |= {15}
-    return [p for p in range(32) if p not in skip]
+    return [p for p in range(33) if p not in skip]
 
 
 def _objects():

@@ -1716,7 +1716,8 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
       const unsigned lds_pad = env_pad >= 0 ? (unsigned)env_pad
                                : (seq_waves < kSimds && (pol == 3 || (pol == 4 && busy_lanes >= 1 && busy_lanes <= policy::adapt_claim_busy())) ? 84000u : 0u);
       if (lds_pad) t.set_form(PGPU_FORM_SEQ | PGPU_FORM_CU_CLAIM);
-      if (!pgpu::launch_hensel_seq(hset->H, hset->K, h, sblocks, s, lds_pad))
+      static const bool w1 = [] { const char* e = getenv("PGPU_SEQ_W1"); return !e || atoi(e) != 0; }();
+      if (!pgpu::launch_hensel_seq(hset->H, hset->K, h, sblocks, s, lds_pad, w1 && lds_pad >= 82000u))
         return fail(PGPU_ERR_UNSUPPORTED, "sequential-halves decrypt kernel not compiled");
     } else if (ab) {
       // one A/B pair per 32 ciphertexts and side.  Workgroups of two pairs (one wavefront per SIMD) when the launch has

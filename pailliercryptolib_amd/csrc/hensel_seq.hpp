@@ -161,8 +161,11 @@ __device__ __forceinline__ void seq_pairmul(uint32_t (&a)[K], uint32_t (&b)[K], 
 
 // One wavefront = 64/G ciphertexts of ONE side (wave parity: even = p, odd = q).  Output: row 2i = mp, row 2i+1 = mq
 // (canonical words) for crt_kernel, like hensel_decrypt_kernel.
-template <int G, int K>
-__global__ __launch_bounds__(kWGThreads, 2) void hensel_decrypt_seq_kernel(HenselArgs A) {
+// MINW: workgroups per CU the build must leave room for (2: 256 registers, the form for launches of two wavefronts per
+// SIMD; 1: the whole register file -- the build for launches that claim whole CUs and therefore run ONE wavefront per SIMD by
+// construction, round 5: no scratch)
+template <int G, int K, int MINW = 2>
+__global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_seq_kernel(HenselArgs A) {
   using HG = Geo<G, K>;
   constexpr int IPW = kWave / G, L2 = G * K, LQ = 2 * L2, W64 = HG::W64;
   raise_wave_priority();
@@ -441,8 +444,8 @@ __global__ __launch_bounds__(kWGThreads, 2) void pair_mul_seq_kernel(PairOpsArgs
 // hs^r as nwin-1 general pair products of table entries -- every one of them a product in which the paired form
 // leaves half A idle for a third of its multiply-accumulates -- then (1 + n*m) as  b += (-k^-1 * m * a) mod n
 // (pair_times_gm without the hand-over between halves).  The table is the one hensel_fb_build_kernel wrote.
-template <int G, int K>
-__global__ __launch_bounds__(kWGThreads, 2) void hensel_fb_encrypt_seq_kernel(HenselFbArgs A) {
+template <int G, int K, int MINW = 2>   // (MINW: as hensel_decrypt_seq_kernel)
+__global__ __launch_bounds__(kWGThreads, MINW) void hensel_fb_encrypt_seq_kernel(HenselFbArgs A) {
   using HG = Geo<G, K>;
   constexpr int IPW = kWave / G, L2 = G * K, LQ = 2 * L2;
   raise_wave_priority();

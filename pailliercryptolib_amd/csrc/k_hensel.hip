@@ -14,7 +14,7 @@
 #endif
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..31"
+#error "compile with -DPGPU_PART=0..32"
 #endif
 
 namespace pgpu {
@@ -125,6 +125,18 @@ bool launch_hensel_seq_part17(int G, int K, const HenselArgs& a, unsigned blocks
   }
   return false;
 }
+#elif PGPU_PART == 32
+// the one-wavefront-per-SIMD build of the (2,19) sequential-halves decrypt: launches under a CU claim only
+bool launch_hensel_seq_w1_part32(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad) {
+  if (G == 2 && K == 19 && lds_pad) {
+    static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_seq_kernel<2, 19, 1>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (once != hipSuccess) return false;
+    hipLaunchKernelGGL((hensel_decrypt_seq_kernel<2, 19, 1>), dim3(blocks), dim3(kWGThreads), lds_pad, s, a);
+    return true;
+  }
+  return false;
+}
 #elif PGPU_PART == 18
 bool launch_hensel_modexp_seq_part18(int G, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
   if (G == 4 && K == 18) {
@@ -161,8 +173,17 @@ bool launch_hensel_fb_encrypt_seq_part20(int G, int K, const HenselFbArgs& a, un
     // asks for: see launch_hensel_seq_part16)
     static const hipError_t once = hipFuncSetAttribute((const void*)hensel_fb_encrypt_seq_kernel<4, 18>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    if (dyn && once != hipSuccess) return false;
-    hipLaunchKernelGGL((hensel_fb_encrypt_seq_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), dyn, s, a);
+    static const hipError_t once1 = hipFuncSetAttribute((const void*)hensel_fb_encrypt_seq_kernel<4, 18, 1>,
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (dyn && (once != hipSuccess || once1 != hipSuccess)) return false;
+    // a claim of more than half a CU's LDS (beside ONE busy lane) means one workgroup per CU, one wavefront per SIMD: the
+    // build that may use the whole register file.  The 80 000-byte claim of the quarter-chip mode puts TWO workgroups on a
+    // CU: the 256-register build.  PGPU_SEQ_W1=0 keeps the 256-register build everywhere
+    static const bool w1 = [] { const char* e = getenv("PGPU_SEQ_W1"); return !e || atoi(e) != 0; }();
+    if (w1 && dyn + own > 82000u && !(lds_pad & kLdsTotalFlag))
+      hipLaunchKernelGGL((hensel_fb_encrypt_seq_kernel<4, 18, 1>), dim3(blocks), dim3(kWGThreads), dyn, s, a);
+    else
+      hipLaunchKernelGGL((hensel_fb_encrypt_seq_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), dyn, s, a);
     return true;
   }
   return false;
@@ -241,8 +262,14 @@ bool launch_hensel_ps_part31(int K, int lb, const HenselArgs& a, unsigned blocks
     const unsigned dyn = lds_pad > kStatic ? lds_pad - kStatic : 0;
     static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_ps_kernel<38, 28, 2>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // (first launch: see part 16)
-    if (dyn && once != hipSuccess) return false;
-    hipLaunchKernelGGL((hensel_decrypt_ps_kernel<38, 28, 2>), dim3(blocks), dim3(kWGThreads), dyn, s, a);
+    static const hipError_t once1 = hipFuncSetAttribute((const void*)hensel_decrypt_ps_kernel<38, 28, 1>,
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (dyn && (once != hipSuccess || once1 != hipSuccess)) return false;
+    // a launch that claims whole CUs runs ONE wavefront per SIMD by construction: the build that may use the whole register
+    // file (no scratch; nothing else fits beside it on the SIMD).  PGPU_PS_W1=0 keeps the 256-register build
+    static const bool w1 = [] { const char* e = getenv("PGPU_PS_W1"); return !e || atoi(e) != 0; }();
+    if (dyn && w1) hipLaunchKernelGGL((hensel_decrypt_ps_kernel<38, 28, 1>), dim3(blocks), dim3(kWGThreads), dyn, s, a);
+    else hipLaunchKernelGGL((hensel_decrypt_ps_kernel<38, 28, 2>), dim3(blocks), dim3(kWGThreads), dyn, s, a);
     return true;
   }
   return false;

@@ -159,7 +159,12 @@ inline bool hensel_seq_has(int G, int K) { return (G == 4 && K == 14) || (G == 2
 bool launch_hensel_seq_part16(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
 bool launch_hensel_seq_part17(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
 bool launch_hensel_seq_part29(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
-inline bool launch_hensel_seq(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad = 0) {
+bool launch_hensel_seq_w1_part32(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
+// one_per_simd: the launch claims whole CUs and runs one wavefront per SIMD: the (2,19) form then has a build of its own
+// that may use the whole register file (part 32; PGPU_SEQ_W1=0 keeps the 256-register build)
+inline bool launch_hensel_seq(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad = 0,
+                              bool one_per_simd = false) {
+  if (one_per_simd && launch_hensel_seq_w1_part32(G, K, a, blocks, s, lds_pad)) return true;
   return launch_hensel_seq_part16(G, K, a, blocks, s, lds_pad) || launch_hensel_seq_part17(G, K, a, blocks, s, lds_pad) ||
          launch_hensel_seq_part29(G, K, a, blocks, s, lds_pad);
 }
