@@ -461,10 +461,11 @@ def run_pool(args):
             result["extras_error"] = repr(e)[:400]
         # the API-visible call (SURVEY 8d's timed region: H2D + kernels + D2H inside the call) next to the resident value
         av = {k: result[k] for k in ("end_to_end", "end_to_end_pinned", "end_to_end_two_callers", "end_to_end_two_callers_pinned",
+                                     "end_to_end_four_callers", "end_to_end_four_callers_pinned",
                                      "end_to_end_pipelined", "end_to_end_pipelined_4_lanes", "api_level") if k in result}
         if av:
             av["what"] = ("co-headline: the same step as a caller sees it -- inputs in host memory before the call, results in host "
-                          "memory after it.  end_to_end*: the C-ABI host-pointer entry points (one synchronous caller / two / one "
+                          "memory after it.  end_to_end*: the C-ABI host-pointer entry points (one synchronous caller / two / four / one "
                           "thread pipelining over the batch lanes); api_level: ipcl::PublicKey::encrypt + PrivateKey::decrypt with "
                           "std::vector<BigNumber> in and out.  `value` is the device-resident rate")
             result["api_visible"] = av
@@ -981,6 +982,15 @@ def extras(pa, L, B, pk, sk, n, p, q, hs, m_host, r_host, per_kind):
             out[key] = two_callers(L, pk, sk, m_host, r_host, variant)
         except Exception as e:                              # noqa: BLE001
             out[key] = {"error": repr(e)[:300]}
+    # ... and FOUR (round 5): each caller sees three others, so its launches take the quarter-chip forms (one-lane decrypt
+    # with a CU claim: 14.5 ms per call, four side by side) -- word ciphertexts through the pair-row conversion on the way in
+    time.sleep(0.1)
+    for variant in ("pageable", "pinned"):
+        key = "end_to_end_four_callers" + ("" if variant == "pageable" else "_pinned")
+        try:
+            out[key] = two_callers(L, pk, sk, m_host, r_host, variant, reps=5, ncall=4)
+        except Exception as e:                              # noqa: BLE001
+            out[key] = {"error": repr(e)[:300]}
     # (1d) ONE thread pipelining host-to-host steps over two (and four) batch lanes
     for ln in (2, 4):
         try:
@@ -1196,8 +1206,8 @@ def two_callers(L, pk, sk, m_host, r_host, variant, reps=6, ncall=2):
         L.pgpu_host_free(pp)
     if not ok:
         raise RuntimeError("two callers: " + "; ".join(errs)[:200])
-    return {"what": "two host threads, each calling pgpu_paillier_encrypt + pgpu_paillier_decrypt_crt synchronously on %s arrays "
-                    "of its own, %d rounds each; aggregate rate" % (variant, reps),
+    return {"what": "%d host threads, each calling pgpu_paillier_encrypt + pgpu_paillier_decrypt_crt synchronously on %s arrays "
+                    "of its own, %d rounds each; aggregate rate" % (ncall, variant, reps),
             "wall_ms": round(wall * 1e3, 3), "ms_per_encrypt_plus_decrypt": round(wall / (reps * ncall) * 1e3, 3),
             "modexps_per_s": round(3 * BATCH * reps * ncall / wall, 1)}
 

@@ -1570,6 +1570,28 @@ int busy_other_lanes(rt::Device& dev, int lane, bool force = false) {
   (void)hipGetLastError();
   return busy >= rr_min ? busy : 0;
 }
+// The same for a synchronous caller of the HOST-ARRAY entry points (pgpu_paillier_encrypt / _decrypt_crt) on its thread's
+// lane.  PGPU_HOST_ADAPT=1: the full adaptive policy (measured slower with one neighbour, kept for A/B).  Otherwise, round 5:
+// the callers see each other through stamps of their own, and only when at least PGPU_RR_ADAPT (3) others have been calling
+// within the activity window do their launches take the quarter-chip forms -- four callers side by side, as four API threads.
+int host_busy(rt::Device& dev, int lane) {
+  if (host_adapt()) return busy_other_lanes(dev, lane, true);
+  const int k = policy::rr_adapt();
+  if (k <= 0) return 0;
+  static const int64_t window_ns = [] {
+    const char* e = std::getenv("PGPU_LANE_ACTIVE_MS");
+    return (int64_t)(e ? std::max(0, std::atoi(e)) : 50) * 1000000;
+  }();
+  const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  dev.host_fed_ns[lane % rt::kBatchLanes].store(now, std::memory_order_relaxed);
+  int busy = 0;
+  for (int j = 0; j < rt::kBatchLanes; ++j) {
+    if (j == lane % rt::kBatchLanes) continue;
+    const int64_t fed = std::max(dev.host_fed_ns[j].load(std::memory_order_relaxed), dev.lane_fed_ns[j].load(std::memory_order_relaxed));
+    if (fed != 0 && now - fed < window_ns) ++busy;
+  }
+  return busy >= k ? busy : 0;
+}
 
 // the split form of the key whose limbs per half have a one-lane kernel, when a decrypt of `count` ciphertexts takes it
 const pgpu_privkey::HenselSet* lane_hset(const pgpu_privkey* key, size_t count) {
@@ -2452,7 +2474,7 @@ int pgpu_paillier_encrypt(const pgpu_pubkey* key, const uint64_t* m, size_t m_st
   // the copies of one under the kernels of the other: 5.45 ms per encrypt + decrypt); on half the chip each, a caller's
   // half idles while its copies and host work run, and the pair of calls takes 6.0 ms.  The part-chip forms need an
   // asynchronous feed -- resident batches on the batch lanes.
-  const int caller_lane = host_adapt() ? thread_batch_lane() : -1;
+  const int caller_lane = thread_batch_lane();
   const pgpu_pubkey::PubForm* pf =
       (key->djn && fixed_base_window() > 0 && 64 * m_words <= key->n.BitSize()) ? pair_form(key) : nullptr;
   int rc = run_sharded(count, sub_min, [=](rt::Lane& lane, size_t lo, size_t hi) -> int {
@@ -2465,7 +2487,7 @@ int pgpu_paillier_encrypt(const pgpu_pubkey* key, const uint64_t* m, size_t m_st
     RC_TRY(dc.alloc(d, s, n * (size_t)W * 8));
     RC_TRY(lane.h2d(dm.p, m + lo * m_stride, n * m_stride * 8, s));
     RC_TRY(lane.h2d(dr.p, r + lo * r_stride, n * r_stride * 8, s));
-    const int busy = caller_lane >= 0 ? busy_other_lanes(d, caller_lane, true) : 0;
+    const int busy = host_busy(d, caller_lane);
     if (pf && busy > 0 && fb_encrypt_seq_pays(pf->H, pf->K, n, busy)) {
       // the sequential-halves kernel leaves pair rows: one pair_ops_kernel pass brings them back to words
       RC_TRY(rows.alloc(d, s, n * (size_t)2 * pf->H * pf->K * sizeof(uint32_t)));
@@ -2477,7 +2499,7 @@ int pgpu_paillier_encrypt(const pgpu_pubkey* key, const uint64_t* m, size_t m_st
                         r_bits, (uint64_t*)dc.p, n, s, false, count));
     }
     const int rcd = lane.d2h(c + lo * (size_t)W, dc.p, n * (size_t)W * 8, s);
-    if (caller_lane >= 0) (void)busy_other_lanes(d, caller_lane, true);   // (stamp: a long call stays visible until it ends)
+    (void)host_busy(d, caller_lane);   // (stamp: a long call stays visible until it ends)
     return rcd;
   });
   if (rc == PGPU_OK && key->djn) {
@@ -2508,7 +2530,7 @@ int pgpu_paillier_decrypt_crt(const pgpu_privkey* key, const uint64_t* c, uint64
   if (count == 0) return PGPU_OK;
   if (!c || !m) return fail(PGPU_ERR_INVALID_PARAM, "null batch pointer");
   const int nw = key->n_words;
-  const int caller_lane = host_adapt() ? thread_batch_lane() : -1;   // (see pgpu_paillier_encrypt)
+  const int caller_lane = thread_batch_lane();   // (see pgpu_paillier_encrypt)
   return run_sharded(count, kSubMinHeavy, [=](rt::Lane& lane, size_t lo, size_t hi) -> int {
     rt::Device& d = *lane.dev;
     hipStream_t s = lane.stream;
@@ -2517,10 +2539,9 @@ int pgpu_paillier_decrypt_crt(const pgpu_privkey* key, const uint64_t* c, uint64
     RC_TRY(dc.alloc(d, s, n * (size_t)2 * nw * 8));
     RC_TRY(dm.alloc(d, s, n * (size_t)nw * 8));
     RC_TRY(lane.h2d(dc.p, c + lo * (size_t)2 * nw, n * (size_t)2 * nw * 8, s));
-    RC_TRY(decrypt_on(d, key, (const uint64_t*)dc.p, (uint64_t*)dm.p, n, s, false, nullptr, 0,
-                      caller_lane >= 0 ? busy_other_lanes(d, caller_lane, true) : 0));
+    RC_TRY(decrypt_on(d, key, (const uint64_t*)dc.p, (uint64_t*)dm.p, n, s, false, nullptr, 0, host_busy(d, caller_lane)));
     const int rcd = lane.d2h(m + lo * (size_t)nw, dm.p, n * (size_t)nw * 8, s);
-    if (caller_lane >= 0) (void)busy_other_lanes(d, caller_lane, true);
+    (void)host_busy(d, caller_lane);
     return rcd;
   });
 }

@@ -125,6 +125,9 @@ struct Device {
   // host clock (ns, steady) of the last operation queued on each batch lane: a lane that was fed a moment ago counts as
   // active for the adaptive kernel-form policy even if the GPU has just drained it (capi.cpp: busy_other_lanes)
   std::atomic<int64_t> lane_fed_ns[kBatchLanes] = {};
+  // ... and when a synchronous caller of the host-array entry points last ran a call on its thread's lane: seen by other
+  // such callers only (capi.cpp: host_busy), not by pipelines of resident batches
+  std::atomic<int64_t> host_fed_ns[kBatchLanes] = {};
   std::mutex mu;                   // allocator, work map, timing, queue
 
   // ---- caching allocator (sizes rounded to 64 KiB; free lists per stream tag) ----

@@ -79,3 +79,58 @@ def test_four_api_threads_take_the_quarter_chip_forms(engine):
         assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         assert json.loads(line)["round_trip_ok"] is True
+
+
+def test_four_host_array_callers_take_the_quarter_chip_forms(engine):
+    """Four threads calling pgpu_paillier_encrypt / pgpu_paillier_decrypt_crt on host arrays of their own (the C-ABI the
+    reference's mod_exp.cpp seam binds; the reference's tests call encrypt / decrypt from four
+    OpenMP threads, test_cryptography.cpp:45-57).  Each caller sees three others, so its launches take the quarter-chip
+    forms -- sequential-halves encrypt onto pair rows and back to words, word ciphertexts converted to pair rows for the
+    one-lane product-scanning decrypt -- and must deliver what a lone caller gets (full-chip paired kernels): ciphertexts
+    bit-identical (the randomness is given), plaintexts back."""
+    import threading
+    import numpy as np
+    from pailliercryptolib_amd import _capi
+    L = _capi.lib()
+    p, q, hs = key_case(2048)
+    n = p * q
+    pk, sk = engine.PublicKey(n, 2048, hs=hs), engine.PrivateKey(p, q)
+    B, nw, pw = 8192, 32, 16
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    sets = []
+    for t in range(4):
+        rng = np.random.default_rng(100 + t)
+        m = np.frombuffer(rng.bytes(B * nw * 8), dtype=np.uint64).reshape(B, nw).copy()
+        m[:, -1] &= np.uint64((1 << 62) - 1)
+        r = np.frombuffer(rng.bytes(B * pw * 8), dtype=np.uint64).reshape(B, pw).copy()
+        sets.append((m, r, np.empty((B, 2 * nw), dtype=np.uint64), np.empty((B, nw), dtype=np.uint64)))
+    # the lone caller's ciphertexts first
+    want = []
+    for m, r, c, d in sets:
+        _capi.check(L.pgpu_paillier_encrypt(pk._h, ptr(m), nw, nw, ptr(r), pw, pw, 64 * pw, ptr(c), B))
+        want.append(c.copy())
+    errs = []
+    bar = threading.Barrier(4)
+
+    def caller(k):
+        m, r, c, d = sets[k]
+        try:
+            bar.wait()
+            for _ in range(4):          # (the first round starts with idle neighbours: the later ones run in the quarter-chip mode)
+                c[:] = 0
+                d[:] = 0
+                _capi.check(L.pgpu_paillier_encrypt(pk._h, ptr(m), nw, nw, ptr(r), pw, pw, 64 * pw, ptr(c), B))
+                _capi.check(L.pgpu_paillier_decrypt_crt(sk._h, ptr(c), ptr(d), B))
+                if not np.array_equal(c, want[k]):
+                    errs.append("caller %d: ciphertexts differ from the lone caller's" % k)
+                if not np.array_equal(d, m):
+                    errs.append("caller %d: round trip failed" % k)
+        except Exception as e:                              # noqa: BLE001
+            errs.append(repr(e))
+            bar.abort()
+    th = [threading.Thread(target=caller, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs[:3]
