@@ -58,7 +58,7 @@ def hensel_parts():
         skip |= {22, 23, 24}
     if not build_ab():
         skip |= {15}
-    return [p for p in range(33) if p not in skip]
+    return [p for p in range(34) if p not in skip]
 
 
 def _objects():
@@ -88,7 +88,7 @@ def _objects():
             hdeps_k.append(os.path.join(CSRC, "hensel_ab.hpp"))
         if part == 30:
             hdeps_k.append(os.path.join(CSRC, "hensel_lane.hpp"))
-        if part == 31:
+        if part in (31, 33):
             hdeps_k.append(os.path.join(CSRC, "hensel_ps.hpp"))
         out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src] + hdeps_k + kdeps))
     for name in ("capi.cpp", "policy.cpp", "runtime.cpp", os.path.join("host", "bignum.cpp")):
@@ -171,8 +171,8 @@ def build_pgpu(force=False):
             or (cfg_changed and os.path.basename(o) in gated)]
     if todo:
         # the 8-lane x 18-limb forms (4096-bit key class, parts 22-24; PGPU_BUILD_4096=1) compile for 10-15 minutes each:
-        # start them first
-        slow = ("k_hensel_22.", "k_hensel_23.", "k_hensel_24.")
+        # start them first; so are the one-lane product-scanning forms (parts 33, 31: fully unrolled column loops, 5 and 3 minutes)
+        slow = ("k_hensel_22.", "k_hensel_23.", "k_hensel_24.", "k_hensel_33.", "k_hensel_31.")
         todo.sort(key=lambda oc: 0 if os.path.basename(oc[0]).startswith(slow) else 1)
         with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
             list(ex.map(lambda oc: compile_one(oc[0], oc[1]), todo))

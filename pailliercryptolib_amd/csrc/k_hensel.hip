@@ -6,7 +6,7 @@
 #if defined(PGPU_PART) && PGPU_PART == 30
 #include "hensel_lane.hpp"   // whole exponentiations in one lane (1024-bit keys, large batches)
 #endif
-#if defined(PGPU_PART) && PGPU_PART == 31
+#if defined(PGPU_PART) && (PGPU_PART == 31 || PGPU_PART == 33)
 #include "hensel_ps.hpp"     // whole exponentiations in one lane by product scanning (2048-bit keys; round 5)
 #endif
 #if defined(PGPU_PART) && PGPU_PART == 15
@@ -14,7 +14,7 @@
 #endif
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..32"
+#error "compile with -DPGPU_PART=0..33"
 #endif
 
 namespace pgpu {
@@ -274,7 +274,23 @@ bool launch_hensel_ps_part31(int K, int lb, const HenselArgs& a, unsigned blocks
   }
   return false;
 }
-size_t hensel_ps_table_words(int K, size_t entries) { return K == 38 ? ps_table_words<38>(entries) : 0; }
+static_assert(ps_table_words<38>(32) == 32 * 2 * ((38 + 3) / 4) * 64 * 4, "launch.hpp: hensel_ps_table_words");
+#elif PGPU_PART == 33
+// 3072-bit keys: 57 limbs of 28 bits per half.  Six 57-limb values live in a pair product: only the build that may use the
+// whole register file (one wavefront per SIMD) -- large launches run as rounds of one wavefront per SIMD
+bool launch_hensel_ps_part33(int K, int lb, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad) {
+  if (K == 57 && lb == 28) {
+    constexpr unsigned kStatic = sizeof(uint4) * kWavesPerWG * ((57 + 3) / 4) * kWave;
+    const unsigned dyn = lds_pad > kStatic ? lds_pad - kStatic : 0;
+    static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_ps_kernel<57, 28, 1>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // (first launch: see part 16)
+    if (dyn && once != hipSuccess) return false;
+    hipLaunchKernelGGL((hensel_decrypt_ps_kernel<57, 28, 1>), dim3(blocks), dim3(kWGThreads), dyn, s, a);
+    return true;
+  }
+  return false;
+}
+static_assert(ps_table_words<57>(32) == 32 * 2 * ((57 + 3) / 4) * 64 * 4, "launch.hpp: hensel_ps_table_words");
 #elif PGPU_PART == 15
 bool launch_hensel_ab_part15(int K, int pairs_per_wg, const HenselArgs& a, unsigned blocks, hipStream_t s) {
   if (K == 19 && pairs_per_wg == 2) {

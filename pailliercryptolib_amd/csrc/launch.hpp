@@ -179,12 +179,15 @@ inline bool launch_hensel_lane(int L2, const HenselArgs& a, unsigned blocks, hip
 
 // CRT decrypt with a whole exponentiation per lane by product scanning (hensel_ps.hpp; k_hensel.hip part 31): pair-row
 // ciphertexts, fixed-window scan, constants in limbs of `lb` bits: K = 38 limbs of 28 bits (2048-bit keys)
-inline bool hensel_ps_has(int K, int lb) { return K == 38 && lb == 28; }
+// (38, 28): 2048-bit keys (k_hensel.hip part 31); (57, 28): 3072-bit keys (part 33 -- the whole register file, one wavefront per SIMD)
+inline bool hensel_ps_has(int K, int lb) { return (K == 38 || K == 57) && lb == 28; }
 bool launch_hensel_ps_part31(int K, int lb, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
+bool launch_hensel_ps_part33(int K, int lb, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
 inline bool launch_hensel_ps(int K, int lb, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad = 0) {
-  return launch_hensel_ps_part31(K, lb, a, blocks, s, lds_pad);
+  return launch_hensel_ps_part31(K, lb, a, blocks, s, lds_pad) || launch_hensel_ps_part33(K, lb, a, blocks, s, lds_pad);
 }
-size_t hensel_ps_table_words(int K, size_t entries);   // 32-bit words of window table per wavefront
+// 32-bit words of window table per wavefront (hensel_ps.hpp: ps_table_words -- per entry two parts of ceil(K/4) 16-byte rows of 64 lanes)
+inline size_t hensel_ps_table_words(int K, size_t entries) { return entries * 2 * (size_t)((K + 3) / 4) * 64 * 4; }
 
 // per-element bases modulo n^2 in the same form (k_hensel.hip part 18): resident pair rows in and out, fixed window
 // (4,18): 2048-bit keys, (8,14): 3072 (part 26), (2,19): 1024 (part 28)

@@ -12,35 +12,38 @@ from test_gpu_round4 import Res, key_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("count", [1, 63, 65, 300, 4100])
-def test_ps_decrypt_kernel_is_bit_identical(engine, count):
-    """csrc/hensel_ps.hpp: a whole half-width exponentiation per lane by product scanning (2048-bit keys; by default from
+@pytest.mark.parametrize("bits,count", [(2048, 1), (2048, 63), (2048, 65), (2048, 300), (2048, 4100),
+                                        (3072, 1), (3072, 65), (3072, 300), (3072, 1100)])
+def test_ps_decrypt_kernel_is_bit_identical(engine, bits, count):
+    """csrc/hensel_ps.hpp: a whole half-width exponentiation per lane by product scanning (2048-bit keys: 38 limbs of 28 bits
+    per half, 3072-bit keys: 57; by default from
     32768 ciphertexts up or beside busy neighbour lanes, forced here): same plaintexts as the default kernels and the
     oracle, ragged batches (padding lanes of the last wavefront), resident ciphertexts from every producer (encrypt,
     CT+CT, CT x PT, uploaded words -- relaxed limbs of the multi-lane kernels and canonical ones), edge plaintexts, and with
     the masked table gather."""
     from oracle import paillier_oracle as orc
     from pailliercryptolib_amd import _capi
-    p, q, hs = key_case(2048)
+    p, q, hs = key_case(bits)
     n = p * q
+    nw = bits // 64
     rng = random.Random(count)
     m = ([0, 1, n - 1] + [rng.randrange(n) for _ in range(count)])[:count]
     m2 = [rng.randrange(n) for _ in range(count)]
-    r = [rng.getrandbits(1024) for _ in range(count)]
+    r = [rng.getrandbits(bits // 2) for _ in range(count)]
     e = [rng.getrandbits(33) for _ in range(count)]
-    pk, sk = engine.PublicKey(n, 2048, hs=hs), engine.PrivateKey(p, q)
+    pk, sk = engine.PublicKey(n, bits, hs=hs), engine.PrivateKey(p, q)
     osk = orc.PrivateKey(n, p, q)
     R = Res()
     L = R.L
     try:
-        c1 = R.op(L.pgpu_batch_encrypt, pk._h, R.up(m, 32), R.up(r, 16), 1024)
-        c2 = R.op(L.pgpu_batch_encrypt, pk._h, R.up(m2, 32), R.up(r, 16), 1024)
+        c1 = R.op(L.pgpu_batch_encrypt, pk._h, R.up(m, nw), R.up(r, nw // 2), bits // 2)
+        c2 = R.op(L.pgpu_batch_encrypt, pk._h, R.up(m2, nw), R.up(r, nw // 2), bits // 2)
         s = R.op(L.pgpu_batch_ct_add, pk._h, c1, c2)
         t = R.op(L.pgpu_batch_ct_mul, pk._h, s, R.up(e, 1), 33)
         raw = [rng.randrange(1, n * n) for _ in range(count)]        # not encryptions: L_p(c^(p-1)) has no structure
         raw[0] = n * n - 1
-        up = R.up(raw, 64)
-        up_pair = R.op(L.pgpu_batch_ct_add, pk._h, up, R.up([1], 64))   # the same values as pair rows
+        up = R.up(raw, 2 * nw)
+        up_pair = R.op(L.pgpu_batch_ct_add, pk._h, up, R.up([1], 2 * nw))   # the same values as pair rows
         want = [R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, x)) for x in (c1, s, t, up_pair)]
         assert want[0] == m and want[1] == [(a + b) % n for a, b in zip(m, m2)]
         assert want[2] == [((a + b) * x) % n for a, b, x in zip(m, m2, e)]
@@ -50,7 +53,7 @@ def test_ps_decrypt_kernel_is_bit_identical(engine, count):
         try:
             split, lanes, limbs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
             _capi.check(L.pgpu_decrypt_kernel_form(sk._h, count, ctypes.byref(split), ctypes.byref(lanes), ctypes.byref(limbs)))
-            assert (split.value, lanes.value, limbs.value) == (4, 1, 38)
+            assert (split.value, lanes.value, limbs.value) == (4, 1, {2048: 38, 3072: 57}[bits])
             got = [R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, x)) for x in (c1, s, t, up_pair, up)]
             assert got[:4] == want
             assert got[4] == want[3]          # word ciphertexts reach the kernel through the pair-row conversion
