@@ -276,21 +276,21 @@ bool launch_hensel_ps_part31(int K, int lb, const HenselArgs& a, unsigned blocks
 }
 static_assert(ps_table_words<38>(32) == 32 * 2 * ((38 + 3) / 4) * 64 * 4, "launch.hpp: hensel_ps_table_words");
 #elif PGPU_PART == 33
-// 3072-bit keys: 57 limbs of 28 bits per half.  Six 57-limb values live in a pair product: only the build that may use the
+// 3072-bit keys: 56 limbs of 28 bits per half.  Six 56-limb values live in a pair product: only the build that may use the
 // whole register file (one wavefront per SIMD) -- large launches run as rounds of one wavefront per SIMD
 bool launch_hensel_ps_part33(int K, int lb, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad) {
-  if (K == 57 && lb == 28) {
-    constexpr unsigned kStatic = sizeof(uint4) * kWavesPerWG * ((57 + 3) / 4) * kWave;
+  if (K == 56 && lb == 28) {
+    constexpr unsigned kStatic = sizeof(uint4) * kWavesPerWG * ((56 + 3) / 4) * kWave;
     const unsigned dyn = lds_pad > kStatic ? lds_pad - kStatic : 0;
-    static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_ps_kernel<57, 28, 1>,
+    static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_ps_kernel<56, 28, 1>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // (first launch: see part 16)
     if (dyn && once != hipSuccess) return false;
-    hipLaunchKernelGGL((hensel_decrypt_ps_kernel<57, 28, 1>), dim3(blocks), dim3(kWGThreads), dyn, s, a);
+    hipLaunchKernelGGL((hensel_decrypt_ps_kernel<56, 28, 1>), dim3(blocks), dim3(kWGThreads), dyn, s, a);
     return true;
   }
   return false;
 }
-static_assert(ps_table_words<57>(32) == 32 * 2 * ((57 + 3) / 4) * 64 * 4, "launch.hpp: hensel_ps_table_words");
+static_assert(ps_table_words<56>(32) == 32 * 2 * ((56 + 3) / 4) * 64 * 4, "launch.hpp: hensel_ps_table_words");
 #elif PGPU_PART == 15
 bool launch_hensel_ab_part15(int K, int pairs_per_wg, const HenselArgs& a, unsigned blocks, hipStream_t s) {
   if (K == 19 && pairs_per_wg == 2) {

@@ -179,8 +179,8 @@ inline bool launch_hensel_lane(int L2, const HenselArgs& a, unsigned blocks, hip
 
 // CRT decrypt with a whole exponentiation per lane by product scanning (hensel_ps.hpp; k_hensel.hip part 31): pair-row
 // ciphertexts, fixed-window scan, constants in limbs of `lb` bits: K = 38 limbs of 28 bits (2048-bit keys)
-// (38, 28): 2048-bit keys (k_hensel.hip part 31); (57, 28): 3072-bit keys (part 33 -- the whole register file, one wavefront per SIMD)
-inline bool hensel_ps_has(int K, int lb) { return (K == 38 || K == 57) && lb == 28; }
+// (38, 28): 2048-bit keys (k_hensel.hip part 31); (56, 28): 3072-bit keys (part 33 -- the whole register file, one wavefront per SIMD)
+inline bool hensel_ps_has(int K, int lb) { return (K == 38 || K == 56) && lb == 28; }
 bool launch_hensel_ps_part31(int K, int lb, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
 bool launch_hensel_ps_part33(int K, int lb, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
 inline bool launch_hensel_ps(int K, int lb, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad = 0) {

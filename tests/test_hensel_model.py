@@ -99,3 +99,53 @@ def test_pair_exponentiation_matches_reference_formula(side):
             assert t < 2 * p and w2 < 2 * p and t % p == hp
             j = 1 if t >= p else 0
             assert (j - w2) % p == ((u - 1) // p) * hp % p          # pri_key.cpp:142, 154-157
+
+
+@pytest.mark.parametrize("bits,K", [(1024, 38), (1536, 56)])
+def test_product_scanning_form_bounds_with_sixteen_fold_headroom(bits, K):
+    """csrc/hensel_ps.hpp keeps a residue in K limbs of 28 bits with R = 2^(28 K) >= 16 P only (capi_keys.inc: build_hensel;
+    the multi-lane forms keep 256).  Upper bounds, as multiples of P, pushed through the kernel's flow with the WORST
+    headroom R = 16 P: the chunked entry (a chunk below R/4, at most 4 chunks summed), the window-table recurrence, the main
+    loop (squarings, products by any table entry), and the column sums of the widest product.  Everything must stay below
+    R (the limbs hold it) and a column below 2^64 (one 64-bit accumulator holds it).  Lazy Montgomery product:
+    redc(T) < T/R + P."""
+    F = lambda a, b=1: a / b * (1 + 1e-12)      # upper bounds in floating point, rounded up a little at every step
+    LBp = 28
+    assert LBp * K >= bits + LBp + 4 and LBp * (K - 1) < bits + LBp + 4          # the K build_hensel picks
+    rho = 16.0                                                                   # R / P, worst case
+    pair_l2 = {1024: 4 * 18, 1536: 8 * 14}[bits]                                 # 29-bit limbs per half of an n^2 pair row
+    chunks = -(-pair_l2 // ((LBp * K - 2) // 29))                                # (build_hensel_set: pchunks)
+    assert chunks <= 4
+
+    def mul(c1, c2):                       # one lazy product of values below c1 P and c2 P
+        return F(c1 * c2, rho) + 1
+
+    def pairmul(x, y):                     # (a, b) (x) (c, d): t = a c, w = a d + b c + q (q < R: + 1 P at most, counted in the +1)
+        (a, b), (c, d) = x, y
+        return (mul(a, c), F(a * d + b * c, rho) + 1 + 1e-6)
+
+    # entry: chunk values below R/4 = rho/4 P, conversion constants below P
+    z = rho / 4
+    a, b = pairmul((z, 0.0), (1.0, 1.0))
+    b += mul(z, 1.0)                      # ps_add(b, tb)
+    base = (chunks * a, chunks * b)        # ps_add(acc, .) over the chunks
+    assert max(base) < rho
+    # window table: entry e = entry e-1 (x) base; the bounds are monotone in the inputs, so their running maximum covers all
+    entry = base
+    worst = base
+    for _ in range(64):
+        entry = pairmul(entry, base)
+        worst = (max(worst[0], entry[0]), max(worst[1], entry[1]))
+    assert max(worst) < rho
+    # main loop from any entry: squarings and products by the worst entry, to a fixed point
+    s = worst
+    top = s
+    for _ in range(200):
+        for _ in range(5):
+            s = pairmul(s, s)
+            top = (max(top[0], s[0]), max(top[1], s[1]))
+        s = pairmul(s, worst)
+        top = (max(top[0], s[0]), max(top[1], s[1]))
+    assert max(top) < rho and max(s) < 3
+    # columns: canonical limbs below 2^28, the doubled operand of a squaring below 2^29: at most 3K products of 2^56 each
+    assert 3 * K * (1 << (2 * LBp)) < 1 << 64
