@@ -58,7 +58,7 @@ def hensel_parts():
         skip |= {22, 23, 24}
     if not build_ab():
         skip |= {15}
-    return [p for p in range(34) if p not in skip]
+    return [p for p in range(35) if p not in skip]
 
 
 def _objects():
@@ -88,7 +88,7 @@ def _objects():
             hdeps_k.append(os.path.join(CSRC, "hensel_ab.hpp"))
         if part == 30:
             hdeps_k.append(os.path.join(CSRC, "hensel_lane.hpp"))
-        if part in (31, 33):
+        if part in (31, 33, 34):
             hdeps_k.append(os.path.join(CSRC, "hensel_ps.hpp"))
         out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src] + hdeps_k + kdeps))
     for name in ("capi.cpp", "policy.cpp", "runtime.cpp", os.path.join("host", "bignum.cpp")):

@@ -35,6 +35,14 @@
 #define PGPU_PS_PIN 1
 #endif
 
+// the wavefronts of a workgroup re-align at a barrier (A/B, tools/build_variant.py): 0 never, 1 before every window of the
+// main loop, 2 before every squaring.  The unrolled squaring is 44 KB of code at K = 38 and 97 KB at K = 56, a window's
+// squarings and product 105 / 250 KB -- against a 64 KB instruction cache shared by two CUs: wavefronts that run the same
+// lines at the same time share the fetches
+#ifndef PGPU_PS_SYNC
+#define PGPU_PS_SYNC 0
+#endif
+
 namespace pgpu {
 
 template <int LB>
@@ -451,8 +459,12 @@ __global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_ps_kernel(Hen
 #pragma unroll 1
   for (; nwin > 0 && win >= 0; --win) {
     const int idx = digit(win);
+    if constexpr (PGPU_PS_SYNC == 1) __builtin_amdgcn_s_barrier();
 #pragma unroll 1
-    for (int i = 0; i < w; ++i) ps_pairsqr<K, LB>(a, b, n, n1p);
+    for (int i = 0; i < w; ++i) {
+      if constexpr (PGPU_PS_SYNC == 2) __builtin_amdgcn_s_barrier();
+      ps_pairsqr<K, LB>(a, b, n, n1p);
+    }
     // (the entry is fetched AFTER the squarings: held across them it would cost 2K registers)
     ps_table_load<K>(ma, mb, tw, idx, tsize, gather);
     ps_pairmul<K, LB, true>(a, b, ma, mb, n, n1p, 0, slot);

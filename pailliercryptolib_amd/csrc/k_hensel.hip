@@ -6,7 +6,7 @@
 #if defined(PGPU_PART) && PGPU_PART == 30
 #include "hensel_lane.hpp"   // whole exponentiations in one lane (1024-bit keys, large batches)
 #endif
-#if defined(PGPU_PART) && (PGPU_PART == 31 || PGPU_PART == 33)
+#if defined(PGPU_PART) && (PGPU_PART == 31 || PGPU_PART == 33 || PGPU_PART == 34)
 #include "hensel_ps.hpp"     // whole exponentiations in one lane by product scanning (2048-bit keys; round 5)
 #endif
 #if defined(PGPU_PART) && PGPU_PART == 15
@@ -14,7 +14,7 @@
 #endif
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..33"
+#error "compile with -DPGPU_PART=0..34"
 #endif
 
 namespace pgpu {
@@ -291,6 +291,21 @@ bool launch_hensel_ps_part33(int K, int lb, const HenselArgs& a, unsigned blocks
   return false;
 }
 static_assert(ps_table_words<56>(32) == 32 * 2 * ((56 + 3) / 4) * 64 * 4, "launch.hpp: hensel_ps_table_words");
+#elif PGPU_PART == 34
+// 1024-bit keys: 19 limbs of 29 bits per half (3 x 19 products of 58 bits fit a 64-bit column); ~150 registers, one build
+bool launch_hensel_ps_part34(int K, int lb, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad) {
+  if (K == 19 && lb == 29) {
+    constexpr unsigned kStatic = sizeof(uint4) * kWavesPerWG * ((19 + 3) / 4) * kWave;
+    const unsigned dyn = lds_pad > kStatic ? lds_pad - kStatic : 0;
+    static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_ps_kernel<19, 29, 2>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // (first launch: see part 16)
+    if (dyn && once != hipSuccess) return false;
+    hipLaunchKernelGGL((hensel_decrypt_ps_kernel<19, 29, 2>), dim3(blocks), dim3(kWGThreads), dyn, s, a);
+    return true;
+  }
+  return false;
+}
+static_assert(ps_table_words<19>(32) == 32 * 2 * ((19 + 3) / 4) * 64 * 4, "launch.hpp: hensel_ps_table_words");
 #elif PGPU_PART == 15
 bool launch_hensel_ab_part15(int K, int pairs_per_wg, const HenselArgs& a, unsigned blocks, hipStream_t s) {
   if (K == 19 && pairs_per_wg == 2) {

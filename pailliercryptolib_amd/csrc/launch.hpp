@@ -180,11 +180,14 @@ inline bool launch_hensel_lane(int L2, const HenselArgs& a, unsigned blocks, hip
 // CRT decrypt with a whole exponentiation per lane by product scanning (hensel_ps.hpp; k_hensel.hip part 31): pair-row
 // ciphertexts, fixed-window scan, constants in limbs of `lb` bits: K = 38 limbs of 28 bits (2048-bit keys)
 // (38, 28): 2048-bit keys (k_hensel.hip part 31); (56, 28): 3072-bit keys (part 33 -- the whole register file, one wavefront per SIMD)
-inline bool hensel_ps_has(int K, int lb) { return (K == 38 || K == 56) && lb == 28; }
+// (19, 29): 1024-bit keys (part 34; a column sums 3 x 19 products of 58 bits)
+inline bool hensel_ps_has(int K, int lb) { return ((K == 38 || K == 56) && lb == 28) || (K == 19 && lb == 29); }
 bool launch_hensel_ps_part31(int K, int lb, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
 bool launch_hensel_ps_part33(int K, int lb, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
+bool launch_hensel_ps_part34(int K, int lb, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad);
 inline bool launch_hensel_ps(int K, int lb, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad = 0) {
-  return launch_hensel_ps_part31(K, lb, a, blocks, s, lds_pad) || launch_hensel_ps_part33(K, lb, a, blocks, s, lds_pad);
+  return launch_hensel_ps_part31(K, lb, a, blocks, s, lds_pad) || launch_hensel_ps_part33(K, lb, a, blocks, s, lds_pad) ||
+         launch_hensel_ps_part34(K, lb, a, blocks, s, lds_pad);
 }
 // 32-bit words of window table per wavefront (hensel_ps.hpp: ps_table_words -- per entry two parts of ceil(K/4) 16-byte rows of 64 lanes)
 inline size_t hensel_ps_table_words(int K, size_t entries) { return entries * 2 * (size_t)((K + 3) / 4) * 64 * 4; }

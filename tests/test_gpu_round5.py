@@ -13,10 +13,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("bits,count", [(2048, 1), (2048, 63), (2048, 65), (2048, 300), (2048, 4100),
-                                        (3072, 1), (3072, 65), (3072, 300), (3072, 1100)])
+                                        (3072, 1), (3072, 65), (3072, 300), (3072, 1100),
+                                        (1024, 1), (1024, 65), (1024, 300), (1024, 4100)])
 def test_ps_decrypt_kernel_is_bit_identical(engine, bits, count):
     """csrc/hensel_ps.hpp: a whole half-width exponentiation per lane by product scanning (2048-bit keys: 38 limbs of 28 bits
-    per half, 3072-bit keys: 56; by default from
+    per half, 3072-bit keys: 56, 1024-bit keys: 19 limbs of 29 bits; by default from
     32768 ciphertexts up or beside busy neighbour lanes, forced here): same plaintexts as the default kernels and the
     oracle, ragged batches (padding lanes of the last wavefront), resident ciphertexts from every producer (encrypt,
     CT+CT, CT x PT, uploaded words -- relaxed limbs of the multi-lane kernels and canonical ones), edge plaintexts, and with
@@ -53,7 +54,7 @@ def test_ps_decrypt_kernel_is_bit_identical(engine, bits, count):
         try:
             split, lanes, limbs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
             _capi.check(L.pgpu_decrypt_kernel_form(sk._h, count, ctypes.byref(split), ctypes.byref(lanes), ctypes.byref(limbs)))
-            assert (split.value, lanes.value, limbs.value) == (4, 1, {2048: 38, 3072: 56}[bits])
+            assert (split.value, lanes.value, limbs.value) == (4, 1, {1024: 19, 2048: 38, 3072: 56}[bits])
             got = [R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, x)) for x in (c1, s, t, up_pair, up)]
             assert got[:4] == want
             assert got[4] == want[3]          # word ciphertexts reach the kernel through the pair-row conversion

@@ -101,19 +101,18 @@ def test_pair_exponentiation_matches_reference_formula(side):
             assert (j - w2) % p == ((u - 1) // p) * hp % p          # pri_key.cpp:142, 154-157
 
 
-@pytest.mark.parametrize("bits,K", [(1024, 38), (1536, 56)])
-def test_product_scanning_form_bounds_with_sixteen_fold_headroom(bits, K):
-    """csrc/hensel_ps.hpp keeps a residue in K limbs of 28 bits with R = 2^(28 K) >= 16 P only (capi_keys.inc: build_hensel;
+@pytest.mark.parametrize("bits,K,LBp", [(512, 19, 29), (1024, 38, 28), (1536, 56, 28)])
+def test_product_scanning_form_bounds_with_sixteen_fold_headroom(bits, K, LBp):
+    """csrc/hensel_ps.hpp keeps a residue in K limbs of LB bits with R = 2^(LB K) >= 16 P only (capi_keys.inc: build_hensel;
     the multi-lane forms keep 256).  Upper bounds, as multiples of P, pushed through the kernel's flow with the WORST
     headroom R = 16 P: the chunked entry (a chunk below R/4, at most 4 chunks summed), the window-table recurrence, the main
     loop (squarings, products by any table entry), and the column sums of the widest product.  Everything must stay below
     R (the limbs hold it) and a column below 2^64 (one 64-bit accumulator holds it).  Lazy Montgomery product:
     redc(T) < T/R + P."""
     F = lambda a, b=1: a / b * (1 + 1e-12)      # upper bounds in floating point, rounded up a little at every step
-    LBp = 28
     assert LBp * K >= bits + LBp + 4 and LBp * (K - 1) < bits + LBp + 4          # the K build_hensel picks
     rho = 16.0                                                                   # R / P, worst case
-    pair_l2 = {1024: 4 * 18, 1536: 8 * 14}[bits]                                 # 29-bit limbs per half of an n^2 pair row
+    pair_l2 = {512: 2 * 19, 1024: 4 * 18, 1536: 8 * 14}[bits]                                 # 29-bit limbs per half of an n^2 pair row
     chunks = -(-pair_l2 // ((LBp * K - 2) // 29))                                # (build_hensel_set: pchunks)
     assert chunks <= 4
 
@@ -147,5 +146,5 @@ def test_product_scanning_form_bounds_with_sixteen_fold_headroom(bits, K):
         s = pairmul(s, worst)
         top = (max(top[0], s[0]), max(top[1], s[1]))
     assert max(top) < rho and max(s) < 3
-    # columns: canonical limbs below 2^28, the doubled operand of a squaring below 2^29: at most 3K products of 2^56 each
+    # columns: canonical limbs below 2^LB, the doubled operand of a squaring below 2^(LB+1): at most 3K products of 2^(2 LB) each
     assert 3 * K * (1 << (2 * LBp)) < 1 << 64

@@ -69,6 +69,7 @@ for tag, label in (("f1", ""), ("f2", "_two_in_flight"), ("f4", "_four_in_flight
         json.dump(out, open(f"{pre}_pmc_counters{label}.json", "w"), indent=1)
         pmc_all[tag] = out
 
+old_summary = json.load(open("profiles/pmc_summary.json")) if os.path.exists("profiles/pmc_summary.json") else {}
 summary = {"source": "profiles/r05*_pmc_counters*.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in passes of their own, tools/profile_r05.sh; "
                      "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 averaged over the full-size launches of the command, the x2 on "
                      "FETCH per MI355X_MICROARCH.md (HBM): gfx950 tallies wide reads at half their size)",
@@ -85,7 +86,8 @@ def pick(tag, prefix):
 for key, tag, prefix in (("modexp_decrypt", "f1", "hensel_decrypt_kernel<"), ("seq_decrypt", "f2", "hensel_decrypt_seq_kernel<"),
                          ("ps_decrypt", "f4", "hensel_decrypt_ps_kernel<"), ("fb_encrypt_seq_quarter", "f4", "hensel_fb_encrypt_seq_kernel<"),
                          ("fb_encrypt", "f1", "hensel_fb_encrypt_kernel<"), ("fb_encrypt_seq", "f2", "hensel_fb_encrypt_seq_kernel<"),
-                         ("config4_decrypt", "c4", "hensel_decrypt_seq_kernel<"), ("config4_encrypt", "c4", "hensel_fb_encrypt_seq_kernel<"),
+                         ("config4_decrypt", "c4", "hensel_decrypt_seq_kernel<"), ("config4_decrypt", "c4", "hensel_decrypt_ps_kernel<"),
+                         ("config4_encrypt", "c4", "hensel_fb_encrypt_seq_kernel<"),
                          ("ct_add", "c5", "pair_mul_seq_kernel<"), ("ct_mul", "c5", "hensel_modexp_seq_kernel<")):
     name, b, raw = pick(tag, prefix)
     if name:
@@ -94,7 +96,12 @@ for key, tag, prefix in (("modexp_decrypt", "f1", "hensel_decrypt_kernel<"), ("s
         summary[key + "_hbm_bytes_per_launch_raw"] = raw
 if "ct_add_hbm_bytes_per_launch" in summary:
     summary["ct_add_pair_mul_hbm_bytes_per_launch"] = summary["ct_add_hbm_bytes_per_launch"]
-if len(summary) > 2:
+if len(summary) > 3:
+    # a partial run (RUNS=... tools/profile_r05.sh) refreshes its own keys only; "build" / "collected" then name the latest pass
+    for k, v in old_summary.items():
+        summary.setdefault(k, v)
+    if old_summary.get("build") and old_summary.get("build") != build and len(pmc_all) < 5:
+        summary["build_note"] = "keys of passes not re-run keep the values of build " + old_summary["build"]
     json.dump(summary, open("profiles/pmc_summary.json", "w"), indent=1)
     print(json.dumps(summary, indent=1))
 

@@ -9,7 +9,8 @@ set -x
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 B="--no-cpu-baseline --no-extras --sustain-seconds 0"
-for run in f1 f2 f4 c4 c5; do
+RUNS=${RUNS:-"f1 f2 f4 c4 c5"}   # RUNS="c4" EXTRA=0: one configuration only, no second half
+for run in $RUNS; do
   OUT=$REPO/gpurun_out/prof_r05$run
   mkdir -p $OUT
   case $run in
@@ -22,7 +23,7 @@ for run in f1 f2 f4 c4 c5; do
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
   timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1
   timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.log 2>&1
-  if [ $run = f1 ] || [ $run = f2 ] || [ $run = f4 ]; then
+  if [ $run = f1 ] || [ $run = f2 ] || [ $run = f4 ] || [ $run = c4 ]; then
     timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/pmc_sq.log 2>&1
     timeout 400 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_WAIT_ANY SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc_sq2 -- $CMD > $OUT/pmc_sq2.log 2>&1
   fi
@@ -31,6 +32,7 @@ done
 cd $REPO
 OUT=$REPO/gpurun_out/r05p
 mkdir -p $OUT
+if [ "${EXTRA:-1}" = 0 ]; then exit 0; fi
 python bench.py --steps 20 --warmup 3 > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 python bench.py --in-flight 1 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $OUT/bench_f1.json 2>/dev/null
 python bench.py --in-flight 2 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $OUT/bench_f2.json 2>/dev/null
