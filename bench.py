@@ -628,7 +628,7 @@ def decrypt_kernel(sk, count, nw, key_bits, busy_lanes=0):
         l2 = limbs.value
         red = l2 * (l2 - 1)
         nmul = (e + 4) // 5 + 30 + 2 + 1
-        return (f"hensel_decrypt_ps_kernel<{l2},28>", e * (l2 * (l2 + 1) // 2 + l2 * l2 + 2 * red) + nmul * (3 * l2 * l2 + 2 * red)
+        return (f"hensel_decrypt_ps_kernel<{l2},{29 if l2 == 19 else 28}>", e * (l2 * (l2 + 1) // 2 + l2 * l2 + 2 * red) + nmul * (3 * l2 * l2 + 2 * red)
                 + 3 * (l2 * l2 + red))
     if split.value == 3:       # a whole exponentiation per lane (csrc/hensel_lane.hpp): the useful count IS what it executes
         l2 = limbs.value

@@ -325,7 +325,7 @@ typedef enum pgpu_kernel_form {
   PGPU_FORM_PAIRED = 1,
   PGPU_FORM_SEQ = 2,
   PGPU_FORM_LANE = 4,      /* a whole exponentiation per lane (hensel_lane.hpp: 1024-bit keys, >= 32768 ciphertexts) */
-  PGPU_FORM_PS = 8,        /* with PGPU_FORM_LANE: by product scanning (hensel_ps.hpp: 2048-bit keys; round 5) */
+  PGPU_FORM_PS = 8,        /* with PGPU_FORM_LANE: by product scanning (hensel_ps.hpp: 1024- to 3072-bit keys; round 5) */
   PGPU_FORM_CU_CLAIM = 16
 } pgpu_kernel_form;
 int pgpu_timing_collect_ex(int* kinds, int* forms, double* ms, int max_entries);
@@ -343,8 +343,9 @@ int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, i
  * resident batch (pair rows), hensel_decrypt_seq_kernel<*lanes, *limbs> -- both halves of a pair in the same *lanes
  * lanes, launches that still put a wavefront on every SIMD that way (PGPU_SEQ_DECRYPT=0 turns it off); *split = 3 (round 4):
  * hensel_decrypt_lane_kernel<*limbs> -- a whole exponentiation in ONE lane, *limbs limbs per half (1024-bit keys, launches of
- * 32768 ciphertexts or more; PGPU_LANE_DECRYPT=0 turns it off); *split = 4 (round 5): hensel_decrypt_ps_kernel<*limbs, 28>
- * -- a whole exponentiation in one lane by product scanning, *limbs limbs of 28 bits per half (2048-bit keys; launches of
+ * 32768 ciphertexts or more when PGPU_PS_DECRYPT=0; PGPU_LANE_DECRYPT=0 turns it off); *split = 4 (round 5):
+ * hensel_decrypt_ps_kernel<*limbs, 28 | 29> -- a whole exponentiation in one lane by product scanning, *limbs limbs per half
+ * (38 / 56 limbs of 28 bits: 2048- / 3072-bit keys, 19 limbs of 29 bits: 1024-bit keys; launches of
  * 32768 ciphertexts or more, or smaller ones that cover the SIMDs together with busy neighbour lanes: 8192 beside three;
  * PGPU_PS_DECRYPT=0 turns it off); *split = 0: the full-width modexp_kernel<Geo<*lanes, *limbs>>.
  * Host-side query. */

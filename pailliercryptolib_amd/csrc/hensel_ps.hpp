@@ -1,6 +1,9 @@
 // pailliercryptolib_amd -- the split form with a whole exponentiation in ONE lane, by PRODUCT SCANNING (round 5):
-// hensel_decrypt_ps_kernel<K, LB>, CRT decrypt of resident batches under 2048-bit keys (K = 38 limbs of LB = 28 bits per
-// half) and, with K = 20 / LB = 29, the successor of hensel_decrypt_lane_kernel<20> for 1024-bit keys.
+// hensel_decrypt_ps_kernel<K, LB, MINW>, CRT decrypt of resident batches under 2048-bit keys (K = 38 limbs of LB = 28 bits
+// per half: the headline's dominant kernel), 3072-bit keys (K = 56, LB = 28; one wavefront per SIMD only) and 1024-bit keys
+// (K = 19, LB = 29: the successor of hensel_decrypt_lane_kernel<20>).  Instantiated in k_hensel.hip parts 31 / 33 / 34.
+// Headroom: R = 2^(LB*K) >= 16 * P is enough here (canonical limbs after every product; the bounds are pushed through the
+// kernel's flow in tests/test_hensel_model.py) -- the multi-lane forms keep 256 for their relaxed limbs.
 //
 // hensel_lane.hpp keeps a residue in one lane as well, but scans by OPERAND: 2K column accumulators (4K registers) that
 // every reduction row normalises with a shift and an add -- at K = 38 those accumulators alone are 152 registers.  Here a
@@ -33,14 +36,6 @@
 // symmetric columns (default), 2 every chain (A/B, tools/build_variant.py)
 #ifndef PGPU_PS_PIN
 #define PGPU_PS_PIN 1
-#endif
-
-// the wavefronts of a workgroup re-align at a barrier (A/B, tools/build_variant.py): 0 never, 1 before every window of the
-// main loop, 2 before every squaring.  The unrolled squaring is 44 KB of code at K = 38 and 97 KB at K = 56, a window's
-// squarings and product 105 / 250 KB -- against a 64 KB instruction cache shared by two CUs: wavefronts that run the same
-// lines at the same time share the fetches
-#ifndef PGPU_PS_SYNC
-#define PGPU_PS_SYNC 0
 #endif
 
 namespace pgpu {
@@ -459,13 +454,11 @@ __global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_ps_kernel(Hen
 #pragma unroll 1
   for (; nwin > 0 && win >= 0; --win) {
     const int idx = digit(win);
-    if constexpr (PGPU_PS_SYNC == 1) __builtin_amdgcn_s_barrier();
 #pragma unroll 1
-    for (int i = 0; i < w; ++i) {
-      if constexpr (PGPU_PS_SYNC == 2) __builtin_amdgcn_s_barrier();
-      ps_pairsqr<K, LB>(a, b, n, n1p);
-    }
-    // (the entry is fetched AFTER the squarings: held across them it would cost 2K registers)
+    for (int i = 0; i < w; ++i) ps_pairsqr<K, LB>(a, b, n, n1p);
+    // (the entry is fetched AFTER the squarings: held across them it would cost 2K registers.  Fetching it before them in
+    // the build that owns the whole register file, and re-aligning a workgroup's wavefronts at a barrier per window or per
+    // squaring -- the unrolled code is larger than the instruction cache -- were both measured at +-0.3 %: DESIGN.md section 4)
     ps_table_load<K>(ma, mb, tw, idx, tsize, gather);
     ps_pairmul<K, LB, true>(a, b, ma, mb, n, n1p, 0, slot);
   }

@@ -138,3 +138,61 @@ def test_four_host_array_callers_take_the_quarter_chip_forms(engine):
     for t in th:
         t.join()
     assert not errs, errs[:3]
+
+
+@pytest.mark.parametrize("bits,limbs", [(1024, 19), (3072, 56)])
+def test_four_lanes_take_the_product_scanning_form_for_other_key_sizes(engine, bits, limbs):
+    """Four resident batches of 8192 in flight under a 1024- / 3072-bit key (the headline's shape, BASELINE configs[1] + [2],
+    at the other key sizes the reference's tests cover: test_cryptography.cpp runs 1024- and 2048-bit keys): beside three busy
+    lanes every decrypt takes hensel_decrypt_ps_kernel<19,29,2> / <56,28,1> with its whole-CU claim (dynamic LDS on top of the
+    kernel's own parking area).  Every lane's round trip must hold over several rounds, and the policy must report the form."""
+    import numpy as np
+    from pailliercryptolib_amd import _capi
+    p, q, hs = key_case(bits)
+    n = p * q
+    nw, count = bits // 64, 8192
+    pk, sk = engine.PublicKey(n, bits, hs=hs), engine.PrivateKey(p, q)
+    L = _capi.lib()
+    split, lanes, lb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _capi.check(L.pgpu_decrypt_kernel_form_ex(sk._h, count, 3, ctypes.byref(split), ctypes.byref(lanes), ctypes.byref(lb)))
+    assert (split.value, lanes.value, lb.value) == (4, 1, limbs)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    live, sets = [], []
+
+    def track(h):
+        live.append(h)
+        return h
+
+    def up(a):
+        h = ctypes.c_void_p()
+        _capi.check(L.pgpu_batch_upload(ptr(a), a.shape[0], a.shape[1], a.shape[1], ctypes.byref(h)))
+        return track(h)
+
+    def op(fn, *a):
+        h = ctypes.c_void_p()
+        _capi.check(fn(*a, ctypes.byref(h)))
+        return track(h)
+    try:
+        for ln in range(4):
+            rng = np.random.default_rng(bits + ln)
+            m = np.frombuffer(rng.bytes(count * nw * 8), dtype=np.uint64).reshape(count, nw).copy()
+            m[:, -1] &= np.uint64((1 << 62) - 1)
+            r = np.frombuffer(rng.bytes(count * nw * 4), dtype=np.uint64).reshape(count, nw // 2).copy()
+            _capi.check(L.pgpu_set_batch_lane(ln))
+            sets.append((m, up(m), up(r)))
+        outs = [None] * 4
+        for _ in range(4):                     # (the first round starts beside idle lanes: the later ones run the quarter-chip forms)
+            for ln in range(4):
+                _capi.check(L.pgpu_set_batch_lane(ln))
+                c = op(L.pgpu_batch_encrypt, pk._h, sets[ln][1], sets[ln][2], bits // 2)
+                outs[ln] = op(L.pgpu_batch_decrypt_crt, sk._h, c)
+        _capi.check(L.pgpu_set_batch_lane(0))
+        _capi.check(L.pgpu_synchronize())
+        for ln in range(4):
+            got = np.empty((count, nw), dtype=np.uint64)
+            _capi.check(L.pgpu_batch_download(outs[ln], ptr(got)))
+            assert np.array_equal(got, sets[ln][0]), "lane %d: round trip failed" % ln
+    finally:
+        _capi.check(L.pgpu_set_batch_lane(0))
+        for h in live:
+            L.pgpu_batch_destroy(h)

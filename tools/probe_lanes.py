@@ -17,6 +17,7 @@ ap.add_argument("--lanes", type=int, nargs="*", default=[1, 2, 3, 4])
 ap.add_argument("--enc-seq", type=int, default=None)
 ap.add_argument("--claim-busy", type=int, default=None)
 ap.add_argument("--gather", type=int, default=0, help="pgpu_set_table_gather_policy")
+ap.add_argument("--bits", type=int, default=2048, help="key size: 2048 (the ISO key), 1024 / 3072 (the seeded DJN fixtures)")
 ap.add_argument("--ps", type=int, default=None, help="PGPU_PS_DECRYPT policy (hensel_ps.hpp): 0 never, 1 adaptive, 2 always")
 args = ap.parse_args()
 pa.initialize(0)
@@ -30,15 +31,22 @@ if args.gather:
 if args.ps is not None:
     L.pgpu_debug_set_ps_decrypt(args.ps)
 print("ps policy", args.ps, "enc_seq", args.enc_seq, "claim_busy", args.claim_busy)
-k = json.load(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "iso_kat.json")))
-p, q, hs = int(k["p"], 16), int(k["q"], 16), int(k["bench_hs"], 16)
+GOLD = os.path.join(os.path.dirname(__file__), "..", "tests", "golden")
+BITS = args.bits
+if BITS == 2048:
+    k = json.load(open(os.path.join(GOLD, "iso_kat.json")))
+    p, q, hs = int(k["p"], 16), int(k["q"], 16), int(k["bench_hs"], 16)
+else:
+    k = [c for c in json.load(open(os.path.join(GOLD, "seeded_vectors.json")))["cases"] if c["bits"] == BITS and c["djn"]][0]
+    p, q, hs = int(k["p"], 16), int(k["q"], 16), int(k["hs"], 16)
+NW = BITS // 64
 n = p * q
-pk, sk = pa.PublicKey(n, 2048, hs=hs), pa.PrivateKey(p, q)
+pk, sk = pa.PublicKey(n, BITS, hs=hs), pa.PrivateKey(p, q)
 count = args.count
 rng = np.random.default_rng(1)
-m = np.frombuffer(rng.bytes(count * 256), dtype=np.uint64).reshape(count, 32).copy()
+m = np.frombuffer(rng.bytes(count * NW * 8), dtype=np.uint64).reshape(count, NW).copy()
 m[:, -1] &= np.uint64((1 << 62) - 1)
-r = np.frombuffer(rng.bytes(count * 128), dtype=np.uint64).reshape(count, 16).copy()
+r = np.frombuffer(rng.bytes(count * NW * 4), dtype=np.uint64).reshape(count, NW // 2).copy()
 
 
 def ptr(a):
@@ -66,13 +74,13 @@ def forms(cap=4096):
     return {f"kind{k}/form{f}": (len(v), round(float(np.mean(v)), 3)) for (k, f), v in sorted(out.items())}
 
 
-print("policy", L.pgpu_debug_get_seq_decrypt(), "count", count, flush=True)
+print("policy", L.pgpu_debug_get_seq_decrypt(), "count", count, "key bits", BITS, flush=True)
 for nl in args.lanes:
     sets = []
     for ln in range(nl):
         _capi.check(L.pgpu_set_batch_lane(ln))
         bm, br = up(m), up(r)
-        sets.append((bm, br, op(L.pgpu_batch_encrypt, pk._h, bm, br, 1024)))
+        sets.append((bm, br, op(L.pgpu_batch_encrypt, pk._h, bm, br, BITS // 2)))
     _capi.check(L.pgpu_set_batch_lane(0))
     _capi.check(L.pgpu_synchronize())
     st = {"c": [None] * nl, "o": [None] * nl, "i": 0}
@@ -92,7 +100,7 @@ for nl in args.lanes:
         kk = st["i"] % nl
         st["i"] += 1
         free(st["c"][kk], st["o"][kk])
-        st["c"][kk] = op(L.pgpu_batch_encrypt, pk._h, sets[kk][0], sets[kk][1], 1024)
+        st["c"][kk] = op(L.pgpu_batch_encrypt, pk._h, sets[kk][0], sets[kk][1], BITS // 2)
         st["o"][kk] = op(L.pgpu_batch_decrypt_crt, sk._h, st["c"][kk])
 
     for name, fn in (("decrypt-only", dec_step), ("encrypt+decrypt", full_step)):
@@ -107,7 +115,7 @@ for nl in args.lanes:
         dt = (time.perf_counter() - t0) / args.steps * 1e3
         _capi.check(L.pgpu_set_timing(0))
         f = forms()
-        out = np.empty((count, 32), dtype=np.uint64)
+        out = np.empty((count, NW), dtype=np.uint64)
         for o in st["o"]:
             if o:
                 _capi.check(L.pgpu_batch_download(o, ptr(out)))
