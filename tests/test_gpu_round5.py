@@ -196,3 +196,42 @@ def test_four_lanes_take_the_product_scanning_form_for_other_key_sizes(engine, b
         _capi.check(L.pgpu_set_batch_lane(0))
         for h in live:
             L.pgpu_batch_destroy(h)
+
+
+def test_ps_decrypt_at_the_tightest_headroom(engine):
+    """The 56-limb product-scanning decrypt keeps R = 2^1568 >= 16 P only (csrc/capi_keys.inc: build_hensel; bounds:
+    tests/test_hensel_model.py).  tests/golden/primes_worst_headroom.json holds primes p, q == 1 (mod 2^28) just below 2^1536:
+    their multiplier k = -p^-1 mod 2^28 is 2^28 - 1, P = p k just below 2^1564 -- R / P = 16.0000001, the tightest any 3072-bit
+    key gets.  Forced kernel against the oracle (pow) on raw values incl. n^2 - 1 and 1, and a round trip of 2100 encryptions
+    (the reference's decryptCRT, ipcl/pri_key.cpp:114-146)."""
+    import json
+    import os
+    from oracle import paillier_oracle as orc
+    from pailliercryptolib_amd import _capi
+    k = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "primes_worst_headroom.json")))
+    p, q = int(k["p"], 16), int(k["q"], 16)
+    assert (-pow(p, -1, 1 << 28)) % (1 << 28) == (1 << 28) - 1 and p.bit_length() == 1536
+    n = p * q
+    bits, nw, count = 3072, 48, 2100
+    rng = random.Random(56)
+    pk, sk = engine.PublicKey(n, bits), engine.PrivateKey(p, q)
+    osk = orc.PrivateKey(n, p, q)
+    R = Res()
+    L = R.L
+    L.pgpu_debug_set_ps_decrypt(2)
+    try:
+        split, lanes, limbs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _capi.check(L.pgpu_decrypt_kernel_form(sk._h, count, ctypes.byref(split), ctypes.byref(lanes), ctypes.byref(limbs)))
+        assert (split.value, lanes.value, limbs.value) == (4, 1, 56)
+        raw = [n * n - 1, 1, n * n - 2, (1 << 6143) + 1] + [rng.randrange(1, n * n) for _ in range(40)]
+        got = R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, R.up(raw, 2 * nw)))
+        assert got == osk.decrypt(raw)
+        m = ([0, 1, n - 1] + [rng.randrange(n) for _ in range(count)])[:count]
+        r = [rng.randrange(1, n) for _ in range(count)]
+        c = R.op(L.pgpu_batch_encrypt, pk._h, R.up(m, nw), R.up(r, nw), bits)
+        assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, c)) == m
+        s = R.op(L.pgpu_batch_ct_add, pk._h, c, c)
+        assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, s)) == [(2 * x) % n for x in m]
+    finally:
+        L.pgpu_debug_set_ps_decrypt(1)
+        R.close()
