@@ -346,7 +346,9 @@ int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, i
  * 32768 ciphertexts or more when PGPU_PS_DECRYPT=0; PGPU_LANE_DECRYPT=0 turns it off); *split = 4 (round 5):
  * hensel_decrypt_ps_kernel<*limbs, 28 | 29> -- a whole exponentiation in one lane by product scanning, *limbs limbs per half
  * (38 / 56 limbs of 28 bits: 2048- / 3072-bit keys, 19 limbs of 29 bits: 1024-bit keys; launches of
- * 32768 ciphertexts or more, or smaller ones that cover the SIMDs together with busy neighbour lanes: 8192 beside three;
+ * more than 16384 ciphertexts (3072-bit keys: 24576) in rounds of 32768 -- the form reported is that of the full rounds; a
+ * mostly empty last round runs as a launch of its own in the form of its size -- or smaller ones that cover the SIMDs
+ * together with busy neighbour lanes: 8192 beside three;
  * PGPU_PS_DECRYPT=0 turns it off); *split = 0: the full-width modexp_kernel<Geo<*lanes, *limbs>>.
  * Host-side query. */
 int pgpu_decrypt_kernel_form(const pgpu_privkey* key, size_t count, int* split, int* lanes, int* limbs);

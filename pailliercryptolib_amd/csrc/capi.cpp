@@ -1602,7 +1602,7 @@ const pgpu_privkey::HenselSet* lane_hset(const pgpu_privkey* key, size_t count) 
 }
 // the one-lane product-scanning form (csrc/hensel_ps.hpp) for a decrypt of `count` resident ciphertexts under this key?
 bool ps_form_pays(const pgpu_privkey* key, size_t count, int busy) {
-  return key->hs_ps && hensel_enabled() && policy::ps_form_pays(count, busy);
+  return key->hs_ps && hensel_enabled() && policy::ps_form_pays(count, busy, key->hs_ps->K);
 }
 int words_to_pair_on(rt::Device& d, const pgpu_pubkey::PubForm* f, const uint64_t* words, size_t stride, int nwords,
                      bool src_mont, uint32_t* out, size_t count, hipStream_t s);
@@ -1611,6 +1611,16 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
   const bool other_lane_busy = busy_lanes > 0;
   // d_pair: the ciphertexts are pair rows of 2*in_pair_l2 limbs (d_c unused); needs a split form of the key
   const int nw = key->n_words;
+  // A lone launch of more than a round of the one-lane product-scanning form whose last round would be mostly empty: the
+  // full rounds first, the rest as a launch of its own in the form ITS size takes (policy.hpp: ps_split_head)
+  if (busy_lanes == 0 && key->hs_ps && hensel_enabled() && secret_policy() != PGPU_EXP_SLIDING && ab_policy() == 0 &&
+      (d_pair ? key->hs_ps->pair_l2 == in_pair_l2 : key->conv_form != nullptr)) {
+    if (const size_t head = policy::ps_split_head(key->hs_ps->K, count)) {
+      RC_TRY(decrypt_on(d, key, d_c, d_m, head, s, in_mont, d_pair, in_pair_l2, busy_lanes));
+      return decrypt_on(d, key, d_c ? d_c + head * (size_t)2 * nw : nullptr, d_m + head * (size_t)nw, count - head, s, in_mont,
+                        d_pair ? d_pair + head * (size_t)2 * in_pair_l2 : nullptr, in_pair_l2, busy_lanes);
+    }
+  }
   rt::StreamWork& w = d.work_for(s);
   std::lock_guard<std::mutex> lk(w.mu);   // the hand-over buffer is ours until both stages are queued
   RC_TRY(w.vbuf.ensure(2 * count * (size_t)nw * 8, s));

@@ -124,10 +124,31 @@ bool lane_form_pays(int L2, size_t count) {
   const int pol = g_lane_policy.load();
   return pol == 2 || (pol == 1 && waves >= kSimds);
 }
-bool ps_form_pays(size_t count, int busy) {
+// Measured on lone launches (profiles/r05_decrypt_partial_rounds.txt).  2048-bit keys (K = 38): a round 14.2 ms against
+// 8.1 ms per 16384 ciphertexts of the sequential-halves form and 4.6 ms for up to 8192 in the paired one -- one round beats
+// them above 16384 ciphertexts, and a tail of up to 16384 is cheaper as a launch of its own.  3072-bit keys (K = 56): a
+// round 47.6 ms against 13.3-15.2 ms per 8192 of the (4,14) sequential-halves form: above 24576.  1024-bit keys (K = 19):
+// a round 2.2-2.3 ms against 1.8 ms for 16384 ciphertexts and 3.0 ms for 24576 in the multi-lane forms: above 16384.
+// PGPU_PS_MIN_COUNT / PGPU_PS_SPLIT_TAIL override both (0: the table below).
+size_t ps_min_count(int K) {
+  static const int forced = env_int("PGPU_PS_MIN_COUNT", 0, 0, 1 << 30);
+  if (forced) return (size_t)forced;
+  return K == 56 ? 24576 + 1 : (K == 38 || K == 19) ? 16384 + 1 : kPsRound;
+}
+static size_t ps_split_tail(int K) {
+  static const int forced = env_int("PGPU_PS_SPLIT_TAIL", -1, -1, 1 << 30);
+  if (forced >= 0) return (size_t)forced;
+  return K == 56 ? 24576 : 16384;
+}
+bool ps_form_pays(size_t count, int busy, int K) {
   const size_t waves = 2 * ((count + 63) / 64);
   const int pol = g_ps_policy.load();
-  return pol == 2 || (pol == 1 && (waves >= kSimds || seq_adaptive(waves, busy)));
+  return pol == 2 || (pol == 1 && (count >= ps_min_count(K) || seq_adaptive(waves, busy)));
+}
+size_t ps_split_head(int K, size_t count) {
+  if (g_ps_policy.load() != 1 || count <= kPsRound) return 0;
+  const size_t tail = count % kPsRound;
+  return (tail != 0 && tail <= ps_split_tail(K)) ? count - tail : 0;
 }
 bool pair_mul_seq_pays(int H, int K, size_t count) {
   if (!pgpu::pair_mul_seq_has(H, K)) return false;

@@ -47,8 +47,18 @@ unsigned adaptive_cu_claim(size_t waves, int busy_lanes);
 bool seq_form_pays(int H, int K, size_t count, int busy = 0);
 // ... the one-lane kernel of hensel_lane.hpp (L2 limbs per half)?
 bool lane_form_pays(int L2, size_t count);
-// ... the one-lane product-scanning kernel of hensel_ps.hpp (the key must have its constant set)?
-bool ps_form_pays(size_t count, int busy);
+// ... the one-lane product-scanning kernel of hensel_ps.hpp with K limbs per half (the key must have its constant set)?
+// A lone launch runs in ROUNDS of kPsRound ciphertexts (one wavefront per SIMD: 2 x 32768 / 64 = 1024 wavefronts), and a
+// round costs the same whether it is full or not -- so the form pays from ps_min_count(K) ciphertexts up, the size from
+// which one round beats the multi-lane forms (whose rounds are 16384 / 8192 ciphertexts for 2048- / 3072-bit keys):
+// 16385 for 1024- and 2048-bit keys, 24577 for 3072-bit keys ...
+constexpr size_t kPsRound = 32768;
+size_t ps_min_count(int K);
+bool ps_form_pays(size_t count, int busy, int K = 38);
+// ... and a lone launch of more than a round whose LAST round would be mostly empty is cut in two: the full rounds take
+// this form, the rest a launch of its own in whatever form its size takes (ps_split_head: ciphertexts of the first
+// launch; 0: one launch).  65536 + 4464 ciphertexts of a 2048-bit key: 42.7 ms in three rounds, 36 ms as 28 + 8.
+size_t ps_split_head(int K, size_t count);
 // DJN encrypt onto pair rows / CT x PT / CT + CT of `count` elements in form (H, K): the sequential-halves kernels?
 bool fb_encrypt_seq_pays(int H, int K, size_t count, int busy = 0);
 bool modexp_seq_form_pays(int H, int K, size_t count);

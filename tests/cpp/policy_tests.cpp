@@ -33,8 +33,17 @@ int main() {
   // the one-lane product-scanning kernel: 64 exponentiations per wavefront
   CHECK(!pol::ps_form_pays(8192, 0) && !pol::ps_form_pays(8192, 1) && !pol::ps_form_pays(8192, 2));
   CHECK(pol::ps_form_pays(8192, 3));               // four lanes: a quarter of the chip each
-  CHECK(pol::ps_form_pays(16384, 1) && !pol::ps_form_pays(16384, 0));
+  CHECK(pol::ps_form_pays(16384, 1) && !pol::ps_form_pays(16384, 0));   // (alone: one round of the sequential-halves form)
   CHECK(pol::ps_form_pays(32768, 0));              // covers the SIMDs alone
+  // a lone launch runs in rounds of 32768 ciphertexts whatever their fill: one round beats the multi-lane forms above
+  // 16384 ciphertexts of a 2048-bit key (K = 38), above 24576 of a 3072-bit key (K = 56); a form without measurements (any other K): full rounds only
+  CHECK(pol::ps_form_pays(16385, 0) && pol::ps_form_pays(20000, 0, 38) && !pol::ps_form_pays(20000, 0, 56));
+  CHECK(pol::ps_form_pays(24577, 0, 56) && pol::ps_form_pays(16385, 0, 19) && !pol::ps_form_pays(32767, 0, 20) && pol::ps_form_pays(32768, 0, 20));
+  // ... and a mostly empty last round is cut off as a launch of its own
+  CHECK(pol::ps_split_head(38, 32768) == 0 && pol::ps_split_head(38, 65536) == 0 && pol::ps_split_head(38, 20000) == 0);
+  CHECK(pol::ps_split_head(38, 36000) == 32768 && pol::ps_split_head(38, 65536 + 16384) == 65536);
+  CHECK(pol::ps_split_head(38, 32768 + 16385) == 0 && pol::ps_split_head(56, 32768 + 24576) == 32768);
+  CHECK(pol::ps_split_head(56, 65536 + 24577) == 0 && pol::ps_split_head(19, 40000) == 32768);
   CHECK(!pol::ps_form_pays(1, 3) && !pol::ps_form_pays(8191 - 64, 3));   // 254 wavefronts x 4 < 1024
   // the operand-scanning one-lane kernel exists for 20-limb halves (1024-bit keys)
   CHECK(pol::lane_form_pays(20, 32768) && !pol::lane_form_pays(20, 32767 - 63) && !pol::lane_form_pays(38, 1 << 20));
@@ -72,9 +81,9 @@ int main() {
   CHECK(pol::seq_form_pays(2, 19, 1, 0) && pol::fb_encrypt_seq_pays(2, 19, 1, 0));
   pol::set_seq_policy(4);
   pol::set_ps_policy(2);
-  CHECK(pol::ps_form_pays(1, 0));
+  CHECK(pol::ps_form_pays(1, 0) && pol::ps_split_head(38, 36000) == 0);    // forced: one launch
   pol::set_ps_policy(0);
-  CHECK(!pol::ps_form_pays(1 << 20, 3));
+  CHECK(!pol::ps_form_pays(1 << 20, 3) && pol::ps_split_head(38, 36000) == 0);
   pol::set_ps_policy(1);
   pol::set_lane_policy(2);
   CHECK(pol::lane_form_pays(20, 1) && !pol::lane_form_pays(19, 1));

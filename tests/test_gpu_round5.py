@@ -235,3 +235,51 @@ def test_ps_decrypt_at_the_tightest_headroom(engine):
     finally:
         L.pgpu_debug_set_ps_decrypt(1)
         R.close()
+
+
+@pytest.mark.parametrize("bits,count", [(2048, 20000), (2048, 32768 + 700), (1024, 32768 + 9000), (3072, 32768 + 300)])
+def test_lone_decrypts_in_rounds_of_the_product_scanning_form(engine, bits, count):
+    """A lone CRT decrypt of more than 16384 / 24576 ciphertexts (2048- / 3072-bit keys) runs in rounds of 32768 of the
+    one-lane product-scanning kernel; a mostly empty last round is cut off as a launch of its own in the form its size takes
+    (csrc/policy.hpp: ps_min_count, ps_split_head; capi.cpp: decrypt_on).  Resident pair rows and word ciphertexts from host
+    arrays (the pair-row conversion of each part) must both give the plaintexts back -- PrivateKey::decrypt on a vector of any
+    size, ipcl/pri_key.cpp:65-112."""
+    import numpy as np
+    from pailliercryptolib_amd import _capi
+    p, q, hs = key_case(bits)
+    n = p * q
+    nw = bits // 64
+    pk, sk = engine.PublicKey(n, bits, hs=hs), engine.PrivateKey(p, q)
+    L = _capi.lib()
+    split, lanes, limbs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _capi.check(L.pgpu_decrypt_kernel_form(sk._h, count, ctypes.byref(split), ctypes.byref(lanes), ctypes.byref(limbs)))
+    assert split.value == 4 and lanes.value == 1
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rng = np.random.default_rng(count)
+    m = np.frombuffer(rng.bytes(count * nw * 8), dtype=np.uint64).reshape(count, nw).copy()
+    m[:, -1] &= np.uint64((1 << 62) - 1)
+    m[0] = 0
+    r = np.frombuffer(rng.bytes(count * nw * 4), dtype=np.uint64).reshape(count, nw // 2).copy()
+    live = []
+
+    def op(fn, *a):
+        h = ctypes.c_void_p()
+        _capi.check(fn(*a, ctypes.byref(h)))
+        live.append(h)
+        return h
+    try:
+        hm = op(L.pgpu_batch_upload, ptr(m), count, nw, nw)
+        hr = op(L.pgpu_batch_upload, ptr(r), count, nw // 2, nw // 2)
+        c = op(L.pgpu_batch_encrypt, pk._h, hm, hr, bits // 2)
+        d = op(L.pgpu_batch_decrypt_crt, sk._h, c)
+        got = np.empty((count, nw), dtype=np.uint64)
+        _capi.check(L.pgpu_batch_download(d, ptr(got)))
+        assert np.array_equal(got, m)
+        cw = np.empty((count, 2 * nw), dtype=np.uint64)          # the same ciphertexts as canonical words, from a host array
+        _capi.check(L.pgpu_batch_download(c, ptr(cw)))
+        got[:] = 0
+        _capi.check(L.pgpu_paillier_decrypt_crt(sk._h, ptr(cw), ptr(got), count))
+        assert np.array_equal(got, m)
+    finally:
+        for h in live:
+            L.pgpu_batch_destroy(h)
