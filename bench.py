@@ -597,6 +597,12 @@ def per_gpu_report(L, N, per_kind0):
     return out
 
 
+def decrypt_window_products(e):
+    """window products of the CRT-decrypt exponentiation incl. its table build (csrc/policy.cpp: pick_decrypt_window):
+    5-bit windows, 6-bit ones for exponents of 1280 bits and more"""
+    return (e + 5) // 6 + 62 if e >= 1280 else (e + 4) // 5 + 30
+
+
 def decrypt_useful_mac32(nw, key_bits):
     """USEFUL multiply-accumulates of one half-width exponentiation of the CRT-decrypt leg: what the split form has to
     compute, whatever kernel computes it -- the count of the sequential-halves form (csrc/hensel_seq.hpp), in which no lane
@@ -606,7 +612,7 @@ def decrypt_useful_mac32(nw, key_bits):
     products nobody needs."""
     g, l2 = {1024: (2, 20), 2048: (2, 38), 3072: (4, 56), 4096: (4, 72)}[key_bits]
     e = key_bits // 2
-    nmul = (e + 4) // 5 + 30 + (2 * nw + e // 64 - 1) // (e // 64) + 2
+    nmul = decrypt_window_products(e) + (2 * nw + e // 64 - 1) // (e // 64) + 2
     return e * (l2 * (l2 + g) // 2 + 3 * l2 * l2) + nmul * 5 * l2 * l2
 
 
@@ -627,19 +633,19 @@ def decrypt_kernel(sk, count, nw, key_bits, busy_lanes=0):
         # 3 L2^2 + 2 L2 (L2 - 1); the entry runs one single and one pair product per chunk, the exit the same
         l2 = limbs.value
         red = l2 * (l2 - 1)
-        nmul = (e + 4) // 5 + 30 + 2 + 1
+        nmul = decrypt_window_products(e) + 2 + 1
         return (f"hensel_decrypt_ps_kernel<{l2},{29 if l2 == 19 else 28}>", e * (l2 * (l2 + 1) // 2 + l2 * l2 + 2 * red) + nmul * (3 * l2 * l2 + 2 * red)
                 + 3 * (l2 * l2 + red))
     if split.value == 3:       # a whole exponentiation per lane (csrc/hensel_lane.hpp): the useful count IS what it executes
         l2 = limbs.value
-        nmul = (e + 4) // 5 + 30 + (2 * nw + e // 64 - 1) // (e // 64) + 2
+        nmul = decrypt_window_products(e) + (2 * nw + e // 64 - 1) // (e // 64) + 2
         return f"hensel_decrypt_lane_kernel<{l2}>", e * (l2 * (l2 + 1) // 2 + 3 * l2 * l2) + nmul * 5 * l2 * l2
     seq = split.value == 2
     l2 = (lanes.value if seq else lanes.value // 2) * limbs.value
     if _capi.lib().pgpu_get_secret_exponent_policy():          # sliding schedule of p-1: ~e/7 products, 32 odd powers
         nsq, nmul = e, e // 7 + 32
     else:                                                      # 5-bit fixed window
-        nsq, nmul = e, (e + 4) // 5 + 30
+        nsq, nmul = e, decrypt_window_products(e)
     nmul += (2 * nw + e // 64 - 1) // (e // 64) + 2            # ciphertext chunks in, exit products
     if seq:    # both halves in the same lanes: the a*a of a squaring uses its symmetry, L2 (L2 + lanes) / 2 products
         sq = l2 * (l2 + lanes.value) // 2 + 3 * l2 * l2

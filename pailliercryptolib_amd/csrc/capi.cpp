@@ -1698,7 +1698,7 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
       h.window = key->sched[0].w;
       entries = (size_t)1 << (h.window - 1);
     } else {
-      h.window = g_ct_gather.load() ? std::min(masked_decrypt_window(), pick_window(h.exp_bits)) : pick_window(h.exp_bits);
+      h.window = g_ct_gather.load() ? std::min(masked_decrypt_window(), pick_window(h.exp_bits)) : policy::pick_decrypt_window(h.exp_bits);
       entries = (size_t)1 << h.window;
     }
     h.ct_gather = g_ct_gather.load();

@@ -161,7 +161,7 @@ bool pair_mul_seq_pays(int H, int K, size_t count) {
 int pick_window(int exp_bits) {
   // PGPU_FIXED_WINDOW=w: A/B measurements of the window width (what an LDS-resident table, which
   // holds 8 entries per exponentiation at most, would have to beat)
-  static const int forced = env_int("PGPU_FIXED_WINDOW", 0, 1, 5);
+  static const int forced = env_int("PGPU_FIXED_WINDOW", 0, 1, 6);
   if (forced) return forced;
   int best = 1;
   long best_cost = 1L << 60;
@@ -170,6 +170,17 @@ int pick_window(int exp_bits) {
     if (cost < best_cost) { best_cost = cost; best = w; }
   }
   return best;
+}
+// Window of the CRT-decrypt exponentiation (one secret exponent per side, shared by the launch): exponents of 1280 bits and
+// more -- 3072-bit keys up -- also try w = 6 (1536 bits: 62 + 256 products instead of 30 + 308; 65536 ciphertexts 95.9 ->
+// 94.7 ms).  Not for shorter ones: 1024 bits would tie on products and double the tables of the four-lane headline; and not
+// in pick_window, whose per-element tables of a 1 M-element CT x PT would double with it.
+int pick_decrypt_window(int exp_bits) {
+  const int w5 = pick_window(exp_bits);
+  static const int forced = env_int("PGPU_FIXED_WINDOW", 0, 1, 6);
+  if (forced || exp_bits < 1280) return w5;
+  const long c5 = ((1L << w5) - 2) + (exp_bits + w5 - 1) / w5, c6 = ((1L << 6) - 2) + (exp_bits + 5) / 6;
+  return c6 < c5 ? 6 : w5;
 }
 // Window of the CRT-decrypt exponentiation under the masked table gather (round 5): every one of the 2^w entries of an
 // exponentiation's table is read at every window product, so the table is what the launch streams -- 9.7 KB per

@@ -65,6 +65,8 @@ bool modexp_seq_form_pays(int H, int K, size_t count);
 bool pair_mul_seq_pays(int H, int K, size_t count);
 // fixed window of a per-element / secret exponent of exp_bits bits: the w in 1..5 with the fewest products
 int pick_window(int exp_bits);
+// ... of the CRT-decrypt exponentiation (a secret exponent shared by the launch): w = 6 as well from 1280 bits up
+int pick_decrypt_window(int exp_bits);
 // ... under the masked table gather (every entry of the table read at every window product: small on purpose)
 int masked_decrypt_window();
 

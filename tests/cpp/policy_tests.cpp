@@ -47,6 +47,9 @@ int main() {
   CHECK(!pol::ps_form_pays(1, 3) && !pol::ps_form_pays(8191 - 64, 3));   // 254 wavefronts x 4 < 1024
   // the operand-scanning one-lane kernel exists for 20-limb halves (1024-bit keys)
   CHECK(pol::lane_form_pays(20, 32768) && !pol::lane_form_pays(20, 32767 - 63) && !pol::lane_form_pays(38, 1 << 20));
+  // the decrypt exponent's window: 5 bits up to 2048-bit keys, 6 from 1280-bit exponents up (3072-bit keys: 318 against 338 products)
+  CHECK(pol::pick_decrypt_window(512) == pol::pick_window(512) && pol::pick_decrypt_window(1024) == 5);
+  CHECK(pol::pick_decrypt_window(1536) == 6 && pol::pick_decrypt_window(2048) == 6 && pol::pick_window(1536) == 5);
   // whole-CU claims of part-chip launches
   CHECK(pol::adaptive_cu_claim(512, 1) == 84000u && pol::adaptive_cu_claim(256, 3) == 84000u);
   CHECK(pol::adaptive_cu_claim(512, 0) == 0u && pol::adaptive_cu_claim(1024, 1) == 0u && pol::adaptive_cu_claim(256, 4) == 0u);
