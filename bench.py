@@ -35,6 +35,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import bench_line  # noqa: E402  (the compact contract line; the record built below goes to bench_detail.json)
 
 BATCH = 8192
 KEY_BITS = 2048
@@ -168,7 +169,7 @@ def run_pool(args):
         result = run_config45(args, pa, L, B, N)
         pa.terminate()
         ctypes.CDLL(None).fflush(None)
-        print(json.dumps(result), flush=True)          # the ONE JSON line, last thing on stdout
+        bench_line.emit(result)                         # detail -> bench_detail.json + stderr; compact line last on stdout
         return
     p, q, hs = iso_key()
     n = p * q
@@ -267,6 +268,7 @@ def run_pool(args):
         # the same step with constant-address table access (pgpu_set_table_gather_policy(1)): every window-table / fixed-base
         # table candidate is read and the wanted one selected, as the reference's mbx_exp_mb8 gathers (mod_exp.cpp:508-516)
         if not args.no_extras:
+            gather_before = L.pgpu_get_table_gather_policy()
             try:
                 _capi.check(L.pgpu_set_table_gather_policy(1))
                 state["i"] = 0
@@ -289,7 +291,7 @@ def run_pool(args):
             except Exception as e:                          # noqa: BLE001
                 measured["hardened"] = {"error": repr(e)[:300]}
             finally:
-                _capi.check(L.pgpu_set_table_gather_policy(0))
+                _capi.check(L.pgpu_set_table_gather_policy(gather_before))
                 state["i"] = 0
                 for _ in range(nfl):       # (the checked results below are those of the default policy)
                     step()
@@ -459,16 +461,6 @@ def run_pool(args):
             result.update(extras(pa, L, B, pk, sk, n, p, q, hs, m_host, r_host, per_kind))
         except Exception as e:                              # noqa: BLE001
             result["extras_error"] = repr(e)[:400]
-        # the API-visible call (SURVEY 8d's timed region: H2D + kernels + D2H inside the call) next to the resident value
-        av = {k: result[k] for k in ("end_to_end", "end_to_end_pinned", "end_to_end_two_callers", "end_to_end_two_callers_pinned",
-                                     "end_to_end_four_callers", "end_to_end_four_callers_pinned",
-                                     "end_to_end_pipelined", "end_to_end_pipelined_4_lanes", "api_level") if k in result}
-        if av:
-            av["what"] = ("co-headline: the same step as a caller sees it -- inputs in host memory before the call, results in host "
-                          "memory after it.  end_to_end*: the C-ABI host-pointer entry points (one synchronous caller / two / four / one "
-                          "thread pipelining over the batch lanes); api_level: ipcl::PublicKey::encrypt + PrivateKey::decrypt with "
-                          "std::vector<BigNumber> in and out.  `value` is the device-resident rate")
-            result["api_visible"] = av
     if N == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(n, p, q, hs, m_host, r_host)
@@ -478,7 +470,7 @@ def run_pool(args):
     del pk, sk
     pa.terminate()
     ctypes.CDLL(None).fflush(None)
-    print(json.dumps(result), flush=True)              # the ONE JSON line, last thing on stdout
+    bench_line.emit(result)                             # detail -> bench_detail.json + stderr; compact line last on stdout
 
 
 FORM_NAMES = {0: "full-width", 1: "paired", 2: "sequential-halves", 18: "sequential-halves+cu-claim", 65: "a/b-wavefronts",
@@ -1532,6 +1524,8 @@ def run_config45(args, pa, L, B, N):
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: k=3072 DJN key, batch=65536 encrypt + CRT decrypt, sharded "
                                    f"contiguously over {N} GPU(s) ({shard} elements each), resident",
+                       "batch_per_gpu": shard, "batches_in_flight_per_gpu": 1,
+                       "secret_table_access": "masked" if L.pgpu_get_table_gather_policy() else "indexed",
                        "elements_per_s": round(total * args.steps / elapsed, 1),
                        "parallelism": f"in-process device pool x{N} (key images: {L.pgpu_pool_transport().decode()})"},
             "roofline": {"bound": "int-alu", "kernel": f"{dec_name} (CRT-decrypt leg, "
@@ -1656,6 +1650,8 @@ def run_config45(args, pa, L, B, N):
         "config": {"workload": "BASELINE configs[4]: k=2048, batch=1M: (i) CT+CT on resident ciphertexts "
                                "(one product each), (ii) CT x PT with 32-bit plaintexts; sharded contiguously over "
                                f"{N} GPU(s) ({shard} elements each)",
+                   "batch_per_gpu": shard, "batches_in_flight_per_gpu": 1,
+                   "secret_table_access": "none (no secret operand in CT+CT / CT x PT)",
                    "resident_ciphertext_form": ("pair rows (%d limbs)" % row_limbs) if row_limbs else "Montgomery-form words",
                    "parallelism": f"in-process device pool x{N} (key images: {L.pgpu_pool_transport().decode()})"},
         "roofline": {"bound": "int-alu", "kernel": f"{add_kernel}, {shard} per GPU",
@@ -1796,12 +1792,13 @@ def run_ranks(args, world):
                       encrypt_kernel(pk, BATCH, nw, KEY_BITS, int(os.environ.get("PGPU_FB_WINDOW", "13"))))
         result["config"]["secret_exponent_policy"] = ["fixed-window", "sliding"][L.pgpu_get_secret_exponent_policy()]
         result["config"]["batches_in_flight_per_gpu"] = nfl
+        result["config"]["secret_table_access"] = "masked" if L.pgpu_get_table_gather_policy() else "indexed"
         result["config"]["resident_ciphertext_form"] = ("pair rows (%d limbs)" % row_limbs) if row_limbs else "Montgomery-form words"
         if nfl == 2:
             result["config"]["workload"] += ("; %d batches in flight per GPU: consecutive steps rotate over %d of the "
                                              "library's batch lanes (streams), exactly K steps timed" % (nfl, nfl))
             result["config"]["lane_priming_steps"] = 2 * nfl
-        print(json.dumps(result), flush=True)
+        bench_line.emit(result)
     B.free(*state["c"], *state["out"], *[h for pair in sets for h in pair])
     dist.barrier()
     dist.destroy_process_group()

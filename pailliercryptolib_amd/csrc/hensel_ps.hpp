@@ -37,6 +37,12 @@
 #ifndef PGPU_PS_PIN
 #define PGPU_PS_PIN 1
 #endif
+// A/B (tools/ubench_ps.hip, round 6): 1 = the operand products of a general column run as a chain of their own, joined to the
+// q*n chain (which sits on the carry of the column below) by ONE 64-bit add per column -- two independent accumulator chains
+// instead of one long one.  Measured: profiles/r06_ubench_ps_cycles.txt.
+#ifndef PGPU_PS_SPLIT
+#define PGPU_PS_SPLIT 0
+#endif
 
 namespace pgpu {
 
@@ -99,7 +105,7 @@ __device__ __forceinline__ void ps_montmul(uint32_t (&r)[K], const uint32_t (&x1
       if constexpr (ihi > ilo) {
         ps_static_for<ihi - ilo>([&](auto ic) __attribute__((always_inline)) {
           constexpr int i = ilo + decltype(ic)::value;
-          if constexpr (PGPU_PS_PIN == 2 || (PGPU_PS_PIN == 1 && SYM)) ps_mac_pinned(acc, q[i], (UNITQ && col - i == 1) ? n1p : n[col - i]);
+          if constexpr (PGPU_PS_PIN == 2 || PGPU_PS_SPLIT == 1 || (PGPU_PS_PIN == 1 && SYM)) ps_mac_pinned(acc, q[i], (UNITQ && col - i == 1) ? n1p : n[col - i]);
           else ps_mac(acc, q[i], (UNITQ && col - i == 1) ? n1p : n[col - i]);
         });
       }
@@ -120,6 +126,15 @@ __device__ __forceinline__ void ps_montmul(uint32_t (&r)[K], const uint32_t (&x1
     } else {
       constexpr int ilo = col < K ? 0 : col - K + 1;
       constexpr int ihi = col < K ? col + 1 : K;
+      if constexpr (PGPU_PS_SPLIT == 1 && (ihi - ilo) * NP >= 4) {
+        uint64_t prod = 0;
+        ps_static_for<ihi - ilo>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int i = ilo + decltype(ic)::value;
+          ps_mac_pinned(prod, x1[i], y1[col - i]);
+          if constexpr (NP == 2) ps_mac_pinned(prod, x2[i], y2[col - i]);
+        });
+        acc += prod;
+      } else
       ps_static_for<ihi - ilo>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = ilo + decltype(ic)::value;
         if constexpr (PGPU_PS_PIN == 2) {

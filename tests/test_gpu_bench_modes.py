@@ -20,7 +20,12 @@ def _run(nproc, port, extra_env):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]           # rank 0 prints ONE JSON line
-    return json.loads(lines[0])
+    assert r.stdout.rstrip("\n").endswith(lines[0]) and len(lines[0].encode()) <= 4096     # last on stdout, compact (bench_line.py)
+    line = json.loads(lines[0])
+    detail = json.load(open(os.path.join(ROOT, line["detail"])))      # the whole record, written beside the script
+    assert detail["value"] == pytest.approx(line["value"], rel=1e-5)
+    line["detail_record"] = detail
+    return line
 
 
 def _check(d, n):
@@ -28,7 +33,8 @@ def _check(d, n):
     assert d["unit"] == "modexps/s" and d["higher_is_better"] is True and d["value"] > 0
     assert abs(d["value"] - 3 * 8192 * n / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
     assert d["roofline"]["bound"] == "int-alu" and 0 < d["roofline"]["frac"] < 1
-    assert d["config"]["resident_ciphertext_form"].startswith("pair rows")      # the same step as the pool path
+    assert d["detail_record"]["config"]["resident_ciphertext_form"].startswith("pair rows")      # the same step as the pool path
+    assert d["config"]["secret_table_access"] == "indexed"
     assert d["config"]["batches_in_flight_per_gpu"] == 4                          # (round 5: four lanes, a quarter of the chip each)
 
 
