@@ -628,10 +628,6 @@ def decrypt_kernel(sk, count, nw, key_bits, busy_lanes=0):
         nmul = decrypt_window_products(e) + 2 + 1
         return (f"hensel_decrypt_ps_kernel<{l2},{29 if l2 == 19 else 28}>", e * (l2 * (l2 + 1) // 2 + l2 * l2 + 2 * red) + nmul * (3 * l2 * l2 + 2 * red)
                 + 3 * (l2 * l2 + red))
-    if split.value == 3:       # a whole exponentiation per lane (csrc/hensel_lane.hpp): the useful count IS what it executes
-        l2 = limbs.value
-        nmul = decrypt_window_products(e) + (2 * nw + e // 64 - 1) // (e // 64) + 2
-        return f"hensel_decrypt_lane_kernel<{l2}>", e * (l2 * (l2 + 1) // 2 + 3 * l2 * l2) + nmul * 5 * l2 * l2
     seq = split.value == 2
     l2 = (lanes.value if seq else lanes.value // 2) * limbs.value
     if _capi.lib().pgpu_get_secret_exponent_policy():          # sliding schedule of p-1: ~e/7 products, 32 odd powers

@@ -87,10 +87,9 @@ int pgpu_is_initialized(void);
 const char* pgpu_last_error(void);
 const char* pgpu_device_name(void); /* of the calling thread's current pool entry */
 /* What this library binary was built with (host-side query, needs no device): bit 0 = the split forms of the 4096-bit
- * key class (build switch PGPU_BUILD_4096=1; without them such keys run the full-width kernels), bit 1 = the
- * A/B-wavefront decrypt experiment (PGPU_BUILD_AB=1).  Results never depend on either. */
+ * key class (build switch PGPU_BUILD_4096=1; without them such keys run the full-width kernels).  Results never depend
+ * on it.  (Bit 1 named the A/B-wavefront decrypt experiment of rounds 3-5; retired, always 0.) */
 #define PGPU_FEATURE_4096_SPLIT 1
-#define PGPU_FEATURE_AB_DECRYPT 2
 int pgpu_build_features(void);
 int pgpu_pool_size(void);           /* entries of the pool (0 before init) */
 int pgpu_set_device(int pool_index);/* pool entry addressed by this thread's `_dev` / dev_alloc / copy calls */
@@ -324,7 +323,7 @@ typedef enum pgpu_kernel_form {
   PGPU_FORM_FULL_WIDTH = 0,
   PGPU_FORM_PAIRED = 1,
   PGPU_FORM_SEQ = 2,
-  PGPU_FORM_LANE = 4,      /* a whole exponentiation per lane (hensel_lane.hpp: 1024-bit keys, >= 32768 ciphertexts) */
+  PGPU_FORM_LANE = 4,      /* a whole exponentiation per lane; always together with PGPU_FORM_PS since round 6 */
   PGPU_FORM_PS = 8,        /* with PGPU_FORM_LANE: by product scanning (hensel_ps.hpp: 1024- to 3072-bit keys; round 5) */
   PGPU_FORM_CU_CLAIM = 16
 } pgpu_kernel_form;
@@ -341,9 +340,8 @@ int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, i
  * hensel_decrypt_kernel<*lanes / 2, *limbs> -- residues modulo p^2 / q^2 as pairs of half-width numbers (DESIGN.md
  * section 3; compiled for 1024- to 4096-bit keys; PGPU_HENSEL=0 turns it off); *split = 2: for ciphertexts of a
  * resident batch (pair rows), hensel_decrypt_seq_kernel<*lanes, *limbs> -- both halves of a pair in the same *lanes
- * lanes, launches that still put a wavefront on every SIMD that way (PGPU_SEQ_DECRYPT=0 turns it off); *split = 3 (round 4):
- * hensel_decrypt_lane_kernel<*limbs> -- a whole exponentiation in ONE lane, *limbs limbs per half (1024-bit keys, launches of
- * 32768 ciphertexts or more when PGPU_PS_DECRYPT=0; PGPU_LANE_DECRYPT=0 turns it off); *split = 4 (round 5):
+ * lanes, launches that still put a wavefront on every SIMD that way (PGPU_SEQ_DECRYPT=0 turns it off); (*split = 3 named
+ * round 4's operand-scanning one-lane kernel, retired in round 6;) *split = 4 (round 5):
  * hensel_decrypt_ps_kernel<*limbs, 28 | 29> -- a whole exponentiation in one lane by product scanning, *limbs limbs per half
  * (38 / 56 limbs of 28 bits: 2048- / 3072-bit keys, 19 limbs of 29 bits: 1024-bit keys; launches of
  * more than 16384 ciphertexts (3072-bit keys: 24576) in rounds of 32768 -- the form reported is that of the full rounds; a

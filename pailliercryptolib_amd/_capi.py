@@ -36,7 +36,7 @@ SYMBOLS = [
     "pgpu_encrypt_kernel_form_ex", "pgpu_host_alloc", "pgpu_host_free", "pgpu_host_wait",
     "pgpu_timing_collect_trace",
 ]
-FEATURE_4096_SPLIT, FEATURE_AB_DECRYPT = 1, 2
+FEATURE_4096_SPLIT = 1
 
 _lib = None
 

@@ -41,23 +41,15 @@ def build_4096():
     return os.environ.get("PGPU_BUILD_4096", "0") == "1"
 
 
-def build_ab():
-    """PGPU_BUILD_AB=1 also builds the A/B-wavefront decrypt experiment (csrc/hensel_ab.hpp, k_hensel.hip part 15):
-    bit-identical, measured slower than the default kernel, never selected by default"""
-    return os.environ.get("PGPU_BUILD_AB", "0") == "1"
-
-
 def _switches():
-    return [f"-DPGPU_WITH_4096={1 if build_4096() else 0}", f"-DPGPU_WITH_AB={1 if build_ab() else 0}"]
+    return [f"-DPGPU_WITH_4096={1 if build_4096() else 0}"]
 
 
 def hensel_parts():
     """translation units of k_hensel.hip that the current switches ask for"""
-    skip = set()
+    skip = {15, 30}      # (retired in round 6: the A/B-wavefront experiment and the operand-scanning one-lane kernel)
     if not build_4096():
         skip |= {22, 23, 24}
-    if not build_ab():
-        skip |= {15}
     return [p for p in range(35) if p not in skip]
 
 
@@ -84,10 +76,6 @@ def _objects():
         src = os.path.join(CSRC, "k_hensel.hip")
         o = os.path.join(obj, f"k_hensel_{part}.o")
         hdeps_k = [os.path.join(CSRC, f) for f in ("hensel.hpp", "hensel_q.hpp", "hensel_seq.hpp")]
-        if part == 15:
-            hdeps_k.append(os.path.join(CSRC, "hensel_ab.hpp"))
-        if part == 30:
-            hdeps_k.append(os.path.join(CSRC, "hensel_lane.hpp"))
         if part in (31, 33, 34):
             hdeps_k.append(os.path.join(CSRC, "hensel_ps.hpp"))
         out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src] + hdeps_k + kdeps))

@@ -30,11 +30,9 @@ namespace rt = pgpu::rt;
 using rt::fail;
 // the kernel-form policy (policy.cpp: pure host logic, unit-tested on the CPU)
 namespace policy = pgpu::policy;
-using pgpu::policy::ab_policy;
 using pgpu::policy::adaptive_cu_claim;
 using pgpu::policy::fb_encrypt_seq_pays;
 using pgpu::policy::kSimds;
-using pgpu::policy::lane_form_pays;
 using pgpu::policy::masked_decrypt_window;
 using pgpu::policy::modexp_seq_form_pays;
 using pgpu::policy::pair_mul_seq_pays;
@@ -1593,13 +1591,6 @@ int host_busy(rt::Device& dev, int lane) {
   return busy >= k ? busy : 0;
 }
 
-// the split form of the key whose limbs per half have a one-lane kernel, when a decrypt of `count` ciphertexts takes it
-const pgpu_privkey::HenselSet* lane_hset(const pgpu_privkey* key, size_t count) {
-  if (!hensel_enabled()) return nullptr;
-  for (const auto& f : key->hs)
-    if (lane_form_pays(f->H * f->K, count)) return f.get();
-  return nullptr;
-}
 // the one-lane product-scanning form (csrc/hensel_ps.hpp) for a decrypt of `count` resident ciphertexts under this key?
 bool ps_form_pays(const pgpu_privkey* key, size_t count, int busy) {
   return key->hs_ps && hensel_enabled() && policy::ps_form_pays(count, busy, key->hs_ps->K);
@@ -1608,12 +1599,11 @@ int words_to_pair_on(rt::Device& d, const pgpu_pubkey::PubForm* f, const uint64_
                      bool src_mont, uint32_t* out, size_t count, hipStream_t s);
 int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m, size_t count,
                hipStream_t s, bool in_mont, const uint32_t* d_pair = nullptr, int in_pair_l2 = 0, int busy_lanes = 0) {
-  const bool other_lane_busy = busy_lanes > 0;
   // d_pair: the ciphertexts are pair rows of 2*in_pair_l2 limbs (d_c unused); needs a split form of the key
   const int nw = key->n_words;
   // A lone launch of more than a round of the one-lane product-scanning form whose last round would be mostly empty: the
   // full rounds first, the rest as a launch of its own in the form ITS size takes (policy.hpp: ps_split_head)
-  if (busy_lanes == 0 && key->hs_ps && hensel_enabled() && secret_policy() != PGPU_EXP_SLIDING && ab_policy() == 0 &&
+  if (busy_lanes == 0 && key->hs_ps && hensel_enabled() && secret_policy() != PGPU_EXP_SLIDING &&
       (d_pair ? key->hs_ps->pair_l2 == in_pair_l2 : key->conv_form != nullptr)) {
     if (const size_t head = policy::ps_split_head(key->hs_ps->K, count)) {
       RC_TRY(decrypt_on(d, key, d_c, d_m, head, s, in_mont, d_pair, in_pair_l2, busy_lanes));
@@ -1633,21 +1623,16 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
   // launch of the adaptive policy.  One pair_ops_kernel pass (a product per chunk), ~1 % of the exponentiation.
   rt::DevMem conv_rows;
   if (!d_pair && !sliding && hset && key->conv_form) {
-    const pgpu_privkey::HenselSet* cand = lane_hset(key, count);
-    if (!cand) cand = hset;
+    const pgpu_privkey::HenselSet* cand = hset;
     const int cl2 = key->conv_form->H * key->conv_form->K;
-    if (cand->pair_l2 == cl2 &&
-        (lane_form_pays(cand->H * cand->K, count) || seq_form_pays(cand->H, cand->K, count, busy_lanes) ||
-         ps_form_pays(key, count, busy_lanes))) {
+    if (cand->pair_l2 == cl2 && (seq_form_pays(cand->H, cand->K, count, busy_lanes) || ps_form_pays(key, count, busy_lanes))) {
       RC_TRY(conv_rows.alloc(d, s, count * (size_t)2 * cl2 * sizeof(uint32_t)));
       RC_TRY(words_to_pair_on(d, key->conv_form.get(), d_c, (size_t)2 * nw, 2 * nw, in_mont, (uint32_t*)conv_rows.p, count, s));
       d_pair = (const uint32_t*)conv_rows.p;
       in_pair_l2 = cl2;
     }
   }
-  if (d_pair && !sliding && hset)
-    if (const pgpu_privkey::HenselSet* ls = lane_hset(key, count)) hset = ls;
-  const bool psf = d_pair && !sliding && hset && ab_policy() == 0 && ps_form_pays(key, count, busy_lanes) &&
+  const bool psf = d_pair && !sliding && hset && ps_form_pays(key, count, busy_lanes) &&
                    key->hs_ps->pair_l2 == in_pair_l2;
   if (psf) hset = key->hs_ps.get();
   if (d_pair && (!hset || hset->pair_l2 != in_pair_l2))
@@ -1711,13 +1696,10 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
     // (the window-table workspace is sized by the form that runs: one allocation per launch at most -- a growing
     // workspace is a hipMallocAsync of a few hundred MB, milliseconds of host time when the pool has to go to the driver)
     TimerScope t(d, s, PGPU_KERNEL_MODEXP);
-    const bool ab = d_pair && !sliding && hset->H == 2 && pgpu::hensel_ab_has(hset->K) && count >= 2048 &&
-                    (ab_policy() == 1 || ab_policy() == 3 || (ab_policy() == 2 && other_lane_busy));   // 3: always, four pairs per workgroup
     const size_t seq_ipw = 64 / (size_t)hset->H;
     const size_t seq_waves = 2 * ((count + seq_ipw - 1) / seq_ipw);
-    const bool lanef = !psf && !ab && d_pair && !sliding && lane_form_pays(L2, count);
-    const bool seq = !psf && !lanef && !ab && d_pair && !sliding && seq_form_pays(hset->H, hset->K, count, busy_lanes);
-    t.set_form(psf ? PGPU_FORM_LANE | PGPU_FORM_PS : lanef ? PGPU_FORM_LANE : seq ? PGPU_FORM_SEQ : (ab ? PGPU_FORM_PAIRED | 64 : PGPU_FORM_PAIRED));
+    const bool seq = !psf && d_pair && !sliding && seq_form_pays(hset->H, hset->K, count, busy_lanes);
+    t.set_form(psf ? PGPU_FORM_LANE | PGPU_FORM_PS : seq ? PGPU_FORM_SEQ : PGPU_FORM_PAIRED);
     if (psf) {
       const size_t lwaves = 2 * ((count + 63) / 64);
       const unsigned lblocks = (unsigned)((lwaves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
@@ -1729,12 +1711,6 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
       if (lds_pad) t.set_form(PGPU_FORM_LANE | PGPU_FORM_PS | PGPU_FORM_CU_CLAIM);
       if (!pgpu::launch_hensel_ps(hset->K, hset->lb, h, lblocks, s, lds_pad))
         return fail(PGPU_ERR_UNSUPPORTED, "one-lane product-scanning decrypt kernel not compiled");
-    } else if (lanef) {
-      const size_t lwaves = 2 * ((count + 63) / 64);
-      const unsigned lblocks = (unsigned)((lwaves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
-      RC_TRY(w.table.ensure((size_t)lblocks * pgpu::kWavesPerWG * 64 * entries * 2 * L2 * sizeof(uint32_t), s));
-      h.table = (uint32_t*)w.table.p;
-      if (!pgpu::launch_hensel_lane(L2, h, lblocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "one-lane decrypt kernel not compiled");
     } else if (seq) {
       const unsigned sblocks = (unsigned)((seq_waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
       RC_TRY(w.table.ensure((size_t)sblocks * pgpu::kWavesPerWG * seq_ipw * entries * 2 * L2 * sizeof(uint32_t), s));
@@ -1751,16 +1727,6 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
       static const bool w1 = [] { const char* e = getenv("PGPU_SEQ_W1"); return !e || atoi(e) != 0; }();
       if (!pgpu::launch_hensel_seq(hset->H, hset->K, h, sblocks, s, lds_pad, w1 && lds_pad >= 82000u))
         return fail(PGPU_ERR_UNSUPPORTED, "sequential-halves decrypt kernel not compiled");
-    } else if (ab) {
-      // one A/B pair per 32 ciphertexts and side.  Workgroups of two pairs (one wavefront per SIMD) when the launch has
-      // the GPU to itself; of four pairs (two wavefronts per SIMD, an A and a B by construction) when it shares the GPU
-      // with a second batch or is large enough to put two wavefronts on every SIMD anyway
-      const int ppw = (other_lane_busy || count >= 16384 || ab_policy() == 3) ? 4 : 2;
-      const size_t pairs = 2 * ((count + 31) / 32);
-      const unsigned ab_blocks = (unsigned)((pairs + ppw - 1) / ppw);
-      RC_TRY(w.table.ensure((size_t)ab_blocks * ppw * 32 * entries * 2 * L2 * sizeof(uint32_t), s));
-      h.table = (uint32_t*)w.table.p;
-      if (!pgpu::launch_hensel_ab(hset->K, ppw, h, ab_blocks, s)) return fail(PGPU_ERR_UNSUPPORTED, "A/B decrypt kernel not compiled");
     } else {
       RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * ipw * entries * 2 * L2 * sizeof(uint32_t), s));
       h.table = (uint32_t*)w.table.p;
@@ -2064,7 +2030,7 @@ void pgpu_shutdown(void) {
 
 int pgpu_is_initialized(void) { return rt::initialized() ? 1 : 0; }
 int pgpu_build_features(void) {
-  return (PGPU_WITH_4096 ? PGPU_FEATURE_4096_SPLIT : 0) | (PGPU_WITH_AB ? PGPU_FEATURE_AB_DECRYPT : 0);
+  return PGPU_WITH_4096 ? PGPU_FEATURE_4096_SPLIT : 0;
 }
 const char* pgpu_last_error(void) { return rt::g_err.c_str(); }
 const char* pgpu_device_name(void) { return rt::initialized() ? rt::current().name.c_str() : ""; }
@@ -2200,21 +2166,14 @@ int pgpu_decrypt_kernel_form_ex(const pgpu_privkey* key, size_t count, int busy_
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_decrypt_kernel_form: bad argument");
   RC_TRY(check_gen(key->gen, "key"));
   if (const pgpu_privkey::HenselSet* f = pick_hensel(key, count)) {
-    if (pair_rows_enabled() && secret_policy() != PGPU_EXP_SLIDING && ab_policy() == 0 && ps_form_pays(key, count, busy_lanes) &&
+    if (pair_rows_enabled() && secret_policy() != PGPU_EXP_SLIDING && ps_form_pays(key, count, busy_lanes) &&
         key->hs_ps->pair_l2 == f->pair_l2) {
       *split = 4;
       *lanes = 1;
       *limbs = key->hs_ps->K;
       return PGPU_OK;
     }
-    if (pair_rows_enabled() && secret_policy() != PGPU_EXP_SLIDING && ab_policy() == 0)
-      if (const pgpu_privkey::HenselSet* ls = lane_hset(key, count)) {
-        *split = 3;
-        *lanes = 1;
-        *limbs = ls->H * ls->K;
-        return PGPU_OK;
-      }
-    if (pair_rows_enabled() && secret_policy() != PGPU_EXP_SLIDING && ab_policy() == 0 && seq_form_pays(f->H, f->K, count, busy_lanes)) {
+    if (pair_rows_enabled() && secret_policy() != PGPU_EXP_SLIDING && seq_form_pays(f->H, f->K, count, busy_lanes)) {
       *split = 2;
       *lanes = f->H;
     } else {
@@ -2264,8 +2223,6 @@ void pgpu_debug_set_hensel(int mode) { g_hensel.store(mode < 0 ? 0 : (mode > 3 ?
 // A/B measurements (bench.py two_streams): 1 = the two-wavefronts-per-SIMD build of the (2,19) decrypt kernel for
 // every launch.  Not part of the public header.
 void pgpu_debug_set_packed_decrypt(int on) { g_packed_decrypt.store(on != 0); }
-// tests / A-B measurements: the A/B-wavefront decrypt kernel (hensel_ab.hpp): 0 never, 1 whenever it applies, 2 when the
-// other batch lane is busy.  Not part of the public header.
 // tests / A-B measurements: hensel_seq.hpp (0 never, 1 by launch size, 2 whenever it applies).  Not part of the public header.
 void pgpu_debug_set_seq_decrypt(int policy) { pgpu::policy::set_seq_policy(policy); }
 int pgpu_debug_set_host_adapt(int on) {
@@ -2273,14 +2230,11 @@ int pgpu_debug_set_host_adapt(int on) {
   return was;
 }
 int pgpu_debug_get_seq_decrypt(void) { return pgpu::policy::seq_policy(); }
-void pgpu_debug_set_lane_decrypt(int policy) { pgpu::policy::set_lane_policy(policy); }
 // tests / A-B measurements: hensel_ps.hpp (0 never, 1 by launch size and neighbour lanes, 2 whenever it is compiled)
 void pgpu_debug_set_ps_decrypt(int policy) { pgpu::policy::set_ps_policy(policy); }
 int pgpu_debug_get_ps_decrypt(void) { return pgpu::policy::ps_policy(); }
 // tests / A-B measurements: from how many active neighbour lanes on threads on round-robin lanes take the adaptive forms (0 never)
 int pgpu_debug_set_rr_adapt(int min_busy) { return pgpu::policy::set_rr_adapt(min_busy); }
-void pgpu_debug_set_adaptive(int enc_seq, int claim_busy) { pgpu::policy::set_adaptive(enc_seq, claim_busy); }
-void pgpu_debug_set_ab_decrypt(int policy) { pgpu::policy::set_ab_policy(policy); }
 
 #include "capi_timing.inc"   // pgpu_set_timing, pgpu_timing_collect*
 

@@ -5,8 +5,9 @@
 // Headroom: R = 2^(LB*K) >= 16 * P is enough here (canonical limbs after every product; the bounds are pushed through the
 // kernel's flow in tests/test_hensel_model.py) -- the multi-lane forms keep 256 for their relaxed limbs.
 //
-// hensel_lane.hpp keeps a residue in one lane as well, but scans by OPERAND: 2K column accumulators (4K registers) that
-// every reduction row normalises with a shift and an add -- at K = 38 those accumulators alone are 152 registers.  Here a
+// Round 4's one-lane kernel (hensel_decrypt_lane_kernel<20>, retired in round 6: this kernel's <19,29,2> build serves its
+// 1024-bit keys 17-20 % faster) scanned by OPERAND: 2K column accumulators (4K registers) that every reduction row
+// normalises with a shift and an add -- at K = 38 those accumulators alone are 152 registers.  Here a
 // Montgomery product runs column by column: ONE 64-bit accumulator takes every product a_i * c_j with i + j = col and
 // every q_i * n_j of the digits found so far, gives up its low limb (the quotient digit of a low column, the result limb
 // of a high one) and shifts down into the next column.  Per column: the products, one v_and_b32, one v_lshrrev_b64 (and

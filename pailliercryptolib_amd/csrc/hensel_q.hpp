@@ -1,5 +1,5 @@
 // pailliercryptolib_amd -- reduction rows with visible quotient digits, shared by the sequential-halves kernels
-// (hensel_seq.hpp) and the A/B-wavefront experiment (hensel_ab.hpp; built only with PGPU_BUILD_AB=1).
+// (hensel_seq.hpp).
 #ifndef PAILLIERCRYPTOLIB_AMD_CSRC_HENSEL_Q_HPP_
 #define PAILLIERCRYPTOLIB_AMD_CSRC_HENSEL_Q_HPP_
 

@@ -7,12 +7,12 @@
 // hensel_decrypt_kernel (hensel.hpp) gives the a half and the b half of a pair x == a - P*b lanes of their own and runs
 // them through one instruction stream; half A then sits through the K^2 products of half B's 2*a*b although its own
 // squaring needs K(K+1)/2 (the squaring symmetry), and idles through d*a in a general product: 12.5 % of the kernel's
-// VALU instructions (PMC, hensel_ab.hpp).  Here a group of G lanes holds a AND b (K limbs of each per lane) and does
+// VALU instructions (PMC; round 3's A/B-wavefront experiment, retired in round 6).  Here a group of G lanes holds a AND b (K limbs of each per lane) and does
 // the two halves one after the other with the same accumulators:
 //     t = a*c            half-width Montgomery product modulo P, symmetric when it is a squaring; its quotient digits
 //                        are kept in registers (G*K of them)
 //     w = a*d + b*c + q  the digits enter column by column (mont_reduce_rows_q, QMODE 2)
-// -- the arithmetic of hensel_ab.hpp without its hand-over: no LDS, no counters, no second wavefront.  Per
+// -- the arithmetic of that experiment without its hand-over: no LDS, no counters, no second wavefront.  Per
 // exponentiation it issues the instructions of one A and one B stream on HALF the lanes of the paired form (3072-bit keys,
 // per squaring and exponentiation: 4 lanes x 3 758 against 8 lanes x ~2 100, -10 %; general products -8 %; 2048-bit
 // keys: 2 x 3 287 against 4 x 1 851, -11 %, and -17 %).  Half the lanes means half the wavefronts per batch, so the

@@ -3,18 +3,12 @@
 // the two-wavefronts-per-SIMD build of the (2,19) decrypt form; 11-13: element-wise operations on pair rows).
 #include "hensel_seq.hpp"
 #include "launch.hpp"
-#if defined(PGPU_PART) && PGPU_PART == 30
-#include "hensel_lane.hpp"   // whole exponentiations in one lane (1024-bit keys, large batches)
-#endif
 #if defined(PGPU_PART) && (PGPU_PART == 31 || PGPU_PART == 33 || PGPU_PART == 34)
 #include "hensel_ps.hpp"     // whole exponentiations in one lane by product scanning (2048-bit keys; round 5)
 #endif
-#if defined(PGPU_PART) && PGPU_PART == 15
-#include "hensel_ab.hpp"   // the A/B-wavefront experiment: built only with PGPU_BUILD_AB=1
-#endif
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..34"
+#error "compile with -DPGPU_PART=0..34 (15 and 30 are retired)"
 #endif
 
 namespace pgpu {
@@ -244,14 +238,6 @@ bool launch_hensel_seq_part29(int G, int K, const HenselArgs& a, unsigned blocks
   }
   return false;
 }
-#elif PGPU_PART == 30
-bool launch_hensel_lane_part30(int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
-  if (K == 20) {
-    hipLaunchKernelGGL((hensel_decrypt_lane_kernel<20>), dim3(blocks), dim3(kWGThreads), 0, s, a);
-    return true;
-  }
-  return false;
-}
 #elif PGPU_PART == 31
 // lds_pad: whole-CU claim (launch_hensel_seq); one_per_simd: the launch runs one wavefront per SIMD by construction
 bool launch_hensel_ps_part31(int K, int lb, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad) {
@@ -306,18 +292,6 @@ bool launch_hensel_ps_part34(int K, int lb, const HenselArgs& a, unsigned blocks
   return false;
 }
 static_assert(ps_table_words<19>(32) == 32 * 2 * ((19 + 3) / 4) * 64 * 4, "launch.hpp: hensel_ps_table_words");
-#elif PGPU_PART == 15
-bool launch_hensel_ab_part15(int K, int pairs_per_wg, const HenselArgs& a, unsigned blocks, hipStream_t s) {
-  if (K == 19 && pairs_per_wg == 2) {
-    hipLaunchKernelGGL((hensel_decrypt_ab_kernel<19, 2>), dim3(blocks), dim3(4 * kWave), 0, s, a);
-    return true;
-  }
-  if (K == 19 && pairs_per_wg == 4) {
-    hipLaunchKernelGGL((hensel_decrypt_ab_kernel<19, 4>), dim3(blocks), dim3(8 * kWave), 0, s, a);
-    return true;
-  }
-  return false;
-}
 #elif PGPU_PART == 14
 bool launch_hensel_fb_encrypt_part14(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
   if (H == 8 && K == 9) {

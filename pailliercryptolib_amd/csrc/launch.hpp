@@ -9,17 +9,13 @@
 
 #include "kargs.hpp"
 
-// Build switches (pailliercryptolib_amd/build.py passes them to every translation unit, device and host alike):
+// Build switch (pailliercryptolib_amd/build.py passes it to every translation unit, device and host alike):
 //   PGPU_WITH_4096 (env PGPU_BUILD_4096=1)  the split forms of the 4096-bit key class -- (8,18) fixed-base / modexp / pair
 //                  rows, (4,18) and (8,9) CRT decrypt: beyond every BASELINE config and the reference's own 2048-bit cap
 //                  (ipcl/keygen.cpp:10), 10-15 minutes of compile time per translation unit.  Off: such keys run the
 //                  full-width kernels (Montgomery-form words), as all keys did before round 2.
-//   PGPU_WITH_AB   (env PGPU_BUILD_AB=1)    the A/B-wavefront decrypt experiment (hensel_ab.hpp; measured slower)
 #ifndef PGPU_WITH_4096
 #define PGPU_WITH_4096 0
-#endif
-#ifndef PGPU_WITH_AB
-#define PGPU_WITH_AB 0
 #endif
 
 namespace pgpu {
@@ -138,19 +134,6 @@ inline bool launch_pair_ops(int H, int K, const PairOpsArgs& a, unsigned blocks,
       ;
 }
 
-// CRT decrypt with the two halves of a residue in different wavefronts (hensel_ab.hpp; k_hensel.hip part 15): pair-row
-// ciphertexts, fixed-window scan, 2048-bit keys (2 lanes x 19 limbs per half)
-inline bool hensel_ab_has(int K) { return PGPU_WITH_AB && K == 19; }
-bool launch_hensel_ab_part15(int K, int pairs_per_wg, const HenselArgs& a, unsigned blocks, hipStream_t s);
-inline bool launch_hensel_ab(int K, int pairs_per_wg, const HenselArgs& a, unsigned blocks, hipStream_t s) {
-#if PGPU_WITH_AB
-  return launch_hensel_ab_part15(K, pairs_per_wg, a, blocks, s);
-#else
-  (void)K; (void)pairs_per_wg; (void)a; (void)blocks; (void)s;
-  return false;
-#endif
-}
-
 // CRT decrypt with both halves of a residue in the same lanes (hensel_seq.hpp; k_hensel.hip parts 16, 17): pair-row
 // ciphertexts, fixed-window scan, launches of two or more wavefronts per SIMD; (4,14): 3072-bit keys, (2,19): 2048-bit
 inline bool hensel_seq_has(int G, int K) { return (G == 4 && K == 14) || (G == 2 && (K == 19 || K == 10)); }   // (2,10): 1024-bit keys (part 29)
@@ -167,14 +150,6 @@ inline bool launch_hensel_seq(int G, int K, const HenselArgs& a, unsigned blocks
   if (one_per_simd && launch_hensel_seq_w1_part32(G, K, a, blocks, s, lds_pad)) return true;
   return launch_hensel_seq_part16(G, K, a, blocks, s, lds_pad) || launch_hensel_seq_part17(G, K, a, blocks, s, lds_pad) ||
          launch_hensel_seq_part29(G, K, a, blocks, s, lds_pad);
-}
-
-// CRT decrypt with a whole exponentiation per lane (hensel_lane.hpp; k_hensel.hip part 30): pair-row ciphertexts,
-// fixed-window scan; L2 = limbs per half of the key's split form: 20 (1024-bit keys)
-inline bool hensel_lane_has(int L2) { return L2 == 20; }
-bool launch_hensel_lane_part30(int L2, const HenselArgs& a, unsigned blocks, hipStream_t s);
-inline bool launch_hensel_lane(int L2, const HenselArgs& a, unsigned blocks, hipStream_t s) {
-  return launch_hensel_lane_part30(L2, a, blocks, s);
 }
 
 // CRT decrypt with a whole exponentiation per lane by product scanning (hensel_ps.hpp; k_hensel.hip part 31): pair-row

@@ -28,27 +28,19 @@ int env_int(const char* name, int dflt, int lo, int hi) {
 // probe is a hipStreamQuery per lane: what it costs when it is wrong is bounded by one launch (a neighbour that drains
 // early leaves a half-chip launch to finish alone: 8.1 instead of 4.6 ms for 8192 ciphertexts).
 std::atomic<int> g_seq_policy{env_int("PGPU_SEQ_DECRYPT", 4, 0, 4)};
-// the one-lane-per-exponentiation form (hensel_lane.hpp): 0 never, 1 (default) launches that put a wavefront on every SIMD
-// that way (64 exponentiations per wavefront: 32768 ciphertexts), 2 whenever it is compiled (tests)
-std::atomic<int> g_lane_policy{env_int("PGPU_LANE_DECRYPT", 1, 0, 2)};
 // the one-lane product-scanning form (hensel_ps.hpp; 2048-bit keys).  64 exponentiations per wavefront: 8192 ciphertexts
 // are 256 wavefronts -- a quarter of the SIMDs.  0 never; 1 (default) launches that put a wavefront on every SIMD that way
 // (32768 ciphertexts), or -- adaptive, like the sequential-halves form -- do so together with the busy neighbour lanes:
 // waves * (1 + busy) >= SIMDs (16384 ciphertexts beside one busy lane, 8192 beside three); 2 whenever compiled (tests)
 std::atomic<int> g_ps_policy{env_int("PGPU_PS_DECRYPT", 1, 0, 2)};
-// hensel_ab.hpp: the two halves of a residue in different wavefronts -- 12.5 % fewer VALU instructions per launch (PMC),
-// but measured (profiles/r03_ab_decrypt.txt): alone its longer half sets the pace (5.41 vs 4.59 ms), and with two batches
-// in flight the gain depends on which wavefronts the dispatcher pairs on a SIMD -- +1.6 % on average.  Kept as an
-// experiment, bit-identical, off by default.  0 never, 1 whenever it applies, 2 when another lane is busy, 3 always
-std::atomic<int> g_ab_policy{env_int("PGPU_AB_DECRYPT", 0, 0, 3)};
-// tuning knobs of the adaptive policy (tools/probe_lanes.py): up to how many busy neighbours the DJN encrypt follows the
-// decrypt into the sequential-halves form with a CU claim.  Round 4 stopped at ONE (two lanes, each owning half the chip:
-// 4.92 -> 4.87 ms per step; with three the paired full-chip encrypt hid under the neighbours' sequential-halves decrypts).
-// Round 5: three -- beside one-lane decrypts a co-resident encrypt wavefront only gets the issue slots the older decrypt
-// wavefront leaves (0.8 -> 10 ms), so the encrypt takes the lane's own quarter of the chip (capi.cpp: encrypt_on).
-std::atomic<int> g_adapt_enc_seq{env_int("PGPU_ADAPT_ENC_SEQ", 3, -100, 100)};
-// ... and up to how many busy neighbours a part-chip launch claims whole CUs
-std::atomic<int> g_adapt_claim_busy{env_int("PGPU_ADAPT_CLAIM_BUSY", 3, -100, 100)};
+// Two constants of the adaptive policy that were knobs (PGPU_ADAPT_ENC_SEQ / PGPU_ADAPT_CLAIM_BUSY) in rounds 4-5 and have
+// sat at these values since: up to how many busy neighbours the DJN encrypt follows the decrypt into the sequential-halves
+// form with a CU claim -- round 4 stopped at ONE (two lanes, each owning half the chip: 4.92 -> 4.87 ms per step); round 5:
+// three, because beside one-lane decrypts a co-resident encrypt wavefront only gets the issue slots the older decrypt
+// wavefront leaves (0.8 -> 10 ms), so the encrypt takes the lane's own quarter of the chip (capi.cpp: encrypt_on) -- and up
+// to how many busy neighbours a part-chip launch claims whole CUs.
+constexpr int kAdaptEncSeq = 3;
+constexpr int kAdaptClaimBusy = 3;
 // PGPU_RR_ADAPT = k > 0 (round 5; default 3): threads on ROUND-ROBIN lanes (synchronous callers of the ipcl:: API side by
 // side) enter the adaptive policy as well, but only when at least k other lanes are active -- with all four lanes busy each
 // caller's launches take a quarter of the chip (17 ms per encrypt + decrypt instead of 5.4 on the whole chip, four of them
@@ -59,18 +51,9 @@ std::atomic<int> g_rr_adapt{env_int("PGPU_RR_ADAPT", 3, 0, 100)};
 
 int seq_policy() { return g_seq_policy.load(); }
 void set_seq_policy(int p) { g_seq_policy.store(p < 0 ? 0 : (p > 4 ? 4 : p)); }
-int lane_policy() { return g_lane_policy.load(); }
-void set_lane_policy(int p) { g_lane_policy.store(p < 0 ? 0 : (p > 2 ? 2 : p)); }
 int ps_policy() { return g_ps_policy.load(); }
 void set_ps_policy(int p) { g_ps_policy.store(p < 0 ? 0 : (p > 2 ? 2 : p)); }
-int ab_policy() { return g_ab_policy.load(); }
-void set_ab_policy(int p) { g_ab_policy.store(p < 0 ? 0 : (p > 3 ? 3 : p)); }
-int adapt_enc_seq() { return g_adapt_enc_seq.load(); }
-int adapt_claim_busy() { return g_adapt_claim_busy.load(); }
-void set_adaptive(int enc_seq, int claim_busy) {
-  g_adapt_enc_seq.store(enc_seq);
-  g_adapt_claim_busy.store(claim_busy);
-}
+int adapt_claim_busy() { return kAdaptClaimBusy; }
 int rr_adapt() { return g_rr_adapt.load(); }
 int set_rr_adapt(int min_busy) { return g_rr_adapt.exchange(min_busy < 0 ? 0 : min_busy); }
 
@@ -82,7 +65,7 @@ bool seq_adaptive(size_t waves, int busy) {
   return g_seq_policy.load() == 4 && busy >= 1 && waves * (size_t)(1 + busy) >= kSimds;
 }
 unsigned adaptive_cu_claim(size_t waves, int busy_lanes) {
-  return (g_seq_policy.load() == 4 && waves < kSimds && busy_lanes >= 1 && busy_lanes <= g_adapt_claim_busy.load()) ? 84000u : 0u;
+  return (g_seq_policy.load() == 4 && waves < kSimds && busy_lanes >= 1 && busy_lanes <= kAdaptClaimBusy) ? 84000u : 0u;
 }
 
 bool fb_encrypt_seq_pays(int H, int K, size_t count, int busy) {
@@ -95,7 +78,7 @@ bool fb_encrypt_seq_pays(int H, int K, size_t count, int busy) {
   // beside ONE neighbour (half the chip each) and beside THREE (a quarter each: the lane's own CUs between its one-lane
   // decrypts); beside two the lanes' sequential-halves decrypts hold every CU and the paired full-chip encrypt squeezes
   // in better than a launch that waits for whole CUs (k = 3 of the lane sweep: 4.9-5.1 against 5.2 ms per step)
-  if (H == 4 && busy != 2 && busy <= g_adapt_enc_seq.load() && seq_adaptive(waves, busy)) return true;
+  if (H == 4 && busy != 2 && busy <= kAdaptEncSeq && seq_adaptive(waves, busy)) return true;
   // (2-lane groups, 1024-bit keys: measured equal or behind the paired kernel at 65536 elements -- 1.04 against 1.02 ms,
   // 0.96 against 0.92 ms: 19 limbs per lane and the LDS staging leave no register room -- so only when forced)
   if (H == 2 && pol != 2) return false;
@@ -118,28 +101,15 @@ bool seq_form_pays(int H, int K, size_t count, int busy) {
   const int pol = g_seq_policy.load();
   return pol == 2 || (pol == 3 && 2 * waves >= kSimds) || ((pol == 1 || pol == 4) && waves >= kSimds) || seq_adaptive(waves, busy);
 }
-bool lane_form_pays(int L2, size_t count) {
-  if (!pgpu::hensel_lane_has(L2)) return false;
-  const size_t waves = 2 * ((count + 63) / 64);
-  const int pol = g_lane_policy.load();
-  return pol == 2 || (pol == 1 && waves >= kSimds);
-}
 // Measured on lone launches (profiles/r05_decrypt_partial_rounds.txt).  2048-bit keys (K = 38): a round 14.2 ms against
 // 8.1 ms per 16384 ciphertexts of the sequential-halves form and 4.6 ms for up to 8192 in the paired one -- one round beats
 // them above 16384 ciphertexts, and a tail of up to 16384 is cheaper as a launch of its own.  3072-bit keys (K = 56): a
 // round 47.6 ms against 13.3-15.2 ms per 8192 of the (4,14) sequential-halves form: above 24576.  1024-bit keys (K = 19):
 // a round 2.2-2.3 ms against 1.8 ms for 16384 ciphertexts and 3.0 ms for 24576 in the multi-lane forms: above 16384.
-// PGPU_PS_MIN_COUNT / PGPU_PS_SPLIT_TAIL override both (0: the table below).
 size_t ps_min_count(int K) {
-  static const int forced = env_int("PGPU_PS_MIN_COUNT", 0, 0, 1 << 30);
-  if (forced) return (size_t)forced;
   return K == 56 ? 24576 + 1 : (K == 38 || K == 19) ? 16384 + 1 : kPsRound;
 }
-static size_t ps_split_tail(int K) {
-  static const int forced = env_int("PGPU_PS_SPLIT_TAIL", -1, -1, 1 << 30);
-  if (forced >= 0) return (size_t)forced;
-  return K == 56 ? 24576 : 16384;
-}
+static size_t ps_split_tail(int K) { return K == 56 ? 24576 : 16384; }
 bool ps_form_pays(size_t count, int busy, int K) {
   const size_t waves = 2 * ((count + 63) / 64);
   const int pol = g_ps_policy.load();
@@ -186,11 +156,8 @@ int pick_decrypt_window(int exp_bits) {
 // exponentiation's table is read at every window product, so the table is what the launch streams -- 9.7 KB per
 // exponentiation at w = 5, 32 entries x 235 products; four batches in flight (636 MB of tables) fall out of the 256 MB
 // Infinity Cache and the one-lane decrypt went from 14.5 to 41 ms.  w = 3: 8 entries x 348 products, a third of the bytes,
-// 11 % more products: 26 ms (lone paired launch: 6.6 -> 6.0 ms against 4.6 indexed).  PGPU_MASKED_DEC_WINDOW: 1..5.
-int masked_decrypt_window() {
-  static const int w = env_int("PGPU_MASKED_DEC_WINDOW", 3, 1, 5);
-  return w;
-}
+// 11 % more products: 26 ms (lone paired launch: 6.6 -> 6.0 ms against 4.6 indexed).
+int masked_decrypt_window() { return 3; }
 
 }  // namespace policy
 }  // namespace pgpu

@@ -8,7 +8,7 @@
 //   paired        hensel.hpp      the two halves of a residue in neighbouring lanes -- most lanes per residue: a lone caller
 //   sequential    hensel_seq.hpp  both halves in the same lanes -- half the wavefronts: launches that still cover the SIMDs,
 //                                 alone or together with one busy neighbour lane (each launch then claims half the chip)
-//   one-lane      hensel_lane.hpp / hensel_ps.hpp   a whole exponentiation per lane -- a quarter of the wavefronts again:
+//   one-lane      hensel_ps.hpp   a whole exponentiation per lane (product scanning) -- a quarter of the wavefronts again:
 //                                 large launches, or 8192-ciphertext launches beside three busy lanes (a quarter chip each)
 #ifndef PAILLIERCRYPTOLIB_AMD_CSRC_POLICY_HPP_
 #define PAILLIERCRYPTOLIB_AMD_CSRC_POLICY_HPP_
@@ -20,18 +20,13 @@ namespace policy {
 
 constexpr size_t kSimds = 256 * 4;   // MI355X: 256 CUs x 4 SIMDs; a launch of fewer wavefronts leaves SIMDs empty
 
-// ---- knobs (environment at start-up; the setters are what pgpu_debug_set_* and the tests use) ----
+// ---- knobs: FOUR (PGPU_SEQ_DECRYPT, PGPU_PS_DECRYPT, PGPU_RR_ADAPT, PGPU_FIXED_WINDOW; environment at start-up; the
+// setters are what pgpu_debug_set_* and the tests use) ----
 int seq_policy();            // PGPU_SEQ_DECRYPT: 0 never, 1 by launch size, 2 always, 3 two-lane mode (r03), 4 adaptive (default)
 void set_seq_policy(int p);
-int lane_policy();           // PGPU_LANE_DECRYPT (hensel_lane.hpp): 0 never, 1 by launch size (default), 2 always
-void set_lane_policy(int p);
 int ps_policy();             // PGPU_PS_DECRYPT (hensel_ps.hpp): 0 never, 1 by launch size / neighbour lanes (default), 2 always
 void set_ps_policy(int p);
-int ab_policy();             // PGPU_AB_DECRYPT (hensel_ab.hpp, an experiment): 0 never (default) .. 3
-void set_ab_policy(int p);
-int adapt_enc_seq();         // PGPU_ADAPT_ENC_SEQ: up to how many busy neighbours the DJN encrypt takes the part-chip form (3)
-int adapt_claim_busy();      // PGPU_ADAPT_CLAIM_BUSY: up to how many busy neighbours a part-chip launch claims whole CUs (3)
-void set_adaptive(int enc_seq, int claim_busy);
+int adapt_claim_busy();      // up to how many busy neighbours a part-chip launch claims whole CUs (3; a constant since round 6)
 int rr_adapt();              // PGPU_RR_ADAPT: from how many active neighbours on threads on round-robin lanes adapt (3; 0 never)
 int set_rr_adapt(int min_busy);   // returns the previous value
 
@@ -45,8 +40,6 @@ bool seq_adaptive(size_t waves, int busy);
 unsigned adaptive_cu_claim(size_t waves, int busy_lanes);
 // CRT decrypt of `count` resident ciphertexts in split form (H, K): the sequential-halves kernel?
 bool seq_form_pays(int H, int K, size_t count, int busy = 0);
-// ... the one-lane kernel of hensel_lane.hpp (L2 limbs per half)?
-bool lane_form_pays(int L2, size_t count);
 // ... the one-lane product-scanning kernel of hensel_ps.hpp with K limbs per half (the key must have its constant set)?
 // A lone launch runs in ROUNDS of kPsRound ciphertexts (one wavefront per SIMD: 2 x 32768 / 64 = 1024 wavefronts), and a
 // round costs the same whether it is full or not -- so the form pays from ps_min_count(K) ciphertexts up, the size from

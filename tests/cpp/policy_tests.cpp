@@ -19,8 +19,8 @@ static int g_failed = 0, g_checks = 0;
   } while (0)
 
 int main() {
-  // ---- defaults: adaptive (4), one-lane forms by size / neighbours (1), experiment off ----
-  CHECK(pol::seq_policy() == 4 && pol::lane_policy() == 1 && pol::ps_policy() == 1 && pol::ab_policy() == 0);
+  // ---- defaults: adaptive (4), the one-lane form by size / neighbours (1) ----
+  CHECK(pol::seq_policy() == 4 && pol::ps_policy() == 1 && pol::adapt_claim_busy() == 3);
   CHECK(pol::seq_policy_by_size() == 1);
   // CRT decrypt, 2048-bit keys, split form (2,19): 32 ciphertexts per sequential-halves wavefront and side
   CHECK(!pol::seq_form_pays(2, 19, 8192, 0));      // 512 wavefronts: a lone caller keeps the paired kernel
@@ -45,8 +45,6 @@ int main() {
   CHECK(pol::ps_split_head(38, 32768 + 16385) == 0 && pol::ps_split_head(56, 32768 + 24576) == 32768);
   CHECK(pol::ps_split_head(56, 65536 + 24577) == 0 && pol::ps_split_head(19, 40000) == 32768);
   CHECK(!pol::ps_form_pays(1, 3) && !pol::ps_form_pays(8191 - 64, 3));   // 254 wavefronts x 4 < 1024
-  // the operand-scanning one-lane kernel exists for 20-limb halves (1024-bit keys)
-  CHECK(pol::lane_form_pays(20, 32768) && !pol::lane_form_pays(20, 32767 - 63) && !pol::lane_form_pays(38, 1 << 20));
   // the decrypt exponent's window: 5 bits up to 2048-bit keys, 6 from 1280-bit exponents up (3072-bit keys: 318 against 338 products)
   CHECK(pol::pick_decrypt_window(512) == pol::pick_window(512) && pol::pick_decrypt_window(1024) == 5);
   CHECK(pol::pick_decrypt_window(1536) == 6 && pol::pick_decrypt_window(2048) == 6 && pol::pick_window(1536) == 5);
@@ -68,11 +66,6 @@ int main() {
   CHECK(pol::pick_window(1024) == 5 && pol::pick_window(512) == 5 && pol::pick_window(33) == 3 && pol::pick_window(1) == 1);
   CHECK(pol::masked_decrypt_window() == 3);
   // ---- knobs ----
-  pol::set_adaptive(1, 3);                                  // the round-4 encrypt rule: part-chip beside ONE neighbour only
-  CHECK(pol::fb_encrypt_seq_pays(4, 18, 8192, 1) && !pol::fb_encrypt_seq_pays(4, 18, 8192, 3));
-  pol::set_adaptive(3, 1);
-  CHECK(pol::adaptive_cu_claim(256, 3) == 0u && pol::adaptive_cu_claim(512, 1) == 84000u);
-  pol::set_adaptive(3, 3);
   pol::set_seq_policy(1);                                   // by size only: no adaptive forms, no claims
   CHECK(!pol::seq_form_pays(2, 19, 8192, 1) && pol::seq_form_pays(2, 19, 16384, 1) && pol::adaptive_cu_claim(512, 1) == 0u);
   CHECK(!pol::ps_form_pays(8192, 3) && pol::ps_form_pays(32768, 0));
@@ -88,9 +81,6 @@ int main() {
   pol::set_ps_policy(0);
   CHECK(!pol::ps_form_pays(1 << 20, 3) && pol::ps_split_head(38, 36000) == 0);
   pol::set_ps_policy(1);
-  pol::set_lane_policy(2);
-  CHECK(pol::lane_form_pays(20, 1) && !pol::lane_form_pays(19, 1));
-  pol::set_lane_policy(1);
   CHECK(pol::set_rr_adapt(0) == 3 && pol::rr_adapt() == 0 && pol::set_rr_adapt(3) == 0);
   std::printf("%d checks, %d failed\n", g_checks, g_failed);
   return g_failed ? 1 : 0;

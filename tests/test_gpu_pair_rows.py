@@ -230,41 +230,6 @@ def test_two_batch_lanes(engine):
         R.close()
 
 
-def test_ab_wavefront_decrypt_kernel_is_bit_identical(engine):
-    """csrc/hensel_ab.hpp (experimental, off by default): the a and b halves of every residue in different wavefronts that
-    hand quotient digits and results over through a ring in LDS.  Same plaintexts as the default kernel, ragged batch,
-    with and without the masked table gather."""
-    from pailliercryptolib_amd import _capi
-    if not _capi.lib().pgpu_build_features() & _capi.FEATURE_AB_DECRYPT:
-        pytest.skip("the A/B-wavefront experiment is not in this build (PGPU_BUILD_AB=1 builds it)")
-    p, q, hs = key_case(2048, True)
-    n = p * q
-    rng = random.Random(777)
-    count = 2048 + 77
-    m = ([0, 1, n - 1] + [rng.randrange(n) for _ in range(count)])[:count]
-    r = [rng.getrandbits(1024) for _ in range(count)]
-    L = _capi.lib()
-    pk, sk = engine.PublicKey(n, 2048, hs=hs), engine.PrivateKey(p, q)
-    R = Res()
-    try:
-        c = R.op(L.pgpu_batch_encrypt, pk._h, R.up(m, 32), R.up(r, 16), 1024)
-        assert L.pgpu_batch_row_limbs(c) == 144
-        want = R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, c))
-        assert want == m
-        L.pgpu_debug_set_ab_decrypt(1)
-        try:
-            assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, c)) == m       # workgroups of two A/B pairs
-            L.pgpu_debug_set_ab_decrypt(3)
-            assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, c)) == m       # workgroups of four pairs (two per SIMD)
-            _capi.check(L.pgpu_set_table_gather_policy(1))
-            assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, c)) == m
-        finally:
-            _capi.check(L.pgpu_set_table_gather_policy(0))
-            L.pgpu_debug_set_ab_decrypt(0)
-    finally:
-        R.close()
-
-
 @pytest.mark.parametrize("bits,count", [(3072, 300), (2048, 515), (1024, 1100)])
 def test_sequential_halves_decrypt_kernel_is_bit_identical(engine, bits, count):
     """csrc/hensel_seq.hpp: both halves of a residue in the same lanes, one after the other (the form large launches take

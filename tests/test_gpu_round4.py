@@ -274,54 +274,6 @@ def test_small_transfers_through_the_bounce_buffer(engine):
         R.close()
 
 
-@pytest.mark.parametrize("count", [1, 63, 65, 300, 4100])
-def test_lane_decrypt_kernel_is_bit_identical(engine, count):
-    """csrc/hensel_lane.hpp: a whole half-width exponentiation per lane (1024-bit keys; by default from 32768 ciphertexts
-    up, forced here): same plaintexts as the default kernels and the oracle, ragged batches (padding lanes of the last
-    wavefront), resident ciphertexts from every producer (encrypt, CT+CT, CT x PT, uploaded words), edge plaintexts, and
-    with the masked table gather."""
-    from oracle import paillier_oracle as orc
-    from pailliercryptolib_amd import _capi
-    p, q, hs = key_case(1024)
-    n = p * q
-    rng = random.Random(count)
-    m = ([0, 1, n - 1] + [rng.randrange(n) for _ in range(count)])[:count]
-    m2 = [rng.randrange(n) for _ in range(count)]
-    r = [rng.getrandbits(512) for _ in range(count)]
-    e = [rng.getrandbits(33) for _ in range(count)]
-    pk, sk = engine.PublicKey(n, 1024, hs=hs), engine.PrivateKey(p, q)
-    osk = orc.PrivateKey(n, p, q)
-    R = Res()
-    L = R.L
-    try:
-        c1 = R.op(L.pgpu_batch_encrypt, pk._h, R.up(m, 16), R.up(r, 8), 512)
-        c2 = R.op(L.pgpu_batch_encrypt, pk._h, R.up(m2, 16), R.up(r, 8), 512)
-        s = R.op(L.pgpu_batch_ct_add, pk._h, c1, c2)
-        t = R.op(L.pgpu_batch_ct_mul, pk._h, s, R.up(e, 1), 33)
-        raw = [rng.randrange(1, n * n) for _ in range(count)]        # not encryptions: L_p(c^(p-1)) has no structure
-        up = R.up(raw, 32)
-        up_pair = R.op(L.pgpu_batch_ct_add, pk._h, up, R.up([1], 32))   # the same values as pair rows
-        want = [R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, x)) for x in (c1, s, t, up_pair)]
-        assert want[0] == m and want[1] == [(a + b) % n for a, b in zip(m, m2)]
-        assert want[2] == [((a + b) * x) % n for a, b, x in zip(m, m2, e)]
-        idx = sorted({0, count // 2, count - 1})
-        assert [want[3][i] for i in idx] == osk.decrypt([raw[i] for i in idx])
-        L.pgpu_debug_set_lane_decrypt(2)
-        try:
-            split, lanes, limbs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-            _capi.check(L.pgpu_decrypt_kernel_form(sk._h, count, ctypes.byref(split), ctypes.byref(lanes), ctypes.byref(limbs)))
-            assert (split.value, lanes.value, limbs.value) == (3, 1, 20)
-            got = [R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, x)) for x in (c1, s, t, up_pair)]
-            assert got == want
-            _capi.check(L.pgpu_set_table_gather_policy(1))
-            assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, t)) == want[2]
-        finally:
-            _capi.check(L.pgpu_set_table_gather_policy(0))
-            L.pgpu_debug_set_lane_decrypt(1)
-    finally:
-        R.close()
-
-
 @pytest.mark.parametrize("bits,count", [(2048, 8192), (2048, 2100), (2048, 20000), (1024, 40000), (3072, 4100)])
 def test_host_array_callers_side_by_side(engine, bits, count):
     """Two threads calling pgpu_paillier_encrypt / pgpu_paillier_decrypt_crt on host arrays of their own (the reference's

@@ -12,6 +12,30 @@ from test_gpu_round4 import Res, key_case
 pytestmark = pytest.mark.gpu
 
 
+def _c_oracle_decrypt(p, q, bits, c_words):
+    """CRT decrypt of EVERY row by the C oracle (fastest backend of the host, all cores): plaintext rows as 64-bit words"""
+    from oracle import c_oracle
+    from test_gpu_sha256_fullsize import key_limbs
+    c_oracle.set_threads(min(c_oracle.lib().orc_max_threads(), c_oracle.usable_cpus()))
+    be = c_oracle.ifma_modexp_batch if c_oracle.ifma_lib() is not None else (
+        c_oracle.openssl_modexp_batch if c_oracle.openssl_lib() is not None else c_oracle.modexp_batch)
+    _, _, sk_l = key_limbs(p, q, None, bits)
+    return c_oracle.paillier_decrypt_crt_with(be, *sk_l, c_words)
+
+
+def _raw_rows(n, bits, count, seed):
+    """`count` values below n^2 that are NOT encryptions (L_p(c^(p-1)) has no structure), incl. n^2 - 1, 1 and n^2 - 2"""
+    import numpy as np
+    from pailliercryptolib_amd.limbs import ints_to_limbs
+    nw = bits // 64
+    rng = np.random.default_rng(seed)
+    raw = np.frombuffer(rng.bytes(count * 2 * nw * 8), dtype=np.uint64).reshape(count, 2 * nw).copy()
+    raw[:, -1] >>= np.uint64(4)                      # below 2^(2 bits - 4) < n^2 (n has its top bit set)
+    edge = ints_to_limbs([n * n - 1, 1, n * n - 2], 2 * nw)
+    raw[0], raw[count // 2], raw[count - 1] = edge[0], edge[1], edge[2]
+    return raw
+
+
 @pytest.mark.parametrize("bits,count", [(2048, 1), (2048, 63), (2048, 65), (2048, 300), (2048, 4100),
                                         (3072, 1), (3072, 65), (3072, 300), (3072, 1100),
                                         (1024, 1), (1024, 65), (1024, 300), (1024, 4100)])
@@ -180,18 +204,41 @@ def test_four_lanes_take_the_product_scanning_form_for_other_key_sizes(engine, b
             r = np.frombuffer(rng.bytes(count * nw * 4), dtype=np.uint64).reshape(count, nw // 2).copy()
             _capi.check(L.pgpu_set_batch_lane(ln))
             sets.append((m, up(m), up(r)))
-        outs = [None] * 4
+        outs, cts, raws, raw_outs = [None] * 4, [None] * 4, [], [None] * 4
+        for ln in range(4):                    # a batch of NON-encryptions per lane (n^2 - 1, 1, n^2 - 2 among them)
+            _capi.check(L.pgpu_set_batch_lane(ln))
+            raw = _raw_rows(n, bits, count, 7000 + bits + ln)
+            raws.append((raw, up(raw)))
         for _ in range(4):                     # (the first round starts beside idle lanes: the later ones run the quarter-chip forms)
             for ln in range(4):
                 _capi.check(L.pgpu_set_batch_lane(ln))
-                c = op(L.pgpu_batch_encrypt, pk._h, sets[ln][1], sets[ln][2], bits // 2)
-                outs[ln] = op(L.pgpu_batch_decrypt_crt, sk._h, c)
+                cts[ln] = op(L.pgpu_batch_encrypt, pk._h, sets[ln][1], sets[ln][2], bits // 2)
+                outs[ln] = op(L.pgpu_batch_decrypt_crt, sk._h, cts[ln])
+        for ln in range(4):                    # the same four lanes busy with the raw batches: quarter-chip launches again
+            _capi.check(L.pgpu_set_batch_lane(ln))
+            raw_outs[ln] = op(L.pgpu_batch_decrypt_crt, sk._h, raws[ln][1])
         _capi.check(L.pgpu_set_batch_lane(0))
         _capi.check(L.pgpu_synchronize())
+        from oracle import paillier_oracle as orc
+        from pailliercryptolib_amd.limbs import limbs_to_ints
+        opk, osk = orc.PublicKey(n, bits), orc.PrivateKey(n, p, q)
+        opk.set_djn(hs)
+        rows = [0, count // 2, count - 1]
         for ln in range(4):
             got = np.empty((count, nw), dtype=np.uint64)
             _capi.check(L.pgpu_batch_download(outs[ln], ptr(got)))
             assert np.array_equal(got, sets[ln][0]), "lane %d: round trip failed" % ln
+            # oracle level, not only the round trip: ciphertext rows against the Python oracle's encrypt ...
+            cw = np.empty((count, 2 * nw), dtype=np.uint64)
+            _capi.check(L.pgpu_batch_download(cts[ln], ptr(cw)))
+            r_rows = np.empty((count, nw // 2), dtype=np.uint64)
+            _capi.check(L.pgpu_batch_download(sets[ln][2], ptr(r_rows)))
+            assert limbs_to_ints(cw[rows]) == opk.encrypt(limbs_to_ints(sets[ln][0][rows]), limbs_to_ints(r_rows[rows])), \
+                "lane %d: ciphertext rows differ from the oracle" % ln
+            # ... and the decrypt of non-encryptions: every row against the C oracle, the edge rows against pow()
+            _capi.check(L.pgpu_batch_download(raw_outs[ln], ptr(got)))
+            assert np.array_equal(got, _c_oracle_decrypt(p, q, bits, raws[ln][0])), "lane %d: raw decrypt differs from the C oracle" % ln
+            assert limbs_to_ints(got[rows]) == osk.decrypt(limbs_to_ints(raws[ln][0][rows]))
     finally:
         _capi.check(L.pgpu_set_batch_lane(0))
         for h in live:
@@ -280,6 +327,27 @@ def test_lone_decrypts_in_rounds_of_the_product_scanning_form(engine, bits, coun
         got[:] = 0
         _capi.check(L.pgpu_paillier_decrypt_crt(sk._h, ptr(cw), ptr(got), count))
         assert np.array_equal(got, m)
+        # Oracle level, not only round trips (the partial-round split -- policy.hpp: ps_split_head -- is launch logic of its
+        # own): three ciphertext rows of every launch part (rounds of 32768, then the tail) against the Python oracle ...
+        from oracle import paillier_oracle as orc
+        from pailliercryptolib_amd.limbs import limbs_to_ints
+        opk, osk = orc.PublicKey(n, bits), orc.PrivateKey(n, p, q)
+        opk.set_djn(hs)
+        rows = sorted({i for lo in range(0, count, 32768) for i in (lo, (lo + min(lo + 32768, count)) // 2, min(lo + 32768, count) - 1)})
+        assert limbs_to_ints(cw[rows]) == opk.encrypt(limbs_to_ints(m[rows]), limbs_to_ints(r[rows])), "ciphertext rows differ from the oracle"
+        # ... and a batch of NON-encryptions of the same size (n^2 - 1, 1, n^2 - 2 among them), resident and from host arrays:
+        # every row against the C oracle, the rows at the part boundaries against pow()
+        raw = _raw_rows(n, bits, count, count + bits)
+        want = _c_oracle_decrypt(p, q, bits, raw)
+        edge = sorted(set(rows) | {count // 2})
+        assert limbs_to_ints(want[edge]) == osk.decrypt(limbs_to_ints(raw[edge]))         # (the checker itself, on the edge rows)
+        hraw = op(L.pgpu_batch_upload, ptr(raw), count, 2 * nw, 2 * nw)
+        draw = op(L.pgpu_batch_decrypt_crt, sk._h, hraw)
+        _capi.check(L.pgpu_batch_download(draw, ptr(got)))
+        assert np.array_equal(got, want), "resident raw decrypt differs from the C oracle"
+        got[:] = 0
+        _capi.check(L.pgpu_paillier_decrypt_crt(sk._h, ptr(raw), ptr(got), count))
+        assert np.array_equal(got, want), "host-array raw decrypt differs from the C oracle"
     finally:
         for h in live:
             L.pgpu_batch_destroy(h)

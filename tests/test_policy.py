@@ -17,7 +17,7 @@ def test_kernel_form_policy(tmp_path):
     exe = str(tmp_path / "policy_tests")
     env = {k: v for k, v in os.environ.items() if not k.startswith("PGPU_")}      # the defaults, not a caller's knobs
     subprocess.run(["g++", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-DPGPU_WITH_4096=0",
-                    "-DPGPU_WITH_AB=0", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+                    "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
                     os.path.join(ROOT, "tests", "cpp", "policy_tests.cpp"), os.path.join(CSRC, "policy.cpp"), "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, env=env)
     print(r.stdout)

@@ -14,8 +14,6 @@ ap.add_argument("--policy", type=int, default=None)
 ap.add_argument("--steps", type=int, default=24)
 ap.add_argument("--count", type=int, default=8192)
 ap.add_argument("--lanes", type=int, nargs="*", default=[1, 2, 3, 4])
-ap.add_argument("--enc-seq", type=int, default=None)
-ap.add_argument("--claim-busy", type=int, default=None)
 ap.add_argument("--gather", type=int, default=0, help="pgpu_set_table_gather_policy")
 ap.add_argument("--bits", type=int, default=2048, help="key size: 2048 (the ISO key), 1024 / 3072 (the seeded DJN fixtures)")
 ap.add_argument("--ps", type=int, default=None, help="PGPU_PS_DECRYPT policy (hensel_ps.hpp): 0 never, 1 adaptive, 2 always")
@@ -24,13 +22,11 @@ pa.initialize(0)
 L = _capi.lib()
 if args.policy is not None:
     L.pgpu_debug_set_seq_decrypt(args.policy)
-if args.enc_seq is not None or args.claim_busy is not None:
-    L.pgpu_debug_set_adaptive(args.enc_seq or 0, 3 if args.claim_busy is None else args.claim_busy)
 if args.gather:
     _capi.check(L.pgpu_set_table_gather_policy(1))
 if args.ps is not None:
     L.pgpu_debug_set_ps_decrypt(args.ps)
-print("ps policy", args.ps, "enc_seq", args.enc_seq, "claim_busy", args.claim_busy)
+print("ps policy", args.ps)
 GOLD = os.path.join(os.path.dirname(__file__), "..", "tests", "golden")
 BITS = args.bits
 if BITS == 2048:
