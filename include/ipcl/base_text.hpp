@@ -74,7 +74,7 @@ class BaseText {
   std::size_t m_size = 0;
   mutable std::shared_ptr<detail::DeviceBatch> m_dev;  // immutable device copy (may be the only copy)
   mutable detail::AtomicFlag m_host_valid{true};
-  int m_bits_hint = -1;         // exact bit length of the widest value when the text was built around host values that
+  mutable int m_bits_hint = -1; // exact bit length of the widest value when the text was built around host values that
                                 // went straight to the GPU (adoptValues); -1: unknown
 
   // construct around a device batch (no host copy yet)
@@ -84,6 +84,7 @@ class BaseText {
   // from the device copy if an accessor ever asks for them.  False: not applicable, the caller copies the values.
   bool adoptValues(const std::vector<BigNumber>& v);
   void ensureHost() const;      // download + unpack if the host copy is missing
+  void dropStaleDevice() const; // a device copy of a pool that has been shut down: values back to the host, copy dropped
   void invalidateDevice();      // before any mutation of m_texts
   // device copy with exactly `words` 64-bit limbs per element (uploaded and cached on demand);
   // values that are negative / too wide are reduced mod *reduce_mod (else: error)

@@ -105,7 +105,23 @@ int BaseText::maxBitsHint() const {
   return detail::max_bits(m_texts);
 }
 
+// A device copy made under a pool that has been shut down since (terminateContext, possibly followed by a new context) is
+// no operand any more: the values come back to the host -- from the pinned block the upload read, DeviceBatch::download --
+// and the copy is dropped, so that the next use uploads to the pool of today.  (The reference's containers own their
+// BigNumbers and keep working across a context restart: base_text.cpp:10-40.)
+void BaseText::dropStaleDevice() const {
+  std::lock_guard<std::mutex> lk(text_mu(this));
+  if (!m_dev || pgpu_batch_is_current(m_dev->h)) return;
+  if (!m_host_valid) {
+    m_texts = m_dev->download();
+    m_host_valid = true;
+  }
+  m_dev.reset();
+  m_bits_hint = -1;
+}
+
 std::shared_ptr<detail::DeviceBatch> BaseText::deviceBatch(int words, const BigNumber* reduce_mod) const {
+  dropStaleDevice();
   {
     std::lock_guard<std::mutex> lk(text_mu(this));
     if (m_dev && m_dev->words == words) return m_dev;
@@ -131,6 +147,7 @@ std::shared_ptr<detail::DeviceBatch> BaseText::deviceBatch(int words, const BigN
 }
 
 std::shared_ptr<detail::DeviceBatch> BaseText::operandBatch(int max_words, const BigNumber* reduce_mod) const {
+  dropStaleDevice();
   if (!m_host_valid) {
     std::lock_guard<std::mutex> lk(text_mu(this));
     if (m_dev && m_dev->words <= max_words) return m_dev;

@@ -6,9 +6,13 @@
 #if defined(PGPU_PART) && (PGPU_PART == 31 || PGPU_PART == 33 || PGPU_PART == 34)
 #include "hensel_ps.hpp"     // whole exponentiations in one lane by product scanning (2048-bit keys; round 5)
 #endif
+#if defined(PGPU_PART) && PGPU_PART == 35
+#include "hensel_ps_n2.hpp"  // ... for the n^2 domain: CT x PT / r^n on resident pair rows (2048-bit keys; round 6)
+#include "launch_n2.hpp"
+#endif
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..34 (15 and 30 are retired)"
+#error "compile with -DPGPU_PART=0..35 (15 and 30 are retired)"
 #endif
 
 namespace pgpu {
@@ -98,9 +102,8 @@ bool launch_hensel_seq_part16(int G, int K, const HenselArgs& a, unsigned blocks
   if (G == 4 && K == 14) {
     // (set at the FIRST launch of the kernel, whatever that launch asks for: a thread that changes the attribute while
     // another thread launches the same function races inside the HIP runtime -- seen as a segfault with four API threads)
-    static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_seq_kernel<4, 14>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    if (lds_pad && once != hipSuccess) return false;
+    const bool once = PGPU_LDS_ATTR_ONCE((hensel_decrypt_seq_kernel<4, 14>), 128 * 1024);
+    if (lds_pad && !once) return false;
     hipLaunchKernelGGL((hensel_decrypt_seq_kernel<4, 14>), dim3(blocks), dim3(kWGThreads), lds_pad, s, a);
     return true;
   }
@@ -111,9 +114,8 @@ bool launch_hensel_seq_part17(int G, int K, const HenselArgs& a, unsigned blocks
   if (G == 2 && K == 19) {
     // (set at the FIRST launch of the kernel, whatever that launch asks for: a thread that changes the attribute while
     // another thread launches the same function races inside the HIP runtime -- seen as a segfault with four API threads)
-    static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_seq_kernel<2, 19>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    if (lds_pad && once != hipSuccess) return false;
+    const bool once = PGPU_LDS_ATTR_ONCE((hensel_decrypt_seq_kernel<2, 19>), 128 * 1024);
+    if (lds_pad && !once) return false;
     hipLaunchKernelGGL((hensel_decrypt_seq_kernel<2, 19>), dim3(blocks), dim3(kWGThreads), lds_pad, s, a);
     return true;
   }
@@ -123,9 +125,8 @@ bool launch_hensel_seq_part17(int G, int K, const HenselArgs& a, unsigned blocks
 // the one-wavefront-per-SIMD build of the (2,19) sequential-halves decrypt: launches under a CU claim only
 bool launch_hensel_seq_w1_part32(int G, int K, const HenselArgs& a, unsigned blocks, hipStream_t s, unsigned lds_pad) {
   if (G == 2 && K == 19 && lds_pad) {
-    static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_seq_kernel<2, 19, 1>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    if (once != hipSuccess) return false;
+    const bool once = PGPU_LDS_ATTR_ONCE((hensel_decrypt_seq_kernel<2, 19, 1>), 128 * 1024);
+    if (!once) return false;
     hipLaunchKernelGGL((hensel_decrypt_seq_kernel<2, 19, 1>), dim3(blocks), dim3(kWGThreads), lds_pad, s, a);
     return true;
   }
@@ -165,11 +166,9 @@ bool launch_hensel_fb_encrypt_seq_part20(int G, int K, const HenselFbArgs& a, un
     // (the kernel's own ~57 KB of LDS + the 84 000-byte claim fit a CU's 160 KB once, not twice; a 128 KB allowance
     // on top of the static part would exceed the CU and the attribute call fails.  Set at the first launch, whatever it
     // asks for: see launch_hensel_seq_part16)
-    static const hipError_t once = hipFuncSetAttribute((const void*)hensel_fb_encrypt_seq_kernel<4, 18>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    static const hipError_t once1 = hipFuncSetAttribute((const void*)hensel_fb_encrypt_seq_kernel<4, 18, 1>,
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    if (dyn && (once != hipSuccess || once1 != hipSuccess)) return false;
+    const bool once = PGPU_LDS_ATTR_ONCE((hensel_fb_encrypt_seq_kernel<4, 18>), 96 * 1024);
+    const bool once1 = PGPU_LDS_ATTR_ONCE((hensel_fb_encrypt_seq_kernel<4, 18, 1>), 96 * 1024);
+    if (dyn && (!once || !once1)) return false;
     // a claim of more than half a CU's LDS (beside ONE busy lane) means one workgroup per CU, one wavefront per SIMD: the
     // build that may use the whole register file.  The 80 000-byte claim of the quarter-chip mode puts TWO workgroups on a
     // CU: the 256-register build.  PGPU_SEQ_W1=0 keeps the 256-register build everywhere
@@ -230,9 +229,8 @@ bool launch_hensel_seq_part29(int G, int K, const HenselArgs& a, unsigned blocks
   if (G == 2 && K == 10) {
     // (set at the FIRST launch of the kernel, whatever that launch asks for: a thread that changes the attribute while
     // another thread launches the same function races inside the HIP runtime -- seen as a segfault with four API threads)
-    static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_seq_kernel<2, 10>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    if (lds_pad && once != hipSuccess) return false;
+    const bool once = PGPU_LDS_ATTR_ONCE((hensel_decrypt_seq_kernel<2, 10>), 128 * 1024);
+    if (lds_pad && !once) return false;
     hipLaunchKernelGGL((hensel_decrypt_seq_kernel<2, 10>), dim3(blocks), dim3(kWGThreads), lds_pad, s, a);
     return true;
   }
@@ -246,11 +244,9 @@ bool launch_hensel_ps_part31(int K, int lb, const HenselArgs& a, unsigned blocks
     // kernel's own parking area (40 KB) counts towards it
     constexpr unsigned kStatic = sizeof(uint4) * kWavesPerWG * ((38 + 3) / 4) * kWave;
     const unsigned dyn = lds_pad > kStatic ? lds_pad - kStatic : 0;
-    static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_ps_kernel<38, 28, 2>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // (first launch: see part 16)
-    static const hipError_t once1 = hipFuncSetAttribute((const void*)hensel_decrypt_ps_kernel<38, 28, 1>,
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    if (dyn && (once != hipSuccess || once1 != hipSuccess)) return false;
+    const bool once = PGPU_LDS_ATTR_ONCE((hensel_decrypt_ps_kernel<38, 28, 2>), 96 * 1024);   // (first launch: see part 16)
+    const bool once1 = PGPU_LDS_ATTR_ONCE((hensel_decrypt_ps_kernel<38, 28, 1>), 96 * 1024);
+    if (dyn && (!once || !once1)) return false;
     // a launch that claims whole CUs runs ONE wavefront per SIMD by construction: the build that may use the whole register
     // file (no scratch; nothing else fits beside it on the SIMD).  PGPU_PS_W1=0 keeps the 256-register build
     static const bool w1 = [] { const char* e = getenv("PGPU_PS_W1"); return !e || atoi(e) != 0; }();
@@ -268,9 +264,8 @@ bool launch_hensel_ps_part33(int K, int lb, const HenselArgs& a, unsigned blocks
   if (K == 56 && lb == 28) {
     constexpr unsigned kStatic = sizeof(uint4) * kWavesPerWG * ((56 + 3) / 4) * kWave;
     const unsigned dyn = lds_pad > kStatic ? lds_pad - kStatic : 0;
-    static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_ps_kernel<56, 28, 1>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // (first launch: see part 16)
-    if (dyn && once != hipSuccess) return false;
+    const bool once = PGPU_LDS_ATTR_ONCE((hensel_decrypt_ps_kernel<56, 28, 1>), 96 * 1024);   // (first launch: see part 16)
+    if (dyn && !once) return false;
     hipLaunchKernelGGL((hensel_decrypt_ps_kernel<56, 28, 1>), dim3(blocks), dim3(kWGThreads), dyn, s, a);
     return true;
   }
@@ -283,15 +278,28 @@ bool launch_hensel_ps_part34(int K, int lb, const HenselArgs& a, unsigned blocks
   if (K == 19 && lb == 29) {
     constexpr unsigned kStatic = sizeof(uint4) * kWavesPerWG * ((19 + 3) / 4) * kWave;
     const unsigned dyn = lds_pad > kStatic ? lds_pad - kStatic : 0;
-    static const hipError_t once = hipFuncSetAttribute((const void*)hensel_decrypt_ps_kernel<19, 29, 2>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // (first launch: see part 16)
-    if (dyn && once != hipSuccess) return false;
+    const bool once = PGPU_LDS_ATTR_ONCE((hensel_decrypt_ps_kernel<19, 29, 2>), 96 * 1024);   // (first launch: see part 16)
+    if (dyn && !once) return false;
     hipLaunchKernelGGL((hensel_decrypt_ps_kernel<19, 29, 2>), dim3(blocks), dim3(kWGThreads), dyn, s, a);
     return true;
   }
   return false;
 }
 static_assert(ps_table_words<19>(32) == 32 * 2 * ((19 + 3) / 4) * 64 * 4, "launch.hpp: hensel_ps_table_words");
+#elif PGPU_PART == 35
+// 2048-bit keys: pair rows of 72 limbs of 29 bits per half, 75 limbs of 28 bits inside the kernel; one wavefront per SIMD
+// (the whole register file); two parking slots per lane in dynamic LDS (155 648 bytes: one workgroup per CU by construction)
+bool launch_hensel_modexp_ps_part35(int L2, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
+  if (L2 == 72) {
+    constexpr unsigned kDyn = 2 * sizeof(uint4) * kWavesPerWG * ((75 + 3) / 4) * kWave;
+    const bool once = PGPU_LDS_ATTR_ONCE((hensel_modexp_ps_kernel<75, 28, 72>), (int)kDyn);
+    if (!once) return false;
+    hipLaunchKernelGGL((hensel_modexp_ps_kernel<75, 28, 72>), dim3(blocks), dim3(kWGThreads), kDyn, s, a);
+    return true;
+  }
+  return false;
+}
+static_assert(psn_table_words<75>(9) == 9 * 2 * ((75 + 3) / 4) * 64 * 4, "launch_n2.hpp: hensel_modexp_ps_table_words");
 #elif PGPU_PART == 14
 bool launch_hensel_fb_encrypt_part14(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
   if (H == 8 && K == 9) {

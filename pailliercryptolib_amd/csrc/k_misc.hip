@@ -29,10 +29,9 @@ bool launch_modmul(int G, int K, const ModmulArgs& a, unsigned blocks, hipStream
       hipFuncAttributes fa{};                                                                                     \
       return hipFuncGetAttributes(&fa, (const void*)crt_kernel<Geo<g, k>>) == hipSuccess ? (unsigned)fa.sharedSizeBytes : ~0u; \
     }();                                                                                                          \
-    static const hipError_t once = hipFuncSetAttribute((const void*)crt_kernel<Geo<g, k>>,                        \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);    \
+    const bool once = PGPU_LDS_ATTR_ONCE((crt_kernel<Geo<g, k>>), 96 * 1024);                                      \
     unsigned dyn = 0;                                                                                             \
-    if (lds_total && own != ~0u && once == hipSuccess && lds_total > own) dyn = lds_total - own;                  \
+    if (lds_total && own != ~0u && once && lds_total > own) dyn = lds_total - own;                  \
     hipLaunchKernelGGL((crt_kernel<Geo<g, k>>), dim3(blocks), dim3(kWGThreads), dyn, s, a);                       \
     return true;                                                                                                  \
   }

@@ -9,6 +9,9 @@
 
 #include "kargs.hpp"
 
+#include <atomic>
+#include <mutex>
+
 // Build switch (pailliercryptolib_amd/build.py passes it to every translation unit, device and host alike):
 //   PGPU_WITH_4096 (env PGPU_BUILD_4096=1)  the split forms of the 4096-bit key class -- (8,18) fixed-base / modexp / pair
 //                  rows, (4,18) and (8,9) CRT decrypt: beyond every BASELINE config and the reference's own 2048-bit cap
@@ -19,6 +22,33 @@
 #endif
 
 namespace pgpu {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize, raised ONCE per (kernel, device): the attribute belongs to the device's copy
+// of the function, so a process-wide once-flag (rounds 3-5) served only the first GPU of a pool that launched the kernel --
+// every other pool entry would have failed its first whole-CU-claim launch (no multi-GPU box had run it).  Set
+// at the FIRST launch of the kernel on that device, whatever the launch asks for, and never changed afterwards: a thread
+// that changes the attribute while another thread launches the same function races inside the HIP runtime (seen as a
+// segfault with four API threads, round 5).  `done`: one bit per HIP device ordinal, owned by the call site.
+inline bool lds_attr_once(const void* fn, int bytes, std::atomic<uint64_t>& done) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  const uint64_t bit = (uint64_t)1 << dev;
+  if (done.load(std::memory_order_acquire) & bit) return true;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.load(std::memory_order_acquire) & bit) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  done.fetch_or(bit, std::memory_order_release);
+  return true;
+}
+#define PGPU_LDS_ATTR_ONCE(kernel_expr, bytes)                                        \
+  ([]() -> bool {                                                                    \
+    static std::atomic<uint64_t> done_{0};                                           \
+    return ::pgpu::lds_attr_once((const void*)(kernel_expr), (bytes), done_);        \
+  }())
 
 // modexp_kernel lives in eight translation units (k_modexp.hip, PGPU_PART 0..7); launch_modexp tries each.
 // regrows: the kernel form whose multiplier rows come from registers (kernels.hpp: modexp_kernel<GEO, true>).

@@ -94,6 +94,12 @@ bool modexp_seq_form_pays(int H, int K, size_t count) {
   if (H == 2 && pol != 2) return false;   // (see fb_encrypt_seq_pays)
   return pol == 2 || (pol == 1 && waves >= (H >= 8 ? 2 : 1) * kSimds);   // (8-lane groups: see fb_encrypt_seq_pays)
 }
+bool modexp_ps_form_pays(size_t count) {
+  const int pol = g_ps_policy.load();
+  if (pol != 1) return pol == 2;
+  const size_t waves = (count + 63) / 64, tail = waves % kSimds;
+  return waves >= kSimds && (tail == 0 || tail >= kSimds / 2 || waves >= 8 * kSimds);
+}
 bool seq_form_pays(int H, int K, size_t count, int busy) {
   if (!pgpu::hensel_seq_has(H, K)) return false;
   const size_t ipw = 64 / (size_t)H;
@@ -145,10 +151,15 @@ int pick_window(int exp_bits) {
 // more -- 3072-bit keys up -- also try w = 6 (1536 bits: 62 + 256 products instead of 30 + 308; 65536 ciphertexts 95.9 ->
 // 94.7 ms).  Not for shorter ones: 1024 bits would tie on products and double the tables of the four-lane headline; and not
 // in pick_window, whose per-element tables of a 1 M-element CT x PT would double with it.
-int pick_decrypt_window(int exp_bits) {
+// The window table of a launch is `entry_bytes` (all exponentiations of the launch, one entry each) x 2^w: w = 6 only while
+// that stays under kDecryptTableCap -- a 65536-ciphertext launch of a 3072-bit key is 3.8 GB at w = 6 (config 4: kept), a
+// 1 M-ciphertext one would be 60 GB for a gain of 1.2 %; entry_bytes = 0: no cap (the by-exponent rule alone).
+constexpr size_t kDecryptTableCap = (size_t)4 << 30;
+int pick_decrypt_window(int exp_bits, size_t entry_bytes) {
   const int w5 = pick_window(exp_bits);
   static const int forced = env_int("PGPU_FIXED_WINDOW", 0, 1, 6);
   if (forced || exp_bits < 1280) return w5;
+  if (entry_bytes > (kDecryptTableCap >> 6)) return w5;
   const long c5 = ((1L << w5) - 2) + (exp_bits + w5 - 1) / w5, c6 = ((1L << 6) - 2) + (exp_bits + 5) / 6;
   return c6 < c5 ? 6 : w5;
 }

@@ -48,6 +48,8 @@ int main() {
   // the decrypt exponent's window: 5 bits up to 2048-bit keys, 6 from 1280-bit exponents up (3072-bit keys: 318 against 338 products)
   CHECK(pol::pick_decrypt_window(512) == pol::pick_window(512) && pol::pick_decrypt_window(1024) == 5);
   CHECK(pol::pick_decrypt_window(1536) == 6 && pol::pick_decrypt_window(2048) == 6 && pol::pick_window(1536) == 5);
+  // ... while the launch's table stays under 4 GiB: 65536 ciphertexts of a 3072-bit key (2 x 65536 entries of 448 B) keep w = 6, 1 M fall back
+  CHECK(pol::pick_decrypt_window(1536, (size_t)2 * 65536 * 448) == 6 && pol::pick_decrypt_window(1536, (size_t)2 * (1 << 20) * 448) == 5);
   // whole-CU claims of part-chip launches
   CHECK(pol::adaptive_cu_claim(512, 1) == 84000u && pol::adaptive_cu_claim(256, 3) == 84000u);
   CHECK(pol::adaptive_cu_claim(512, 0) == 0u && pol::adaptive_cu_claim(1024, 1) == 0u && pol::adaptive_cu_claim(256, 4) == 0u);
@@ -62,6 +64,9 @@ int main() {
   // CT x PT and CT + CT
   CHECK(pol::modexp_seq_form_pays(4, 18, 1 << 20) && !pol::modexp_seq_form_pays(4, 18, 8192));
   CHECK(pol::pair_mul_seq_pays(4, 18, 1 << 20) && !pol::pair_mul_seq_pays(4, 18, 16383 - 16));
+  // ... and the one-lane product-scanning form of the n^2 domain: rounds of 65536 elements
+  CHECK(pol::modexp_ps_form_pays(1 << 20) && pol::modexp_ps_form_pays(65536) && !pol::modexp_ps_form_pays(65535 - 64) && !pol::modexp_ps_form_pays(8192));
+  CHECK(!pol::modexp_ps_form_pays(65536 + 4096) && pol::modexp_ps_form_pays(65536 + 32768) && pol::modexp_ps_form_pays(8 * 65536 + 64));
   // windows
   CHECK(pol::pick_window(1024) == 5 && pol::pick_window(512) == 5 && pol::pick_window(33) == 3 && pol::pick_window(1) == 1);
   CHECK(pol::masked_decrypt_window() == 3);
