@@ -23,7 +23,6 @@
 #include "ipcl/bignum.h"
 #include "kargs.hpp"
 #include "launch.hpp"
-#include "launch_n2.hpp"
 #include "policy.hpp"
 #include "runtime.hpp"
 
@@ -36,7 +35,6 @@ using pgpu::policy::fb_encrypt_seq_pays;
 using pgpu::policy::kSimds;
 using pgpu::policy::masked_decrypt_window;
 using pgpu::policy::modexp_seq_form_pays;
-using pgpu::policy::modexp_ps_form_pays;
 using pgpu::policy::pair_mul_seq_pays;
 using pgpu::policy::pick_window;
 using pgpu::policy::seq_adaptive;
@@ -1285,16 +1283,6 @@ const pgpu_pubkey::PubForm* split_modexp_form(const pgpu_pubkey* key, size_t cou
   const size_t ipw = 64 / (2 * (size_t)last->H);
   return (count + ipw - 1) / ipw > max_waves ? nullptr : last;
 }
-// the one-lane product-scanning kernel of the n^2 domain (hensel_ps_n2.hpp) for `count` exponentiations on rows of this form?
-// The kernel carries a row value shifted left by s = 28*75 - 29*L2 bits: bits(n) + 29 (k) + 3 (lazy: below 8P) + s must fit its
-// 75 limbs of 28 bits.
-bool modexp_ps_applies(const pgpu_pubkey::PubForm* form, size_t count) {
-  const int L2 = form->H * form->K;
-  if (!hensel_enabled() || !pair_rows_enabled() || !pgpu::hensel_modexp_ps_has(L2)) return false;
-  const int s = 28 * 75 - pgpu::kLimbBits * L2;
-  if (s < 0 || s >= 28 || form->n.BitSize() + pgpu::kLimbBits + 3 + s > 28 * 75) return false;
-  return modexp_ps_form_pays(count);
-}
 int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::PubForm* form, const uint64_t* d_base, size_t base_stride,
                     int base_words, bool base_mont, const uint64_t* d_exp, size_t exp_stride, int exp_words,
                     int exp_bits, const SchedRef* sched, int final_mul, const uint64_t* d_m, size_t m_stride,
@@ -1334,25 +1322,6 @@ int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::Pu
   a.out = d_out;
   a.out_stride = (size_t)2 * key->n_words;
   a.count = count;
-  // A whole exponentiation per lane by product scanning (hensel_ps_n2.hpp; round 6): resident rows in and out, a fixed window
-  // (per-element exponents, or one shared exponent scanned the same way), launches that put a wavefront on every SIMD with 64
-  // exponentiations per wavefront (policy.hpp: modexp_ps_form_pays)
-  const bool psn = modexp_ps_applies(form, count) && base_pair && out_pair && base_pair_stride && !a.sched && final_mul == pgpu::FM_UNIT;
-  if (psn) {
-    const int L2 = H * K;
-    const size_t waves = (count + 63) / 64;
-    const unsigned blocks = (unsigned)((waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
-    rt::StreamWork& w = d.work_for(s);
-    std::lock_guard<std::mutex> lk(w.mu);
-    RC_TRY(w.table.ensure((size_t)blocks * pgpu::kWavesPerWG * pgpu::hensel_modexp_ps_table_words(L2, entries) * sizeof(uint32_t), s));
-    a.table = (uint32_t*)w.table.p;
-    TimerScope t(d, s, PGPU_KERNEL_MODEXP, PGPU_FORM_LANE | PGPU_FORM_PS);
-    if (!pgpu::launch_hensel_modexp_ps(L2, a, blocks, s))
-      return fail(PGPU_ERR_UNSUPPORTED, "one-lane product-scanning modexp kernel not compiled");
-    HIP_TRY(hipGetLastError());
-    t.stop();
-    return PGPU_OK;
-  }
   // both halves of a residue in the same lanes (hensel_seq.hpp) when the launch still puts a wavefront on every SIMD
   // that way: resident rows in and out, per-element exponents
   const bool seq = modexp_seq_form_pays(H, K, count) && base_pair && out_pair && !a.sched && final_mul == pgpu::FM_UNIT;
@@ -2154,12 +2123,6 @@ int pgpu_modexp_n2_kernel_form(const pgpu_pubkey* key, size_t count, int* split,
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_modexp_n2_kernel_form: bad argument");
   RC_TRY(check_gen(key->gen, "key"));
   if (const pgpu_pubkey::PubForm* mf = split_modexp_form(key, count)) {
-    if (modexp_ps_applies(mf, count)) {     // (resident rows, fixed window: a whole exponentiation per lane, 75 limbs of 28 bits)
-      *split = 4;
-      *lanes = 1;
-      *limbs = 75;
-      return PGPU_OK;
-    }
     if (pair_rows_enabled() && modexp_seq_form_pays(mf->H, mf->K, count)) {   // (resident rows, per-element exponents)
       *split = 2;
       *lanes = mf->H;

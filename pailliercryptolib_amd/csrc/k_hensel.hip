@@ -6,13 +6,9 @@
 #if defined(PGPU_PART) && (PGPU_PART == 31 || PGPU_PART == 33 || PGPU_PART == 34)
 #include "hensel_ps.hpp"     // whole exponentiations in one lane by product scanning (2048-bit keys; round 5)
 #endif
-#if defined(PGPU_PART) && PGPU_PART == 35
-#include "hensel_ps_n2.hpp"  // ... for the n^2 domain: CT x PT / r^n on resident pair rows (2048-bit keys; round 6)
-#include "launch_n2.hpp"
-#endif
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..35 (15 and 30 are retired)"
+#error "compile with -DPGPU_PART=0..34 (15 and 30 are retired)"
 #endif
 
 namespace pgpu {
@@ -286,20 +282,6 @@ bool launch_hensel_ps_part34(int K, int lb, const HenselArgs& a, unsigned blocks
   return false;
 }
 static_assert(ps_table_words<19>(32) == 32 * 2 * ((19 + 3) / 4) * 64 * 4, "launch.hpp: hensel_ps_table_words");
-#elif PGPU_PART == 35
-// 2048-bit keys: pair rows of 72 limbs of 29 bits per half, 75 limbs of 28 bits inside the kernel; one wavefront per SIMD
-// (the whole register file); two parking slots per lane in dynamic LDS (155 648 bytes: one workgroup per CU by construction)
-bool launch_hensel_modexp_ps_part35(int L2, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
-  if (L2 == 72) {
-    constexpr unsigned kDyn = 2 * sizeof(uint4) * kWavesPerWG * ((75 + 3) / 4) * kWave;
-    const bool once = PGPU_LDS_ATTR_ONCE((hensel_modexp_ps_kernel<75, 28, 72>), (int)kDyn);
-    if (!once) return false;
-    hipLaunchKernelGGL((hensel_modexp_ps_kernel<75, 28, 72>), dim3(blocks), dim3(kWGThreads), kDyn, s, a);
-    return true;
-  }
-  return false;
-}
-static_assert(psn_table_words<75>(9) == 9 * 2 * ((75 + 3) / 4) * 64 * 4, "launch_n2.hpp: hensel_modexp_ps_table_words");
 #elif PGPU_PART == 14
 bool launch_hensel_fb_encrypt_part14(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
   if (H == 8 && K == 9) {

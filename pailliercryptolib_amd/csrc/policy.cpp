@@ -94,12 +94,6 @@ bool modexp_seq_form_pays(int H, int K, size_t count) {
   if (H == 2 && pol != 2) return false;   // (see fb_encrypt_seq_pays)
   return pol == 2 || (pol == 1 && waves >= (H >= 8 ? 2 : 1) * kSimds);   // (8-lane groups: see fb_encrypt_seq_pays)
 }
-bool modexp_ps_form_pays(size_t count) {
-  const int pol = g_ps_policy.load();
-  if (pol != 1) return pol == 2;
-  const size_t waves = (count + 63) / 64, tail = waves % kSimds;
-  return waves >= kSimds && (tail == 0 || tail >= kSimds / 2 || waves >= 8 * kSimds);
-}
 bool seq_form_pays(int H, int K, size_t count, int busy) {
   if (!pgpu::hensel_seq_has(H, K)) return false;
   const size_t ipw = 64 / (size_t)H;

@@ -55,10 +55,6 @@ size_t ps_split_head(int K, size_t count);
 // DJN encrypt onto pair rows / CT x PT / CT + CT of `count` elements in form (H, K): the sequential-halves kernels?
 bool fb_encrypt_seq_pays(int H, int K, size_t count, int busy = 0);
 bool modexp_seq_form_pays(int H, int K, size_t count);
-// CT x PT / r^n of `count` resident elements with a whole exponentiation per lane (hensel_ps_n2.hpp): launches that put a
-// wavefront on every SIMD at 64 exponentiations per wavefront (65536 elements), in rounds of that size -- a last round that
-// is less than half full would cost a whole round: not below 8 rounds then.  PGPU_PS_DECRYPT=0 turns it off, 2 forces it.
-bool modexp_ps_form_pays(size_t count);
 bool pair_mul_seq_pays(int H, int K, size_t count);
 // fixed window of a per-element / secret exponent of exp_bits bits: the w in 1..5 with the fewest products
 int pick_window(int exp_bits);

@@ -64,9 +64,6 @@ int main() {
   // CT x PT and CT + CT
   CHECK(pol::modexp_seq_form_pays(4, 18, 1 << 20) && !pol::modexp_seq_form_pays(4, 18, 8192));
   CHECK(pol::pair_mul_seq_pays(4, 18, 1 << 20) && !pol::pair_mul_seq_pays(4, 18, 16383 - 16));
-  // ... and the one-lane product-scanning form of the n^2 domain: rounds of 65536 elements
-  CHECK(pol::modexp_ps_form_pays(1 << 20) && pol::modexp_ps_form_pays(65536) && !pol::modexp_ps_form_pays(65535 - 64) && !pol::modexp_ps_form_pays(8192));
-  CHECK(!pol::modexp_ps_form_pays(65536 + 4096) && pol::modexp_ps_form_pays(65536 + 32768) && pol::modexp_ps_form_pays(8 * 65536 + 64));
   // windows
   CHECK(pol::pick_window(1024) == 5 && pol::pick_window(512) == 5 && pol::pick_window(33) == 3 && pol::pick_window(1) == 1);
   CHECK(pol::masked_decrypt_window() == 3);

@@ -149,105 +149,3 @@ def test_product_scanning_form_bounds_with_sixteen_fold_headroom(bits, K, LBp):
     # columns: canonical limbs below 2^LB, the doubled operand of a squaring below 2^(LB+1): at most 3K products of 2^(2 LB) each
     assert 3 * K * (1 << (2 * LBp)) < 1 << 64
 
-
-def test_one_lane_n2_form_shifted_radix_three_scans():
-    """csrc/hensel_ps_n2.hpp, limb for limb with Python integers: the SAME loop modulus P = n k (k = -n^-1 mod 2^29, so P == -1
-    modulo 2^28 as well) scanned in K = 75 limbs of 28 bits; the row value x (Montgomery radix R = 2^(29*72)) carried as
-    x~ = x 2^s, s = 28*75 - 29*72 = 12; the general pair product as three column scans (t = a c with its digits; U = a d + q
-    unreduced; b = b c + U reduced); the exit as two s-bit digit steps.  CT x PT with a fixed window must give pow(c, e, n^2)
-    as a pair row of the 29-bit domain; every value stays below 2^(28*75) and every column below 2^64."""
-    LBk, K, L2, RB = 28, 75, 72, 29
-    M = (1 << LBk) - 1
-    k = json.load(open(os.path.join(GOLD, "iso_kat.json")))
-    p, q = int(k["p"], 16), int(k["q"], 16)
-    n = p * q
-    nsq = n * n
-    kk = (-pow(n, -1, 1 << RB)) % (1 << RB)
-    P = n * kk
-    assert P % (1 << RB) == (1 << RB) - 1 and P % (1 << LBk) == M
-    R, Rp = 1 << (RB * L2), 1 << (LBk * K)
-    S = LBk * K - RB * L2
-    assert S == 12 and n.bit_length() + RB + 3 + S <= LBk * K          # capi.cpp: modexp_ps_applies
-    limbs = lambda v, cnt: [(v >> (LBk * i)) & M for i in range(cnt)]
-    num = lambda ls: sum(v << (LBk * i) for i, v in enumerate(ls))
-    nl = limbs(P, K)
-    n1p = nl[1] + 1
-    colmax = [0]
-
-    def scan(x, y, addend, reduce):
-        """one column scan: sum x_i y_(col-i) (+ addend[col]) (+ q_i n_(col-i) with unit digits when reduce); returns
-        (result limbs, digits)"""
-        acc, qd, out = 0, [], []
-        for col in range(2 * K):
-            lo, hi = max(0, col - K + 1), min(col, K - 1)
-            if reduce:
-                for i in range(lo, min(col - 1, K - 1) + 1):          # q_i n_(col-i), i <= col - 1; n_0 rides on n1p
-                    acc += qd[i] * (n1p if col - i == 1 else nl[col - i])
-            for i in range(lo, hi + 1):
-                acc += x[i] * y[col - i]
-            if addend is not None and col < len(addend):
-                acc += addend[col]
-            colmax[0] = max(colmax[0], acc)
-            if reduce and col < K:
-                qd.append(acc & M)
-            else:
-                out.append(acc & M)
-            acc >>= LBk
-        assert acc == 0
-        return out, qd
-
-    def pairmul_mem(x, y):                     # ps_pairmul_mem
-        (a, b), (c, d) = x, y
-        t, qd = scan(a, c, None, True)         # psn_mul_digits
-        U, _ = scan(a, d, qd, False)           # psn_mul_plain: 2K limbs
-        assert len(U) == 2 * K
-        w, _ = scan(b, c, U, True)             # psn_mul_add
-        return (t, w)
-
-    def pairsqr(x):                            # ps_pairsqr: t = a a with digits; b = 2 a b + q reduced
-        a, b = x
-        t, qd = scan(a, a, None, True)
-        w, _ = scan(a, [2 * v for v in b], qd, True)
-        return (t, w)
-
-    def pval(pr):                              # the residue a pair of limb vectors stands for
-        return (num(pr[0]) - P * num(pr[1])) % (P * P)
-
-    def digit_step(x):                         # psn_digit_step
-        v = num(x)
-        qq = v & ((1 << S) - 1)
-        v2 = v + qq * P
-        assert v2 % (1 << S) == 0
-        return limbs(v2 >> S, K), qq
-
-    rng = random.Random(75)
-    for c, e, w in ((rng.randrange(nsq), rng.getrandbits(33), 3), (nsq - 1, (1 << 17) - 1, 3), (rng.randrange(nsq), 0, 1),
-                    (0, 5, 2), (rng.randrange(nsq), rng.getrandbits(64), 4)):
-        # A row as a multi-lane kernel may leave it: components up to 4P.  (+3P, +3P) is NOT another representative of c R --
-        # it is the pair of another residue, c_eff R -- but it has the largest components a row can have, which is what the
-        # bounds are about; the kernel's contract is on the VALUE a - P b of the row, so that value is the base here.
-        a0, b0 = to_pair(c * R, P)
-        a0, b0 = a0 + 3 * P, b0 + 3 * P
-        c_eff = (a0 - P * b0) * pow(R, -1, nsq) % nsq
-        base = ((a0 << S, b0 << S))                            # psn_relimb_in with the shift
-        assert max(base) < 1 << (LBk * K)
-        x1 = (limbs(base[0], K), limbs(base[1], K))
-        one = to_pair(R, P)
-        tbl = [(limbs(one[0] << S, K), limbs(one[1] << S, K)), x1]
-        for _ in range(2, 1 << w):
-            tbl.append(pairmul_mem(tbl[-1], x1))
-        nwin = (max(e.bit_length(), 1) + w - 1) // w
-        x = tbl[(e >> (w * (nwin - 1))) & ((1 << w) - 1)]
-        for i in range(nwin - 2, -1, -1):
-            for _ in range(w):
-                x = pairsqr(x)
-            x = pairmul_mem(x, tbl[(e >> (w * i)) & ((1 << w) - 1)])
-        assert pval(x) % nsq == pow(c_eff, e, nsq) * R * (1 << S) % nsq          # x~ = (c^e R) 2^s
-        # exit: ps_pair_shift_out
-        a1, q1 = digit_step(x[0])
-        b1 = limbs(num(x[1]) + q1, K)
-        b2, _ = digit_step(b1)
-        out = (num(a1), num(b2))
-        assert max(out) < 1 << (RB * L2)                                          # fits the 72 limbs of 29 bits of a row
-        assert (out[0] - P * out[1]) % nsq == pow(c_eff, e, nsq) * R % nsq         # the row of c^e
-    assert colmax[0] < 1 << 64

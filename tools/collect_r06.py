@@ -1,5 +1,5 @@
-"""Copies the round-4 evidence from gpurun_out/ into profiles/r05_* and refreshes profiles/pmc_summary.json
-(tools/, bookkeeping only).  Inputs: tools/profile_r05.sh (gpurun_out/prof_r05{f1,f2,c4,c5}, gpurun_out/r05p)."""
+"""Copies the round-6 evidence from gpurun_out/ into profiles/r06_* and refreshes profiles/pmc_summary.json
+(tools/, bookkeeping only).  Inputs: tools/profile_r06.sh (gpurun_out/prof_r06{f1,f2,c4,c5}, gpurun_out/r06p)."""
 import collections, csv, glob, json, os, shutil, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
@@ -11,19 +11,25 @@ def short(name):
 
 
 def bench_line(src, dst):
-    txt = open(src).read().strip().splitlines()
-    j = json.loads([l for l in txt if l.startswith("{")][-1])
+    """src: the DETAIL record of a bench.py run (bench_detail.json as tools/profile_r06.sh copied it); the compact contract
+    line of the same run lies beside it as *.line.json and is copied beside the record"""
+    j = json.load(open(src))
     open(dst, "w").write(json.dumps(j) + "\n")
+    ln = src[:-5] + ".line.json"
+    if os.path.exists(ln):
+        txt = [l for l in open(ln).read().strip().splitlines() if l.startswith("{")]
+        if txt:
+            open(dst[:-5] + ".line.json", "w").write(txt[-1] + "\n")
     return j
 
 
 build = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 pmc_all = {}
 for tag, label in (("f1", ""), ("f2", "_two_in_flight"), ("f4", "_four_in_flight"), ("c4", ""), ("c5", "")):
-    src = f"gpurun_out/prof_r05{tag}"
+    src = f"gpurun_out/prof_r06{tag}"
     if not os.path.isdir(src):
         continue
-    pre = "profiles/r05" + ("c4" if tag == "c4" else "c5" if tag == "c5" else "")
+    pre = "profiles/r06" + ("c4" if tag == "c4" else "c5" if tag == "c5" else "")
     stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
@@ -70,10 +76,10 @@ for tag, label in (("f1", ""), ("f2", "_two_in_flight"), ("f4", "_four_in_flight
         pmc_all[tag] = out
 
 old_summary = json.load(open("profiles/pmc_summary.json")) if os.path.exists("profiles/pmc_summary.json") else {}
-summary = {"source": "profiles/r05*_pmc_counters*.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in passes of their own, tools/profile_r05.sh; "
+summary = {"source": "profiles/r06*_pmc_counters*.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in passes of their own, tools/profile_r06.sh; "
                      "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 averaged over the full-size launches of the command, the x2 on "
                      "FETCH per MI355X_MICROARCH.md (HBM): gfx950 tallies wide reads at half their size)",
-           "build": build, "collected": __import__("datetime").date.today().isoformat() + " (round 5, tools/profile_r05.sh)"}
+           "build": build, "collected": __import__("datetime").date.today().isoformat() + " (round 6, tools/profile_r06.sh)"}
 
 
 def pick(tag, prefix):
@@ -97,7 +103,7 @@ for key, tag, prefix in (("modexp_decrypt", "f1", "hensel_decrypt_kernel<"), ("s
 if "ct_add_hbm_bytes_per_launch" in summary:
     summary["ct_add_pair_mul_hbm_bytes_per_launch"] = summary["ct_add_hbm_bytes_per_launch"]
 if len(summary) > 3:
-    # a partial run (RUNS=... tools/profile_r05.sh) refreshes its own keys only; "build" / "collected" then name the latest pass
+    # a partial run (RUNS=... tools/profile_r06.sh) refreshes its own keys only; "build" / "collected" then name the latest pass
     for k, v in old_summary.items():
         summary.setdefault(k, v)
     if old_summary.get("build") and old_summary.get("build") != build and len(pmc_all) < 5:
@@ -105,14 +111,14 @@ if len(summary) > 3:
     json.dump(summary, open("profiles/pmc_summary.json", "w"), indent=1)
     print(json.dumps(summary, indent=1))
 
-pairs = [("gpurun_out/r05p/bench_n1.json", "profiles/r05_bench_n1.json"),
-         ("gpurun_out/r05p/bench_f1.json", "profiles/r05_bench_n1_one_in_flight.json"),
-         ("gpurun_out/r05p/bench_f2.json", "profiles/r05_bench_n1_two_in_flight.json"),
-         ("gpurun_out/r05p/bench_c4.json", "profiles/r05_bench_config4_n1.json"),
-         ("gpurun_out/r05p/bench_c5.json", "profiles/r05_bench_config5_n1.json"),
-         ("gpurun_out/r05p/bench_n8_pool_1dev.json", "profiles/r05_bench_n8_pool_1dev.json"),
-         ("gpurun_out/r05p/bench_c4_n8_pool_1dev.json", "profiles/r05_bench_config4_n8_pool_1dev.json"),
-         ("gpurun_out/r05p/bench_c5_n8_pool_1dev.json", "profiles/r05_bench_config5_n8_pool_1dev.json")]
+pairs = [("gpurun_out/r06p/bench_n1.json", "profiles/r06_bench_n1.json"),
+         ("gpurun_out/r06p/bench_f1.json", "profiles/r06_bench_n1_one_in_flight.json"),
+         ("gpurun_out/r06p/bench_f2.json", "profiles/r06_bench_n1_two_in_flight.json"),
+         ("gpurun_out/r06p/bench_c4.json", "profiles/r06_bench_config4_n1.json"),
+         ("gpurun_out/r06p/bench_c5.json", "profiles/r06_bench_config5_n1.json"),
+         ("gpurun_out/r06p/bench_n8_pool_1dev.json", "profiles/r06_bench_n8_pool_1dev.json"),
+         ("gpurun_out/r06p/bench_c4_n8_pool_1dev.json", "profiles/r06_bench_config4_n8_pool_1dev.json"),
+         ("gpurun_out/r06p/bench_c5_n8_pool_1dev.json", "profiles/r06_bench_config5_n8_pool_1dev.json")]
 for s, d in pairs:
     if os.path.exists(s):
         try:
@@ -120,45 +126,39 @@ for s, d in pairs:
             print(d, j["value"], j["ms_per_step"], j["roofline"].get("kernel_ms"), j["roofline"].get("frac"), j.get("host_issue_ms_per_step"))
         except Exception as e:                                  # noqa: BLE001
             print(d, "unreadable:", e)
-for s, d in [("gpurun_out/r05p/ipcl_api_bench.txt", "profiles/r05_ipcl_api_bench.txt"),
-             ("gpurun_out/r05p/lanes.txt", "profiles/r05_lanes.txt"),
-             ("gpurun_out/r05p/trace_2lanes.txt", "profiles/r05_trace_2lanes.txt"),
-             ("gpurun_out/r05p/trace_4lanes.txt", "profiles/r05_trace_4lanes.txt"),
-             ("gpurun_out/r05p/lanes_masked.txt", "profiles/r05_lanes_masked_gather.txt"),
-             ("gpurun_out/r05p/big_ps1.txt", "profiles/r05_decrypt_65536_ps.txt"),
-             ("gpurun_out/r05p/big_ps0.txt", "profiles/r05_decrypt_65536_seq.txt")]:
+for s, d in [("gpurun_out/r06p/ipcl_api_bench.txt", "profiles/r06_ipcl_api_bench.txt"),
+             ("gpurun_out/r06p/lanes.txt", "profiles/r06_lanes.txt"),
+             ("gpurun_out/r06p/trace_2lanes.txt", "profiles/r06_trace_2lanes.txt"),
+             ("gpurun_out/r06p/trace_4lanes.txt", "profiles/r06_trace_4lanes.txt"),
+             ("gpurun_out/r06p/lanes_masked.txt", "profiles/r06_lanes_masked_gather.txt"),
+             ("gpurun_out/r06p/big_ps1.txt", "profiles/r06_decrypt_65536_ps.txt"),
+             ("gpurun_out/r06p/big_ps0.txt", "profiles/r06_decrypt_65536_seq.txt")]:
     if os.path.exists(s):
         txt = [l for l in open(s).read().splitlines() if "amdgpu.ids" not in l]
         open(d, "w").write("\n".join(txt) + "\n")
-if os.path.exists("gpurun_out/r05p/two_callers.txt"):
-    with open("profiles/r05_two_callers.txt", "w") as f:
+if os.path.exists("gpurun_out/r06p/two_callers.txt"):
+    with open("profiles/r06_two_callers.txt", "w") as f:
         f.write("# tools/probe_two_callers.py <pageable|pinned> <callers> <rounds>: host threads calling pgpu_paillier_encrypt +\n"
                 "# pgpu_paillier_decrypt_crt (8192 x 2048-bit) synchronously on host arrays of their own; per-caller start / encrypt / decrypt\n"
                 "# wall times (ms) and the aggregate rate.  PGPU_D2H_PRESYNC=1 (the default): a download is handed to the copy engine only\n"
                 "# once the kernels in front of it have run -- otherwise it parks the engine's ring on that kernel and the other caller's\n"
                 "# uploads wait behind it (=0: the behaviour before).  PGPU_HOST_ADAPT=1: the callers' launches take the half-chip forms of\n"
                 "# the adaptive policy (off by default: slower for synchronous callers).\n")
-        f.write("".join(l for l in open("gpurun_out/r05p/two_callers.txt") if not l.startswith("+")))
-if os.path.exists("gpurun_out/r05p/ipcl_api_threads.txt"):
-    with open("profiles/r05_ipcl_api_threads.txt", "w") as f:
+        f.write("".join(l for l in open("gpurun_out/r06p/two_callers.txt") if not l.startswith("+")))
+if os.path.exists("gpurun_out/r06p/ipcl_api_threads.txt"):
+    with open("profiles/r06_ipcl_api_threads.txt", "w") as f:
         f.write("# pailliercryptolib_amd/ipcl_api_bench --threads T 8192 8 (tests/cpp/ipcl_bench.cpp): T host threads, each\n"
                 "# ipcl::PublicKey::encrypt + PrivateKey::decrypt with vector<BigNumber> in and out (the benchmark key: 2047-bit injected r)\n")
-        f.write("".join(l for l in open("gpurun_out/r05p/ipcl_api_threads.txt") if not l.startswith("+")))
-if os.path.exists("gpurun_out/r05p/ipcl_api_threads_small.txt"):
-    shutil.copy("gpurun_out/r05p/ipcl_api_threads_small.txt", "profiles/r05_ipcl_api_threads_small.txt")
-if os.path.exists("gpurun_out/r05p/lane_decrypt.txt"):
-    with open("profiles/r05_lane_decrypt.txt", "w") as f:
-        f.write("# tools/run_r05_e.sh: CRT decrypt of 65536 ciphertexts under a 1024-bit key, one-lane kernel (csrc/hensel_lane.hpp, default from\n"
-                "# 32768 ciphertexts) against the sequential-halves kernel (PGPU_LANE_DECRYPT=0): rocprofv3 kernel stats and, in a pass of\n"
-                "# its own, PMC.  GRBM_GUI_ACTIVE / 8 XCDs / kernel time = the clock the chip held under the kernel.\n")
-        f.write("".join(l for l in open("gpurun_out/r05p/lane_decrypt.txt") if "amdgpu.ids" not in l and not l.startswith("+")))
-ks = [f"gpurun_out/r05p/keysizes_{c}.txt" for c in (16384, 65536, 131072)]
+        f.write("".join(l for l in open("gpurun_out/r06p/ipcl_api_threads.txt") if not l.startswith("+")))
+if os.path.exists("gpurun_out/r06p/ipcl_api_threads_small.txt"):
+    shutil.copy("gpurun_out/r06p/ipcl_api_threads_small.txt", "profiles/r06_ipcl_api_threads_small.txt")
+ks = [f"gpurun_out/r06p/keysizes_{c}.txt" for c in (16384, 65536)]
 if all(os.path.exists(f) for f in ks):
-    with open("profiles/r05_keysizes_split_on_off.txt", "w") as f:
-        f.write("# tools/bench_keysizes.py <count> (tools/profile_r05.sh): resident batches per key class, wall time of the second call incl.\n"
+    with open("profiles/r06_keysizes_split_on_off.txt", "w") as f:
+        f.write("# tools/bench_keysizes.py <count> (tools/profile_r06.sh): resident batches per key class, wall time of the second call incl.\n"
                 "# launch overhead, PGPU_HENSEL off / on; decrypt leg as a fraction of the int-ALU peak (39.32 T MAC32/s): executed by the\n"
                 "# kernel that ran / useful count of the split form.  Build without the 4096-bit split forms (PGPU_BUILD_4096=0, the default).\n")
         for fn in ks:
             f.write("".join(l for l in open(fn) if "amdgpu.ids" not in l))
             f.write("\n")
-    print(open("profiles/r05_keysizes_split_on_off.txt").read())
+    print(open("profiles/r06_keysizes_split_on_off.txt").read())
