@@ -325,7 +325,8 @@ typedef enum pgpu_kernel_form {
   PGPU_FORM_SEQ = 2,
   PGPU_FORM_LANE = 4,      /* a whole exponentiation per lane; always together with PGPU_FORM_PS since round 6 */
   PGPU_FORM_PS = 8,        /* with PGPU_FORM_LANE: by product scanning (hensel_ps.hpp: 1024- to 3072-bit keys; round 5) */
-  PGPU_FORM_CU_CLAIM = 16
+  PGPU_FORM_CU_CLAIM = 16,
+  PGPU_FORM_WAVE = 32      /* one exponentiation per WAVEFRONT, a limb per lane (hensel_wave.hpp: CRT decrypt of small batches; round 6) */
 } pgpu_kernel_form;
 int pgpu_timing_collect_ex(int* kinds, int* forms, double* ms, int max_entries);
 /* ... and as a small kernel trace: batch lane of each launch (-1: another stream) and its start relative to the first
@@ -347,7 +348,9 @@ int pgpu_kernel_geometry(int in_words, int mod_bits, size_t count, int* lanes, i
  * more than 16384 ciphertexts (3072-bit keys: 24576) in rounds of 32768 -- the form reported is that of the full rounds; a
  * mostly empty last round runs as a launch of its own in the form of its size -- or smaller ones that cover the SIMDs
  * together with busy neighbour lanes: 8192 beside three;
- * PGPU_PS_DECRYPT=0 turns it off); *split = 0: the full-width modexp_kernel<Geo<*lanes, *limbs>>.
+ * PGPU_PS_DECRYPT=0 turns it off); *split = 5 (round 6): hensel_decrypt_wave_kernel<*limbs, 28 | 29> -- one exponentiation per
+ * wavefront (*lanes = 64), a limb per lane: lone decrypts of up to 512 ciphertexts of 1024- to 3072-bit keys;
+ * *split = 0: the full-width modexp_kernel<Geo<*lanes, *limbs>>.
  * Host-side query. */
 int pgpu_decrypt_kernel_form(const pgpu_privkey* key, size_t count, int* split, int* lanes, int* limbs);
 /* ... when `busy_lanes` OTHER batch lanes of the GPU have work queued at launch time (round 4, the adaptive policy: a

@@ -50,7 +50,7 @@ def hensel_parts():
     skip = {15, 30}      # (retired in round 6: the A/B-wavefront experiment and the operand-scanning one-lane kernel)
     if not build_4096():
         skip |= {22, 23, 24}
-    return [p for p in range(35) if p not in skip]
+    return [p for p in range(36) if p not in skip]
 
 
 def _objects():
@@ -76,8 +76,10 @@ def _objects():
         src = os.path.join(CSRC, "k_hensel.hip")
         o = os.path.join(obj, f"k_hensel_{part}.o")
         hdeps_k = [os.path.join(CSRC, f) for f in ("hensel.hpp", "hensel_q.hpp", "hensel_seq.hpp")]
-        if part in (31, 33, 34):
+        if part in (31, 33, 34, 35):
             hdeps_k.append(os.path.join(CSRC, "hensel_ps.hpp"))
+        if part == 35:
+            hdeps_k.append(os.path.join(CSRC, "hensel_wave.hpp"))
         out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src] + hdeps_k + kdeps))
     for name in ("capi.cpp", "policy.cpp", "runtime.cpp", os.path.join("host", "bignum.cpp")):
         src = os.path.join(CSRC, name)

@@ -1595,6 +1595,10 @@ int host_busy(rt::Device& dev, int lane) {
 bool ps_form_pays(const pgpu_privkey* key, size_t count, int busy) {
   return key->hs_ps && hensel_enabled() && policy::ps_form_pays(count, busy, key->hs_ps->K);
 }
+// the latency form on the same constants (csrc/hensel_wave.hpp: one exponentiation per wavefront) for a small lone decrypt?
+bool wave_form_pays(const pgpu_privkey* key, size_t count, int busy) {
+  return key->hs_ps && hensel_enabled() && pgpu::hensel_wave_has(key->hs_ps->K, key->hs_ps->lb) && policy::wave_form_pays(count, busy);
+}
 int words_to_pair_on(rt::Device& d, const pgpu_pubkey::PubForm* f, const uint64_t* words, size_t stride, int nwords,
                      bool src_mont, uint32_t* out, size_t count, hipStream_t s);
 int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint64_t* d_m, size_t count,
@@ -1625,15 +1629,17 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
   if (!d_pair && !sliding && hset && key->conv_form) {
     const pgpu_privkey::HenselSet* cand = hset;
     const int cl2 = key->conv_form->H * key->conv_form->K;
-    if (cand->pair_l2 == cl2 && (seq_form_pays(cand->H, cand->K, count, busy_lanes) || ps_form_pays(key, count, busy_lanes))) {
+    if (cand->pair_l2 == cl2 && (seq_form_pays(cand->H, cand->K, count, busy_lanes) || ps_form_pays(key, count, busy_lanes) ||
+                                 wave_form_pays(key, count, busy_lanes))) {
       RC_TRY(conv_rows.alloc(d, s, count * (size_t)2 * cl2 * sizeof(uint32_t)));
       RC_TRY(words_to_pair_on(d, key->conv_form.get(), d_c, (size_t)2 * nw, 2 * nw, in_mont, (uint32_t*)conv_rows.p, count, s));
       d_pair = (const uint32_t*)conv_rows.p;
       in_pair_l2 = cl2;
     }
   }
-  const bool psf = d_pair && !sliding && hset && ps_form_pays(key, count, busy_lanes) &&
-                   key->hs_ps->pair_l2 == in_pair_l2;
+  const bool wavef = d_pair && !sliding && hset && wave_form_pays(key, count, busy_lanes) && key->hs_ps->pair_l2 == in_pair_l2;
+  const bool psf = wavef || (d_pair && !sliding && hset && ps_form_pays(key, count, busy_lanes) &&
+                             key->hs_ps->pair_l2 == in_pair_l2);
   if (psf) hset = key->hs_ps.get();
   if (d_pair && (!hset || hset->pair_l2 != in_pair_l2))
     return fail(PGPU_ERR_UNSUPPORTED, "decrypt: pair-row ciphertexts need the split-form kernel of this key size");
@@ -1684,6 +1690,7 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
       entries = (size_t)1 << (h.window - 1);
     } else {
       h.window = g_ct_gather.load() ? std::min(masked_decrypt_window(), pick_window(h.exp_bits)) : policy::pick_decrypt_window(h.exp_bits, 2 * count * (size_t)2 * L2 * sizeof(uint32_t));
+      if (wavef) h.window = std::min(h.window, 5);      // (its table is LDS: 32 entries per wavefront at most)
       entries = (size_t)1 << h.window;
     }
     h.ct_gather = g_ct_gather.load();
@@ -1700,7 +1707,15 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
     const size_t seq_waves = 2 * ((count + seq_ipw - 1) / seq_ipw);
     const bool seq = !psf && d_pair && !sliding && seq_form_pays(hset->H, hset->K, count, busy_lanes);
     t.set_form(psf ? PGPU_FORM_LANE | PGPU_FORM_PS : seq ? PGPU_FORM_SEQ : PGPU_FORM_PAIRED);
-    if (psf) {
+    if (wavef) {
+      // the latency form: entry (one lane per exponentiation) -> one wavefront per exponentiation -> exit; the workspace
+      // is the pair buffer between the three launches, the window table lives in the wave kernel's LDS
+      t.set_form(PGPU_FORM_WAVE | PGPU_FORM_PS);
+      RC_TRY(w.table.ensure(2 * count * pgpu::hensel_wave_pair_words(hset->K) * sizeof(uint32_t), s));
+      h.table = (uint32_t*)w.table.p;
+      if (!pgpu::launch_hensel_wave(hset->K, hset->lb, h, s))
+        return fail(PGPU_ERR_UNSUPPORTED, "wavefront-wide decrypt kernel not compiled");
+    } else if (psf) {
       const size_t lwaves = 2 * ((count + 63) / 64);
       const unsigned lblocks = (unsigned)((lwaves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
       RC_TRY(w.table.ensure((size_t)lblocks * pgpu::kWavesPerWG * pgpu::hensel_ps_table_words(hset->K, entries) * sizeof(uint32_t), s));
@@ -2166,6 +2181,13 @@ int pgpu_decrypt_kernel_form_ex(const pgpu_privkey* key, size_t count, int busy_
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_decrypt_kernel_form: bad argument");
   RC_TRY(check_gen(key->gen, "key"));
   if (const pgpu_privkey::HenselSet* f = pick_hensel(key, count)) {
+    if (pair_rows_enabled() && secret_policy() != PGPU_EXP_SLIDING && wave_form_pays(key, count, busy_lanes) &&
+        key->hs_ps->pair_l2 == f->pair_l2) {
+      *split = 5;
+      *lanes = 64;
+      *limbs = key->hs_ps->K;
+      return PGPU_OK;
+    }
     if (pair_rows_enabled() && secret_policy() != PGPU_EXP_SLIDING && ps_form_pays(key, count, busy_lanes) &&
         key->hs_ps->pair_l2 == f->pair_l2) {
       *split = 4;
@@ -2232,6 +2254,9 @@ int pgpu_debug_set_host_adapt(int on) {
 int pgpu_debug_get_seq_decrypt(void) { return pgpu::policy::seq_policy(); }
 // tests / A-B measurements: hensel_ps.hpp (0 never, 1 by launch size and neighbour lanes, 2 whenever it is compiled)
 void pgpu_debug_set_ps_decrypt(int policy) { pgpu::policy::set_ps_policy(policy); }
+// tests / A-B measurements: hensel_wave.hpp (0 never, 1 small lone launches, 2 whenever it is compiled)
+void pgpu_debug_set_wave_decrypt(int policy) { pgpu::policy::set_wave_policy(policy); }
+int pgpu_debug_get_wave_decrypt(void) { return pgpu::policy::wave_policy(); }
 int pgpu_debug_get_ps_decrypt(void) { return pgpu::policy::ps_policy(); }
 // tests / A-B measurements: from how many active neighbour lanes on threads on round-robin lanes take the adaptive forms (0 never)
 int pgpu_debug_set_rr_adapt(int min_busy) { return pgpu::policy::set_rr_adapt(min_busy); }

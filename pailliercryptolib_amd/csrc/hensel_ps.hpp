@@ -359,46 +359,16 @@ __device__ __forceinline__ void ps_table_load(uint32_t (&a)[K], uint32_t (&b)[K]
   }
 }
 
-// One wavefront = 64 ciphertexts of ONE side (wave parity: even = p, odd = q).  Output: row 2i = mp, row 2i+1 = mq
-// (canonical words) for crt_kernel, like hensel_decrypt_kernel.  K limbs of LB bits per half; the constants of A.ctx are
-// in THAT limb width, the pair rows of A.ct_pair in the 29-bit limbs (kLimbBits) every other kernel writes.
-// A.table: ps_table_words<K>(entries) 32-bit words per wavefront.
-template <int K>
-constexpr size_t ps_table_words(size_t entries) { return entries * 2 * ((K + 3) / 4) * kWave * 4; }
-
-template <int K, int LB, int MINW>
-__global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_ps_kernel(HenselArgs A) {
-  constexpr int K4 = (K + 3) / 4, RB = kLimbBits;
+// c*R modulo the side's P^2 as a pair (a, b) from the pair row of the n^2 domain (hensel_decrypt_kernel: the ct_pair entry):
+// per chunk of the row a single product for its b half and a pair product for its a half.  ma / mb: scratch of the caller
+// (they leave holding copies of a / b: the base of the window table).
+template <int K, int LB>
+__device__ __forceinline__ void ps_entry_from_pair_row(const HenselArgs& A, int side, size_t elem, const uint32_t (&n)[K],
+                                                       uint32_t n1p, uint4* slot, uint32_t (&a)[K], uint32_t (&b)[K],
+                                                       uint32_t (&ma)[K], uint32_t (&mb)[K]) {
+  constexpr int RB = kLimbBits;
   constexpr int NI = (K * LB - 2) / RB + 1;      // row limbs per entry chunk that fit a half, plus one for the carry
-  constexpr int W64 = (K * LB + 63) / 64;
-  raise_wave_priority();
-  __shared__ uint4 park_[kWavesPerWG][K4][kWave];
-  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
-  uint4* slot = &park_[wv][0][lane];
-  const size_t wave_id = (size_t)blockIdx.x * kWavesPerWG + wv;
-  const int side = __builtin_amdgcn_readfirstlane((int)(wave_id & 1));
-  const size_t first_elem = (wave_id >> 1) * kWave;
-  size_t elem = first_elem + lane;
-  if (elem >= A.count) elem = A.count - 1;
 #define HCTX(field) (side ? A.ctx[1].field : A.ctx[0].field)
-  uint32_t n[K], a[K], b[K], ma[K], mb[K];
-#pragma unroll
-  for (int j = 0; j < K; ++j) n[j] = ps_uniform(HCTX(nhat)[j]);   // wave-uniform: SGPR operands of the products
-  const uint32_t n1p = n[1] + 1;
-  const int w = A.window, tsize = 1 << w;
-  uint4* tw = reinterpret_cast<uint4*>(A.table + wave_id * ps_table_words<K>((size_t)tsize)) + lane;
-  const uint64_t* ep = A.exp + (size_t)side * A.exp_stride;
-  const int nwin = (A.exp_bits + w - 1) / w;
-  auto digit = [&](int i) -> int {
-    int bit = i * w;
-    int word = bit >> 6, sh = bit & 63;
-    uint64_t v = (word < A.exp_words) ? ep[word] >> sh : 0;
-    if (sh + w > 64 && word + 1 < A.exp_words) v |= ep[word + 1] << (64 - sh);
-    return (int)(v & (uint64_t)(tsize - 1));
-  };
-  const bool gather = A.ct_gather != 0;
-
-  // ---- c*R as a pair from the pair row of the n^2 domain (hensel_decrypt_kernel: the ct_pair entry) ----
   {
     const uint32_t* row = A.ct_pair + elem * A.ct_pair_stride;
     uint32_t acc_a[K], acc_b[K];
@@ -437,6 +407,105 @@ __global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_ps_kernel(Hen
       b[j] = mb[j] = acc_b[j];
     }
   }
+#undef HCTX
+}
+
+// Exit under the TRUE prime: (a, k*b mod p) times (hp, 0);  mp = ([a' >= p] - b') mod p, written as canonical words to row
+// 2*elem + side of A.out (crt_kernel's input).  a, b: the pair of c^(p-1) R in canonical limbs; ma / mb: scratch.
+template <int K, int LB>
+__device__ __forceinline__ void ps_exit_words(const HenselArgs& A, int side, size_t elem, bool live, uint4* slot,
+                                              uint32_t (&a)[K], uint32_t (&b)[K], uint32_t (&ma)[K], uint32_t (&mb)[K]) {
+  constexpr int W64 = (K * LB + 63) / 64;
+#define HCTX(field) (side ? A.ctx[1].field : A.ctx[0].field)
+  uint32_t np[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    np[j] = ps_uniform(HCTX(n)[j]);
+    ma[j] = HCTX(kr)[j];
+  }
+  const uint32_t n0 = HCTX(n0inv);
+  {
+    uint32_t kb[K];
+    ps_mul<K, LB, false>(kb, b, ma, np, 0, n0);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      b[j] = kb[j];
+      ma[j] = HCTX(h)[j];
+      mb[j] = 0;
+    }
+  }
+  ps_pairmul<K, LB, false>(a, b, ma, mb, np, 0, n0, slot);
+  uint32_t d[K];
+  const uint32_t below_a = ps_sub<K, LB>(d, a, np);
+  const uint32_t jflag = below_a ^ 1u;
+  const uint32_t below = ps_sub<K, LB>(d, b, np);
+  if (!below) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) b[j] = d[j];
+  }
+  (void)ps_sub<K, LB>(d, np, b);
+  {
+    uint32_t jf[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) jf[j] = j == 0 ? jflag : 0u;
+    ps_add<K, LB>(d, jf);
+  }
+  const uint32_t small = ps_sub<K, LB>(b, d, np);
+  if (small) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) b[j] = d[j];
+  }
+  if (live) {
+    uint64_t* out = A.out + (2 * elem + side) * A.out_stride;
+    const int ow = A.out_words;
+    ps_static_for<W64>([&](auto wc) __attribute__((always_inline)) {
+      constexpr int ww = decltype(wc)::value;
+      if (ww < ow) out[ww] = ps_word<K, LB, ww>(b);
+    });
+    for (int ww = W64; ww < ow; ++ww) out[ww] = 0;
+  }
+#undef HCTX
+}
+
+// One wavefront = 64 ciphertexts of ONE side (wave parity: even = p, odd = q).  Output: row 2i = mp, row 2i+1 = mq
+// (canonical words) for crt_kernel, like hensel_decrypt_kernel.  K limbs of LB bits per half; the constants of A.ctx are
+// in THAT limb width, the pair rows of A.ct_pair in the 29-bit limbs (kLimbBits) every other kernel writes.
+// A.table: ps_table_words<K>(entries) 32-bit words per wavefront.
+template <int K>
+constexpr size_t ps_table_words(size_t entries) { return entries * 2 * ((K + 3) / 4) * kWave * 4; }
+
+template <int K, int LB, int MINW>
+__global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_ps_kernel(HenselArgs A) {
+  constexpr int K4 = (K + 3) / 4;
+  raise_wave_priority();
+  __shared__ uint4 park_[kWavesPerWG][K4][kWave];
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  uint4* slot = &park_[wv][0][lane];
+  const size_t wave_id = (size_t)blockIdx.x * kWavesPerWG + wv;
+  const int side = __builtin_amdgcn_readfirstlane((int)(wave_id & 1));
+  const size_t first_elem = (wave_id >> 1) * kWave;
+  size_t elem = first_elem + lane;
+  if (elem >= A.count) elem = A.count - 1;
+#define HCTX(field) (side ? A.ctx[1].field : A.ctx[0].field)
+  uint32_t n[K], a[K], b[K], ma[K], mb[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) n[j] = ps_uniform(HCTX(nhat)[j]);   // wave-uniform: SGPR operands of the products
+  const uint32_t n1p = n[1] + 1;
+  const int w = A.window, tsize = 1 << w;
+  uint4* tw = reinterpret_cast<uint4*>(A.table + wave_id * ps_table_words<K>((size_t)tsize)) + lane;
+  const uint64_t* ep = A.exp + (size_t)side * A.exp_stride;
+  const int nwin = (A.exp_bits + w - 1) / w;
+  auto digit = [&](int i) -> int {
+    int bit = i * w;
+    int word = bit >> 6, sh = bit & 63;
+    uint64_t v = (word < A.exp_words) ? ep[word] >> sh : 0;
+    if (sh + w > 64 && word + 1 < A.exp_words) v |= ep[word + 1] << (64 - sh);
+    return (int)(v & (uint64_t)(tsize - 1));
+  };
+  const bool gather = A.ct_gather != 0;
+
+  // ---- c*R as a pair from the pair row of the n^2 domain (hensel_decrypt_kernel: the ct_pair entry) ----
+  ps_entry_from_pair_row<K, LB>(A, side, elem, n, n1p, slot, a, b, ma, mb);
   // ---- window table: entry 0 = one, entry 1 = base, entry e = entry e-1 times base ----
   ps_table_store<K>(tw, 1, a, b);
   {
@@ -479,53 +548,7 @@ __global__ __launch_bounds__(kWGThreads, MINW) void hensel_decrypt_ps_kernel(Hen
     ps_pairmul<K, LB, true>(a, b, ma, mb, n, n1p, 0, slot);
   }
   // ---- exit under the TRUE prime: (a, k*b mod p) times (hp, 0);  mp = ([a' >= p] - b') mod p ----
-  uint32_t np[K];
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    np[j] = ps_uniform(HCTX(n)[j]);
-    ma[j] = HCTX(kr)[j];
-  }
-  const uint32_t n0 = HCTX(n0inv);
-  {
-    uint32_t kb[K];
-    ps_mul<K, LB, false>(kb, b, ma, np, 0, n0);
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      b[j] = kb[j];
-      ma[j] = HCTX(h)[j];
-      mb[j] = 0;
-    }
-  }
-  ps_pairmul<K, LB, false>(a, b, ma, mb, np, 0, n0, slot);
-  uint32_t d[K];
-  const uint32_t below_a = ps_sub<K, LB>(d, a, np);
-  const uint32_t jflag = below_a ^ 1u;
-  const uint32_t below = ps_sub<K, LB>(d, b, np);
-  if (!below) {
-#pragma unroll
-    for (int j = 0; j < K; ++j) b[j] = d[j];
-  }
-  (void)ps_sub<K, LB>(d, np, b);
-  {
-    uint32_t jf[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) jf[j] = j == 0 ? jflag : 0u;
-    ps_add<K, LB>(d, jf);
-  }
-  const uint32_t small = ps_sub<K, LB>(b, d, np);
-  if (small) {
-#pragma unroll
-    for (int j = 0; j < K; ++j) b[j] = d[j];
-  }
-  if (first_elem + lane < A.count) {
-    uint64_t* out = A.out + (2 * elem + side) * A.out_stride;
-    const int ow = A.out_words;
-    ps_static_for<W64>([&](auto wc) __attribute__((always_inline)) {
-      constexpr int ww = decltype(wc)::value;
-      if (ww < ow) out[ww] = ps_word<K, LB, ww>(b);
-    });
-    for (int ww = W64; ww < ow; ++ww) out[ww] = 0;
-  }
+  ps_exit_words<K, LB>(A, side, elem, first_elem + lane < A.count, slot, a, b, ma, mb);
 #undef HCTX
 }
 

@@ -1,0 +1,271 @@
+// pailliercryptolib_amd -- the LATENCY form of the CRT-decrypt exponentiation (round 6): ONE exponentiation per WAVEFRONT, one
+// limb per lane.  hensel_decrypt_wave_kernel<K, LB> with hensel_ps_entry_kernel / hensel_ps_exit_kernel around it; CRT decrypt of
+// SMALL batches (up to 512 ciphertexts: 2 x count wavefronts, at most one per SIMD) -- the reference's BM_Decrypt sizes 16 ... 512,
+// benchmark/bench_cryptography.cpp:10-19.  The two half-width exponentiations of PrivateKey::decryptCRT, ipcl/pri_key.cpp:114-146.
+//
+// A launch of fewer wavefronts than SIMDs lasts as long as ONE exponentiation's serial chain: 1024 pair squarings + 235 pair
+// products for a 2048-bit key.  The multi-lane latency forms (hensel_decrypt_kernel<8,5>: 16 lanes per exponentiation) spend
+// 1.94 us per pair squaring -- block-serial reduction rows with cross-lane digit broadcasts and limb hand-overs.  Here a
+// residue's half is spread over the WHOLE wavefront, lane l holding limb l (K <= 63 of the 64 lanes), and a Montgomery product is
+// the textbook operand scan with the accumulator sliding down the lanes:
+//     step i:   acc_l += a_i * b_l                      a_i wave-uniform: an SGPR (v_readlane, once per product and limb)
+//               q = acc_0 mod 2^LB                      v_readfirstlane + s_and: the digit is an SGPR as well (P == -1: no multiply)
+//               acc_l += q * P_l                        lane 0's low limb becomes zero
+//               acc_l = (acc_{l+1} mod 2^LB) + (acc_l >> LB)       one v_lshrrev_b64, one v_and_b32_dpp wave_shl:1, one multiply-add
+// -- seven instructions per step whatever K is, K steps per half-width product, no LDS, no waiting for memory.  The last line
+// both slides the window and keeps every accumulator below 2^37 (each lane passes its own carry one column up while it
+// takes over its neighbour's low limb), so limbs need not be canonical anywhere: products leave RELAXED limbs (below
+// 2^LB + 2^9).  The pair product of hensel.hpp on top of it: t = a*c with its digits q_i kept in SGPRs; w = a*d + b*c + q
+// with q_i added to lane 0 in step i.  ~620 instructions per pair squaring against ~900 of the 16-lane form, on a chain
+// without LDS round trips.
+// The same constants as hensel_decrypt_ps_kernel (the key's hs_ps set: K limbs of LB bits, P == -1 mod 2^LB), and its entry
+// and exit CODE: hensel_ps_entry_kernel runs ps_entry_from_pair_row one lane per exponentiation and leaves the pair in a
+// buffer, hensel_ps_exit_kernel picks the result up, makes its limbs canonical and runs ps_exit_words -- ~60 us of one-lane
+// work around 1.7 ms, in exchange for not restating either in the limb-per-lane layout.
+// The window table lives in LDS (2^w entries x 2 x K limbs per wavefront); the exponent is the side's secret p-1 / q-1, the
+// same for every wavefront of a side: its digits are scalar, and under the masked-access policy every entry is read and the
+// wanted one selected with a per-lane compare (no branch on the digit).
+#ifndef PAILLIERCRYPTOLIB_AMD_CSRC_HENSEL_WAVE_HPP_
+#define PAILLIERCRYPTOLIB_AMD_CSRC_HENSEL_WAVE_HPP_
+
+#include "hensel_ps.hpp"
+
+namespace pgpu {
+
+// lane l <- lane l+1 of the wavefront (lane 63 <- 0), ANDed with a mask held in a VGPR: ONE v_and_b32_dpp wave_shl:1
+__device__ __forceinline__ uint32_t wv_down_and(uint32_t x, uint32_t maskv) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xf, 0xf, true) & maskv;
+}
+// lane l <- lane l-1 (lane 0 <- 0): v_mov_b32_dpp wave_shr:1
+__device__ __forceinline__ uint32_t wv_up(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+}
+
+// what every lane of the kernel carries along: its limb of the loop modulus, the lane-0 indicator, the limb mask and a one
+// (VGPRs: so that "+= 32-bit value" stays one v_mad_u64_u32 and the AND fuses into the DPP move)
+struct WaveCtx {
+  uint32_t nl, e0, maskv, onev;
+};
+
+template <int K>
+__device__ __forceinline__ void wv_bcast_limbs(uint32_t (&s)[K], uint32_t x) {
+  ps_static_for<K>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    s[i] = (uint32_t)__builtin_amdgcn_readlane((int)x, i);
+  });
+}
+
+// one reduction step: the digit, its multiple of P, the slide (header)
+template <int LB>
+__device__ __forceinline__ uint32_t wv_reduce_slide(uint64_t& acc, const WaveCtx& c) {
+  const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)acc) & PsLimb<LB>::mask;
+  acc += (uint64_t)q * c.nl;
+  uint64_t hi = acc >> LB;
+  hi += (uint64_t)wv_down_and((uint32_t)acc, c.maskv) * c.onev;
+  acc = hi;
+  return q;
+}
+// accumulators -> relaxed limbs: own low limb plus the carry of the lane below
+template <int LB>
+__device__ __forceinline__ uint32_t wv_finish(uint64_t acc) {
+  return ((uint32_t)acc & PsLimb<LB>::mask) + wv_up((uint32_t)(acc >> LB));
+}
+
+// (a, b) = (a, b)^2: t = a*a with its digits; b = 2*a*b + q reduced
+template <int K, int LB>
+__device__ __forceinline__ void wv_pairsqr(uint32_t& a, uint32_t& b, const WaveCtx& c) {
+  uint32_t sa[K], sq[K];
+  wv_bcast_limbs<K>(sa, a);
+  uint64_t acc = 0;
+  ps_static_for<K>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    acc += (uint64_t)sa[i] * a;
+    sq[i] = wv_reduce_slide<LB>(acc, c);
+  });
+  const uint32_t t = wv_finish<LB>(acc);
+  const uint32_t b2 = b << 1;
+  acc = 0;
+  ps_static_for<K>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    acc += (uint64_t)sa[i] * b2;
+    acc += (uint64_t)sq[i] * c.e0;
+    (void)wv_reduce_slide<LB>(acc, c);
+  });
+  b = wv_finish<LB>(acc);
+  a = t;
+}
+
+// (a, b) = (a, b) (x) (cm, dm): t = a*cm with its digits; b = a*dm + b*cm + q reduced
+template <int K, int LB>
+__device__ __forceinline__ void wv_pairmul(uint32_t& a, uint32_t& b, uint32_t cm, uint32_t dm, const WaveCtx& c) {
+  uint32_t sa[K], sq[K];
+  wv_bcast_limbs<K>(sa, a);
+  uint64_t acc = 0;
+  ps_static_for<K>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    acc += (uint64_t)sa[i] * cm;
+    sq[i] = wv_reduce_slide<LB>(acc, c);
+  });
+  const uint32_t t = wv_finish<LB>(acc);
+  acc = 0;
+  ps_static_for<K>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    acc += (uint64_t)sa[i] * dm;
+    acc += (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)b, i) * cm;
+    acc += (uint64_t)sq[i] * c.e0;
+    (void)wv_reduce_slide<LB>(acc, c);
+  });
+  b = wv_finish<LB>(acc);
+  a = t;
+}
+
+// 32-bit words of pair buffer per exponentiation (entry kernel -> wave kernel -> exit kernel): a then b, K limbs each
+template <int K>
+constexpr size_t wv_pair_words() { return 2 * (size_t)K; }
+// 32-bit words of LDS table per wavefront
+template <int K>
+constexpr size_t wv_table_words(size_t entries) { return entries * 2 * (size_t)K; }
+
+// One wavefront = ONE exponentiation: wavefront 2*i + side serves ciphertext i under side (0: p, 1: q).
+// A.table: the pair buffer ([2*count][2][K] 32-bit limbs of LB bits): the base on entry, the result on exit (relaxed limbs).
+// Dynamic LDS: kWavesPerWG * wv_table_words<K>(2^A.window) * 4 bytes.
+template <int K, int LB>
+__global__ __launch_bounds__(kWGThreads, 1) void hensel_decrypt_wave_kernel(HenselArgs A) {
+  static_assert(K < kWave, "one limb per lane and a zero lane above them");
+  raise_wave_priority();
+  extern __shared__ uint32_t wv_tbl_[];
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  const size_t idx = (size_t)blockIdx.x * kWavesPerWG + wv;
+  if (idx >= 2 * A.count) return;                       // (wave-uniform)
+  const int side = __builtin_amdgcn_readfirstlane((int)(idx & 1));
+#define HCTX(field) (side ? A.ctx[1].field : A.ctx[0].field)
+  const bool in = lane < K;
+  const int lk = in ? lane : 0;
+  WaveCtx c;
+  c.nl = in ? HCTX(nhat)[lk] : 0u;
+  c.e0 = lane == 0 ? 1u : 0u;
+  c.maskv = PsLimb<LB>::mask;
+  c.onev = 1;
+  asm("" : "+v"(c.maskv), "+v"(c.onev), "+v"(c.e0));
+  const int w = A.window, tsize = 1 << w;
+  uint32_t* tbl = wv_tbl_ + (size_t)wv * wv_table_words<K>((size_t)tsize);     // entry e: a limbs at e*2K, b limbs at e*2K + K
+  const uint64_t* ep = A.exp + (size_t)side * A.exp_stride;
+  const int nwin = (A.exp_bits + w - 1) / w;
+  auto digit = [&](int i) -> int {
+    int bit = i * w;
+    int word = bit >> 6, sh = bit & 63;
+    uint64_t v = (word < A.exp_words) ? ep[word] >> sh : 0;
+    if (sh + w > 64 && word + 1 < A.exp_words) v |= ep[word + 1] << (64 - sh);
+    return (int)(v & (uint64_t)(tsize - 1));
+  };
+  const bool gather = A.ct_gather != 0;
+  auto entry_load = [&](uint32_t& x, uint32_t& y, int e) {
+    if (!gather) {
+      x = in ? tbl[(size_t)e * 2 * K + lk] : 0u;
+      y = in ? tbl[(size_t)e * 2 * K + K + lk] : 0u;
+      return;
+    }
+    // masked access: every entry read, the wanted one selected under a PER-LANE compare (a VGPR copy of the digit: a
+    // v_cmp / v_cndmask pair per entry, never a scalar branch on the secret digit)
+    uint32_t ev = (uint32_t)e;
+    asm("" : "+v"(ev));
+    x = y = 0;
+    for (int t = 0; t < tsize; ++t) {
+      const uint32_t tx = in ? tbl[(size_t)t * 2 * K + lk] : 0u, ty = in ? tbl[(size_t)t * 2 * K + K + lk] : 0u;
+      const bool sel = ev == (uint32_t)t;
+      x = sel ? tx : x;
+      y = sel ? ty : y;
+    }
+  };
+  auto entry_store = [&](int e, uint32_t x, uint32_t y) {
+    if (in) {
+      tbl[(size_t)e * 2 * K + lk] = x;
+      tbl[(size_t)e * 2 * K + K + lk] = y;
+    }
+  };
+  uint32_t* buf = A.table + idx * wv_pair_words<K>();
+  uint32_t a = in ? buf[lk] : 0u, b = in ? buf[K + lk] : 0u;
+  // ---- window table: entry 0 = one, entry 1 = base, entry e = entry e-1 times base ----
+  const uint32_t ba = a, bb = b;
+  entry_store(1, a, b);
+  entry_store(0, in ? HCTX(one)[lk] : 0u, in ? HCTX(one)[K + lk] : 0u);
+#pragma unroll 1
+  for (int e = 2; e < tsize; ++e) {
+    wv_pairmul<K, LB>(a, b, ba, bb, c);
+    entry_store(e, a, b);
+  }
+  // ---- main loop: w squarings, one multiplication by a table entry (always, also entry 0 = one) ----
+  entry_load(a, b, nwin > 0 ? digit(nwin - 1) : 0);
+#pragma unroll 1
+  for (int win = nwin - 2; win >= 0; --win) {
+    const int d = digit(win);
+#pragma unroll 1
+    for (int i = 0; i < w; ++i) wv_pairsqr<K, LB>(a, b, c);
+    uint32_t ma, mb;
+    entry_load(ma, mb, d);
+    wv_pairmul<K, LB>(a, b, ma, mb, c);
+  }
+  if (in) {
+    buf[lk] = a;
+    buf[K + lk] = b;
+  }
+#undef HCTX
+}
+
+// The entry of hensel_decrypt_ps_kernel as a kernel of its own: one lane per exponentiation (wave parity = side, as there),
+// c*R as a pair from the pair row, left in A.table + (2*elem + side) * 2K as canonical limbs of LB bits.
+template <int K, int LB>
+__global__ __launch_bounds__(kWGThreads, 1) void hensel_ps_entry_kernel(HenselArgs A) {
+  constexpr int K4 = (K + 3) / 4;
+  __shared__ uint4 park_[kWavesPerWG][K4][kWave];
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  uint4* slot = &park_[wv][0][lane];
+  const size_t wave_id = (size_t)blockIdx.x * kWavesPerWG + wv;
+  const int side = __builtin_amdgcn_readfirstlane((int)(wave_id & 1));
+  const size_t first_elem = (wave_id >> 1) * kWave;
+  size_t elem = first_elem + lane;
+  const bool live = elem < A.count;
+  if (!live) elem = A.count - 1;
+  uint32_t n[K], a[K], b[K], ma[K], mb[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) n[j] = ps_uniform((side ? A.ctx[1].nhat : A.ctx[0].nhat)[j]);
+  const uint32_t n1p = n[1] + 1;
+  ps_entry_from_pair_row<K, LB>(A, side, elem, n, n1p, slot, a, b, ma, mb);
+  if (live) {
+    uint32_t* buf = A.table + (2 * elem + side) * wv_pair_words<K>();
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      buf[j] = a[j];
+      buf[K + j] = b[j];
+    }
+  }
+}
+
+// ... and its exit: the pair the wave kernel left (relaxed limbs) made canonical, then ps_exit_words -> mp / mq words
+template <int K, int LB>
+__global__ __launch_bounds__(kWGThreads, 1) void hensel_ps_exit_kernel(HenselArgs A) {
+  constexpr int K4 = (K + 3) / 4;
+  __shared__ uint4 park_[kWavesPerWG][K4][kWave];
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  uint4* slot = &park_[wv][0][lane];
+  const size_t wave_id = (size_t)blockIdx.x * kWavesPerWG + wv;
+  const int side = __builtin_amdgcn_readfirstlane((int)(wave_id & 1));
+  const size_t first_elem = (wave_id >> 1) * kWave;
+  size_t elem = first_elem + lane;
+  const bool live = elem < A.count;
+  if (!live) elem = A.count - 1;
+  uint32_t a[K], b[K], ma[K], mb[K];
+  const uint32_t* buf = A.table + (2 * elem + side) * wv_pair_words<K>();
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    ma[j] = buf[j];
+    mb[j] = buf[K + j];
+  }
+  ps_relimb<K, LB, K, LB>(a, ma);
+  ps_relimb<K, LB, K, LB>(b, mb);
+  ps_exit_words<K, LB>(A, side, elem, live, slot, a, b, ma, mb);
+}
+
+}  // namespace pgpu
+
+#endif  // PAILLIERCRYPTOLIB_AMD_CSRC_HENSEL_WAVE_HPP_

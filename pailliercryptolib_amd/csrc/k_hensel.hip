@@ -6,9 +6,12 @@
 #if defined(PGPU_PART) && (PGPU_PART == 31 || PGPU_PART == 33 || PGPU_PART == 34)
 #include "hensel_ps.hpp"     // whole exponentiations in one lane by product scanning (2048-bit keys; round 5)
 #endif
+#if defined(PGPU_PART) && PGPU_PART == 35
+#include "hensel_wave.hpp"   // one exponentiation per WAVEFRONT, a limb per lane: the latency form of small batches (round 6)
+#endif
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..34 (15 and 30 are retired)"
+#error "compile with -DPGPU_PART=0..35 (15 and 30 are retired)"
 #endif
 
 namespace pgpu {
@@ -282,6 +285,27 @@ bool launch_hensel_ps_part34(int K, int lb, const HenselArgs& a, unsigned blocks
   return false;
 }
 static_assert(ps_table_words<19>(32) == 32 * 2 * ((19 + 3) / 4) * 64 * 4, "launch.hpp: hensel_ps_table_words");
+#elif PGPU_PART == 35
+// the latency form: entry (one lane per exponentiation) -> wave kernel (one wavefront per exponentiation) -> exit; a.table is
+// the pair buffer between them (launch.hpp: hensel_wave_pair_words), the window table is dynamic LDS of the wave kernel
+template <int K, int LB>
+static bool launch_wave_one(const HenselArgs& a, hipStream_t s) {
+  const size_t lane_waves = 2 * ((a.count + kWave - 1) / kWave);
+  const unsigned lane_blocks = (unsigned)((lane_waves + kWavesPerWG - 1) / kWavesPerWG);
+  const unsigned wave_blocks = (unsigned)((2 * a.count + kWavesPerWG - 1) / kWavesPerWG);
+  const unsigned lds = (unsigned)(kWavesPerWG * wv_table_words<K>((size_t)1 << a.window) * sizeof(uint32_t));
+  if (lds > 64 * 1024) return false;
+  hipLaunchKernelGGL((hensel_ps_entry_kernel<K, LB>), dim3(lane_blocks), dim3(kWGThreads), 0, s, a);
+  hipLaunchKernelGGL((hensel_decrypt_wave_kernel<K, LB>), dim3(wave_blocks), dim3(kWGThreads), lds, s, a);
+  hipLaunchKernelGGL((hensel_ps_exit_kernel<K, LB>), dim3(lane_blocks), dim3(kWGThreads), 0, s, a);
+  return true;
+}
+bool launch_hensel_wave_part35(int K, int lb, const HenselArgs& a, hipStream_t s) {
+  if (K == 38 && lb == 28) return launch_wave_one<38, 28>(a, s);
+  if (K == 56 && lb == 28) return launch_wave_one<56, 28>(a, s);
+  if (K == 19 && lb == 29) return launch_wave_one<19, 29>(a, s);
+  return false;
+}
 #elif PGPU_PART == 14
 bool launch_hensel_fb_encrypt_part14(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
   if (H == 8 && K == 9) {

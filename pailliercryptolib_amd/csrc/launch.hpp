@@ -194,6 +194,12 @@ inline bool launch_hensel_ps(int K, int lb, const HenselArgs& a, unsigned blocks
   return launch_hensel_ps_part31(K, lb, a, blocks, s, lds_pad) || launch_hensel_ps_part33(K, lb, a, blocks, s, lds_pad) ||
          launch_hensel_ps_part34(K, lb, a, blocks, s, lds_pad);
 }
+// the latency form on the same constants (hensel_wave.hpp; k_hensel.hip part 35): one exponentiation per wavefront, a limb per
+// lane, between the one-lane entry and exit of the kernel above; a.table = the pair buffer, 2K 32-bit words per exponentiation
+inline bool hensel_wave_has(int K, int lb) { return (K == 38 && lb == 28) || (K == 56 && lb == 28) || (K == 19 && lb == 29); }
+inline size_t hensel_wave_pair_words(int K) { return 2 * (size_t)K; }
+bool launch_hensel_wave_part35(int K, int lb, const HenselArgs& a, hipStream_t s);
+inline bool launch_hensel_wave(int K, int lb, const HenselArgs& a, hipStream_t s) { return launch_hensel_wave_part35(K, lb, a, s); }
 // 32-bit words of window table per wavefront (hensel_ps.hpp: ps_table_words -- per entry two parts of ceil(K/4) 16-byte rows of 64 lanes)
 inline size_t hensel_ps_table_words(int K, size_t entries) { return entries * 2 * (size_t)((K + 3) / 4) * 64 * 4; }
 

@@ -46,6 +46,8 @@ constexpr int kAdaptClaimBusy = 3;
 // caller's launches take a quarter of the chip (17 ms per encrypt + decrypt instead of 5.4 on the whole chip, four of them
 // side by side: 5.3 against 5.9 ms per pair), which pays although every caller's quarter idles through its copies and host
 // work; with one busy neighbour (half-chip forms) it does not (r04: 11.8 against 7.2 ms per pair).  0: lone-caller forms.
+// the latency form of small decrypts (hensel_wave.hpp): set by tests only
+std::atomic<int> g_wave_policy{1};
 std::atomic<int> g_rr_adapt{env_int("PGPU_RR_ADAPT", 3, 0, 100)};
 }  // namespace
 
@@ -54,6 +56,8 @@ void set_seq_policy(int p) { g_seq_policy.store(p < 0 ? 0 : (p > 4 ? 4 : p)); }
 int ps_policy() { return g_ps_policy.load(); }
 void set_ps_policy(int p) { g_ps_policy.store(p < 0 ? 0 : (p > 2 ? 2 : p)); }
 int adapt_claim_busy() { return kAdaptClaimBusy; }
+int wave_policy() { return g_wave_policy.load(); }
+void set_wave_policy(int p) { g_wave_policy.store(p < 0 ? 0 : (p > 2 ? 2 : p)); }
 int rr_adapt() { return g_rr_adapt.load(); }
 int set_rr_adapt(int min_busy) { return g_rr_adapt.exchange(min_busy < 0 ? 0 : min_busy); }
 
@@ -110,6 +114,11 @@ size_t ps_min_count(int K) {
   return K == 56 ? 24576 + 1 : (K == 38 || K == 19) ? 16384 + 1 : kPsRound;
 }
 static size_t ps_split_tail(int K) { return K == 56 ? 24576 : 16384; }
+bool wave_form_pays(size_t count, int busy) {
+  const int pol = g_wave_policy.load();
+  if (pol == 2) return true;
+  return pol == 1 && g_ps_policy.load() == 1 && busy == 0 && 2 * count <= kSimds;
+}
 bool ps_form_pays(size_t count, int busy, int K) {
   const size_t waves = 2 * ((count + 63) / 64);
   const int pol = g_ps_policy.load();

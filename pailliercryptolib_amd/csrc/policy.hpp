@@ -27,6 +27,8 @@ void set_seq_policy(int p);
 int ps_policy();             // PGPU_PS_DECRYPT (hensel_ps.hpp): 0 never, 1 by launch size / neighbour lanes (default), 2 always
 void set_ps_policy(int p);
 int adapt_claim_busy();      // up to how many busy neighbours a part-chip launch claims whole CUs (3; a constant since round 6)
+int wave_policy();           // the latency form (hensel_wave.hpp): 0 never, 1 small lone launches (default), 2 always; no environment knob
+void set_wave_policy(int p);
 int rr_adapt();              // PGPU_RR_ADAPT: from how many active neighbours on threads on round-robin lanes adapt (3; 0 never)
 int set_rr_adapt(int min_busy);   // returns the previous value
 
@@ -52,6 +54,9 @@ bool ps_form_pays(size_t count, int busy, int K = 38);
 // this form, the rest a launch of its own in whatever form its size takes (ps_split_head: ciphertexts of the first
 // launch; 0: one launch).  65536 + 4464 ciphertexts of a 2048-bit key: 42.7 ms in three rounds, 36 ms as 28 + 8.
 size_t ps_split_head(int K, size_t count);
+// ... the latency form (hensel_wave.hpp: one exponentiation per wavefront): a lone launch that leaves SIMDs empty even at two
+// wavefronts per ciphertext -- up to kSimds / 2 = 512 ciphertexts; not while the one-lane form is forced or switched off
+bool wave_form_pays(size_t count, int busy);
 // DJN encrypt onto pair rows / CT x PT / CT + CT of `count` elements in form (H, K): the sequential-halves kernels?
 bool fb_encrypt_seq_pays(int H, int K, size_t count, int busy = 0);
 bool modexp_seq_form_pays(int H, int K, size_t count);

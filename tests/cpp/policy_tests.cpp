@@ -64,6 +64,18 @@ int main() {
   // CT x PT and CT + CT
   CHECK(pol::modexp_seq_form_pays(4, 18, 1 << 20) && !pol::modexp_seq_form_pays(4, 18, 8192));
   CHECK(pol::pair_mul_seq_pays(4, 18, 1 << 20) && !pol::pair_mul_seq_pays(4, 18, 16383 - 16));
+  // the latency form (one exponentiation per wavefront): small LONE launches only, and never while the one-lane form is forced / off
+  CHECK(pol::wave_form_pays(1, 0) && pol::wave_form_pays(512, 0) && !pol::wave_form_pays(513, 0) && !pol::wave_form_pays(16, 1));
+  pol::set_ps_policy(2);
+  CHECK(!pol::wave_form_pays(16, 0));
+  pol::set_ps_policy(0);
+  CHECK(!pol::wave_form_pays(16, 0));
+  pol::set_ps_policy(1);
+  pol::set_wave_policy(2);
+  CHECK(pol::wave_form_pays(100000, 3));
+  pol::set_wave_policy(0);
+  CHECK(!pol::wave_form_pays(16, 0));
+  pol::set_wave_policy(1);
   // windows
   CHECK(pol::pick_window(1024) == 5 && pol::pick_window(512) == 5 && pol::pick_window(33) == 3 && pol::pick_window(1) == 1);
   CHECK(pol::masked_decrypt_window() == 3);
