@@ -9,10 +9,11 @@
 // residue's half is spread over the WHOLE wavefront, lane l holding limb l (K <= 63 of the 64 lanes), and a Montgomery product is
 // the textbook operand scan with the accumulator sliding down the lanes:
 //     step i:   acc_l += a_i * b_l                      a_i wave-uniform: an SGPR (v_readlane, once per product and limb)
-//               q = acc_0 mod 2^LB                      v_readfirstlane + s_and: the digit is an SGPR as well (P == -1: no multiply)
+//               q = acc_0 mod 2^LB                      v_and + v_readfirstlane: the digit is an SGPR as well (P == -1: no multiply)
 //               acc_l += q * P_l                        lane 0's low limb becomes zero
 //               acc_l = (acc_{l+1} mod 2^LB) + (acc_l >> LB)       one v_lshrrev_b64, one v_and_b32_dpp wave_shl:1, one multiply-add
-// -- seven instructions per step whatever K is, K steps per half-width product, no LDS, no waiting for memory.  The last line
+// -- seven instructions per step whatever K is, K steps per half-width product, no LDS, no waiting for memory; the two scans
+// of a pair product run in lock-step, so that each one's digit broadcast is covered by the other's instructions.  The last line
 // both slides the window and keeps every accumulator below 2^37 (each lane passes its own carry one column up while it
 // takes over its neighbour's low limb), so limbs need not be canonical anywhere: products leave RELAXED limbs (below
 // 2^LB + 2^9).  The pair product of hensel.hpp on top of it: t = a*c with its digits q_i kept in SGPRs; w = a*d + b*c + q
@@ -55,15 +56,23 @@ __device__ __forceinline__ void wv_bcast_limbs(uint32_t (&s)[K], uint32_t x) {
   });
 }
 
-// one reduction step: the digit, its multiple of P, the slide (header)
+// acc += x * y as a link of a chain the optimiser must leave in this order (hensel_ps.hpp: ps_mac_pinned): left alone it
+// starts every step's sum from zero and adds the slid accumulator last -- one more 64-bit add per step
+__device__ __forceinline__ void wv_mac(uint64_t& acc, uint32_t x, uint32_t y) {
+  acc += (uint64_t)x * y;
+  asm volatile("" ::"v"(acc));
+}
+// the digit of a step: lane 0's low limb, masked in the VALU and broadcast through an SGPR (no scalar-ALU hop in the chain)
 template <int LB>
-__device__ __forceinline__ uint32_t wv_reduce_slide(uint64_t& acc, const WaveCtx& c) {
-  const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)acc) & PsLimb<LB>::mask;
-  acc += (uint64_t)q * c.nl;
-  uint64_t hi = acc >> LB;
-  hi += (uint64_t)wv_down_and((uint32_t)acc, c.maskv) * c.onev;
-  acc = hi;
-  return q;
+__device__ __forceinline__ uint32_t wv_digit(uint64_t acc, const WaveCtx& c) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)acc & c.maskv));
+}
+// the slide: acc_l = (acc_{l+1} mod 2^LB) + (acc_l >> LB)
+template <int LB>
+__device__ __forceinline__ void wv_slide(uint64_t& acc, const WaveCtx& c) {
+  const uint32_t lo = wv_down_and((uint32_t)acc, c.maskv);
+  acc >>= LB;
+  wv_mac(acc, lo, c.onev);
 }
 // accumulators -> relaxed limbs: own low limb plus the carry of the lane below
 template <int LB>
@@ -71,52 +80,53 @@ __device__ __forceinline__ uint32_t wv_finish(uint64_t acc) {
   return ((uint32_t)acc & PsLimb<LB>::mask) + wv_up((uint32_t)(acc >> LB));
 }
 
-// (a, b) = (a, b)^2: t = a*a with its digits; b = 2*a*b + q reduced
+// (a, b) = (a, b)^2: t = a*a with its digits; b = 2*a*b + q reduced.  The two scans run in LOCK-STEP -- step i of the second
+// needs digit i of the first and nothing else of it --, so that one chain's broadcast round trip (VALU -> SGPR -> VALU) is
+// covered by the other chain's instructions: a lone wavefront has nobody else to issue from.
 template <int K, int LB>
 __device__ __forceinline__ void wv_pairsqr(uint32_t& a, uint32_t& b, const WaveCtx& c) {
-  uint32_t sa[K], sq[K];
+  uint32_t sa[K];
   wv_bcast_limbs<K>(sa, a);
-  uint64_t acc = 0;
-  ps_static_for<K>([&](auto ic) __attribute__((always_inline)) {
-    constexpr int i = decltype(ic)::value;
-    acc += (uint64_t)sa[i] * a;
-    sq[i] = wv_reduce_slide<LB>(acc, c);
-  });
-  const uint32_t t = wv_finish<LB>(acc);
   const uint32_t b2 = b << 1;
-  acc = 0;
+  uint64_t acc1 = 0, acc2 = 0;
   ps_static_for<K>([&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
-    acc += (uint64_t)sa[i] * b2;
-    acc += (uint64_t)sq[i] * c.e0;
-    (void)wv_reduce_slide<LB>(acc, c);
+    wv_mac(acc1, sa[i], a);
+    const uint32_t q1 = wv_digit<LB>(acc1, c);
+    wv_mac(acc2, sa[i], b2);
+    wv_mac(acc1, q1, c.nl);
+    wv_mac(acc2, q1, c.e0);
+    const uint32_t q2 = wv_digit<LB>(acc2, c);
+    wv_slide<LB>(acc1, c);
+    wv_mac(acc2, q2, c.nl);
+    wv_slide<LB>(acc2, c);
   });
-  b = wv_finish<LB>(acc);
-  a = t;
+  a = wv_finish<LB>(acc1);
+  b = wv_finish<LB>(acc2);
 }
 
-// (a, b) = (a, b) (x) (cm, dm): t = a*cm with its digits; b = a*dm + b*cm + q reduced
+// (a, b) = (a, b) (x) (cm, dm): t = a*cm with its digits; b = a*dm + b*cm + q reduced; in lock-step like the squaring
 template <int K, int LB>
 __device__ __forceinline__ void wv_pairmul(uint32_t& a, uint32_t& b, uint32_t cm, uint32_t dm, const WaveCtx& c) {
-  uint32_t sa[K], sq[K];
+  uint32_t sa[K];
   wv_bcast_limbs<K>(sa, a);
-  uint64_t acc = 0;
+  uint64_t acc1 = 0, acc2 = 0;
+  const uint32_t b0 = b;
   ps_static_for<K>([&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
-    acc += (uint64_t)sa[i] * cm;
-    sq[i] = wv_reduce_slide<LB>(acc, c);
+    wv_mac(acc1, sa[i], cm);
+    const uint32_t q1 = wv_digit<LB>(acc1, c);
+    wv_mac(acc2, sa[i], dm);
+    wv_mac(acc2, (uint32_t)__builtin_amdgcn_readlane((int)b0, i), cm);
+    wv_mac(acc1, q1, c.nl);
+    wv_mac(acc2, q1, c.e0);
+    const uint32_t q2 = wv_digit<LB>(acc2, c);
+    wv_slide<LB>(acc1, c);
+    wv_mac(acc2, q2, c.nl);
+    wv_slide<LB>(acc2, c);
   });
-  const uint32_t t = wv_finish<LB>(acc);
-  acc = 0;
-  ps_static_for<K>([&](auto ic) __attribute__((always_inline)) {
-    constexpr int i = decltype(ic)::value;
-    acc += (uint64_t)sa[i] * dm;
-    acc += (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)b, i) * cm;
-    acc += (uint64_t)sq[i] * c.e0;
-    (void)wv_reduce_slide<LB>(acc, c);
-  });
-  b = wv_finish<LB>(acc);
-  a = t;
+  a = wv_finish<LB>(acc1);
+  b = wv_finish<LB>(acc2);
 }
 
 // 32-bit words of pair buffer per exponentiation (entry kernel -> wave kernel -> exit kernel): a then b, K limbs each

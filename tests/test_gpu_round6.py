@@ -1,0 +1,94 @@
+"""Round 6, through the C-ABI against the oracle:
+  * the LATENCY form of the CRT-decrypt exponentiation (csrc/hensel_wave.hpp: one exponentiation per wavefront, a limb per
+    lane, between the one-lane entry and exit of the product-scanning kernel) -- what a lone decrypt of up to 512 ciphertexts
+    takes by default: the reference's BM_Decrypt sizes 16 ... 512 (benchmark/bench_cryptography.cpp:10-19), the two half-width
+    exponentiations of PrivateKey::decryptCRT (ipcl/pri_key.cpp:114-146)."""
+import ctypes
+import random
+
+import pytest
+
+from test_gpu_round4 import Res, key_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("bits,count", [(2048, 1), (2048, 7), (2048, 16), (2048, 65), (2048, 300), (2048, 512), (2048, 1100),
+                                        (3072, 1), (3072, 9), (3072, 130), (1024, 1), (1024, 16), (1024, 300)])
+def test_wave_decrypt_kernel_is_bit_identical(engine, bits, count):
+    """Forced on (also beyond its default range: 1100 ciphertexts are two wavefronts per SIMD) and off: same plaintexts as
+    the multi-lane latency forms and the oracle -- ciphertexts from every producer (encrypt, CT+CT, CT x PT, uploaded words:
+    relaxed and canonical rows), NON-encryptions incl. n^2 - 1 and 1 against pow(), edge plaintexts, masked table access."""
+    from oracle import paillier_oracle as orc
+    from pailliercryptolib_amd import _capi
+    p, q, hs = key_case(bits)
+    n = p * q
+    nw = bits // 64
+    rng = random.Random(7 * count + bits)
+    m = ([0, 1, n - 1] + [rng.randrange(n) for _ in range(count)])[:count]
+    m2 = [rng.randrange(n) for _ in range(count)]
+    r = [rng.getrandbits(bits // 2) for _ in range(count)]
+    e = [rng.getrandbits(33) for _ in range(count)]
+    pk, sk = engine.PublicKey(n, bits, hs=hs), engine.PrivateKey(p, q)
+    osk = orc.PrivateKey(n, p, q)
+    R = Res()
+    L = R.L
+    form = lambda: tuple(v.value for v in _form(L, _capi, sk, count))
+    try:
+        c1 = R.op(L.pgpu_batch_encrypt, pk._h, R.up(m, nw), R.up(r, nw // 2), bits // 2)
+        c2 = R.op(L.pgpu_batch_encrypt, pk._h, R.up(m2, nw), R.up(r, nw // 2), bits // 2)
+        s = R.op(L.pgpu_batch_ct_add, pk._h, c1, c2)
+        t = R.op(L.pgpu_batch_ct_mul, pk._h, s, R.up(e, 1), 33)
+        raw = ([n * n - 1, 1, n * n - 2] + [rng.randrange(1, n * n) for _ in range(count)])[:count]
+        up = R.up(raw, 2 * nw)
+        srcs = (c1, s, t, up)
+        L.pgpu_debug_set_wave_decrypt(0)
+        try:
+            assert form()[0] != 5
+            want = [R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, x)) for x in srcs]
+            assert want[0] == m and want[1] == [(a + b) % n for a, b in zip(m, m2)]
+            assert want[2] == [((a + b) * x) % n for a, b, x in zip(m, m2, e)]
+            idx = sorted({0, 1, 2, count // 2, count - 1} & set(range(count)))
+            assert [want[3][i] for i in idx] == osk.decrypt([raw[i] for i in idx])
+            L.pgpu_debug_set_wave_decrypt(2)
+            assert form() == (5, 64, {1024: 19, 2048: 38, 3072: 56}[bits])
+            got = [R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, x)) for x in srcs]
+            assert got == want, "the wavefront-wide form differs from the multi-lane forms"
+            _capi.check(L.pgpu_set_table_gather_policy(1))
+            assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, t)) == want[2]
+            assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, up)) == want[3]
+        finally:
+            _capi.check(L.pgpu_set_table_gather_policy(0))
+            L.pgpu_debug_set_wave_decrypt(1)
+        assert (form()[0] == 5) == (count <= 512)                 # the default: small lone launches
+    finally:
+        R.close()
+
+
+def _form(L, _capi, sk, count):
+    split, lanes, limbs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _capi.check(L.pgpu_decrypt_kernel_form(sk._h, count, ctypes.byref(split), ctypes.byref(lanes), ctypes.byref(limbs)))
+    return split, lanes, limbs
+
+
+def test_wave_decrypt_from_host_arrays_and_the_api(engine):
+    """The host-pointer entry point (word ciphertexts through the pair-row conversion) and the python engine's decrypt at the
+    reference's small benchmark sizes: whatever form the policy picks, plaintexts back; every row of a batch of
+    non-encryptions against the C oracle."""
+    import numpy as np
+    from pailliercryptolib_amd import _capi
+    from test_gpu_round5 import _c_oracle_decrypt, _raw_rows
+    p, q, hs = key_case(2048)
+    n = p * q
+    pk, sk = engine.PublicKey(n, 2048, hs=hs), engine.PrivateKey(p, q)
+    L = _capi.lib()
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rng = random.Random(606)
+    for count in (16, 64, 128, 256, 512):
+        m = [rng.randrange(n) for _ in range(count)]
+        r = [rng.getrandbits(1024) for _ in range(count)]
+        assert sk.decrypt(pk.encrypt(m, r)) == m
+        raw = _raw_rows(n, 2048, count, 9000 + count)
+        got = np.zeros((count, 32), dtype=np.uint64)
+        _capi.check(L.pgpu_paillier_decrypt_crt(sk._h, ptr(raw), ptr(got), count))
+        assert np.array_equal(got, _c_oracle_decrypt(p, q, 2048, raw)), "host-array decrypt of %d raw rows differs from the C oracle" % count
