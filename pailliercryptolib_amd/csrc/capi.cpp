@@ -1713,7 +1713,11 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
       t.set_form(PGPU_FORM_WAVE | PGPU_FORM_PS);
       RC_TRY(w.table.ensure(2 * count * pgpu::hensel_wave_pair_words(hset->K) * sizeof(uint32_t), s));
       h.table = (uint32_t*)w.table.p;
-      if (!pgpu::launch_hensel_wave(hset->K, hset->lb, h, s))
+      // 32-bit quotient digits (one instruction less per step and scan) where the radix leaves room: values then stay below
+      // 17 P instead of 2 P, which needs R = 2^(lb K) >= 2^10 P; P = p k < 2^(exp_bits + lb)  (3072-bit keys: R >= 16 P only)
+      static const bool wide_ok = [] { const char* e = getenv("PGPU_WAVE_WIDEQ"); return !e || atoi(e) != 0; }();
+      const bool wide = wide_ok && hset->lb * hset->K - (key->exp_bits + hset->lb) >= 10;
+      if (!pgpu::launch_hensel_wave(hset->K, hset->lb, wide, h, s))
         return fail(PGPU_ERR_UNSUPPORTED, "wavefront-wide decrypt kernel not compiled");
     } else if (psf) {
       const size_t lwaves = 2 * ((count + 63) / 64);

@@ -16,7 +16,7 @@
 // of a pair product run in lock-step, so that each one's digit broadcast is covered by the other's instructions.  The last line
 // both slides the window and keeps every accumulator below 2^37 (each lane passes its own carry one column up while it
 // takes over its neighbour's low limb), so limbs need not be canonical anywhere: products leave RELAXED limbs (below
-// 2^LB + 2^9).  The pair product of hensel.hpp on top of it: t = a*c with its digits q_i kept in SGPRs; w = a*d + b*c + q
+// 2^LB + 2^9; with 32-bit digits -- wv_digit -- values stay below 17 P instead of 2 P).  The pair product of hensel.hpp on top of it: t = a*c with its digits q_i kept in SGPRs; w = a*d + b*c + q
 // with q_i added to lane 0 in step i.  ~620 instructions per pair squaring against ~900 of the 16-lane form, on a chain
 // without LDS round trips.
 // The same constants as hensel_decrypt_ps_kernel (the key's hs_ps set: K limbs of LB bits, P == -1 mod 2^LB), and its entry
@@ -62,10 +62,14 @@ __device__ __forceinline__ void wv_mac(uint64_t& acc, uint32_t x, uint32_t y) {
   acc += (uint64_t)x * y;
   asm volatile("" ::"v"(acc));
 }
-// the digit of a step: lane 0's low limb, masked in the VALU and broadcast through an SGPR (no scalar-ALU hop in the chain)
-template <int LB>
+// the digit of a step: lane 0's low limb, masked in the VALU and broadcast through an SGPR (no scalar-ALU hop in the chain).
+// WIDEQ: lane 0's whole low WORD is the digit.  Any q == acc_0 (mod 2^LB) clears lane 0's low limb (P_0 = 2^LB - 1), and the
+// bits above LB only add a larger multiple of P: with 32-bit digits a product stays below (2^(32-LB) + 1) P instead of 2P
+// -- sound as long as R >= 2^10 P (the host checks: capi.cpp decrypt_on), and one v_and less in every step of both scans.
+template <int LB, bool WIDEQ>
 __device__ __forceinline__ uint32_t wv_digit(uint64_t acc, const WaveCtx& c) {
-  return (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)acc & c.maskv));
+  if constexpr (WIDEQ) return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)acc);
+  else return (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)acc & c.maskv));
 }
 // the slide: acc_l = (acc_{l+1} mod 2^LB) + (acc_l >> LB)
 template <int LB>
@@ -83,7 +87,7 @@ __device__ __forceinline__ uint32_t wv_finish(uint64_t acc) {
 // (a, b) = (a, b)^2: t = a*a with its digits; b = 2*a*b + q reduced.  The two scans run in LOCK-STEP -- step i of the second
 // needs digit i of the first and nothing else of it --, so that one chain's broadcast round trip (VALU -> SGPR -> VALU) is
 // covered by the other chain's instructions: a lone wavefront has nobody else to issue from.
-template <int K, int LB>
+template <int K, int LB, bool WIDEQ>
 __device__ __forceinline__ void wv_pairsqr(uint32_t& a, uint32_t& b, const WaveCtx& c) {
   uint32_t sa[K];
   wv_bcast_limbs<K>(sa, a);
@@ -92,11 +96,11 @@ __device__ __forceinline__ void wv_pairsqr(uint32_t& a, uint32_t& b, const WaveC
   ps_static_for<K>([&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     wv_mac(acc1, sa[i], a);
-    const uint32_t q1 = wv_digit<LB>(acc1, c);
+    const uint32_t q1 = wv_digit<LB, WIDEQ>(acc1, c);
     wv_mac(acc2, sa[i], b2);
     wv_mac(acc1, q1, c.nl);
     wv_mac(acc2, q1, c.e0);
-    const uint32_t q2 = wv_digit<LB>(acc2, c);
+    const uint32_t q2 = wv_digit<LB, WIDEQ>(acc2, c);
     wv_slide<LB>(acc1, c);
     wv_mac(acc2, q2, c.nl);
     wv_slide<LB>(acc2, c);
@@ -106,7 +110,7 @@ __device__ __forceinline__ void wv_pairsqr(uint32_t& a, uint32_t& b, const WaveC
 }
 
 // (a, b) = (a, b) (x) (cm, dm): t = a*cm with its digits; b = a*dm + b*cm + q reduced; in lock-step like the squaring
-template <int K, int LB>
+template <int K, int LB, bool WIDEQ>
 __device__ __forceinline__ void wv_pairmul(uint32_t& a, uint32_t& b, uint32_t cm, uint32_t dm, const WaveCtx& c) {
   uint32_t sa[K];
   wv_bcast_limbs<K>(sa, a);
@@ -115,12 +119,12 @@ __device__ __forceinline__ void wv_pairmul(uint32_t& a, uint32_t& b, uint32_t cm
   ps_static_for<K>([&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     wv_mac(acc1, sa[i], cm);
-    const uint32_t q1 = wv_digit<LB>(acc1, c);
+    const uint32_t q1 = wv_digit<LB, WIDEQ>(acc1, c);
     wv_mac(acc2, sa[i], dm);
     wv_mac(acc2, (uint32_t)__builtin_amdgcn_readlane((int)b0, i), cm);
     wv_mac(acc1, q1, c.nl);
     wv_mac(acc2, q1, c.e0);
-    const uint32_t q2 = wv_digit<LB>(acc2, c);
+    const uint32_t q2 = wv_digit<LB, WIDEQ>(acc2, c);
     wv_slide<LB>(acc1, c);
     wv_mac(acc2, q2, c.nl);
     wv_slide<LB>(acc2, c);
@@ -139,7 +143,7 @@ constexpr size_t wv_table_words(size_t entries) { return entries * 2 * (size_t)K
 // One wavefront = ONE exponentiation: wavefront 2*i + side serves ciphertext i under side (0: p, 1: q).
 // A.table: the pair buffer ([2*count][2][K] 32-bit limbs of LB bits): the base on entry, the result on exit (relaxed limbs).
 // Dynamic LDS: kWavesPerWG * wv_table_words<K>(2^A.window) * 4 bytes.
-template <int K, int LB>
+template <int K, int LB, bool WIDEQ>
 __global__ __launch_bounds__(kWGThreads, 1) void hensel_decrypt_wave_kernel(HenselArgs A) {
   static_assert(K < kWave, "one limb per lane and a zero lane above them");
   raise_wave_priority();
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(kWGThreads, 1) void hensel_decrypt_wave_kernel(Hens
   entry_store(0, in ? HCTX(one)[lk] : 0u, in ? HCTX(one)[K + lk] : 0u);
 #pragma unroll 1
   for (int e = 2; e < tsize; ++e) {
-    wv_pairmul<K, LB>(a, b, ba, bb, c);
+    wv_pairmul<K, LB, WIDEQ>(a, b, ba, bb, c);
     entry_store(e, a, b);
   }
   // ---- main loop: w squarings, one multiplication by a table entry (always, also entry 0 = one) ----
@@ -210,10 +214,10 @@ __global__ __launch_bounds__(kWGThreads, 1) void hensel_decrypt_wave_kernel(Hens
   for (int win = nwin - 2; win >= 0; --win) {
     const int d = digit(win);
 #pragma unroll 1
-    for (int i = 0; i < w; ++i) wv_pairsqr<K, LB>(a, b, c);
+    for (int i = 0; i < w; ++i) wv_pairsqr<K, LB, WIDEQ>(a, b, c);
     uint32_t ma, mb;
     entry_load(ma, mb, d);
-    wv_pairmul<K, LB>(a, b, ma, mb, c);
+    wv_pairmul<K, LB, WIDEQ>(a, b, ma, mb, c);
   }
   if (in) {
     buf[lk] = a;

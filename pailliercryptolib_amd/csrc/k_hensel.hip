@@ -289,21 +289,23 @@ static_assert(ps_table_words<19>(32) == 32 * 2 * ((19 + 3) / 4) * 64 * 4, "launc
 // the latency form: entry (one lane per exponentiation) -> wave kernel (one wavefront per exponentiation) -> exit; a.table is
 // the pair buffer between them (launch.hpp: hensel_wave_pair_words), the window table is dynamic LDS of the wave kernel
 template <int K, int LB>
-static bool launch_wave_one(const HenselArgs& a, hipStream_t s) {
+static bool launch_wave_one(bool wide, const HenselArgs& a, hipStream_t s) {
   const size_t lane_waves = 2 * ((a.count + kWave - 1) / kWave);
   const unsigned lane_blocks = (unsigned)((lane_waves + kWavesPerWG - 1) / kWavesPerWG);
   const unsigned wave_blocks = (unsigned)((2 * a.count + kWavesPerWG - 1) / kWavesPerWG);
   const unsigned lds = (unsigned)(kWavesPerWG * wv_table_words<K>((size_t)1 << a.window) * sizeof(uint32_t));
   if (lds > 64 * 1024) return false;
   hipLaunchKernelGGL((hensel_ps_entry_kernel<K, LB>), dim3(lane_blocks), dim3(kWGThreads), 0, s, a);
-  hipLaunchKernelGGL((hensel_decrypt_wave_kernel<K, LB>), dim3(wave_blocks), dim3(kWGThreads), lds, s, a);
+  if (wide) hipLaunchKernelGGL((hensel_decrypt_wave_kernel<K, LB, true>), dim3(wave_blocks), dim3(kWGThreads), lds, s, a);
+  else hipLaunchKernelGGL((hensel_decrypt_wave_kernel<K, LB, false>), dim3(wave_blocks), dim3(kWGThreads), lds, s, a);
   hipLaunchKernelGGL((hensel_ps_exit_kernel<K, LB>), dim3(lane_blocks), dim3(kWGThreads), 0, s, a);
   return true;
 }
-bool launch_hensel_wave_part35(int K, int lb, const HenselArgs& a, hipStream_t s) {
-  if (K == 38 && lb == 28) return launch_wave_one<38, 28>(a, s);
-  if (K == 56 && lb == 28) return launch_wave_one<56, 28>(a, s);
-  if (K == 19 && lb == 29) return launch_wave_one<19, 29>(a, s);
+// wide: 32-bit quotient digits (hensel_wave.hpp: wv_digit) -- the caller has checked R >= 2^10 P
+bool launch_hensel_wave_part35(int K, int lb, bool wide, const HenselArgs& a, hipStream_t s) {
+  if (K == 38 && lb == 28) return launch_wave_one<38, 28>(wide, a, s);
+  if (K == 56 && lb == 28) return launch_wave_one<56, 28>(wide, a, s);
+  if (K == 19 && lb == 29) return launch_wave_one<19, 29>(wide, a, s);
   return false;
 }
 #elif PGPU_PART == 14

@@ -198,8 +198,10 @@ inline bool launch_hensel_ps(int K, int lb, const HenselArgs& a, unsigned blocks
 // lane, between the one-lane entry and exit of the kernel above; a.table = the pair buffer, 2K 32-bit words per exponentiation
 inline bool hensel_wave_has(int K, int lb) { return (K == 38 && lb == 28) || (K == 56 && lb == 28) || (K == 19 && lb == 29); }
 inline size_t hensel_wave_pair_words(int K) { return 2 * (size_t)K; }
-bool launch_hensel_wave_part35(int K, int lb, const HenselArgs& a, hipStream_t s);
-inline bool launch_hensel_wave(int K, int lb, const HenselArgs& a, hipStream_t s) { return launch_hensel_wave_part35(K, lb, a, s); }
+bool launch_hensel_wave_part35(int K, int lb, bool wide_digits, const HenselArgs& a, hipStream_t s);
+inline bool launch_hensel_wave(int K, int lb, bool wide_digits, const HenselArgs& a, hipStream_t s) {
+  return launch_hensel_wave_part35(K, lb, wide_digits, a, s);
+}
 // 32-bit words of window table per wavefront (hensel_ps.hpp: ps_table_words -- per entry two parts of ceil(K/4) 16-byte rows of 64 lanes)
 inline size_t hensel_ps_table_words(int K, size_t entries) { return entries * 2 * (size_t)((K + 3) / 4) * 64 * 4; }
 

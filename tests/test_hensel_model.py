@@ -149,3 +149,80 @@ def test_product_scanning_form_bounds_with_sixteen_fold_headroom(bits, K, LBp):
     # columns: canonical limbs below 2^LB, the doubled operand of a squaring below 2^(LB+1): at most 3K products of 2^(2 LB) each
     assert 3 * K * (1 << (2 * LBp)) < 1 << 64
 
+
+
+@pytest.mark.parametrize("pbits,K,LBk,wide", [(1024, 38, 28, False), (1024, 38, 28, True), (512, 19, 29, True), (1536, 56, 28, False)])
+def test_wavefront_wide_form_lane_model(pbits, K, LBk, wide):
+    """csrc/hensel_wave.hpp lane for lane with Python integers: one limb per lane, operand scan with the accumulators sliding
+    down the lanes, the two scans of a pair product in lock-step, relaxed limbs, and -- `wide` -- whole-word (32-bit) quotient
+    digits where R >= 2^10 P.  Squarings and products from worst-case inputs must give the pair product of hensel.hpp, every
+    accumulator must stay below 2^64, and the values must settle below the bound the exit relies on (2 P, or 17 P / 9 P with
+    wide digits) and fit the K limbs."""
+    M = (1 << LBk) - 1
+    rng = random.Random(pbits + K + wide)
+    while True:                                     # a prime-like odd modulus is enough for the algebra: any odd p works
+        p = rng.getrandbits(pbits) | (1 << (pbits - 1)) | 1
+        if p % 3 and p % 5:
+            break
+    k = (-pow(p, -1, 1 << LBk)) % (1 << LBk)
+    P = p * k
+    R = 1 << (LBk * K)
+    assert P % (1 << LBk) == M and R >= 16 * P and (not wide or LBk * K - (pbits + LBk) >= 10)      # capi.cpp: decrypt_on
+    nl = [(P >> (LBk * l)) & M for l in range(K)] + [0]
+    worst = [0]
+
+    def lanes(v):                                   # canonical limbs, lane K is the zero lane above them
+        return [(v >> (LBk * l)) & M for l in range(K)] + [0]
+
+    def num(ls):
+        return sum(v << (LBk * l) for l, v in enumerate(ls))
+
+    def slide(acc):
+        return [(acc[l + 1] & M if l + 1 <= K else 0) + (acc[l] >> LBk) for l in range(K + 1)]
+
+    def digit(acc):
+        return acc[0] & (0xFFFFFFFF if wide else M)
+
+    def finish(acc):
+        return [(acc[l] & M) + ((acc[l - 1] >> LBk) if l else 0) for l in range(K + 1)]
+
+    def pairop(a, b, c, d, sqr):
+        """wv_pairsqr (c = a, d = b, the b operand doubled) / wv_pairmul, lock-step"""
+        acc1, acc2 = [0] * (K + 1), [0] * (K + 1)
+        mul2 = [2 * v for v in b] if sqr else d
+        for i in range(K):
+            acc1 = [acc1[l] + a[i] * c[l] for l in range(K + 1)]
+            q1 = digit(acc1)
+            acc2 = [acc2[l] + a[i] * mul2[l] for l in range(K + 1)]
+            if not sqr:
+                acc2 = [acc2[l] + b[i] * c[l] for l in range(K + 1)]
+            acc1 = [acc1[l] + q1 * nl[l] for l in range(K + 1)]
+            acc2[0] += q1
+            q2 = digit(acc2)
+            worst[0] = max(worst[0], max(acc1), max(acc2) + q2 * M)
+            assert acc1[0] & M == 0
+            acc1 = slide(acc1)
+            acc2 = [acc2[l] + q2 * nl[l] for l in range(K + 1)]
+            assert acc2[0] & M == 0
+            acc2 = slide(acc2)
+        t, w = finish(acc1), finish(acc2)
+        assert t[K] == 0 and w[K] == 0
+        return t, w
+
+    bound = ((1 << (32 - LBk)) + 1) * P if wide else 2 * P
+    start = 4 * P - 1 if not wide else bound - 1              # the largest values the flow can hand in
+    a, b = lanes(start), lanes(start - 12345)
+    c, d = lanes(start - 99), lanes(start - 7)
+    x, y = (num(a), num(b)), (num(c), num(d))
+    for rounds in range(3):
+        t, w = pairop(a, b, c, d, False)
+        assert (num(t) - P * num(w)) % (P * P) == (x[0] - P * x[1]) * (y[0] - P * y[1]) * pow(R, -1, P * P) % (P * P)
+        assert num(t) < bound and num(w) < bound and max(t + w) < (1 << LBk) + (1 << 9)
+        a, b = t, w
+        x = (num(a), num(b))
+        t, w = pairop(a, b, a, b, True)
+        assert (num(t) - P * num(w)) % (P * P) == (x[0] - P * x[1]) ** 2 * pow(R, -1, P * P) % (P * P)
+        assert num(t) < bound and num(w) < bound
+        a, b = t, w
+        x = (num(a), num(b))
+    assert worst[0] < 1 << 64
