@@ -127,6 +127,8 @@ for s, d in pairs:
         except Exception as e:                                  # noqa: BLE001
             print(d, "unreadable:", e)
 for s, d in [("gpurun_out/r06p/ipcl_api_bench.txt", "profiles/r06_ipcl_api_bench.txt"),
+             ("gpurun_out/r06p/small_batch_cpu_ifma.txt", "profiles/r06_small_batch_cpu_ifma.txt"),
+             ("gpurun_out/r06p/wave_form_sizes.txt", "profiles/r06_wave_form_sizes.txt"),
              ("gpurun_out/r06p/lanes.txt", "profiles/r06_lanes.txt"),
              ("gpurun_out/r06p/trace_2lanes.txt", "profiles/r06_trace_2lanes.txt"),
              ("gpurun_out/r06p/trace_4lanes.txt", "profiles/r06_trace_4lanes.txt"),

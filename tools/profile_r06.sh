@@ -37,6 +37,8 @@ line bench_c4 --config 4 --steps 5 --warmup 1
 line bench_c5 --config 5 --steps 12
 BENCH_SINGLE_DEVICE=1 line bench_n8_pool_1dev --gpus 8 --steps 10 --warmup 2 --no-cpu-baseline --no-extras --sustain-seconds 0
 ./pailliercryptolib_amd/ipcl_api_bench > $OUT/ipcl_api_bench.txt 2>&1
+python tools/bench_small_cpu.py > $OUT/small_batch_cpu_ifma.txt 2>&1
+(for b in 2048 3072 1024; do python tools/bench_wave_sizes.py $b; done; echo '# PGPU_WAVE_WIDEQ=0 (masked quotient digits)'; PGPU_WAVE_WIDEQ=0 python tools/bench_wave_sizes.py 2048 16 512) 2>&1 | grep -v amdgpu.ids > $OUT/wave_form_sizes.txt
 for c in 16384 65536; do python tools/bench_keysizes.py $c > $OUT/keysizes_$c.txt 2>&1; done
 (for t in 1 2 4; do ./pailliercryptolib_amd/ipcl_api_bench --threads $t 8192 8 2>&1 | grep -v amdgpu.ids; done) > $OUT/ipcl_api_threads.txt 2>&1
 ls $OUT
