@@ -79,7 +79,7 @@ def _objects():
         if part in (31, 33, 34, 35):
             hdeps_k.append(os.path.join(CSRC, "hensel_ps.hpp"))
         if part == 35:
-            hdeps_k.append(os.path.join(CSRC, "hensel_wave.hpp"))
+            hdeps_k += [os.path.join(CSRC, "hensel_wave.hpp"), os.path.join(CSRC, "hensel_wave_n2.hpp")]
         out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src] + hdeps_k + kdeps))
     for name in ("capi.cpp", "policy.cpp", "runtime.cpp", os.path.join("host", "bignum.cpp")):
         src = os.path.join(CSRC, name)

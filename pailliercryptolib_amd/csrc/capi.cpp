@@ -1322,6 +1322,19 @@ int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::Pu
   a.out = d_out;
   a.out_stride = (size_t)2 * key->n_words;
   a.count = count;
+  // The latency form (hensel_wave_n2.hpp; round 6): small launches on resident rows -- one wavefront per element, the window
+  // table in its LDS; 32-bit quotient digits where the rows' radix leaves room (R = 2^(29 L2) >= 2^10 P, P < 2^(bits(n) + 29))
+  if (base_pair && out_pair && !a.sched && final_mul == pgpu::FM_UNIT && hensel_enabled() && pgpu::hensel_modexp_wave_has(H * K) &&
+      policy::modexp_wave_form_pays(count) && a.window <= 5) {
+    static const bool wide_ok = [] { const char* e = getenv("PGPU_WAVE_WIDEQ"); return !e || atoi(e) != 0; }();
+    const bool wide = wide_ok && pgpu::kLimbBits * H * K - (form->n.BitSize() + pgpu::kLimbBits) >= 10;
+    TimerScope t(d, s, PGPU_KERNEL_MODEXP, PGPU_FORM_WAVE);
+    if (!pgpu::launch_hensel_modexp_wave(H * K, wide, a, s))
+      return fail(PGPU_ERR_UNSUPPORTED, "wavefront-wide modexp kernel not compiled");
+    HIP_TRY(hipGetLastError());
+    t.stop();
+    return PGPU_OK;
+  }
   // both halves of a residue in the same lanes (hensel_seq.hpp) when the launch still puts a wavefront on every SIMD
   // that way: resident rows in and out, per-element exponents
   const bool seq = modexp_seq_form_pays(H, K, count) && base_pair && out_pair && !a.sched && final_mul == pgpu::FM_UNIT;
@@ -2142,6 +2155,13 @@ int pgpu_modexp_n2_kernel_form(const pgpu_pubkey* key, size_t count, int* split,
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_modexp_n2_kernel_form: bad argument");
   RC_TRY(check_gen(key->gen, "key"));
   if (const pgpu_pubkey::PubForm* mf = split_modexp_form(key, count)) {
+    if (const pgpu_pubkey::PubForm* pf = pair_form(key))                       // (resident rows, small launches: the latency form)
+      if (pgpu::hensel_modexp_wave_has(pf->H * pf->K) && policy::modexp_wave_form_pays(count)) {
+        *split = 5;
+        *lanes = 64;
+        *limbs = pf->H * pf->K;
+        return PGPU_OK;
+      }
     if (pair_rows_enabled() && modexp_seq_form_pays(mf->H, mf->K, count)) {   // (resident rows, per-element exponents)
       *split = 2;
       *lanes = mf->H;

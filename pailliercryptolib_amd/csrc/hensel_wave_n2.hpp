@@ -1,0 +1,227 @@
+// pailliercryptolib_amd -- the LATENCY form for the n^2 domain (round 6): ONE exponentiation per WAVEFRONT on resident pair rows,
+// hensel_modexp_wave_kernel<L2, LPL> -- CipherText * PlainText (ipcl/ciphertext.cpp:83-106, 143-162) of small batches: the
+// reference's BM_Mul_CTPT sizes 16 ... 1024 (benchmark/bench_ops.cpp:138-149; one wavefront per element, at most one per SIMD).
+//
+// The same idea as hensel_wave.hpp (operand scan with the accumulators sliding down the lanes, the two scans of a pair product in
+// lock-step, whole-word quotient digits), for halves of L2 limbs that do not fit one limb per lane: lane l holds LPL consecutive
+// limbs (2048-bit keys: L2 = 72 limbs of 29 bits as 36 lanes x 2; 3072-bit: 112 as 56 x 2; 1024-bit: 38 x 1).  Nothing is
+// converted: the limbs ARE the row's limbs (29 bits, relaxed), the loop modulus is the row's P = n k == -1 (mod 2^29), the
+// radix the row's R = 2^(29 L2) -- a row goes in, a row comes out, like hensel_modexp_seq_kernel.  The slide moves the window
+// by ONE limb per step: inside a lane limb j takes over limb j+1's low part, the lane's top limb takes the low part of the
+// next lane's limb 0 (the one cross-lane move of a step and scan).
+// Whole-word (32-bit) digits (hensel_wave.hpp: wv_digit): values stay below 9 P instead of 2 P, sound for R >= 2^10 P -- the pair
+// rows' radix leaves 2^11 (2048-bit keys: 2^2088 against P < 2^2077); the host checks per key.  Results are relaxed limbs below
+// 2^29 + 2^9, which every consumer of pair rows accepts (kargs.hpp); the kernel's LAST product runs with masked digits, so
+// that the row it stores is below 2 P like every other producer's.
+// Window table in LDS (2^w entries x 2 x L2 limbs per wavefront); per-element exponents are per-WAVEFRONT here: scalar digits;
+// masked access selects under a per-lane compare.
+#ifndef PAILLIERCRYPTOLIB_AMD_CSRC_HENSEL_WAVE_N2_HPP_
+#define PAILLIERCRYPTOLIB_AMD_CSRC_HENSEL_WAVE_N2_HPP_
+
+#include "hensel_wave.hpp"
+
+namespace pgpu {
+
+template <int LPL>
+struct WaveCtxN {
+  uint32_t nl[LPL];
+  uint32_t e0, maskv, onev;
+};
+
+// limb i of a lane-distributed value (LPL limbs per lane) as an SGPR
+template <int LPL, int I>
+__device__ __forceinline__ uint32_t wvn_limb(const uint32_t (&x)[LPL]) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)x[I % LPL], I / LPL);
+}
+
+template <int LPL, bool WIDEQ>
+__device__ __forceinline__ uint32_t wvn_digit(const uint64_t (&acc)[LPL], uint32_t maskv) {
+  if constexpr (WIDEQ) return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)acc[0]);
+  else return (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)acc[0] & maskv));
+}
+
+// the slide by one limb: limb j <- low(limb j+1) + high(limb j); the lane's top limb takes the next lane's limb 0
+template <int LPL, int LB>
+__device__ __forceinline__ void wvn_slide(uint64_t (&acc)[LPL], uint32_t maskv, uint32_t onev) {
+  uint32_t lo[LPL];
+  lo[0] = wv_down_and((uint32_t)acc[0], maskv);
+#pragma unroll
+  for (int j = 1; j < LPL; ++j) lo[j] = (uint32_t)acc[j] & maskv;
+#pragma unroll
+  for (int j = 0; j < LPL; ++j) {
+    acc[j] >>= LB;
+    wv_mac(acc[j], j + 1 < LPL ? lo[j + 1] : lo[0], onev);
+  }
+}
+
+template <int LPL, int LB>
+__device__ __forceinline__ void wvn_finish(uint32_t (&r)[LPL], const uint64_t (&acc)[LPL]) {
+  r[0] = ((uint32_t)acc[0] & ((1u << LB) - 1)) + wv_up((uint32_t)(acc[LPL - 1] >> LB));
+#pragma unroll
+  for (int j = 1; j < LPL; ++j) r[j] = ((uint32_t)acc[j] & ((1u << LB) - 1)) + (uint32_t)(acc[j - 1] >> LB);
+}
+
+// (a, b) = (a, b) (x) (cm, dm), or the square (SQR: cm / dm unused): t = a*cm with its digits; b = a*dm + b*cm + q reduced; the
+// two scans in lock-step (hensel_wave.hpp: wv_pairmul)
+template <int L2, int LPL, int LB, bool SQR, bool WIDEQ>
+__device__ __forceinline__ void wvn_pairop(uint32_t (&a)[LPL], uint32_t (&b)[LPL], const uint32_t (&cm)[LPL],
+                                           const uint32_t (&dm)[LPL], const WaveCtxN<LPL>& c) {
+  uint64_t acc1[LPL], acc2[LPL];
+  uint32_t m2[LPL];
+#pragma unroll
+  for (int j = 0; j < LPL; ++j) {
+    acc1[j] = acc2[j] = 0;
+    m2[j] = SQR ? b[j] << 1 : dm[j];
+  }
+  ps_static_for<L2>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    const uint32_t sa = wvn_limb<LPL, i>(a);
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) wv_mac(acc1[j], sa, SQR ? a[j] : cm[j]);
+    const uint32_t q1 = wvn_digit<LPL, WIDEQ>(acc1, c.maskv);
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) wv_mac(acc2[j], sa, m2[j]);
+    if constexpr (!SQR) {
+      const uint32_t sb = wvn_limb<LPL, i>(b);
+#pragma unroll
+      for (int j = 0; j < LPL; ++j) wv_mac(acc2[j], sb, cm[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) wv_mac(acc1[j], q1, c.nl[j]);
+    wv_mac(acc2[0], q1, c.e0);
+    const uint32_t q2 = wvn_digit<LPL, WIDEQ>(acc2, c.maskv);
+    wvn_slide<LPL, LB>(acc1, c.maskv, c.onev);
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) wv_mac(acc2[j], q2, c.nl[j]);
+    wvn_slide<LPL, LB>(acc2, c.maskv, c.onev);
+  });
+  wvn_finish<LPL, LB>(a, acc1);
+  wvn_finish<LPL, LB>(b, acc2);
+}
+
+// 32-bit words of LDS table per wavefront: entry e, part (a / b), limb slot j, lane
+template <int LPL>
+constexpr size_t wvn_table_words(size_t entries) { return entries * 2 * LPL * kWave; }
+
+// One wavefront = ONE element.  Pair rows of 2*L2 29-bit limbs in (A.base_pair; stride 0: one shared row) and out (A.out_pair);
+// A.ctx.nhat / A.ctx.one in 29-bit limbs; per-element exponents (A.exp_stride > 0) or one shared one; fixed window A.window.
+// Dynamic LDS: kWavesPerWG * wvn_table_words<LPL>(2^A.window) * 4 bytes.
+template <int L2, int LPL, bool WIDEQ>
+__global__ __launch_bounds__(kWGThreads, 1) void hensel_modexp_wave_kernel(HenselModexpArgs A) {
+  constexpr int LB = kLimbBits, NL = L2 / LPL;
+  static_assert(L2 % LPL == 0 && NL < kWave, "LPL limbs per lane and a zero lane above them");
+  raise_wave_priority();
+  extern __shared__ uint32_t wvn_tbl_[];
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  const size_t inst = (size_t)blockIdx.x * kWavesPerWG + wv;
+  if (inst >= A.count) return;                       // (wave-uniform)
+  const bool in = lane < NL;
+  const int lk = in ? lane : 0;
+  WaveCtxN<LPL> c;
+#pragma unroll
+  for (int j = 0; j < LPL; ++j) c.nl[j] = in ? A.ctx.nhat[lk * LPL + j] : 0u;
+  c.e0 = lane == 0 ? 1u : 0u;
+  c.maskv = (1u << LB) - 1;
+  c.onev = 1;
+  asm("" : "+v"(c.maskv), "+v"(c.onev), "+v"(c.e0));
+  const int w = A.window, tsize = 1 << w;
+  uint32_t* tbl = wvn_tbl_ + (size_t)wv * wvn_table_words<LPL>((size_t)tsize) + lane;
+  const uint64_t* ep = A.exp + inst * A.exp_stride;
+  const int nwin = (A.exp_bits + w - 1) / w;
+  auto digit = [&](int i) -> int {
+    int bit = i * w;
+    int word = bit >> 6, sh = bit & 63;
+    uint64_t v = (word < A.exp_words) ? ep[word] >> sh : 0;
+    if (sh + w > 64 && word + 1 < A.exp_words) v |= ep[word + 1] << (64 - sh);
+    return __builtin_amdgcn_readfirstlane((int)(v & (uint64_t)(tsize - 1)));
+  };
+  const bool gather = A.ct_gather != 0;
+  auto entry_load = [&](uint32_t (&x)[LPL], uint32_t (&y)[LPL], int e) {
+    if (!gather) {
+#pragma unroll
+      for (int j = 0; j < LPL; ++j) {
+        x[j] = tbl[((size_t)e * 2 * LPL + j) * kWave];
+        y[j] = tbl[((size_t)e * 2 * LPL + LPL + j) * kWave];
+      }
+      return;
+    }
+    uint32_t ev = (uint32_t)e;          // (a VGPR copy of the digit: per-lane compare and select, never a branch on it)
+    asm("" : "+v"(ev));
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) x[j] = y[j] = 0;
+    for (int t = 0; t < tsize; ++t) {
+      const bool sel = ev == (uint32_t)t;
+#pragma unroll
+      for (int j = 0; j < LPL; ++j) {
+        const uint32_t tx = tbl[((size_t)t * 2 * LPL + j) * kWave], ty = tbl[((size_t)t * 2 * LPL + LPL + j) * kWave];
+        x[j] = sel ? tx : x[j];
+        y[j] = sel ? ty : y[j];
+      }
+    }
+  };
+  auto entry_store = [&](int e, const uint32_t (&x)[LPL], const uint32_t (&y)[LPL]) {
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) {     // (lanes above the limbs store their zeros: loads need no lane test)
+      tbl[((size_t)e * 2 * LPL + j) * kWave] = x[j];
+      tbl[((size_t)e * 2 * LPL + LPL + j) * kWave] = y[j];
+    }
+  };
+  uint32_t a[LPL], b[LPL], ba[LPL], bb[LPL];
+  {
+    const uint32_t* row = A.base_pair + inst * A.base_pair_stride;
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) {
+      a[j] = ba[j] = in ? row[lk * LPL + j] : 0u;
+      b[j] = bb[j] = in ? row[L2 + lk * LPL + j] : 0u;
+    }
+  }
+  // ---- window table: entry 0 = one, entry 1 = base, entry e = entry e-1 times base ----
+  entry_store(1, a, b);
+  {
+    uint32_t oa[LPL], ob[LPL];
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) {
+      oa[j] = in ? A.ctx.one[lk * LPL + j] : 0u;
+      ob[j] = in ? A.ctx.one[L2 + lk * LPL + j] : 0u;
+    }
+    entry_store(0, oa, ob);
+  }
+#pragma unroll 1
+  for (int e = 2; e < tsize; ++e) {
+    wvn_pairop<L2, LPL, LB, false, WIDEQ>(a, b, ba, bb, c);
+    entry_store(e, a, b);
+  }
+  // ---- main loop: w squarings, one multiplication by a table entry (always, also entry 0 = one); the LAST product with
+  // masked digits, so that the row it leaves is below 2 P like every other producer's ----
+  entry_load(a, b, nwin > 0 ? digit(nwin - 1) : 0);
+  uint32_t ma[LPL], mb[LPL];
+#pragma unroll 1
+  for (int win = nwin - 2; win >= 1; --win) {
+    const int d = digit(win);
+#pragma unroll 1
+    for (int i = 0; i < w; ++i) wvn_pairop<L2, LPL, LB, true, WIDEQ>(a, b, a, b, c);
+    entry_load(ma, mb, d);
+    wvn_pairop<L2, LPL, LB, false, WIDEQ>(a, b, ma, mb, c);
+  }
+  if (nwin >= 2) {
+    const int d = digit(0);
+#pragma unroll 1
+    for (int i = 0; i < w; ++i) wvn_pairop<L2, LPL, LB, true, WIDEQ>(a, b, a, b, c);
+    entry_load(ma, mb, d);
+  } else {                              // (a single window: the entry itself, times one)
+    entry_load(ma, mb, 0);
+  }
+  wvn_pairop<L2, LPL, LB, false, false>(a, b, ma, mb, c);
+  if (in) {
+    uint32_t* out = A.out_pair + inst * (size_t)(2 * L2);
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) {
+      out[lk * LPL + j] = a[j];
+      out[L2 + lk * LPL + j] = b[j];
+    }
+  }
+}
+
+}  // namespace pgpu
+
+#endif  // PAILLIERCRYPTOLIB_AMD_CSRC_HENSEL_WAVE_N2_HPP_

@@ -8,6 +8,7 @@
 #endif
 #if defined(PGPU_PART) && PGPU_PART == 35
 #include "hensel_wave.hpp"   // one exponentiation per WAVEFRONT, a limb per lane: the latency form of small batches (round 6)
+#include "hensel_wave_n2.hpp"   // ... for the n^2 domain: CT x PT of small batches on pair rows
 #endif
 
 #ifndef PGPU_PART
@@ -306,6 +307,25 @@ bool launch_hensel_wave_part35(int K, int lb, bool wide, const HenselArgs& a, hi
   if (K == 38 && lb == 28) return launch_wave_one<38, 28>(wide, a, s);
   if (K == 56 && lb == 28) return launch_wave_one<56, 28>(wide, a, s);
   if (K == 19 && lb == 29) return launch_wave_one<19, 29>(wide, a, s);
+  return false;
+}
+// CT x PT of small batches on pair rows: one wavefront per element; the window table is dynamic LDS (up to 128 KB)
+template <int L2, int LPL>
+static bool launch_modexp_wave_one(bool wide, const HenselModexpArgs& a, hipStream_t s) {
+  const unsigned blocks = (unsigned)((a.count + kWavesPerWG - 1) / kWavesPerWG);
+  const unsigned lds = (unsigned)(kWavesPerWG * wvn_table_words<LPL>((size_t)1 << a.window) * sizeof(uint32_t));
+  if (lds > 144 * 1024) return false;
+  const bool once = PGPU_LDS_ATTR_ONCE((hensel_modexp_wave_kernel<L2, LPL, true>), 144 * 1024);
+  const bool once0 = PGPU_LDS_ATTR_ONCE((hensel_modexp_wave_kernel<L2, LPL, false>), 144 * 1024);
+  if (!once || !once0) return false;
+  if (wide) hipLaunchKernelGGL((hensel_modexp_wave_kernel<L2, LPL, true>), dim3(blocks), dim3(kWGThreads), lds, s, a);
+  else hipLaunchKernelGGL((hensel_modexp_wave_kernel<L2, LPL, false>), dim3(blocks), dim3(kWGThreads), lds, s, a);
+  return true;
+}
+bool launch_hensel_modexp_wave_part35(int L2, bool wide, const HenselModexpArgs& a, hipStream_t s) {
+  if (L2 == 72) return launch_modexp_wave_one<72, 2>(wide, a, s);
+  if (L2 == 112) return launch_modexp_wave_one<112, 2>(wide, a, s);
+  if (L2 == 38) return launch_modexp_wave_one<38, 1>(wide, a, s);
   return false;
 }
 #elif PGPU_PART == 14

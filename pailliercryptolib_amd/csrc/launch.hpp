@@ -202,6 +202,13 @@ bool launch_hensel_wave_part35(int K, int lb, bool wide_digits, const HenselArgs
 inline bool launch_hensel_wave(int K, int lb, bool wide_digits, const HenselArgs& a, hipStream_t s) {
   return launch_hensel_wave_part35(K, lb, wide_digits, a, s);
 }
+// ... and for the n^2 domain (hensel_wave_n2.hpp): CT x PT of small batches on pair rows, one wavefront per element; L2 = limbs
+// per half of the rows (72: 2048-bit keys, 112: 3072, 38: 1024)
+inline bool hensel_modexp_wave_has(int L2) { return L2 == 72 || L2 == 112 || L2 == 38; }
+bool launch_hensel_modexp_wave_part35(int L2, bool wide_digits, const HenselModexpArgs& a, hipStream_t s);
+inline bool launch_hensel_modexp_wave(int L2, bool wide_digits, const HenselModexpArgs& a, hipStream_t s) {
+  return launch_hensel_modexp_wave_part35(L2, wide_digits, a, s);
+}
 // 32-bit words of window table per wavefront (hensel_ps.hpp: ps_table_words -- per entry two parts of ceil(K/4) 16-byte rows of 64 lanes)
 inline size_t hensel_ps_table_words(int K, size_t entries) { return entries * 2 * (size_t)((K + 3) / 4) * 64 * 4; }
 

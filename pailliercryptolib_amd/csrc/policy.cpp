@@ -119,6 +119,11 @@ bool wave_form_pays(size_t count, int busy) {
   if (pol == 2) return true;
   return pol == 1 && g_ps_policy.load() == 1 && busy == 0 && 2 * count <= kSimds;
 }
+bool modexp_wave_form_pays(size_t count) {
+  const int pol = g_wave_policy.load();
+  if (pol == 2) return true;
+  return pol == 1 && g_ps_policy.load() == 1 && count <= kSimds;
+}
 bool ps_form_pays(size_t count, int busy, int K) {
   const size_t waves = 2 * ((count + 63) / 64);
   const int pol = g_ps_policy.load();

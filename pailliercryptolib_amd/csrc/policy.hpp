@@ -57,6 +57,8 @@ size_t ps_split_head(int K, size_t count);
 // ... the latency form (hensel_wave.hpp: one exponentiation per wavefront): a lone launch that leaves SIMDs empty even at two
 // wavefronts per ciphertext -- up to kSimds / 2 = 512 ciphertexts; not while the one-lane form is forced or switched off
 bool wave_form_pays(size_t count, int busy);
+// ... and for CT x PT on resident rows (hensel_wave_n2.hpp: one wavefront per ELEMENT): launches of at most one wavefront per SIMD
+bool modexp_wave_form_pays(size_t count);
 // DJN encrypt onto pair rows / CT x PT / CT + CT of `count` elements in form (H, K): the sequential-halves kernels?
 bool fb_encrypt_seq_pays(int H, int K, size_t count, int busy = 0);
 bool modexp_seq_form_pays(int H, int K, size_t count);

@@ -66,8 +66,9 @@ int main() {
   CHECK(pol::pair_mul_seq_pays(4, 18, 1 << 20) && !pol::pair_mul_seq_pays(4, 18, 16383 - 16));
   // the latency form (one exponentiation per wavefront): small LONE launches only, and never while the one-lane form is forced / off
   CHECK(pol::wave_form_pays(1, 0) && pol::wave_form_pays(512, 0) && !pol::wave_form_pays(513, 0) && !pol::wave_form_pays(16, 1));
+  CHECK(pol::modexp_wave_form_pays(1) && pol::modexp_wave_form_pays(1024) && !pol::modexp_wave_form_pays(1025));
   pol::set_ps_policy(2);
-  CHECK(!pol::wave_form_pays(16, 0));
+  CHECK(!pol::wave_form_pays(16, 0) && !pol::modexp_wave_form_pays(16));
   pol::set_ps_policy(0);
   CHECK(!pol::wave_form_pays(16, 0));
   pol::set_ps_policy(1);

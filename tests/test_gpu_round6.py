@@ -92,3 +92,64 @@ def test_wave_decrypt_from_host_arrays_and_the_api(engine):
         got = np.zeros((count, 32), dtype=np.uint64)
         _capi.check(L.pgpu_paillier_decrypt_crt(sk._h, ptr(raw), ptr(got), count))
         assert np.array_equal(got, _c_oracle_decrypt(p, q, 2048, raw)), "host-array decrypt of %d raw rows differs from the C oracle" % count
+
+
+@pytest.mark.parametrize("bits,count,e_bits", [(2048, 1, 33), (2048, 7, 1024), (2048, 65, 64), (2048, 300, 17), (2048, 1024, 33),
+                                               (2048, 1100, 5), (3072, 9, 40), (3072, 130, 1536), (1024, 16, 33), (1024, 300, 512)])
+def test_wave_modexp_n2_kernel_is_bit_identical(engine, bits, count, e_bits):
+    """csrc/hensel_wave_n2.hpp: CipherText * PlainText (ipcl/ciphertext.cpp:143-162) with one exponentiation per wavefront on
+    pair rows -- what launches of up to 1024 resident ciphertexts take by default (the reference's BM_Mul_CTPT sizes,
+    bench_ops.cpp:138-149, with its 1024-bit plaintexts; its tests use 32-bit ones, test_ops.cpp:294-325).  Forced on and
+    off: pow(c, e, n^2) either way, for every producer of rows, edge exponents (0, 1, all ones) and bases (0, 1, n^2 - 1, n),
+    one exponent for the whole batch, results re-read by CT+CT / CRT decrypt / the kernel itself, masked table access."""
+    from pailliercryptolib_amd import _capi
+    p, q, hs = key_case(bits)
+    n = p * q
+    nsq = n * n
+    nw, ew = bits // 64, (e_bits + 63) // 64
+    rng = random.Random(count * 1000 + e_bits + bits)
+    m = ([0, 1, n - 1] + [rng.randrange(n) for _ in range(count)])[:count]
+    r = [rng.getrandbits(bits // 2) for _ in range(count)]
+    e = ([0, 1, (1 << e_bits) - 1, 2] + [rng.getrandbits(e_bits) for _ in range(count)])[:count]
+    pk, sk = engine.PublicKey(n, bits, hs=hs), engine.PrivateKey(p, q)
+    R = Res()
+    L = R.L
+
+    def form():
+        split, lanes, limbs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _capi.check(L.pgpu_modexp_n2_kernel_form(pk._h, count, ctypes.byref(split), ctypes.byref(lanes), ctypes.byref(limbs)))
+        return split.value, lanes.value, limbs.value
+    try:
+        c1 = R.op(L.pgpu_batch_encrypt, pk._h, R.up(m, nw), R.up(r, nw // 2), bits // 2)      # rows of the encrypt kernel
+        s = R.op(L.pgpu_batch_ct_add, pk._h, c1, c1)                                        # ... of CT + CT
+        raw = ([0, 1, nsq - 1, n, n + 1] + [rng.randrange(nsq) for _ in range(count)])[:count]
+        up = R.up(raw, 2 * nw)                                                               # ... uploaded words
+        eh = R.up(e, ew)
+        srcs = [c1, s, up]
+        vals = [R.down(x) for x in srcs]
+        want = [[pow(c, x, nsq) for c, x in zip(v, e)] for v in vals]
+        L.pgpu_debug_set_wave_decrypt(0)
+        try:
+            assert form()[0] != 5
+            assert [R.down(R.op(L.pgpu_batch_ct_mul, pk._h, x, eh, e_bits)) for x in srcs] == want, "the multi-lane kernels differ from pow()"
+            L.pgpu_debug_set_wave_decrypt(2)
+            assert form() == (5, 64, {1024: 38, 2048: 72, 3072: 112}[bits])
+            outs = [R.op(L.pgpu_batch_ct_mul, pk._h, x, eh, e_bits) for x in srcs]
+            assert [R.down(o) for o in outs] == want, "the wavefront-wide kernel differs from pow()"
+            t2 = R.op(L.pgpu_batch_ct_mul, pk._h, outs[0], eh, e_bits)                       # its rows, read by itself,
+            assert R.down(t2) == [pow(c, x, nsq) for c, x in zip(want[0], e)]
+            one_e = R.up([e[-1]], ew)                                                        # one exponent for the whole batch
+            assert R.down(R.op(L.pgpu_batch_ct_mul, pk._h, c1, one_e, e_bits)) == [pow(c, e[-1], nsq) for c in vals[0]]
+            if count <= 300:
+                _capi.check(L.pgpu_set_table_gather_policy(1))
+                assert R.down(R.op(L.pgpu_batch_ct_mul, pk._h, s, eh, e_bits)) == want[1]
+                _capi.check(L.pgpu_set_table_gather_policy(0))
+            L.pgpu_debug_set_wave_decrypt(0)                                                 # ... by the multi-lane kernels
+            assert R.down(R.op(L.pgpu_batch_ct_add, pk._h, outs[0], c1)) == [a * b % nsq for a, b in zip(want[0], vals[0])]
+            assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, outs[0])) == [a * x % n for a, x in zip(m, e)]
+        finally:
+            _capi.check(L.pgpu_set_table_gather_policy(0))
+            L.pgpu_debug_set_wave_decrypt(1)
+        assert (form()[0] == 5) == (count <= 1024)
+    finally:
+        R.close()
