@@ -12,8 +12,9 @@
 //               q = acc_0 mod 2^LB                      v_and + v_readfirstlane: the digit is an SGPR as well (P == -1: no multiply)
 //               acc_l += q * P_l                        lane 0's low limb becomes zero
 //               acc_l = (acc_{l+1} mod 2^LB) + (acc_l >> LB)       one v_lshrrev_b64, one v_and_b32_dpp wave_shl:1, one multiply-add
-// -- seven instructions per step whatever K is, K steps per half-width product, no LDS, no waiting for memory; the two scans
-// of a pair product run in lock-step, so that each one's digit broadcast is covered by the other's instructions.  The last line
+// -- six or seven instructions per step whatever K is, K steps per half-width product, no LDS, no waiting for memory; the two
+// scans of a pair product run in lock-step and in a pinned order (wv_pairop), so that each one's digit broadcast is covered by
+// the other's instructions.  The last line
 // both slides the window and keeps every accumulator below 2^37 (each lane passes its own carry one column up while it
 // takes over its neighbour's low limb), so limbs need not be canonical anywhere: products leave RELAXED limbs (below
 // 2^LB + 2^9; with 32-bit digits -- wv_digit -- values stay below 17 P instead of 2 P).  The pair product of hensel.hpp on top of it: t = a*c with its digits q_i kept in SGPRs; w = a*d + b*c + q
@@ -84,53 +85,108 @@ __device__ __forceinline__ uint32_t wv_finish(uint64_t acc) {
   return ((uint32_t)acc & PsLimb<LB>::mask) + wv_up((uint32_t)(acc >> LB));
 }
 
-// (a, b) = (a, b)^2: t = a*a with its digits; b = 2*a*b + q reduced.  The two scans run in LOCK-STEP -- step i of the second
-// needs digit i of the first and nothing else of it --, so that one chain's broadcast round trip (VALU -> SGPR -> VALU) is
-// covered by the other chain's instructions: a lone wavefront has nobody else to issue from.
-template <int K, int LB, bool WIDEQ>
-__device__ __forceinline__ void wv_pairsqr(uint32_t& a, uint32_t& b, const WaveCtx& c) {
-  uint32_t sa[K];
-  wv_bcast_limbs<K>(sa, a);
-  const uint32_t b2 = b << 1;
+// (a, b) = (a, b) (x) (cm, dm), or the square (SQR: cm = a, dm = b): t = a*cm with its digits; b = a*dm + b*cm + q reduced.
+// The two scans run in LOCK-STEP -- step i of the second needs digit i of the first and nothing else of it --, so that one
+// chain's broadcast round trip (VALU -> SGPR -> VALU) is covered by the other chain's instructions: a lone wavefront has
+// nobody else to issue from.  And in a PINNED order (a scheduling barrier behind every instruction, the first product of
+// step i+1 pulled into step i): gfx950 wants two instructions between a VALU write of an SGPR and a VALU read of it, and
+// between a VALU write of a VGPR and a DPP read of it (one before a v_readfirstlane); in this order every such pair has them --
+// 14 instructions per step and pair, the broadcast of the limb a_(i+2) among them as a filler (16 with the b_i broadcast of a
+// general product), no s_nop.  Left to the scheduler: 14 plus 3 s_nop.
+#define WV_PIN __builtin_amdgcn_sched_barrier(0)
+template <int K, int LB, bool SQR, bool WIDEQ>
+__device__ __forceinline__ void wv_pairop(uint32_t& a, uint32_t& b, uint32_t cm, uint32_t dm, const WaveCtx& c) {
+  const uint32_t m1 = SQR ? a : cm, m2 = SQR ? b << 1 : dm, a0 = a, b0 = b;
+  uint32_t sa[K + 2];                                            // the limbs of a as SGPRs, fetched two steps ahead (RL below)
+  sa[0] = (uint32_t)__builtin_amdgcn_readlane((int)a0, 0);
+  sa[1] = (uint32_t)__builtin_amdgcn_readlane((int)a0, K > 1 ? 1 : 0);
+  uint32_t sb[K + 2];                                            // ... and of b (general product)
+  if constexpr (!SQR) {
+    sb[0] = (uint32_t)__builtin_amdgcn_readlane((int)b0, 0);
+    sb[1] = (uint32_t)__builtin_amdgcn_readlane((int)b0, K > 1 ? 1 : 0);
+  }
   uint64_t acc1 = 0, acc2 = 0;
+  uint32_t lo2 = 0;
+  WV_PIN;
+  wv_mac(acc1, sa[0], m1);                                       // A1 of step 0
+  WV_PIN;
   ps_static_for<K>([&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
-    wv_mac(acc1, sa[i], a);
-    const uint32_t q1 = wv_digit<LB, WIDEQ>(acc1, c);
-    wv_mac(acc2, sa[i], b2);
-    wv_mac(acc1, q1, c.nl);
-    wv_mac(acc2, q1, c.e0);
-    const uint32_t q2 = wv_digit<LB, WIDEQ>(acc2, c);
-    wv_slide<LB>(acc1, c);
-    wv_mac(acc2, q2, c.nl);
-    wv_slide<LB>(acc2, c);
+    uint32_t q1;
+    if constexpr (WIDEQ) {
+      q1 = wv_digit<LB, true>(acc1, c);                          // R1
+      WV_PIN;
+      if constexpr (i > 0) {
+        wv_mac(acc2, lo2, c.onev);                               // S2c of step i-1
+        WV_PIN;
+      }
+    } else {                                                     // (masked digits: the v_and one instruction ahead of the broadcast)
+      const uint32_t t1 = (uint32_t)acc1 & c.maskv;
+      WV_PIN;
+      if constexpr (i > 0) {
+        wv_mac(acc2, lo2, c.onev);
+        WV_PIN;
+      }
+      q1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t1);
+      WV_PIN;
+    }
+    wv_mac(acc2, sa[i], m2);                                     // A2
+    WV_PIN;
+    if constexpr (!SQR) {
+      wv_mac(acc2, sb[i], m1);
+      WV_PIN;
+    }
+    wv_mac(acc2, q1, c.e0);                                      // B2
+    WV_PIN;
+    wv_mac(acc1, q1, c.nl);                                      // B1
+    WV_PIN;
+    uint32_t q2;
+    if constexpr (WIDEQ) {
+      q2 = wv_digit<LB, true>(acc2, c);                          // R2
+      WV_PIN;
+      if constexpr (i + 2 < K) sa[i + 2] = (uint32_t)__builtin_amdgcn_readlane((int)a0, i + 2);   // RL: fills the slot a DPP
+      WV_PIN;                                                    //     read of acc1 needs behind B1
+    } else {
+      const uint32_t t2 = (uint32_t)acc2 & c.maskv;
+      WV_PIN;
+      if constexpr (i + 2 < K) sa[i + 2] = (uint32_t)__builtin_amdgcn_readlane((int)a0, i + 2);
+      WV_PIN;
+      q2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t2);
+      WV_PIN;
+    }
+    if constexpr (!SQR && i + 2 < K) {
+      sb[i + 2] = (uint32_t)__builtin_amdgcn_readlane((int)b0, i + 2);
+      WV_PIN;
+    }
+    const uint32_t lo1 = wv_down_and((uint32_t)acc1, c.maskv);   // S1a
+    WV_PIN;
+    acc1 >>= LB;                                                 // S1b
+    WV_PIN;
+    wv_mac(acc2, q2, c.nl);                                      // C2
+    WV_PIN;
+    wv_mac(acc1, lo1, c.onev);                                   // S1c
+    WV_PIN;
+    if constexpr (i + 1 < K) {
+      wv_mac(acc1, sa[i + 1], m1);                               // A1 of step i+1
+      WV_PIN;
+    }
+    lo2 = wv_down_and((uint32_t)acc2, c.maskv);                  // S2a
+    WV_PIN;
+    acc2 >>= LB;                                                 // S2b
+    WV_PIN;
   });
+  wv_mac(acc2, lo2, c.onev);                                     // S2c of the last step
   a = wv_finish<LB>(acc1);
   b = wv_finish<LB>(acc2);
 }
-
-// (a, b) = (a, b) (x) (cm, dm): t = a*cm with its digits; b = a*dm + b*cm + q reduced; in lock-step like the squaring
+#undef WV_PIN
+template <int K, int LB, bool WIDEQ>
+__device__ __forceinline__ void wv_pairsqr(uint32_t& a, uint32_t& b, const WaveCtx& c) {
+  wv_pairop<K, LB, true, WIDEQ>(a, b, a, b, c);
+}
 template <int K, int LB, bool WIDEQ>
 __device__ __forceinline__ void wv_pairmul(uint32_t& a, uint32_t& b, uint32_t cm, uint32_t dm, const WaveCtx& c) {
-  uint32_t sa[K];
-  wv_bcast_limbs<K>(sa, a);
-  uint64_t acc1 = 0, acc2 = 0;
-  const uint32_t b0 = b;
-  ps_static_for<K>([&](auto ic) __attribute__((always_inline)) {
-    constexpr int i = decltype(ic)::value;
-    wv_mac(acc1, sa[i], cm);
-    const uint32_t q1 = wv_digit<LB, WIDEQ>(acc1, c);
-    wv_mac(acc2, sa[i], dm);
-    wv_mac(acc2, (uint32_t)__builtin_amdgcn_readlane((int)b0, i), cm);
-    wv_mac(acc1, q1, c.nl);
-    wv_mac(acc2, q1, c.e0);
-    const uint32_t q2 = wv_digit<LB, WIDEQ>(acc2, c);
-    wv_slide<LB>(acc1, c);
-    wv_mac(acc2, q2, c.nl);
-    wv_slide<LB>(acc2, c);
-  });
-  a = wv_finish<LB>(acc1);
-  b = wv_finish<LB>(acc2);
+  wv_pairop<K, LB, false, WIDEQ>(a, b, cm, dm, c);
 }
 
 // 32-bit words of pair buffer per exponentiation (entry kernel -> wave kernel -> exit kernel): a then b, K limbs each

@@ -34,26 +34,6 @@ __device__ __forceinline__ uint32_t wvn_limb(const uint32_t (&x)[LPL]) {
   return (uint32_t)__builtin_amdgcn_readlane((int)x[I % LPL], I / LPL);
 }
 
-template <int LPL, bool WIDEQ>
-__device__ __forceinline__ uint32_t wvn_digit(const uint64_t (&acc)[LPL], uint32_t maskv) {
-  if constexpr (WIDEQ) return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)acc[0]);
-  else return (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)acc[0] & maskv));
-}
-
-// the slide by one limb: limb j <- low(limb j+1) + high(limb j); the lane's top limb takes the next lane's limb 0
-template <int LPL, int LB>
-__device__ __forceinline__ void wvn_slide(uint64_t (&acc)[LPL], uint32_t maskv, uint32_t onev) {
-  uint32_t lo[LPL];
-  lo[0] = wv_down_and((uint32_t)acc[0], maskv);
-#pragma unroll
-  for (int j = 1; j < LPL; ++j) lo[j] = (uint32_t)acc[j] & maskv;
-#pragma unroll
-  for (int j = 0; j < LPL; ++j) {
-    acc[j] >>= LB;
-    wv_mac(acc[j], j + 1 < LPL ? lo[j + 1] : lo[0], onev);
-  }
-}
-
 template <int LPL, int LB>
 __device__ __forceinline__ void wvn_finish(uint32_t (&r)[LPL], const uint64_t (&acc)[LPL]) {
   r[0] = ((uint32_t)acc[0] & ((1u << LB) - 1)) + wv_up((uint32_t)(acc[LPL - 1] >> LB));
@@ -61,43 +41,118 @@ __device__ __forceinline__ void wvn_finish(uint32_t (&r)[LPL], const uint64_t (&
   for (int j = 1; j < LPL; ++j) r[j] = ((uint32_t)acc[j] & ((1u << LB) - 1)) + (uint32_t)(acc[j - 1] >> LB);
 }
 
-// (a, b) = (a, b) (x) (cm, dm), or the square (SQR: cm / dm unused): t = a*cm with its digits; b = a*dm + b*cm + q reduced; the
-// two scans in lock-step (hensel_wave.hpp: wv_pairmul)
+// (a, b) = (a, b) (x) (cm, dm), or the square (SQR: cm = a, dm = b): t = a*cm with its digits; b = a*dm + b*cm + q reduced; the
+// two scans in lock-step and in the pinned order of hensel_wave.hpp: wv_pairop (its comment names the steps), every step on
+// LPL limbs.  The slide by one limb: limb j <- low(limb j+1) + high(limb j); the lane's top limb takes the next lane's limb 0.
+#define WV_PIN __builtin_amdgcn_sched_barrier(0)
 template <int L2, int LPL, int LB, bool SQR, bool WIDEQ>
 __device__ __forceinline__ void wvn_pairop(uint32_t (&a)[LPL], uint32_t (&b)[LPL], const uint32_t (&cm)[LPL],
                                            const uint32_t (&dm)[LPL], const WaveCtxN<LPL>& c) {
   uint64_t acc1[LPL], acc2[LPL];
-  uint32_t m2[LPL];
+  uint32_t m1[LPL], m2[LPL], a0[LPL], b0[LPL], lo1[LPL], lo2[LPL];
 #pragma unroll
   for (int j = 0; j < LPL; ++j) {
     acc1[j] = acc2[j] = 0;
+    a0[j] = a[j];
+    b0[j] = b[j];
+    m1[j] = SQR ? a[j] : cm[j];
     m2[j] = SQR ? b[j] << 1 : dm[j];
+    lo1[j] = lo2[j] = 0;
   }
+  uint32_t sa[L2 + 2], sb[L2 + 2];                               // the limbs of a (and b) as SGPRs, fetched two steps ahead
+  sa[0] = wvn_limb<LPL, 0>(a0);
+  sa[1] = wvn_limb<LPL, (L2 > 1 ? 1 : 0)>(a0);
+  if constexpr (!SQR) {
+    sb[0] = wvn_limb<LPL, 0>(b0);
+    sb[1] = wvn_limb<LPL, (L2 > 1 ? 1 : 0)>(b0);
+  }
+  WV_PIN;
+#pragma unroll
+  for (int j = 0; j < LPL; ++j) wv_mac(acc1[j], sa[0], m1[j]);   // A1 of step 0
+  WV_PIN;
   ps_static_for<L2>([&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
-    const uint32_t sa = wvn_limb<LPL, i>(a);
+    uint32_t q1, t1 = 0;
+    if constexpr (WIDEQ) {
+      q1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)acc1[0]);                       // R1
+      asm volatile("" : "+v"(acc2[0]) : "s"(q1));       // (what follows on acc2 stays behind the broadcast: it is its filler)
+    } else {
+      t1 = (uint32_t)acc1[0] & c.maskv;
+    }
+    WV_PIN;
+    if constexpr (i > 0) {
 #pragma unroll
-    for (int j = 0; j < LPL; ++j) wv_mac(acc1[j], sa, SQR ? a[j] : cm[j]);
-    const uint32_t q1 = wvn_digit<LPL, WIDEQ>(acc1, c.maskv);
-#pragma unroll
-    for (int j = 0; j < LPL; ++j) wv_mac(acc2[j], sa, m2[j]);
-    if constexpr (!SQR) {
-      const uint32_t sb = wvn_limb<LPL, i>(b);
-#pragma unroll
-      for (int j = 0; j < LPL; ++j) wv_mac(acc2[j], sb, cm[j]);
+      for (int j = 0; j < LPL; ++j) wv_mac(acc2[j], lo2[(j + 1) % LPL], c.onev);                   // S2c of step i-1
+      WV_PIN;
+    }
+    if constexpr (!WIDEQ) {
+      q1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t1);
+      asm volatile("" : "+v"(acc2[0]) : "s"(q1));
+      WV_PIN;
     }
 #pragma unroll
-    for (int j = 0; j < LPL; ++j) wv_mac(acc1[j], q1, c.nl[j]);
-    wv_mac(acc2[0], q1, c.e0);
-    const uint32_t q2 = wvn_digit<LPL, WIDEQ>(acc2, c.maskv);
-    wvn_slide<LPL, LB>(acc1, c.maskv, c.onev);
+    for (int j = 0; j < LPL; ++j) wv_mac(acc2[j], sa[i], m2[j]);                                   // A2
+    WV_PIN;
+    if constexpr (!SQR) {
 #pragma unroll
-    for (int j = 0; j < LPL; ++j) wv_mac(acc2[j], q2, c.nl[j]);
-    wvn_slide<LPL, LB>(acc2, c.maskv, c.onev);
+      for (int j = 0; j < LPL; ++j) wv_mac(acc2[j], sb[i], m1[j]);
+      WV_PIN;
+    }
+    wv_mac(acc2[0], q1, c.e0);                                                                     // B2
+    WV_PIN;
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) wv_mac(acc1[j], q1, c.nl[j]);                                    // B1
+    WV_PIN;
+    uint32_t q2, t2 = 0;
+    if constexpr (WIDEQ) {
+      q2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)acc2[0]);                       // R2
+      asm volatile("" : "+v"(acc1[0]) : "s"(q2));
+    } else {
+      t2 = (uint32_t)acc2[0] & c.maskv;
+    }
+    WV_PIN;
+    if constexpr (i + 2 < L2) {                                                                    // RL
+      sa[i + 2] = wvn_limb<LPL, (i + 2 < L2 ? i + 2 : 0)>(a0);
+      if constexpr (!SQR) sb[i + 2] = wvn_limb<LPL, (i + 2 < L2 ? i + 2 : 0)>(b0);
+    }
+    WV_PIN;
+    if constexpr (!WIDEQ) {
+      q2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t2);
+      asm volatile("" : "+v"(acc1[0]) : "s"(q2));
+      WV_PIN;
+    }
+    lo1[0] = wv_down_and((uint32_t)acc1[0], c.maskv);                                              // S1a
+#pragma unroll
+    for (int j = 1; j < LPL; ++j) lo1[j] = (uint32_t)acc1[j] & c.maskv;
+    WV_PIN;
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) acc1[j] >>= LB;                                                  // S1b
+    WV_PIN;
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) wv_mac(acc2[j], q2, c.nl[j]);                                    // C2
+    WV_PIN;
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) wv_mac(acc1[j], lo1[(j + 1) % LPL], c.onev);                     // S1c
+    WV_PIN;
+    if constexpr (i + 1 < L2) {
+#pragma unroll
+      for (int j = 0; j < LPL; ++j) wv_mac(acc1[j], sa[i + 1], m1[j]);                             // A1 of step i+1
+      WV_PIN;
+    }
+    lo2[0] = wv_down_and((uint32_t)acc2[0], c.maskv);                                              // S2a
+#pragma unroll
+    for (int j = 1; j < LPL; ++j) lo2[j] = (uint32_t)acc2[j] & c.maskv;
+    WV_PIN;
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) acc2[j] >>= LB;                                                  // S2b
+    WV_PIN;
   });
+#pragma unroll
+  for (int j = 0; j < LPL; ++j) wv_mac(acc2[j], lo2[(j + 1) % LPL], c.onev);                       // S2c of the last step
   wvn_finish<LPL, LB>(a, acc1);
   wvn_finish<LPL, LB>(b, acc2);
 }
+#undef WV_PIN
 
 // 32-bit words of LDS table per wavefront: entry e, part (a / b), limb slot j, lane
 template <int LPL>
