@@ -1442,6 +1442,18 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
       f.out_pair = d_pair;
       f.ct_gather = masked ? 1 : 0;
       TimerScope t(d, s, PGPU_KERNEL_FB_ENCRYPT);
+      // The latency form (hensel_wave_n2.hpp; round 6): small launches onto pair rows -- one wavefront per element; 32-bit
+      // quotient digits where the rows' radix leaves room (modexp_split_on)
+      if (d_pair && pgpu::hensel_modexp_wave_has(form->H * form->K) && policy::modexp_wave_form_pays(count)) {
+        static const bool wide_ok = [] { const char* e = getenv("PGPU_WAVE_WIDEQ"); return !e || atoi(e) != 0; }();
+        const bool wide = wide_ok && pgpu::kLimbBits * form->H * form->K - (form->n.BitSize() + pgpu::kLimbBits) >= 10;
+        t.set_form(PGPU_FORM_WAVE);
+        if (!pgpu::launch_hensel_fb_encrypt_wave(form->H * form->K, wide, f, s))
+          return fail(PGPU_ERR_UNSUPPORTED, "wavefront-wide fixed-base kernel not compiled");
+        HIP_TRY(hipGetLastError());
+        t.stop();
+        return PGPU_OK;
+      }
       // resident results of launches that still put a wavefront on every SIMD with half the lanes per element: both
       // halves of a residue in the same lanes (hensel_seq.hpp)
       const bool seq = d_pair && fb_encrypt_seq_pays(form->H, form->K, count, busy_lanes);
@@ -2130,6 +2142,17 @@ int pgpu_encrypt_kernel_form_ex(const pgpu_pubkey* key, int m_words, size_t coun
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_encrypt_kernel_form: bad argument");
   RC_TRY(check_gen(key->gen, "key"));
   const pgpu_pubkey::PubForm* ef = key->djn && fixed_base_window() > 0 ? use_split_encrypt(key, m_words, count) : nullptr;
+  if (key->djn && fixed_base_window() > 0) {
+    // resident results (pair rows) of small launches: one wavefront per element (hensel_wave_n2.hpp), whatever form a launch
+    // from host arrays of this size would take
+    const pgpu_pubkey::PubForm* pf = pair_form(key);
+    if (pf && m_words <= key->n_words && pgpu::hensel_modexp_wave_has(pf->H * pf->K) && policy::modexp_wave_form_pays(count)) {
+      *split = 5;
+      *lanes = 64;
+      *limbs = pf->H * pf->K;
+      return PGPU_OK;
+    }
+  }
   if (ef) {
     // resident results (pair rows) take the key's pair form, and from a launch size on both halves in the same lanes
     const pgpu_pubkey::PubForm* pf = pair_form(key);

@@ -1,4 +1,5 @@
-// pailliercryptolib_amd -- the LATENCY form for the n^2 domain (round 6): ONE exponentiation per WAVEFRONT on resident pair rows,
+// pailliercryptolib_amd -- the LATENCY forms for the n^2 domain (round 6): ONE exponentiation per WAVEFRONT on resident pair rows,
+// hensel_fb_encrypt_wave_kernel<L2, LPL> (DJN encrypt of small batches: at the end of this file) and
 // hensel_modexp_wave_kernel<L2, LPL> -- CipherText * PlainText (ipcl/ciphertext.cpp:83-106, 143-162) of small batches: the
 // reference's BM_Mul_CTPT sizes 16 ... 1024 (benchmark/bench_ops.cpp:138-149; one wavefront per element, at most one per SIMD).
 //
@@ -267,6 +268,147 @@ __global__ __launch_bounds__(kWGThreads, 1) void hensel_modexp_wave_kernel(Hense
     entry_load(ma, mb, 0);
   }
   wvn_pairop<L2, LPL, LB, false, false>(a, b, ma, mb, c);
+  if (in) {
+    uint32_t* out = A.out_pair + inst * (size_t)(2 * L2);
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) {
+      out[lk * LPL + j] = a[j];
+      out[L2 + lk * LPL + j] = b[j];
+    }
+  }
+}
+
+// r = x*y*R^-1 mod n under the TRUE modulus n (not == -1 mod 2^29: the digit takes a multiply by n0inv), one scan; x, y, r
+// lane-distributed.  Used twice per element by the encrypt exit below: no lock-step partner, the scheduler's order.
+template <int L2, int LPL, int LB>
+__device__ __forceinline__ void wvn_montmul_true(uint32_t (&r)[LPL], const uint32_t (&x)[LPL], const uint32_t (&y)[LPL],
+                                                 const uint32_t (&n)[LPL], uint32_t n0inv, uint32_t maskv, uint32_t onev) {
+  uint64_t acc[LPL];
+#pragma unroll
+  for (int j = 0; j < LPL; ++j) acc[j] = 0;
+  ps_static_for<L2>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    const uint32_t sx = wvn_limb<LPL, i>(x);
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) wv_mac(acc[j], sx, y[j]);
+    const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)acc[0] * n0inv) & maskv));
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) wv_mac(acc[j], q, n[j]);
+    uint32_t lo[LPL];
+    lo[0] = wv_down_and((uint32_t)acc[0], maskv);
+#pragma unroll
+    for (int j = 1; j < LPL; ++j) lo[j] = (uint32_t)acc[j] & maskv;
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) {
+      acc[j] >>= LB;
+      wv_mac(acc[j], lo[(j + 1) % LPL], onev);
+    }
+  });
+  wvn_finish<LPL, LB>(r, acc);
+}
+
+// DJN encrypt of small batches on the fixed-base table of pairs (hensel.hpp: hensel_fb_encrypt_kernel; PublicKey::encrypt,
+// ipcl/pub_key.cpp:51-64, 88-105): ONE wavefront per element.  hs^r = the product of one table entry per w-bit digit of r --
+// nwin - 1 pair products, the entry of the next step fetched while this one's product runs --, then times g^m = 1 + n*m as
+// two half-width products under the true modulus n (hensel.hpp: pair_times_gm: only b changes, b += (-k^-1 m a) mod n);
+// the result leaves as a pair row (A.out_pair).  The last pair product runs with masked digits (rows below 2 P).
+template <int L2, int LPL, bool WIDEQ>
+__global__ __launch_bounds__(kWGThreads, 1) void hensel_fb_encrypt_wave_kernel(HenselFbArgs A) {
+  constexpr int LB = kLimbBits, NL = L2 / LPL;
+  static_assert(L2 % LPL == 0 && NL < kWave, "LPL limbs per lane and a zero lane above them");
+  raise_wave_priority();
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  const size_t inst = (size_t)blockIdx.x * kWavesPerWG + wv;
+  if (inst >= A.count) return;                       // (wave-uniform)
+  const bool in = lane < NL;
+  const int lk = in ? lane : 0;
+  WaveCtxN<LPL> c;
+#pragma unroll
+  for (int j = 0; j < LPL; ++j) c.nl[j] = in ? A.ctx.nhat[lk * LPL + j] : 0u;
+  c.e0 = lane == 0 ? 1u : 0u;
+  c.maskv = (1u << LB) - 1;
+  c.onev = 1;
+  asm("" : "+v"(c.maskv), "+v"(c.onev), "+v"(c.e0));
+  const int w = A.w, tsize = 1 << w;
+  const uint64_t* ep = A.exp + inst * A.exp_stride;
+  auto digit = [&](int i) -> int {
+    int bit = i * w;
+    int word = bit >> 6, sh = bit & 63;
+    uint64_t v = (word < A.exp_words) ? ep[word] >> sh : 0;
+    if (sh + w > 64 && word + 1 < A.exp_words) v |= ep[word + 1] << (64 - sh);
+    return __builtin_amdgcn_readfirstlane((int)(v & (uint64_t)(tsize - 1)));
+  };
+  const bool gather = A.ct_gather != 0;
+  auto load_entry = [&](uint32_t (&x)[LPL], uint32_t (&y)[LPL], int i) {
+    const uint32_t* win = A.table + (size_t)i * tsize * (2 * L2);
+    const int d = digit(i);
+    if (!gather) {
+      const uint32_t* row = win + (size_t)d * (2 * L2);
+#pragma unroll
+      for (int j = 0; j < LPL; ++j) {
+        x[j] = in ? row[lk * LPL + j] : 0u;
+        y[j] = in ? row[L2 + lk * LPL + j] : 0u;
+      }
+      return;
+    }
+    // masked: every entry of the window is read, the wanted one selected under a per-lane compare (no address, no branch
+    // follows the digit of r)
+    uint32_t dv = (uint32_t)d;
+    asm("" : "+v"(dv));
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) x[j] = y[j] = 0;
+    for (int t = 0; t < tsize; ++t) {
+      const uint32_t* row = win + (size_t)t * (2 * L2);
+      const bool sel = dv == (uint32_t)t;
+#pragma unroll
+      for (int j = 0; j < LPL; ++j) {
+        const uint32_t tx = in ? row[lk * LPL + j] : 0u, ty = in ? row[L2 + lk * LPL + j] : 0u;
+        x[j] = sel ? tx : x[j];
+        y[j] = sel ? ty : y[j];
+      }
+    }
+  };
+  uint32_t a[LPL], b[LPL], ma[LPL], mb[LPL], na[LPL], nb[LPL];
+  load_entry(a, b, 0);
+  if (A.nwin > 1) load_entry(ma, mb, 1);
+#pragma unroll 1
+  for (int i = 1; i + 1 < A.nwin; ++i) {
+    load_entry(na, nb, i + 1);                      // (in flight while the product runs)
+    wvn_pairop<L2, LPL, LB, false, WIDEQ>(a, b, ma, mb, c);
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) {
+      ma[j] = na[j];
+      mb[j] = nb[j];
+    }
+  }
+  if (A.nwin > 1) wvn_pairop<L2, LPL, LB, false, false>(a, b, ma, mb, c);
+  // ---- times g^m: b += (-k^-1 m a) mod n, two products under the true modulus ----
+  {
+    uint32_t nt[LPL], gm[LPL], mv[LPL], u[LPL], v[LPL];
+    const uint64_t* mw = A.fm_words + inst * A.fm_stride;
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) {
+      nt[j] = in ? A.ctx.n[lk * LPL + j] : 0u;
+      gm[j] = in ? A.ctx.gm[lk * LPL + j] : 0u;
+      const int bit = (lk * LPL + j) * LB, word = bit >> 6, sh = bit & 63;
+      uint64_t val = (in && word < A.fm_nwords) ? mw[word] >> sh : 0;
+      if (in && sh > 64 - LB && word + 1 < A.fm_nwords) val |= mw[word + 1] << (64 - sh);
+      mv[j] = (uint32_t)val & c.maskv;
+    }
+    wvn_montmul_true<L2, LPL, LB>(u, mv, gm, nt, A.ctx.n0inv, c.maskv, c.onev);
+    wvn_montmul_true<L2, LPL, LB>(v, u, a, nt, A.ctx.n0inv, c.maskv, c.onev);
+    // b += v, then one carry round: limbs back below 2^29 + 2 (what the readers of pair rows are sized for)
+    uint32_t cy[LPL];
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) {
+      b[j] += v[j];
+      cy[j] = b[j] >> LB;
+      b[j] &= c.maskv;
+    }
+    b[0] += wv_up(cy[LPL - 1]);
+#pragma unroll
+    for (int j = 1; j < LPL; ++j) b[j] += cy[j - 1];
+  }
   if (in) {
     uint32_t* out = A.out_pair + inst * (size_t)(2 * L2);
 #pragma unroll

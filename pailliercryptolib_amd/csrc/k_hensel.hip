@@ -328,6 +328,20 @@ bool launch_hensel_modexp_wave_part35(int L2, bool wide, const HenselModexpArgs&
   if (L2 == 38) return launch_modexp_wave_one<38, 1>(wide, a, s);
   return false;
 }
+// DJN encrypt of small batches onto pair rows: one wavefront per element (no LDS)
+template <int L2, int LPL>
+static bool launch_fb_encrypt_wave_one(bool wide, const HenselFbArgs& a, hipStream_t s) {
+  const unsigned blocks = (unsigned)((a.count + kWavesPerWG - 1) / kWavesPerWG);
+  if (wide) hipLaunchKernelGGL((hensel_fb_encrypt_wave_kernel<L2, LPL, true>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+  else hipLaunchKernelGGL((hensel_fb_encrypt_wave_kernel<L2, LPL, false>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+  return true;
+}
+bool launch_hensel_fb_encrypt_wave_part35(int L2, bool wide, const HenselFbArgs& a, hipStream_t s) {
+  if (L2 == 72) return launch_fb_encrypt_wave_one<72, 2>(wide, a, s);
+  if (L2 == 112) return launch_fb_encrypt_wave_one<112, 2>(wide, a, s);
+  if (L2 == 38) return launch_fb_encrypt_wave_one<38, 1>(wide, a, s);
+  return false;
+}
 #elif PGPU_PART == 14
 bool launch_hensel_fb_encrypt_part14(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
   if (H == 8 && K == 9) {

@@ -209,6 +209,11 @@ bool launch_hensel_modexp_wave_part35(int L2, bool wide_digits, const HenselMode
 inline bool launch_hensel_modexp_wave(int L2, bool wide_digits, const HenselModexpArgs& a, hipStream_t s) {
   return launch_hensel_modexp_wave_part35(L2, wide_digits, a, s);
 }
+// ... and DJN encrypt of small batches onto pair rows (hensel_fb_encrypt_wave_kernel), the same L2
+bool launch_hensel_fb_encrypt_wave_part35(int L2, bool wide_digits, const HenselFbArgs& a, hipStream_t s);
+inline bool launch_hensel_fb_encrypt_wave(int L2, bool wide_digits, const HenselFbArgs& a, hipStream_t s) {
+  return launch_hensel_fb_encrypt_wave_part35(L2, wide_digits, a, s);
+}
 // 32-bit words of window table per wavefront (hensel_ps.hpp: ps_table_words -- per entry two parts of ceil(K/4) 16-byte rows of 64 lanes)
 inline size_t hensel_ps_table_words(int K, size_t entries) { return entries * 2 * (size_t)((K + 3) / 4) * 64 * 4; }
 

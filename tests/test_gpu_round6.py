@@ -153,3 +153,55 @@ def test_wave_modexp_n2_kernel_is_bit_identical(engine, bits, count, e_bits):
         assert (form()[0] == 5) == (count <= 1024)
     finally:
         R.close()
+
+
+@pytest.mark.parametrize("bits,count", [(2048, 1), (2048, 7), (2048, 65), (2048, 300), (2048, 1024), (2048, 1100),
+                                        (3072, 9), (3072, 130), (1024, 16), (1024, 300)])
+def test_wave_fb_encrypt_kernel_is_bit_identical(engine, bits, count):
+    """csrc/hensel_wave_n2.hpp: hensel_fb_encrypt_wave_kernel -- DJN encrypt (ipcl/pub_key.cpp:51-64, 88-105) of up to 1024
+    elements onto pair rows with one wavefront per element: the oracle's ciphertexts, forced on and off, edge plaintexts
+    (0, 1, n - 1) and randomness (0, 1, all ones), masked table access; the rows decrypt and add like any others."""
+    from oracle import paillier_oracle as orc
+    from pailliercryptolib_amd import _capi
+    p, q, hs = key_case(bits)
+    n = p * q
+    nsq = n * n
+    nw, rb = bits // 64, bits // 2
+    rng = random.Random(31 * count + bits)
+    m = ([0, 1, n - 1] + [rng.randrange(n) for _ in range(count)])[:count]
+    r = ([0, 1, (1 << rb) - 1] + [rng.getrandbits(rb) for _ in range(count)])[:count]
+    pk, sk = engine.PublicKey(n, bits, hs=hs), engine.PrivateKey(p, q)
+    opk = orc.PublicKey(n, bits)
+    opk.set_djn(hs)
+    want = opk.encrypt(m, r)
+    R = Res()
+    L = R.L
+
+    def form():
+        split, lanes, limbs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _capi.check(L.pgpu_encrypt_kernel_form(pk._h, nw, count, ctypes.byref(split), ctypes.byref(lanes), ctypes.byref(limbs)))
+        return split.value, lanes.value, limbs.value
+    try:
+        hm, hr = R.up(m, nw), R.up(r, nw // 2)
+        L.pgpu_debug_set_wave_decrypt(0)
+        try:
+            assert form()[0] != 5
+            assert R.down(R.op(L.pgpu_batch_encrypt, pk._h, hm, hr, rb)) == want, "the multi-lane kernels differ from the oracle"
+            L.pgpu_debug_set_wave_decrypt(2)
+            assert form() == (5, 64, {1024: 38, 2048: 72, 3072: 112}[bits])
+            c = R.op(L.pgpu_batch_encrypt, pk._h, hm, hr, rb)
+            assert L.pgpu_batch_row_limbs(c) == 2 * {1024: 38, 2048: 72, 3072: 112}[bits]
+            assert R.down(c) == want, "the wavefront-wide kernel differs from the oracle"
+            if count <= 300:
+                _capi.check(L.pgpu_set_table_gather_policy(1))
+                assert R.down(R.op(L.pgpu_batch_encrypt, pk._h, hm, hr, rb)) == want, "masked access differs"
+                _capi.check(L.pgpu_set_table_gather_policy(0))
+            L.pgpu_debug_set_wave_decrypt(0)                       # its rows, read by the multi-lane kernels
+            assert R.down(R.op(L.pgpu_batch_decrypt_crt, sk._h, c)) == m
+            assert R.down(R.op(L.pgpu_batch_ct_add, pk._h, c, c)) == [x * x % nsq for x in want]
+        finally:
+            _capi.check(L.pgpu_set_table_gather_policy(0))
+            L.pgpu_debug_set_wave_decrypt(1)
+        assert (form()[0] == 5) == (count <= 1024)
+    finally:
+        R.close()
