@@ -326,7 +326,8 @@ typedef enum pgpu_kernel_form {
   PGPU_FORM_LANE = 4,      /* a whole exponentiation per lane; always together with PGPU_FORM_PS since round 6 */
   PGPU_FORM_PS = 8,        /* with PGPU_FORM_LANE: by product scanning (hensel_ps.hpp: 1024- to 3072-bit keys; round 5) */
   PGPU_FORM_CU_CLAIM = 16,
-  PGPU_FORM_WAVE = 32      /* one exponentiation per WAVEFRONT, a limb per lane (hensel_wave.hpp: CRT decrypt of small batches; round 6) */
+  PGPU_FORM_WAVE = 32      /* one exponentiation per WAVEFRONT (hensel_wave.hpp, hensel_wave_n2.hpp: small launches of CRT decrypt, DJN
+                              encrypt onto pair rows, CT x PT on pair rows; round 6) */
 } pgpu_kernel_form;
 int pgpu_timing_collect_ex(int* kinds, int* forms, double* ms, int max_entries);
 /* ... and as a small kernel trace: batch lane of each launch (-1: another stream) and its start relative to the first
@@ -361,14 +362,17 @@ int pgpu_decrypt_kernel_form_ex(const pgpu_privkey* key, size_t count, int busy_
  * *limbs> (DJN keys with a fixed-base window, 1024- to 3072-bit keys, plaintext rows no wider than n, batches that
  * fill the chip); *split = 2: results that stay resident as pair rows, launches that still put a wavefront on every SIMD
  * with half the lanes per element: hensel_fb_encrypt_seq_kernel<*lanes, *limbs> (PGPU_SEQ_DECRYPT=0 turns it off);
- * *split = 0: fb_encrypt_kernel / modexp_kernel <Geo<*lanes, *limbs>>. */
+ * *split = 5 (round 6): results that stay resident, at most 1024 elements: hensel_fb_encrypt_wave_kernel<*limbs, ...> -- one
+ * wavefront per element (*lanes = 64), *limbs limbs per half of the row; *split = 0: fb_encrypt_kernel / modexp_kernel
+ * <Geo<*lanes, *limbs>>. */
 int pgpu_encrypt_kernel_form(const pgpu_pubkey* key, int m_words, size_t count, int* split, int* lanes, int* limbs);
 int pgpu_encrypt_kernel_form_ex(const pgpu_pubkey* key, int m_words, size_t count, int busy_lanes, int* split, int* lanes,
                                 int* limbs);
 /* The same for the exponentiations modulo n^2 with per-element bases (CT x PT of a resident batch, the non-DJN
  * obfuscator r^n): *split = 1: hensel_modexp_kernel<*lanes / 2, *limbs>; *split = 2: the same for r^n, and for CT x PT
  * of a resident batch (pair rows in and out, per-element exponents) hensel_modexp_seq_kernel<*lanes, *limbs> (both halves
- * of a pair in the same *lanes lanes; PGPU_SEQ_DECRYPT=0 turns it off); *split = 0: modexp_kernel<Geo<*lanes, *limbs>>. */
+ * of a pair in the same *lanes lanes; PGPU_SEQ_DECRYPT=0 turns it off); *split = 5 (round 6): CT x PT of at most 1024 resident
+ * elements, hensel_modexp_wave_kernel<*limbs, ...> -- one wavefront per element; *split = 0: modexp_kernel<Geo<*lanes, *limbs>>. */
 int pgpu_modexp_n2_kernel_form(const pgpu_pubkey* key, size_t count, int* split, int* lanes, int* limbs);
 /* The same for CT + CT of two resident batches of `count` elements (per device): *split = 1: pair_ops_kernel<*lanes / 2,
  * *limbs> (one pair product on pair rows); *split = 2: pair_mul_seq_kernel<*lanes, *limbs> (both halves of a pair in the

@@ -50,7 +50,7 @@ def hensel_parts():
     skip = {15, 30}      # (retired in round 6: the A/B-wavefront experiment and the operand-scanning one-lane kernel)
     if not build_4096():
         skip |= {22, 23, 24}
-    return [p for p in range(36) if p not in skip]
+    return [p for p in range(38) if p not in skip]
 
 
 def _objects():
@@ -76,10 +76,12 @@ def _objects():
         src = os.path.join(CSRC, "k_hensel.hip")
         o = os.path.join(obj, f"k_hensel_{part}.o")
         hdeps_k = [os.path.join(CSRC, f) for f in ("hensel.hpp", "hensel_q.hpp", "hensel_seq.hpp")]
-        if part in (31, 33, 34, 35):
+        if part in (31, 33, 34, 35, 36, 37):
             hdeps_k.append(os.path.join(CSRC, "hensel_ps.hpp"))
-        if part == 35:
-            hdeps_k += [os.path.join(CSRC, "hensel_wave.hpp"), os.path.join(CSRC, "hensel_wave_n2.hpp")]
+        if part in (35, 36, 37):
+            hdeps_k.append(os.path.join(CSRC, "hensel_wave.hpp"))
+        if part in (36, 37):
+            hdeps_k.append(os.path.join(CSRC, "hensel_wave_n2.hpp"))
         out.append((o, hip + [f"-DPGPU_PART={part}", "-c", src, "-o", o], [src] + hdeps_k + kdeps))
     for name in ("capi.cpp", "policy.cpp", "runtime.cpp", os.path.join("host", "bignum.cpp")):
         src = os.path.join(CSRC, name)
@@ -162,7 +164,7 @@ def build_pgpu(force=False):
     if todo:
         # the 8-lane x 18-limb forms (4096-bit key class, parts 22-24; PGPU_BUILD_4096=1) compile for 10-15 minutes each:
         # start them first; so are the one-lane product-scanning forms (parts 33, 31: fully unrolled column loops, 5 and 3 minutes)
-        slow = ("k_hensel_22.", "k_hensel_23.", "k_hensel_24.", "k_hensel_33.", "k_hensel_31.")
+        slow = ("k_hensel_22.", "k_hensel_23.", "k_hensel_24.", "k_hensel_33.", "k_hensel_31.", "k_hensel_37.", "k_hensel_36.")
         todo.sort(key=lambda oc: 0 if os.path.basename(oc[0]).startswith(slow) else 1)
         with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
             list(ex.map(lambda oc: compile_one(oc[0], oc[1]), todo))

@@ -1283,6 +1283,15 @@ const pgpu_pubkey::PubForm* split_modexp_form(const pgpu_pubkey* key, size_t cou
   const size_t ipw = 64 / (2 * (size_t)last->H);
   return (count + ipw - 1) / ipw > max_waves ? nullptr : last;
 }
+// the latency forms of the n^2 domain (hensel_wave_n2.hpp: one wavefront per element on pair rows of this form) for a launch
+// of `count` elements?  They run with 32-bit quotient digits (values below 9 P instead of 2 P): the rows' radix must leave
+// room, R = 2^(29 L2) >= 2^10 P with P = n k < 2^(bits(n) + 29) -- true for every key size that has these rows but its
+// largest two or three bit lengths.
+bool wave_n2_applies(const pgpu_pubkey::PubForm* form, size_t count) {
+  const int L2 = form->H * form->K;
+  return hensel_enabled() && pair_rows_enabled() && pgpu::hensel_modexp_wave_has(L2) && policy::modexp_wave_form_pays(count) &&
+         pgpu::kLimbBits * L2 - (form->n.BitSize() + pgpu::kLimbBits) >= 10;
+}
 int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::PubForm* form, const uint64_t* d_base, size_t base_stride,
                     int base_words, bool base_mont, const uint64_t* d_exp, size_t exp_stride, int exp_words,
                     int exp_bits, const SchedRef* sched, int final_mul, const uint64_t* d_m, size_t m_stride,
@@ -1323,13 +1332,10 @@ int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::Pu
   a.out_stride = (size_t)2 * key->n_words;
   a.count = count;
   // The latency form (hensel_wave_n2.hpp; round 6): small launches on resident rows -- one wavefront per element, the window
-  // table in its LDS; 32-bit quotient digits where the rows' radix leaves room (R = 2^(29 L2) >= 2^10 P, P < 2^(bits(n) + 29))
-  if (base_pair && out_pair && !a.sched && final_mul == pgpu::FM_UNIT && hensel_enabled() && pgpu::hensel_modexp_wave_has(H * K) &&
-      policy::modexp_wave_form_pays(count) && a.window <= 5) {
-    static const bool wide_ok = [] { const char* e = getenv("PGPU_WAVE_WIDEQ"); return !e || atoi(e) != 0; }();
-    const bool wide = wide_ok && pgpu::kLimbBits * H * K - (form->n.BitSize() + pgpu::kLimbBits) >= 10;
+  // table in its LDS
+  if (base_pair && out_pair && !a.sched && final_mul == pgpu::FM_UNIT && wave_n2_applies(form, count) && a.window <= 5) {
     TimerScope t(d, s, PGPU_KERNEL_MODEXP, PGPU_FORM_WAVE);
-    if (!pgpu::launch_hensel_modexp_wave(H * K, wide, a, s))
+    if (!pgpu::launch_hensel_modexp_wave(H * K, a, s))
       return fail(PGPU_ERR_UNSUPPORTED, "wavefront-wide modexp kernel not compiled");
     HIP_TRY(hipGetLastError());
     t.stop();
@@ -1442,13 +1448,10 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
       f.out_pair = d_pair;
       f.ct_gather = masked ? 1 : 0;
       TimerScope t(d, s, PGPU_KERNEL_FB_ENCRYPT);
-      // The latency form (hensel_wave_n2.hpp; round 6): small launches onto pair rows -- one wavefront per element; 32-bit
-      // quotient digits where the rows' radix leaves room (modexp_split_on)
-      if (d_pair && pgpu::hensel_modexp_wave_has(form->H * form->K) && policy::modexp_wave_form_pays(count)) {
-        static const bool wide_ok = [] { const char* e = getenv("PGPU_WAVE_WIDEQ"); return !e || atoi(e) != 0; }();
-        const bool wide = wide_ok && pgpu::kLimbBits * form->H * form->K - (form->n.BitSize() + pgpu::kLimbBits) >= 10;
+      // The latency form (hensel_wave_n2.hpp; round 6): small launches onto pair rows -- one wavefront per element
+      if (d_pair && wave_n2_applies(form, count)) {
         t.set_form(PGPU_FORM_WAVE);
-        if (!pgpu::launch_hensel_fb_encrypt_wave(form->H * form->K, wide, f, s))
+        if (!pgpu::launch_hensel_fb_encrypt_wave(form->H * form->K, f, s))
           return fail(PGPU_ERR_UNSUPPORTED, "wavefront-wide fixed-base kernel not compiled");
         HIP_TRY(hipGetLastError());
         t.stop();
@@ -2146,7 +2149,7 @@ int pgpu_encrypt_kernel_form_ex(const pgpu_pubkey* key, int m_words, size_t coun
     // resident results (pair rows) of small launches: one wavefront per element (hensel_wave_n2.hpp), whatever form a launch
     // from host arrays of this size would take
     const pgpu_pubkey::PubForm* pf = pair_form(key);
-    if (pf && m_words <= key->n_words && pgpu::hensel_modexp_wave_has(pf->H * pf->K) && policy::modexp_wave_form_pays(count)) {
+    if (pf && m_words <= key->n_words && wave_n2_applies(pf, count)) {
       *split = 5;
       *lanes = 64;
       *limbs = pf->H * pf->K;
@@ -2179,7 +2182,7 @@ int pgpu_modexp_n2_kernel_form(const pgpu_pubkey* key, size_t count, int* split,
   RC_TRY(check_gen(key->gen, "key"));
   if (const pgpu_pubkey::PubForm* mf = split_modexp_form(key, count)) {
     if (const pgpu_pubkey::PubForm* pf = pair_form(key))                       // (resident rows, small launches: the latency form)
-      if (pgpu::hensel_modexp_wave_has(pf->H * pf->K) && policy::modexp_wave_form_pays(count)) {
+      if (wave_n2_applies(pf, count)) {
         *split = 5;
         *lanes = 64;
         *limbs = pf->H * pf->K;

@@ -8,11 +8,13 @@
 #endif
 #if defined(PGPU_PART) && PGPU_PART == 35
 #include "hensel_wave.hpp"   // one exponentiation per WAVEFRONT, a limb per lane: the latency form of small batches (round 6)
-#include "hensel_wave_n2.hpp"   // ... for the n^2 domain: CT x PT of small batches on pair rows
+#endif
+#if defined(PGPU_PART) && (PGPU_PART == 36 || PGPU_PART == 37)
+#include "hensel_wave_n2.hpp"   // ... for the n^2 domain: DJN encrypt and CT x PT of small batches on pair rows
 #endif
 
 #ifndef PGPU_PART
-#error "compile with -DPGPU_PART=0..35 (15 and 30 are retired)"
+#error "compile with -DPGPU_PART=0..37 (15 and 30 are retired)"
 #endif
 
 namespace pgpu {
@@ -309,39 +311,47 @@ bool launch_hensel_wave_part35(int K, int lb, bool wide, const HenselArgs& a, hi
   if (K == 19 && lb == 29) return launch_wave_one<19, 29>(wide, a, s);
   return false;
 }
-// CT x PT of small batches on pair rows: one wavefront per element; the window table is dynamic LDS (up to 128 KB)
+#elif PGPU_PART == 36 || PGPU_PART == 37
+// The latency forms of the n^2 domain (hensel_wave_n2.hpp), one wavefront per element; part 36: 2048-bit keys (rows of 72 limbs
+// per half), part 37: 3072- and 1024-bit keys (112, 38).  Only the builds with 32-bit quotient digits: the caller takes these
+// forms only where the rows' radix leaves room for them (capi.cpp).
+// CT x PT on pair rows; the window table is dynamic LDS (up to 128 KB)
 template <int L2, int LPL>
-static bool launch_modexp_wave_one(bool wide, const HenselModexpArgs& a, hipStream_t s) {
+static bool launch_modexp_wave_one(const HenselModexpArgs& a, hipStream_t s) {
   const unsigned blocks = (unsigned)((a.count + kWavesPerWG - 1) / kWavesPerWG);
   const unsigned lds = (unsigned)(kWavesPerWG * wvn_table_words<LPL>((size_t)1 << a.window) * sizeof(uint32_t));
   if (lds > 144 * 1024) return false;
   const bool once = PGPU_LDS_ATTR_ONCE((hensel_modexp_wave_kernel<L2, LPL, true>), 144 * 1024);
-  const bool once0 = PGPU_LDS_ATTR_ONCE((hensel_modexp_wave_kernel<L2, LPL, false>), 144 * 1024);
-  if (!once || !once0) return false;
-  if (wide) hipLaunchKernelGGL((hensel_modexp_wave_kernel<L2, LPL, true>), dim3(blocks), dim3(kWGThreads), lds, s, a);
-  else hipLaunchKernelGGL((hensel_modexp_wave_kernel<L2, LPL, false>), dim3(blocks), dim3(kWGThreads), lds, s, a);
+  if (!once) return false;
+  hipLaunchKernelGGL((hensel_modexp_wave_kernel<L2, LPL, true>), dim3(blocks), dim3(kWGThreads), lds, s, a);
   return true;
 }
-bool launch_hensel_modexp_wave_part35(int L2, bool wide, const HenselModexpArgs& a, hipStream_t s) {
-  if (L2 == 72) return launch_modexp_wave_one<72, 2>(wide, a, s);
-  if (L2 == 112) return launch_modexp_wave_one<112, 2>(wide, a, s);
-  if (L2 == 38) return launch_modexp_wave_one<38, 1>(wide, a, s);
-  return false;
-}
-// DJN encrypt of small batches onto pair rows: one wavefront per element (no LDS)
+// DJN encrypt onto pair rows (no LDS)
 template <int L2, int LPL>
-static bool launch_fb_encrypt_wave_one(bool wide, const HenselFbArgs& a, hipStream_t s) {
+static bool launch_fb_encrypt_wave_one(const HenselFbArgs& a, hipStream_t s) {
   const unsigned blocks = (unsigned)((a.count + kWavesPerWG - 1) / kWavesPerWG);
-  if (wide) hipLaunchKernelGGL((hensel_fb_encrypt_wave_kernel<L2, LPL, true>), dim3(blocks), dim3(kWGThreads), 0, s, a);
-  else hipLaunchKernelGGL((hensel_fb_encrypt_wave_kernel<L2, LPL, false>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+  hipLaunchKernelGGL((hensel_fb_encrypt_wave_kernel<L2, LPL, true>), dim3(blocks), dim3(kWGThreads), 0, s, a);
   return true;
 }
-bool launch_hensel_fb_encrypt_wave_part35(int L2, bool wide, const HenselFbArgs& a, hipStream_t s) {
-  if (L2 == 72) return launch_fb_encrypt_wave_one<72, 2>(wide, a, s);
-  if (L2 == 112) return launch_fb_encrypt_wave_one<112, 2>(wide, a, s);
-  if (L2 == 38) return launch_fb_encrypt_wave_one<38, 1>(wide, a, s);
+#if PGPU_PART == 36
+bool launch_hensel_modexp_wave_part36(int L2, const HenselModexpArgs& a, hipStream_t s) {
+  return L2 == 72 && launch_modexp_wave_one<72, 2>(a, s);
+}
+bool launch_hensel_fb_encrypt_wave_part36(int L2, const HenselFbArgs& a, hipStream_t s) {
+  return L2 == 72 && launch_fb_encrypt_wave_one<72, 2>(a, s);
+}
+#else
+bool launch_hensel_modexp_wave_part37(int L2, const HenselModexpArgs& a, hipStream_t s) {
+  if (L2 == 112) return launch_modexp_wave_one<112, 2>(a, s);
+  if (L2 == 38) return launch_modexp_wave_one<38, 1>(a, s);
   return false;
 }
+bool launch_hensel_fb_encrypt_wave_part37(int L2, const HenselFbArgs& a, hipStream_t s) {
+  if (L2 == 112) return launch_fb_encrypt_wave_one<112, 2>(a, s);
+  if (L2 == 38) return launch_fb_encrypt_wave_one<38, 1>(a, s);
+  return false;
+}
+#endif
 #elif PGPU_PART == 14
 bool launch_hensel_fb_encrypt_part14(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
   if (H == 8 && K == 9) {

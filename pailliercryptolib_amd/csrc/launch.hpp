@@ -203,16 +203,19 @@ inline bool launch_hensel_wave(int K, int lb, bool wide_digits, const HenselArgs
   return launch_hensel_wave_part35(K, lb, wide_digits, a, s);
 }
 // ... and for the n^2 domain (hensel_wave_n2.hpp): CT x PT of small batches on pair rows, one wavefront per element; L2 = limbs
-// per half of the rows (72: 2048-bit keys, 112: 3072, 38: 1024)
+// per half of the rows (72: 2048-bit keys, 112: 3072, 38: 1024; k_hensel.hip parts 36 / 37); 32-bit quotient digits only: the
+// caller checks that the rows' radix leaves room (R >= 2^10 P)
 inline bool hensel_modexp_wave_has(int L2) { return L2 == 72 || L2 == 112 || L2 == 38; }
-bool launch_hensel_modexp_wave_part35(int L2, bool wide_digits, const HenselModexpArgs& a, hipStream_t s);
-inline bool launch_hensel_modexp_wave(int L2, bool wide_digits, const HenselModexpArgs& a, hipStream_t s) {
-  return launch_hensel_modexp_wave_part35(L2, wide_digits, a, s);
+bool launch_hensel_modexp_wave_part36(int L2, const HenselModexpArgs& a, hipStream_t s);
+bool launch_hensel_modexp_wave_part37(int L2, const HenselModexpArgs& a, hipStream_t s);
+inline bool launch_hensel_modexp_wave(int L2, const HenselModexpArgs& a, hipStream_t s) {
+  return launch_hensel_modexp_wave_part36(L2, a, s) || launch_hensel_modexp_wave_part37(L2, a, s);
 }
 // ... and DJN encrypt of small batches onto pair rows (hensel_fb_encrypt_wave_kernel), the same L2
-bool launch_hensel_fb_encrypt_wave_part35(int L2, bool wide_digits, const HenselFbArgs& a, hipStream_t s);
-inline bool launch_hensel_fb_encrypt_wave(int L2, bool wide_digits, const HenselFbArgs& a, hipStream_t s) {
-  return launch_hensel_fb_encrypt_wave_part35(L2, wide_digits, a, s);
+bool launch_hensel_fb_encrypt_wave_part36(int L2, const HenselFbArgs& a, hipStream_t s);
+bool launch_hensel_fb_encrypt_wave_part37(int L2, const HenselFbArgs& a, hipStream_t s);
+inline bool launch_hensel_fb_encrypt_wave(int L2, const HenselFbArgs& a, hipStream_t s) {
+  return launch_hensel_fb_encrypt_wave_part36(L2, a, s) || launch_hensel_fb_encrypt_wave_part37(L2, a, s);
 }
 // 32-bit words of window table per wavefront (hensel_ps.hpp: ps_table_words -- per entry two parts of ceil(K/4) 16-byte rows of 64 lanes)
 inline size_t hensel_ps_table_words(int K, size_t entries) { return entries * 2 * (size_t)((K + 3) / 4) * 64 * 4; }
