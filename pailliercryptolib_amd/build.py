@@ -164,7 +164,7 @@ def build_pgpu(force=False):
     if todo:
         # the 8-lane x 18-limb forms (4096-bit key class, parts 22-24; PGPU_BUILD_4096=1) compile for 10-15 minutes each:
         # start them first; so are the one-lane product-scanning forms (parts 33, 31: fully unrolled column loops, 5 and 3 minutes)
-        slow = ("k_hensel_22.", "k_hensel_23.", "k_hensel_24.", "k_hensel_33.", "k_hensel_31.", "k_hensel_37.", "k_hensel_36.")
+        slow = ("k_hensel_22.", "k_hensel_23.", "k_hensel_24.", "k_hensel_33.", "k_hensel_31.", "k_hensel_37.", "k_hensel_36.", "k_hensel_35.")
         todo.sort(key=lambda oc: 0 if os.path.basename(oc[0]).startswith(slow) else 1)
         with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
             list(ex.map(lambda oc: compile_one(oc[0], oc[1]), todo))
