@@ -362,8 +362,8 @@ int pgpu_decrypt_kernel_form_ex(const pgpu_privkey* key, size_t count, int busy_
  * *limbs> (DJN keys with a fixed-base window, 1024- to 3072-bit keys, plaintext rows no wider than n, batches that
  * fill the chip); *split = 2: results that stay resident as pair rows, launches that still put a wavefront on every SIMD
  * with half the lanes per element: hensel_fb_encrypt_seq_kernel<*lanes, *limbs> (PGPU_SEQ_DECRYPT=0 turns it off);
- * *split = 5 (round 6): results that stay resident, at most 1024 elements: hensel_fb_encrypt_wave_kernel<*limbs, ...> -- one
- * wavefront per element (*lanes = 64), *limbs limbs per half of the row; *split = 0: fb_encrypt_kernel / modexp_kernel
+ * *split = 5 (round 6; asked for with busy_lanes = -1 through the _ex form: "the results stay resident as pair rows"): at most
+ * 1024 elements: hensel_fb_encrypt_wave_kernel<*limbs, ...> -- one wavefront per element (*lanes = 64), *limbs limbs per half of the row; *split = 0: fb_encrypt_kernel / modexp_kernel
  * <Geo<*lanes, *limbs>>. */
 int pgpu_encrypt_kernel_form(const pgpu_pubkey* key, int m_words, size_t count, int* split, int* lanes, int* limbs);
 int pgpu_encrypt_kernel_form_ex(const pgpu_pubkey* key, int m_words, size_t count, int busy_lanes, int* split, int* lanes,

@@ -2144,8 +2144,11 @@ int pgpu_encrypt_kernel_form_ex(const pgpu_pubkey* key, int m_words, size_t coun
                                 int* limbs) {
   if (!key || !split || !lanes || !limbs) return fail(PGPU_ERR_INVALID_PARAM, "pgpu_encrypt_kernel_form: bad argument");
   RC_TRY(check_gen(key->gen, "key"));
+  // busy_lanes < 0: the question is about RESIDENT results (pgpu_batch_encrypt: pair rows) of a lone caller
+  const bool resident = busy_lanes < 0;
+  if (resident) busy_lanes = 0;
   const pgpu_pubkey::PubForm* ef = key->djn && fixed_base_window() > 0 ? use_split_encrypt(key, m_words, count) : nullptr;
-  if (key->djn && fixed_base_window() > 0) {
+  if (resident && key->djn && fixed_base_window() > 0) {
     // resident results (pair rows) of small launches: one wavefront per element (hensel_wave_n2.hpp), whatever form a launch
     // from host arrays of this size would take
     const pgpu_pubkey::PubForm* pf = pair_form(key);

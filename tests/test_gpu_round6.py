@@ -179,7 +179,7 @@ def test_wave_fb_encrypt_kernel_is_bit_identical(engine, bits, count):
 
     def form():
         split, lanes, limbs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-        _capi.check(L.pgpu_encrypt_kernel_form(pk._h, nw, count, ctypes.byref(split), ctypes.byref(lanes), ctypes.byref(limbs)))
+        _capi.check(L.pgpu_encrypt_kernel_form_ex(pk._h, nw, count, -1, ctypes.byref(split), ctypes.byref(lanes), ctypes.byref(limbs)))   # (-1: resident results)
         return split.value, lanes.value, limbs.value
     try:
         hm, hr = R.up(m, nw), R.up(r, nw // 2)
