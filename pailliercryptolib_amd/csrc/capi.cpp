@@ -1739,7 +1739,7 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
       // the latency form: entry (one lane per exponentiation) -> one wavefront per exponentiation -> exit; the workspace
       // is the pair buffer between the three launches, the window table lives in the wave kernel's LDS
       t.set_form(PGPU_FORM_WAVE | PGPU_FORM_PS);
-      RC_TRY(w.table.ensure(2 * count * pgpu::hensel_wave_pair_words(hset->K) * sizeof(uint32_t), s));
+      RC_TRY(w.table.ensure(2 * count * (size_t)(2 * hset->pchunks) * pgpu::hensel_wave_pair_words(hset->K) * sizeof(uint32_t), s));   // (a partial pair per entry role)
       h.table = (uint32_t*)w.table.p;
       // 32-bit quotient digits (one instruction less per step and scan) where the radix leaves room: values then stay below
       // 17 P instead of 2 P, which needs R = 2^(lb K) >= 2^10 P; P = p k < 2^(exp_bits + lb)  (3072-bit keys: R >= 16 P only)

@@ -21,9 +21,9 @@
 // with q_i added to lane 0 in step i.  ~620 instructions per pair squaring against ~900 of the 16-lane form, on a chain
 // without LDS round trips.
 // The same constants as hensel_decrypt_ps_kernel (the key's hs_ps set: K limbs of LB bits, P == -1 mod 2^LB), and its entry
-// and exit CODE: hensel_ps_entry_kernel runs ps_entry_from_pair_row one lane per exponentiation and leaves the pair in a
-// buffer, hensel_ps_exit_kernel picks the result up, makes its limbs canonical and runs ps_exit_words -- ~60 us of one-lane
-// work around 1.7 ms, in exchange for not restating either in the limb-per-lane layout.
+// and exit CODE: hensel_ps_entry_kernel runs the products of ps_entry_from_pair_row one lane per exponentiation and product and
+// leaves the partial pairs in a buffer, hensel_ps_exit_kernel picks the result up, makes its limbs canonical and runs
+// ps_exit_words -- ~40 us of one-lane work around 1.4 ms, in exchange for not restating either in the limb-per-lane layout.
 // The window table lives in LDS (2^w entries x 2 x K limbs per wavefront); the exponent is the side's secret p-1 / q-1, the
 // same for every wavefront of a side: its digits are scalar, and under the masked-access policy every entry is read and the
 // wanted one selected with a per-lane compare (no branch on the digit).
@@ -197,7 +197,8 @@ template <int K>
 constexpr size_t wv_table_words(size_t entries) { return entries * 2 * (size_t)K; }
 
 // One wavefront = ONE exponentiation: wavefront 2*i + side serves ciphertext i under side (0: p, 1: q).
-// A.table: the pair buffer ([2*count][2][K] 32-bit limbs of LB bits): the base on entry, the result on exit (relaxed limbs).
+// A.table: the pair buffer ([2*count][2 * pchunks roles][2][K] 32-bit limbs of LB bits): the entry's partial pairs on entry,
+// the result on exit in slot 0 (relaxed limbs).
 // Dynamic LDS: kWavesPerWG * wv_table_words<K>(2^A.window) * 4 bytes.
 template <int K, int LB, bool WIDEQ>
 __global__ __launch_bounds__(kWGThreads, 1) void hensel_decrypt_wave_kernel(HenselArgs A) {
@@ -253,8 +254,15 @@ __global__ __launch_bounds__(kWGThreads, 1) void hensel_decrypt_wave_kernel(Hens
       tbl[(size_t)e * 2 * K + K + lk] = y;
     }
   };
-  uint32_t* buf = A.table + idx * wv_pair_words<K>();
-  uint32_t a = in ? buf[lk] : 0u, b = in ? buf[K + lk] : 0u;
+  // the base: the entry kernel leaves one partial pair per ROLE (chunk of the row x {pair product of its a half, single product
+  // of its b half}); their sum is c*R -- limbs simply add up (relaxed limbs are fine here), the result goes back into slot 0
+  const int nroles = 2 * A.pchunks;
+  uint32_t* buf = A.table + idx * (size_t)nroles * wv_pair_words<K>();
+  uint32_t a = 0, b = 0;
+  for (int r = 0; r < nroles; ++r) {
+    if ((r & 1) == 0) a += in ? buf[(size_t)r * wv_pair_words<K>() + lk] : 0u;
+    b += in ? buf[(size_t)r * wv_pair_words<K>() + K + lk] : 0u;
+  }
   // ---- window table: entry 0 = one, entry 1 = base, entry e = entry e-1 times base ----
   const uint32_t ba = a, bb = b;
   entry_store(1, a, b);
@@ -282,27 +290,63 @@ __global__ __launch_bounds__(kWGThreads, 1) void hensel_decrypt_wave_kernel(Hens
 #undef HCTX
 }
 
-// The entry of hensel_decrypt_ps_kernel as a kernel of its own: one lane per exponentiation (wave parity = side, as there),
-// c*R as a pair from the pair row, left in A.table + (2*elem + side) * 2K as canonical limbs of LB bits.
+// The entry of hensel_decrypt_ps_kernel (ps_entry_from_pair_row: per chunk of the pair row a single product for its b half and
+// a pair product for its a half, all summed) as a kernel of its own, one lane per exponentiation and ROLE: the 2 * pchunks
+// products of an entry are independent, so each runs in a lane of its own -- of a wavefront of its own: the role is
+// wave-uniform (wavefront w: role w mod nroles, side (w / nroles) & 1, ciphertexts 64 * (w / (2 nroles)) ...) -- and leaves its
+// partial pair in A.table + ((2*elem + side) * nroles + role) * 2K; the wave kernel adds them up.  18 us instead of 72 for the
+// whole entry in one lane (a launch this small leaves the chip idle anyway).
 template <int K, int LB>
 __global__ __launch_bounds__(kWGThreads, 1) void hensel_ps_entry_kernel(HenselArgs A) {
-  constexpr int K4 = (K + 3) / 4;
+  constexpr int K4 = (K + 3) / 4, RB = kLimbBits;
+  constexpr int NI = (K * LB - 2) / RB + 1;      // row limbs per entry chunk that fit a half, plus one for the carry
   __shared__ uint4 park_[kWavesPerWG][K4][kWave];
   const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
   uint4* slot = &park_[wv][0][lane];
   const size_t wave_id = (size_t)blockIdx.x * kWavesPerWG + wv;
-  const int side = __builtin_amdgcn_readfirstlane((int)(wave_id & 1));
-  const size_t first_elem = (wave_id >> 1) * kWave;
+  const int nroles = 2 * A.pchunks;
+  const int role = __builtin_amdgcn_readfirstlane((int)(wave_id % (size_t)nroles));
+  const size_t grp = wave_id / (size_t)nroles;
+  const int side = __builtin_amdgcn_readfirstlane((int)(grp & 1));
+  const size_t first_elem = (grp >> 1) * kWave;
   size_t elem = first_elem + lane;
   const bool live = elem < A.count;
+  if (first_elem >= A.count) return;             // (wave-uniform)
   if (!live) elem = A.count - 1;
-  uint32_t n[K], a[K], b[K], ma[K], mb[K];
+#define HCTX(field) (side ? A.ctx[1].field : A.ctx[0].field)
+  uint32_t n[K], a[K], b[K];
 #pragma unroll
-  for (int j = 0; j < K; ++j) n[j] = ps_uniform((side ? A.ctx[1].nhat : A.ctx[0].nhat)[j]);
+  for (int j = 0; j < K; ++j) n[j] = ps_uniform(HCTX(nhat)[j]);
   const uint32_t n1p = n[1] + 1;
-  ps_entry_from_pair_row<K, LB>(A, side, elem, n, n1p, slot, a, b, ma, mb);
+  const int i = role >> 1, first = i * A.pchunk_limbs;
+  const uint32_t* row = A.ct_pair + elem * A.ct_pair_stride + ((role & 1) ? A.pair_l2 : 0);
+  uint32_t z[NI], zl[K];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) z[j] = (j < A.pchunk_limbs && first + j < A.pair_l2) ? row[first + j] : 0u;
+  // (rows written by the multi-lane kernels hold RELAXED limbs; ps_relimb makes them canonical in this kernel's width)
+  ps_relimb<K, LB, NI, RB>(zl, z);
+  if (role & 1) {                                // the b half of the chunk: one product, a contribution to b only
+    uint32_t cb[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      cb[j] = HCTX(pcb)[(size_t)i * K + j];
+      a[j] = 0;
+    }
+    ps_mul<K, LB, true>(b, zl, cb, n, n1p, 0);
+  } else {                                       // the a half: (z, 0) (x) pconv_i
+    uint32_t ma[K], mb[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      a[j] = zl[j];
+      b[j] = 0;
+      ma[j] = HCTX(pconv)[(size_t)i * 2 * K + j];
+      mb[j] = HCTX(pconv)[(size_t)i * 2 * K + K + j];
+    }
+    ps_pairmul<K, LB, true>(a, b, ma, mb, n, n1p, 0, slot);
+  }
+#undef HCTX
   if (live) {
-    uint32_t* buf = A.table + (2 * elem + side) * wv_pair_words<K>();
+    uint32_t* buf = A.table + ((2 * elem + side) * (size_t)nroles + role) * wv_pair_words<K>();
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       buf[j] = a[j];
@@ -325,7 +369,7 @@ __global__ __launch_bounds__(kWGThreads, 1) void hensel_ps_exit_kernel(HenselArg
   const bool live = elem < A.count;
   if (!live) elem = A.count - 1;
   uint32_t a[K], b[K], ma[K], mb[K];
-  const uint32_t* buf = A.table + (2 * elem + side) * wv_pair_words<K>();
+  const uint32_t* buf = A.table + (2 * elem + side) * (size_t)(2 * A.pchunks) * wv_pair_words<K>();   // (slot 0 of the roles)
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     ma[j] = buf[j];

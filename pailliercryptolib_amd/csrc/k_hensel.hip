@@ -295,10 +295,11 @@ template <int K, int LB>
 static bool launch_wave_one(bool wide, const HenselArgs& a, hipStream_t s) {
   const size_t lane_waves = 2 * ((a.count + kWave - 1) / kWave);
   const unsigned lane_blocks = (unsigned)((lane_waves + kWavesPerWG - 1) / kWavesPerWG);
+  const unsigned entry_blocks = (unsigned)((lane_waves * 2 * (size_t)a.pchunks + kWavesPerWG - 1) / kWavesPerWG);   // a wavefront per role
   const unsigned wave_blocks = (unsigned)((2 * a.count + kWavesPerWG - 1) / kWavesPerWG);
   const unsigned lds = (unsigned)(kWavesPerWG * wv_table_words<K>((size_t)1 << a.window) * sizeof(uint32_t));
   if (lds > 64 * 1024) return false;
-  hipLaunchKernelGGL((hensel_ps_entry_kernel<K, LB>), dim3(lane_blocks), dim3(kWGThreads), 0, s, a);
+  hipLaunchKernelGGL((hensel_ps_entry_kernel<K, LB>), dim3(entry_blocks), dim3(kWGThreads), 0, s, a);
   if (wide) hipLaunchKernelGGL((hensel_decrypt_wave_kernel<K, LB, true>), dim3(wave_blocks), dim3(kWGThreads), lds, s, a);
   else hipLaunchKernelGGL((hensel_decrypt_wave_kernel<K, LB, false>), dim3(wave_blocks), dim3(kWGThreads), lds, s, a);
   hipLaunchKernelGGL((hensel_ps_exit_kernel<K, LB>), dim3(lane_blocks), dim3(kWGThreads), 0, s, a);
