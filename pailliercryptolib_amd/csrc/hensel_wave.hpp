@@ -14,12 +14,11 @@
 //               acc_l = (acc_{l+1} mod 2^LB) + (acc_l >> LB)       one v_lshrrev_b64, one v_and_b32_dpp wave_shl:1, one multiply-add
 // -- six or seven instructions per step whatever K is, K steps per half-width product, no LDS, no waiting for memory; the two
 // scans of a pair product run in lock-step and in a pinned order (wv_pairop), so that each one's digit broadcast is covered by
-// the other's instructions.  The last line
-// both slides the window and keeps every accumulator below 2^37 (each lane passes its own carry one column up while it
-// takes over its neighbour's low limb), so limbs need not be canonical anywhere: products leave RELAXED limbs (below
-// 2^LB + 2^9; with 32-bit digits -- wv_digit -- values stay below 17 P instead of 2 P).  The pair product of hensel.hpp on top of it: t = a*c with its digits q_i kept in SGPRs; w = a*d + b*c + q
-// with q_i added to lane 0 in step i.  ~620 instructions per pair squaring against ~900 of the 16-lane form, on a chain
-// without LDS round trips.
+// the other's instructions.  The slide both moves the window and keeps every accumulator below 2^37 (each lane passes its own
+// carry one column up while it takes over its neighbour's low limb), so limbs need not be canonical anywhere: products leave
+// RELAXED limbs (below 2^LB + 2^9; with 32-bit digits -- wv_digit -- values stay below 17 P instead of 2 P).  The pair product
+// of hensel.hpp on top of it: t = a*c with its digits; w = a*d + b*c + q with digit q_i added to lane 0 in step i.  550
+// instructions per pair squaring at K = 38 against ~900 of the 16-lane form, on a chain without LDS round trips.
 // The same constants as hensel_decrypt_ps_kernel (the key's hs_ps set: K limbs of LB bits, P == -1 mod 2^LB), and its entry
 // and exit CODE: hensel_ps_entry_kernel runs the products of ps_entry_from_pair_row one lane per exponentiation and product and
 // leaves the partial pairs in a buffer, hensel_ps_exit_kernel picks the result up, makes its limbs canonical and runs
@@ -71,13 +70,6 @@ template <int LB, bool WIDEQ>
 __device__ __forceinline__ uint32_t wv_digit(uint64_t acc, const WaveCtx& c) {
   if constexpr (WIDEQ) return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)acc);
   else return (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)acc & c.maskv));
-}
-// the slide: acc_l = (acc_{l+1} mod 2^LB) + (acc_l >> LB)
-template <int LB>
-__device__ __forceinline__ void wv_slide(uint64_t& acc, const WaveCtx& c) {
-  const uint32_t lo = wv_down_and((uint32_t)acc, c.maskv);
-  acc >>= LB;
-  wv_mac(acc, lo, c.onev);
 }
 // accumulators -> relaxed limbs: own low limb plus the carry of the lane below
 template <int LB>
