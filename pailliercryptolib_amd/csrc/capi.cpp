@@ -1283,6 +1283,30 @@ const pgpu_pubkey::PubForm* split_modexp_form(const pgpu_pubkey* key, size_t cou
   const size_t ipw = 64 / (2 * (size_t)last->H);
   return (count + ipw - 1) / ipw > max_waves ? nullptr : last;
 }
+// Other batch lanes of `dev` with work queued right now or fed within the activity window, seen from the lane that owns stream
+// `s` (0 when `s` is no batch lane); no PGPU_RR_ADAPT threshold: the latency forms spend a whole wavefront per
+// exponentiation, which only pays while the chip has SIMDs to spare -- two API threads with 700-element batches already fill it
+// (measured: four threads x 700 elements 1.78 ms per encrypt + decrypt with the throughput forms, 2.01 with the latency forms)
+int wave_neighbours(rt::Device& dev, hipStream_t s) {
+  int lane = -1;
+  for (int k = 0; k < rt::kBatchLanes; ++k)
+    if (dev.bs(k) == s) lane = k;
+  if (lane < 0) return 0;
+  static const int64_t window_ns = [] {
+    const char* e = std::getenv("PGPU_LANE_ACTIVE_MS");
+    return (int64_t)(e ? std::max(0, std::atoi(e)) : 50) * 1000000;
+  }();
+  const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  dev.lane_fed_ns[lane].store(now, std::memory_order_relaxed);   // (CT x PT callers are seen by their neighbours through this stamp)
+  int busy = 0;
+  for (int k = 0; k < rt::kBatchLanes; ++k) {
+    if (k == lane) continue;
+    const int64_t fed = std::max(dev.lane_fed_ns[k].load(std::memory_order_relaxed), dev.host_fed_ns[k].load(std::memory_order_relaxed));
+    if ((fed != 0 && now - fed < window_ns) || hipStreamQuery(dev.bs(k)) == hipErrorNotReady) ++busy;
+  }
+  (void)hipGetLastError();
+  return busy;
+}
 // the latency forms of the n^2 domain (hensel_wave_n2.hpp: one wavefront per element on pair rows of this form) for a launch
 // of `count` elements?  They run with 32-bit quotient digits (values below 9 P instead of 2 P): the rows' radix must leave
 // room, R = 2^(29 L2) >= 2^10 P with P = n k < 2^(bits(n) + 29) -- true for every key size that has these rows but its
@@ -1333,7 +1357,8 @@ int modexp_split_on(rt::Device& d, const pgpu_pubkey* key, const pgpu_pubkey::Pu
   a.count = count;
   // The latency form (hensel_wave_n2.hpp; round 6): small launches on resident rows -- one wavefront per element, the window
   // table in its LDS
-  if (base_pair && out_pair && !a.sched && final_mul == pgpu::FM_UNIT && wave_n2_applies(form, count) && a.window <= 5) {
+  if (base_pair && out_pair && !a.sched && final_mul == pgpu::FM_UNIT && wave_n2_applies(form, count) && a.window <= 5 &&
+      (policy::wave_policy() == 2 || count * (size_t)(1 + wave_neighbours(d, s)) <= kSimds)) {
     TimerScope t(d, s, PGPU_KERNEL_MODEXP, PGPU_FORM_WAVE);
     if (!pgpu::launch_hensel_modexp_wave(H * K, a, s))
       return fail(PGPU_ERR_UNSUPPORTED, "wavefront-wide modexp kernel not compiled");
@@ -1449,7 +1474,8 @@ int encrypt_on(rt::Device& d, const pgpu_pubkey* key, const uint64_t* d_m, size_
       f.ct_gather = masked ? 1 : 0;
       TimerScope t(d, s, PGPU_KERNEL_FB_ENCRYPT);
       // The latency form (hensel_wave_n2.hpp; round 6): small launches onto pair rows -- one wavefront per element
-      if (d_pair && wave_n2_applies(form, count)) {
+      if (d_pair && busy_lanes == 0 && wave_n2_applies(form, count) &&
+          (policy::wave_policy() == 2 || count * (size_t)(1 + wave_neighbours(d, s)) <= kSimds)) {
         t.set_form(PGPU_FORM_WAVE);
         if (!pgpu::launch_hensel_fb_encrypt_wave(form->H * form->K, f, s))
           return fail(PGPU_ERR_UNSUPPORTED, "wavefront-wide fixed-base kernel not compiled");
@@ -1665,7 +1691,8 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
       in_pair_l2 = cl2;
     }
   }
-  const bool wavef = d_pair && !sliding && hset && wave_form_pays(key, count, busy_lanes) && key->hs_ps->pair_l2 == in_pair_l2;
+  const bool wavef = d_pair && !sliding && hset && wave_form_pays(key, count, busy_lanes) && key->hs_ps->pair_l2 == in_pair_l2 &&
+                     (policy::wave_policy() == 2 || 2 * count * (size_t)(1 + wave_neighbours(d, s)) <= kSimds);
   const bool psf = wavef || (d_pair && !sliding && hset && ps_form_pays(key, count, busy_lanes) &&
                              key->hs_ps->pair_l2 == in_pair_l2);
   if (psf) hset = key->hs_ps.get();

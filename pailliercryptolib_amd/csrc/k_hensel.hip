@@ -21,7 +21,7 @@ namespace pgpu {
 
 #define PGPU_HENSEL_ONE(h, k)                                                                             \
   if (H == h && K == k) {                                                                                 \
-    hipLaunchKernelGGL((hensel_decrypt_kernel<h, k>), dim3(blocks), dim3(kWGThreads), 0, s, a);           \
+    hipLaunchKernelGGL((hensel_decrypt_kernel<h, k>), dim3(blocks), dim3(kWGThreads), PGPU_PLACE_PAD((hensel_decrypt_kernel<h, k>), blocks), s, a);           \
     return true;                                                                                          \
   }
 
@@ -65,7 +65,7 @@ bool PGPU_FB_NAME(launch_hensel_fb_build)(int H, int K, const HenselFbBuildArgs&
 }
 bool PGPU_FB_NAME(launch_hensel_fb_encrypt)(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
   if (H == PGPU_FB_H && K == PGPU_FB_K) {
-    hipLaunchKernelGGL((hensel_fb_encrypt_kernel<PGPU_FB_H, PGPU_FB_K>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    hipLaunchKernelGGL((hensel_fb_encrypt_kernel<PGPU_FB_H, PGPU_FB_K>), dim3(blocks), dim3(kWGThreads), PGPU_PLACE_PAD((hensel_fb_encrypt_kernel<PGPU_FB_H, PGPU_FB_K>), blocks), s, a);
     return true;
   }
   return false;
@@ -356,7 +356,7 @@ bool launch_hensel_fb_encrypt_wave_part37(int L2, const HenselFbArgs& a, hipStre
 #elif PGPU_PART == 14
 bool launch_hensel_fb_encrypt_part14(int H, int K, const HenselFbArgs& a, unsigned blocks, hipStream_t s) {
   if (H == 8 && K == 9) {
-    hipLaunchKernelGGL((hensel_fb_encrypt_kernel<8, 9>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    hipLaunchKernelGGL((hensel_fb_encrypt_kernel<8, 9>), dim3(blocks), dim3(kWGThreads), PGPU_PLACE_PAD((hensel_fb_encrypt_kernel<8, 9>), blocks), s, a);
     return true;
   }
   return false;
@@ -364,15 +364,15 @@ bool launch_hensel_fb_encrypt_part14(int H, int K, const HenselFbArgs& a, unsign
 #elif PGPU_PART == 8
 bool launch_hensel_modexp_part8(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
   if (H == 2 && K == 19) {
-    hipLaunchKernelGGL((hensel_modexp_kernel<2, 19>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    hipLaunchKernelGGL((hensel_modexp_kernel<2, 19>), dim3(blocks), dim3(kWGThreads), PGPU_PLACE_PAD((hensel_modexp_kernel<2, 19>), blocks), s, a);
     return true;
   }
   if (H == 8 && K == 5) {
-    hipLaunchKernelGGL((hensel_modexp_kernel<8, 5>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    hipLaunchKernelGGL((hensel_modexp_kernel<8, 5>), dim3(blocks), dim3(kWGThreads), PGPU_PLACE_PAD((hensel_modexp_kernel<8, 5>), blocks), s, a);
     return true;
   }
   if (H == 4 && K == 10) {
-    hipLaunchKernelGGL((hensel_modexp_kernel<4, 10>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    hipLaunchKernelGGL((hensel_modexp_kernel<4, 10>), dim3(blocks), dim3(kWGThreads), PGPU_PLACE_PAD((hensel_modexp_kernel<4, 10>), blocks), s, a);
     return true;
   }
   return false;
@@ -380,7 +380,7 @@ bool launch_hensel_modexp_part8(int H, int K, const HenselModexpArgs& a, unsigne
 #elif PGPU_PART == 9
 bool launch_hensel_modexp_part9(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
   if (H == 8 && K == 14) {
-    hipLaunchKernelGGL((hensel_modexp_kernel<8, 14>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    hipLaunchKernelGGL((hensel_modexp_kernel<8, 14>), dim3(blocks), dim3(kWGThreads), PGPU_PLACE_PAD((hensel_modexp_kernel<8, 14>), blocks), s, a);
     return true;
   }
   return false;
@@ -388,7 +388,7 @@ bool launch_hensel_modexp_part9(int H, int K, const HenselModexpArgs& a, unsigne
 #elif PGPU_PART == 7
 bool launch_hensel_part7(int H, int K, const HenselArgs& a, unsigned blocks, hipStream_t s) {
   if (H == 2 && K == 19) {
-    hipLaunchKernelGGL((hensel_decrypt_kernel<2, 19, 2>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    hipLaunchKernelGGL((hensel_decrypt_kernel<2, 19, 2>), dim3(blocks), dim3(kWGThreads), PGPU_PLACE_PAD((hensel_decrypt_kernel<2, 19, 2>), blocks), s, a);
     return true;
   }
   return false;
@@ -396,7 +396,7 @@ bool launch_hensel_part7(int H, int K, const HenselArgs& a, unsigned blocks, hip
 #elif PGPU_PART == 5
 bool launch_hensel_modexp_part5(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
   if (H == 4 && K == 18) {
-    hipLaunchKernelGGL((hensel_modexp_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    hipLaunchKernelGGL((hensel_modexp_kernel<4, 18>), dim3(blocks), dim3(kWGThreads), PGPU_PLACE_PAD((hensel_modexp_kernel<4, 18>), blocks), s, a);
     return true;
   }
   return false;
@@ -404,7 +404,7 @@ bool launch_hensel_modexp_part5(int H, int K, const HenselModexpArgs& a, unsigne
 #elif PGPU_PART == 23
 bool launch_hensel_modexp_part23(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
   if (H == 8 && K == 18) {
-    hipLaunchKernelGGL((hensel_modexp_kernel<8, 18>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    hipLaunchKernelGGL((hensel_modexp_kernel<8, 18>), dim3(blocks), dim3(kWGThreads), PGPU_PLACE_PAD((hensel_modexp_kernel<8, 18>), blocks), s, a);
     return true;
   }
   return false;
@@ -412,7 +412,7 @@ bool launch_hensel_modexp_part23(int H, int K, const HenselModexpArgs& a, unsign
 #elif PGPU_PART == 6
 bool launch_hensel_modexp_part6(int H, int K, const HenselModexpArgs& a, unsigned blocks, hipStream_t s) {
   if (H == 8 && K == 9) {
-    hipLaunchKernelGGL((hensel_modexp_kernel<8, 9>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+    hipLaunchKernelGGL((hensel_modexp_kernel<8, 9>), dim3(blocks), dim3(kWGThreads), PGPU_PLACE_PAD((hensel_modexp_kernel<8, 9>), blocks), s, a);
     return true;
   }
   return false;

@@ -9,7 +9,9 @@
 
 #include "kargs.hpp"
 
+#include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <mutex>
 
 // Build switch (pailliercryptolib_amd/build.py passes it to every translation unit, device and host alike):
@@ -48,6 +50,44 @@ inline bool lds_attr_once(const void* fn, int bytes, std::atomic<uint64_t>& done
   ([]() -> bool {                                                                    \
     static std::atomic<uint64_t> done_{0};                                           \
     return ::pgpu::lds_attr_once((const void*)(kernel_expr), (bytes), done_);        \
+  }())
+
+// Placement pad (round 6).  The workgroup dispatcher starts every launch on the same CUs: two launches of 32 workgroups side by
+// side (two API threads with 512-element batches) land on the same SIMDs and slow each other down although seven eighths of
+// the chip idle (rocprofv3 kernel trace: a CT x PT kernel 5.6 ms alone, 6-9.6 ms beside a second one; aggregate 3.6 ms per
+// call).  A workgroup that owns more than half of a CU's 160 KB of LDS cannot share its CU, so small launches of the
+// multi-lane forms ask for unused dynamic LDS up to 81 KB per workgroup and the dispatcher has to spread them: 2.87 ms per
+// call, the two launches fully overlapped; four threads x 700-element encrypt + decrypt 1.85 -> 1.24 ms, four x 1024-element
+// CT x PT 2.5-3.6 -> 1.48 ms (profiles/r06_place_pad.txt).  Only launches of at most PGPU_PLACE_PAD workgroups (default 192,
+// three quarters of the CUs; 0: never): a launch that puts a workgroup on every CU gains from a neighbour's second wavefront
+// on its SIMDs (256: encrypt + decrypt of 2048 elements from two threads 2.8 -> 3.15 ms; 128 and 192 measure alike).  The
+// attribute is raised at the kernel's first launch on the device whatever its size (lds_attr_once).  Returns the dynamic LDS
+// bytes to launch with.
+inline unsigned place_pad(const void* fn, unsigned blocks, std::atomic<uint64_t>& done, std::atomic<int>& pad_bytes) {
+  static const int limit = [] {
+    const char* e = std::getenv("PGPU_PLACE_PAD");
+    return e ? std::max(0, std::atoi(e)) : 192;
+  }();
+  if (limit == 0) return 0;
+  int pad = pad_bytes.load(std::memory_order_acquire);
+  if (pad < 0) {
+    hipFuncAttributes fa{};
+    if (hipFuncGetAttributes(&fa, fn) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    const int want = 81 * 1024, have = (int)fa.sharedSizeBytes;
+    pad = have >= want ? 0 : ((want - have + 1023) / 1024) * 1024;
+    pad_bytes.store(pad, std::memory_order_release);
+  }
+  if (pad == 0 || !lds_attr_once(fn, pad, done)) return 0;
+  return blocks <= (unsigned)limit ? (unsigned)pad : 0;
+}
+#define PGPU_PLACE_PAD(kernel_expr, blocks)                                                      \
+  ([&]() -> unsigned {                                                                          \
+    static std::atomic<uint64_t> done_{0};                                                      \
+    static std::atomic<int> pad_{-1};                                                           \
+    return ::pgpu::place_pad((const void*)(kernel_expr), (blocks), done_, pad_);                \
   }())
 
 // modexp_kernel lives in eight translation units (k_modexp.hip, PGPU_PART 0..7); launch_modexp tries each.

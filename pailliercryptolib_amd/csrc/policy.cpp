@@ -46,8 +46,9 @@ constexpr int kAdaptClaimBusy = 3;
 // caller's launches take a quarter of the chip (17 ms per encrypt + decrypt instead of 5.4 on the whole chip, four of them
 // side by side: 5.3 against 5.9 ms per pair), which pays although every caller's quarter idles through its copies and host
 // work; with one busy neighbour (half-chip forms) it does not (r04: 11.8 against 7.2 ms per pair).  0: lone-caller forms.
-// the latency form of small decrypts (hensel_wave.hpp): set by tests only
-std::atomic<int> g_wave_policy{1};
+// PGPU_WAVE_FORMS: the latency forms (hensel_wave.hpp, hensel_wave_n2.hpp: one wavefront per exponentiation) -- 0 never,
+// 1 (default) for small launches of a caller that has the chip to itself, 2 always where a kernel exists (tests)
+std::atomic<int> g_wave_policy{env_int("PGPU_WAVE_FORMS", 1, 0, 2)};
 std::atomic<int> g_rr_adapt{env_int("PGPU_RR_ADAPT", 3, 0, 100)};
 }  // namespace
 
