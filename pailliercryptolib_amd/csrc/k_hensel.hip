@@ -300,8 +300,17 @@ static bool launch_wave_one(bool wide, const HenselArgs& a, hipStream_t s) {
   const unsigned lds = (unsigned)(kWavesPerWG * wv_table_words<K>((size_t)1 << a.window) * sizeof(uint32_t));
   if (lds > 64 * 1024) return false;
   hipLaunchKernelGGL((hensel_ps_entry_kernel<K, LB>), dim3(entry_blocks), dim3(kWGThreads), 0, s, a);
-  if (wide) hipLaunchKernelGGL((hensel_decrypt_wave_kernel<K, LB, true>), dim3(wave_blocks), dim3(kWGThreads), lds, s, a);
-  else hipLaunchKernelGGL((hensel_decrypt_wave_kernel<K, LB, false>), dim3(wave_blocks), dim3(kWGThreads), lds, s, a);
+  // (placement pad, launch.hpp: two callers' launches of this form on different CUs -- the table alone lets two workgroups
+  //  share a CU, two wavefronts per SIMD at 1.7x the time while other CUs idle)
+  const unsigned claim = 82 * 1024;
+  unsigned dyn = lds;
+  if (place_pad_limit() > 0) {
+    const bool ok = wide ? PGPU_LDS_ATTR_ONCE((hensel_decrypt_wave_kernel<K, LB, true>), (int)claim)
+                         : PGPU_LDS_ATTR_ONCE((hensel_decrypt_wave_kernel<K, LB, false>), (int)claim);
+    if (ok && wave_blocks <= (unsigned)place_pad_limit()) dyn = claim;
+  }
+  if (wide) hipLaunchKernelGGL((hensel_decrypt_wave_kernel<K, LB, true>), dim3(wave_blocks), dim3(kWGThreads), dyn, s, a);
+  else hipLaunchKernelGGL((hensel_decrypt_wave_kernel<K, LB, false>), dim3(wave_blocks), dim3(kWGThreads), dyn, s, a);
   hipLaunchKernelGGL((hensel_ps_exit_kernel<K, LB>), dim3(lane_blocks), dim3(kWGThreads), 0, s, a);
   return true;
 }
@@ -331,7 +340,8 @@ static bool launch_modexp_wave_one(const HenselModexpArgs& a, hipStream_t s) {
 template <int L2, int LPL>
 static bool launch_fb_encrypt_wave_one(const HenselFbArgs& a, hipStream_t s) {
   const unsigned blocks = (unsigned)((a.count + kWavesPerWG - 1) / kWavesPerWG);
-  hipLaunchKernelGGL((hensel_fb_encrypt_wave_kernel<L2, LPL, true>), dim3(blocks), dim3(kWGThreads), 0, s, a);
+  hipLaunchKernelGGL((hensel_fb_encrypt_wave_kernel<L2, LPL, true>), dim3(blocks), dim3(kWGThreads),
+                     PGPU_PLACE_PAD((hensel_fb_encrypt_wave_kernel<L2, LPL, true>), blocks), s, a);
   return true;
 }
 #if PGPU_PART == 36

@@ -63,11 +63,15 @@ inline bool lds_attr_once(const void* fn, int bytes, std::atomic<uint64_t>& done
 // on its SIMDs (256: encrypt + decrypt of 2048 elements from two threads 2.8 -> 3.15 ms; 128 and 192 measure alike).  The
 // attribute is raised at the kernel's first launch on the device whatever its size (lds_attr_once).  Returns the dynamic LDS
 // bytes to launch with.
-inline unsigned place_pad(const void* fn, unsigned blocks, std::atomic<uint64_t>& done, std::atomic<int>& pad_bytes) {
+inline int place_pad_limit() {
   static const int limit = [] {
     const char* e = std::getenv("PGPU_PLACE_PAD");
     return e ? std::max(0, std::atoi(e)) : 192;
   }();
+  return limit;
+}
+inline unsigned place_pad(const void* fn, unsigned blocks, std::atomic<uint64_t>& done, std::atomic<int>& pad_bytes) {
+  const int limit = place_pad_limit();
   if (limit == 0) return 0;
   int pad = pad_bytes.load(std::memory_order_acquire);
   if (pad < 0) {
