@@ -1604,7 +1604,11 @@ const pgpu_privkey::HenselSet* pick_hensel(const pgpu_privkey* key, size_t count
 // in one mode: right after a synchronisation every lane is empty for a moment, and a policy that only looked at the
 // queues would start each burst with a full-chip launch that the next lane's half-chip launch then has to share CUs
 // with (measured: ~7 ms lost at the head of a 20-step run, 5.31 instead of 4.95 ms per step).  Also stamps `lane`.
-int busy_other_lanes(rt::Device& dev, int lane, bool force = false) {
+// `count`: threads on round-robin lanes with launches under policy::kRrAdaptMinCount elements keep the lone caller's forms
+// (stamped all the same): since the placement pad (launch.hpp) spreads small launches over the CUs those beat the part-chip
+// forms -- four threads x 64 elements 0.76 against 1.03 ms per encrypt + decrypt, x 256 0.97 against 1.05, x 2048 2.18 against
+// 2.26, level at 4096, 5.2 against 5.8 at 8192 (profiles/r06_place_pad.txt)
+int busy_other_lanes(rt::Device& dev, int lane, bool force = false, size_t count = (size_t)-1) {
   const int rr_min = (!force && !t_lane_explicit) ? policy::rr_adapt() : 1;
   if (rr_min <= 0) return 0;   // (synchronous callers on round-robin lanes: lone-caller forms, no stamp)
   static const int64_t window_ns = [] {
@@ -1620,13 +1624,14 @@ int busy_other_lanes(rt::Device& dev, int lane, bool force = false) {
     if ((fed != 0 && now - fed < window_ns) || hipStreamQuery(dev.bs(k)) == hipErrorNotReady) ++busy;
   }
   (void)hipGetLastError();
+  if (!force && !t_lane_explicit && count < policy::kRrAdaptMinCount) return 0;
   return busy >= rr_min ? busy : 0;
 }
 // The same for a synchronous caller of the HOST-ARRAY entry points (pgpu_paillier_encrypt / _decrypt_crt) on its thread's
 // lane.  PGPU_HOST_ADAPT=1: the full adaptive policy (measured slower with one neighbour, kept for A/B).  Otherwise, round 5:
 // the callers see each other through stamps of their own, and only when at least PGPU_RR_ADAPT (3) others have been calling
 // within the activity window do their launches take the quarter-chip forms -- four callers side by side, as four API threads.
-int host_busy(rt::Device& dev, int lane) {
+int host_busy(rt::Device& dev, int lane, size_t count = (size_t)-1) {
   if (host_adapt()) return busy_other_lanes(dev, lane, true);
   const int k = policy::rr_adapt();
   if (k <= 0) return 0;
@@ -1642,6 +1647,7 @@ int host_busy(rt::Device& dev, int lane) {
     const int64_t fed = std::max(dev.host_fed_ns[j].load(std::memory_order_relaxed), dev.lane_fed_ns[j].load(std::memory_order_relaxed));
     if (fed != 0 && now - fed < window_ns) ++busy;
   }
+  if (count < policy::kRrAdaptMinCount) return 0;   // (busy_other_lanes: small launches keep the lone caller's forms)
   return busy >= k ? busy : 0;
 }
 
@@ -2556,7 +2562,7 @@ int pgpu_paillier_encrypt(const pgpu_pubkey* key, const uint64_t* m, size_t m_st
     RC_TRY(dc.alloc(d, s, n * (size_t)W * 8));
     RC_TRY(lane.h2d(dm.p, m + lo * m_stride, n * m_stride * 8, s));
     RC_TRY(lane.h2d(dr.p, r + lo * r_stride, n * r_stride * 8, s));
-    const int busy = host_busy(d, caller_lane);
+    const int busy = host_busy(d, caller_lane, n);
     if (pf && busy > 0 && fb_encrypt_seq_pays(pf->H, pf->K, n, busy)) {
       // the sequential-halves kernel leaves pair rows: one pair_ops_kernel pass brings them back to words
       RC_TRY(rows.alloc(d, s, n * (size_t)2 * pf->H * pf->K * sizeof(uint32_t)));
@@ -2608,7 +2614,7 @@ int pgpu_paillier_decrypt_crt(const pgpu_privkey* key, const uint64_t* c, uint64
     RC_TRY(dc.alloc(d, s, n * (size_t)2 * nw * 8));
     RC_TRY(dm.alloc(d, s, n * (size_t)nw * 8));
     RC_TRY(lane.h2d(dc.p, c + lo * (size_t)2 * nw, n * (size_t)2 * nw * 8, s));
-    RC_TRY(decrypt_on(d, key, (const uint64_t*)dc.p, (uint64_t*)dm.p, n, s, false, nullptr, 0, host_busy(d, caller_lane)));
+    RC_TRY(decrypt_on(d, key, (const uint64_t*)dc.p, (uint64_t*)dm.p, n, s, false, nullptr, 0, host_busy(d, caller_lane, n)));
     const int rcd = lane.d2h(m + lo * (size_t)nw, dm.p, n * (size_t)nw * 8, s);
     (void)host_busy(d, caller_lane);
     return rcd;

@@ -19,15 +19,18 @@ namespace pgpu {
 namespace policy {
 
 constexpr size_t kSimds = 256 * 4;   // MI355X: 256 CUs x 4 SIMDs; a launch of fewer wavefronts leaves SIMDs empty
+// threads on round-robin lanes enter the adaptive policy only with launches of at least this many elements (capi.cpp:
+// busy_other_lanes)
+constexpr size_t kRrAdaptMinCount = 4096;
 
-// ---- knobs: FOUR (PGPU_SEQ_DECRYPT, PGPU_PS_DECRYPT, PGPU_RR_ADAPT, PGPU_FIXED_WINDOW; environment at start-up; the
+// ---- knobs: PGPU_SEQ_DECRYPT, PGPU_PS_DECRYPT, PGPU_RR_ADAPT, PGPU_FIXED_WINDOW, PGPU_WAVE_FORMS (environment at start-up; the
 // setters are what pgpu_debug_set_* and the tests use) ----
 int seq_policy();            // PGPU_SEQ_DECRYPT: 0 never, 1 by launch size, 2 always, 3 two-lane mode (r03), 4 adaptive (default)
 void set_seq_policy(int p);
 int ps_policy();             // PGPU_PS_DECRYPT (hensel_ps.hpp): 0 never, 1 by launch size / neighbour lanes (default), 2 always
 void set_ps_policy(int p);
 int adapt_claim_busy();      // up to how many busy neighbours a part-chip launch claims whole CUs (3; a constant since round 6)
-int wave_policy();           // the latency form (hensel_wave.hpp): 0 never, 1 small lone launches (default), 2 always; no environment knob
+int wave_policy();           // the latency form (hensel_wave.hpp): PGPU_WAVE_FORMS: 0 never, 1 small launches while SIMDs are spare (default), 2 always
 void set_wave_policy(int p);
 int rr_adapt();              // PGPU_RR_ADAPT: from how many active neighbours on threads on round-robin lanes adapt (3; 0 never)
 int set_rr_adapt(int min_busy);   // returns the previous value

@@ -35,6 +35,15 @@ def main():
                 "workgroups share a CU; hensel_fb_encrypt_wave_kernel: no LDS of its own) -- tools/run_wave_pad.sh:", ""]
         for (op, n, t), v in table(wp, "PGPU_PLACE_PAD").items():
             out.append(f"{op:24s} {n:6d} {t:7d}   {fmt(v.get('0', [])):>28s}   {fmt(v.get('192', [])):>28s}")
+    rr = os.path.join(ROOT, "gpurun_out", "r06_rr_adapt.txt")
+    if os.path.exists(rr):
+        out += ["", "Four API threads: the part-chip forms of the adaptive policy (PGPU_RR_ADAPT=3) against the lone caller's forms",
+                "(PGPU_RR_ADAPT=0), measured with the part-chip forms entered from 1024 elements per launch (tools/run_rr_adapt.sh; below",
+                "that both columns run the same forms -- before the threshold the left column read 1033 us at 64 and 1045 us at 256).",
+                "The threshold that ships is 4096 (policy.hpp: kRrAdaptMinCount).", "",
+                f"{'op':24s} {'batch':>6s} {'threads':>7s}   {'PGPU_RR_ADAPT=3 (default)':>28s}   {'PGPU_RR_ADAPT=0':>28s}"]
+        for (op, n, t), v in table(rr, "PGPU_RR_ADAPT").items():
+            out.append(f"{op:24s} {n:6d} {t:7d}   {fmt(v.get('3', [])):>28s}   {fmt(v.get('0', [])):>28s}")
     out += ["",
             "Four threads are bimodal from run to run (CT x PT 1024 x 4: 1.47-1.53 ms in most runs, 1.9-2.8 ms in others; same kernels,",
             "same durations, four distinct hardware queues in the rocprofv3 trace with GPU_MAX_HW_QUEUES = 4 and 8 alike): in the slow",
