@@ -205,3 +205,23 @@ def test_wave_fb_encrypt_kernel_is_bit_identical(engine, bits, count):
         assert (form()[0] == 5) == (count <= 1024)
     finally:
         R.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,threads,batch", [("--threads", 2, 200), ("--threads", 3, 64), ("--threads", 4, 700),
+                                                ("--threads-mul", 2, 512), ("--threads-mul", 3, 600), ("--threads-mul", 4, 128)])
+def test_small_batches_from_several_api_threads(engine, mode, threads, batch):
+    """Several host threads with SMALL vectors at the ipcl:: API (the reference's OpenMP tests, test_cryptography.cpp:45-57 /
+    test_ops.cpp, at benchmark sizes): their launches are a mix of the latency forms (while wavefronts x (1 + active
+    neighbours) fit the SIMDs: capi.cpp wave_neighbours) and the padded multi-lane forms (launch.hpp place_pad), chosen per
+    launch from what the other lanes are doing at that instant.  Every thread's round trips (encrypt + decrypt) resp.
+    products (CipherText * PlainText, checked as m * e mod n after a decrypt) must hold whatever the mix."""
+    import json
+    import subprocess
+    from pailliercryptolib_amd import build
+    exe = build.build_api_bench()
+    for _ in range(2):
+        r = subprocess.run([exe, mode, str(threads), str(batch), "6"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+        rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert rec.get("round_trip_ok", rec.get("products_ok")) is True
