@@ -1762,7 +1762,7 @@ int decrypt_on(rt::Device& d, const pgpu_privkey* key, const uint64_t* d_c, uint
     const size_t waves = 2 * ((count + ipw - 1) / ipw);
     const unsigned blocks = (unsigned)((waves + pgpu::kWavesPerWG - 1) / pgpu::kWavesPerWG);
     // (the window-table workspace is sized by the form that runs: one allocation per launch at most -- a growing
-    // workspace is a hipMallocAsync of a few hundred MB, milliseconds of host time when the pool has to go to the driver)
+    // workspace is an allocation of a few hundred MB, milliseconds of host time when the arena has to go to the driver)
     TimerScope t(d, s, PGPU_KERNEL_MODEXP);
     const size_t seq_ipw = 64 / (size_t)hset->H;
     const size_t seq_waves = 2 * ((count + seq_ipw - 1) / seq_ipw);

@@ -131,45 +131,26 @@ void lane_main(Device* d, Lane* lane) {
 // ---------------- Workspace ----------------
 int Workspace::ensure(size_t need, hipStream_t s) {
   if (need <= bytes) return PGPU_OK;
-  // Stream-ordered growth (hipMallocAsync / hipFreeAsync on the owning stream): the launches already queued on `s`
-  // keep the old block until they have run, later ones see the new block; no other stream of the device waits.
-  // Grow by half at least, so that a slowly growing batch does not reallocate on every call.
+  // Growth through the device's block arena (Device::alloc / free, free lists keyed by stream): the old block goes back to
+  // the list of ITS stream, where only later launches of that stream can pick it up -- behind the ones that still read it.
+  // Rounds 3-6 grew with hipMallocAsync / hipFreeAsync on the owning stream; round 6 found four API threads that grew their
+  // workspaces at the same moment (first decrypt of 1024 ciphertexts each, launches sharing CUs) delivering zeros for the tail
+  // of a batch in 2 % of the runs -- device memory checked by a second copy, inputs intact, a repeated decrypt right -- and none
+  // in 300 runs without the stream-ordered pool (profiles/r06_thread_race.txt).  Grow by half at least, so that a slowly
+  // growing batch does not reallocate on every call.
+  if (!dev) return fail(PGPU_ERR_INVALID_PARAM, "workspace without a device");
   const size_t want = std::max(need, bytes + bytes / 2);
   void* np = nullptr;
-  hipError_t e = hipMallocAsync(&np, want, s);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    // no stream-ordered pool (or it is exhausted): the synchronous path, as before round 3
-    if (p) {
-      HIP_TRY(hipStreamSynchronize(s));
-      HIP_TRY(hipFree(p));
-      p = nullptr;
-      bytes = 0;
-      async_ = false;
-    }
-    HIP_TRY(hipMalloc(&np, need));
-    p = np;
-    bytes = need;
-    async_ = false;
-    return PGPU_OK;
-  }
-  if (p) {
-    if (async_) HIP_TRY(hipFreeAsync(p, s));
-    else {
-      HIP_TRY(hipStreamSynchronize(s));
-      HIP_TRY(hipFree(p));
-    }
-  }
+  RC_TRY(dev->alloc(want, s, &np));
+  if (p) dev->free(p, s);
   p = np;
   bytes = want;
-  async_ = true;
   return PGPU_OK;
 }
 void Workspace::release() {
-  if (p) (void)hipFree(p);   // (hipFree accepts stream-ordered allocations too; it synchronises the device)
+  if (p) (void)hipFree(p);   // (synchronises the device; the caller has dropped the arena's record of the block)
   p = nullptr;
   bytes = 0;
-  async_ = false;
 }
 
 // ---------------- Device ----------------
@@ -251,6 +232,8 @@ StreamWork& Device::work_for(hipStream_t s) {
     (void)hipDeviceSynchronize();
     for (auto& w : work) {
       if (w.second->mu.try_lock()) {
+        block_size.erase(w.second->table.p);
+        block_size.erase(w.second->vbuf.p);
         w.second->table.release();
         w.second->vbuf.release();
         w.second->mu.unlock();
@@ -259,6 +242,8 @@ StreamWork& Device::work_for(hipStream_t s) {
   }
   auto& slot = work[s];
   slot.reset(new StreamWork);
+  slot->table.dev = this;
+  slot->vbuf.dev = this;
   return *slot;
 }
 
@@ -704,6 +689,8 @@ void pool_shutdown() {
     (void)hipSetDevice(d->ordinal);
     (void)hipDeviceSynchronize();
     for (auto& kv : d->work) {
+      d->block_size.erase(kv.second->table.p);
+      d->block_size.erase(kv.second->vbuf.p);
       kv.second->table.release();
       kv.second->vbuf.release();
     }

@@ -69,15 +69,15 @@ struct DeviceGuard {
   }
 };
 
-// grow-only device buffer owned by one (device, stream) pair.  Growth is stream-ordered: the old block is handed
-// to the runtime's free-async queue behind the work already queued on the stream and the new one is allocated in
-// stream order too, so a busy pool never sees a device-wide synchronisation because one stream's batch grew.
+// grow-only device buffer owned by one (device, stream) pair.  Growth goes through the device's block arena: the old
+// block returns to the free list of ITS stream (only later launches of that stream can reuse it, behind the ones that
+// still read it), so a busy pool never sees a device-wide synchronisation because one stream's batch grew.
 struct Workspace {
   void* p = nullptr;
   size_t bytes = 0;
+  Device* dev = nullptr;   // whose block arena the memory comes from (set by Device::work_for)
   int ensure(size_t need, hipStream_t s);
   void release();
-  bool async_ = false;   // p came from hipMallocAsync
 };
 
 // launch scratch of one stream: `mu` is held from sizing the workspace until the launch is queued

@@ -71,6 +71,8 @@ static int threads_mode(int T, size_t dsize, int rounds) {
   for (int t = 0; t < T; ++t)
     for (size_t i = 0; i < dsize; i++) m[(size_t)t][i] = P - BigNumber((unsigned int)(i * 1024 + (size_t)t));
   std::vector<int> ok((size_t)T, 1);
+  std::vector<double> slowest((size_t)T, 0.0);
+  std::vector<std::chrono::steady_clock::time_point> done_at((size_t)T);
   std::atomic<int> ready{0}, go{0};
   std::vector<std::thread> th;
   std::chrono::steady_clock::time_point t0;
@@ -82,22 +84,29 @@ static int threads_mode(int T, size_t dsize, int rounds) {
           ready.fetch_add(1);
           while (!go.load()) std::this_thread::yield();
         }
+        const auto r0 = std::chrono::steady_clock::now();
         c = pk.encrypt(ipcl::PlainText(m[(size_t)t])).getTexts();
         d = sk.decrypt(ipcl::CipherText(pk, c)).getTexts();
+        if (r >= 2) slowest[(size_t)t] = std::max(slowest[(size_t)t], std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - r0).count());
       }
+      done_at[(size_t)t] = std::chrono::steady_clock::now();
       for (size_t i = 0; i < dsize; ++i) ok[(size_t)t] &= d[i] == m[(size_t)t][i];
     });
   while (ready.load() < T) std::this_thread::yield();
   t0 = std::chrono::steady_clock::now();
   go.store(1);
   for (auto& x : th) x.join();
-  const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  double us = 0, worst = 0;
+  for (int t = 0; t < T; ++t) {
+    us = std::max(us, std::chrono::duration<double, std::micro>(done_at[(size_t)t] - t0).count());
+    worst = std::max(worst, slowest[(size_t)t]);
+  }
   bool all = true;
   for (int v : ok) all = all && v;
   std::printf("{\"what\": \"%d host threads, each ipcl::PublicKey::encrypt + PrivateKey::decrypt with vector<BigNumber> in and out, "
               "batch %zu, %d rounds each\", \"threads\": %d, \"us_per_encrypt_plus_decrypt\": %.1f, \"modexps_per_s\": %.1f, "
-              "\"round_trip_ok\": %s}\n",
-              T, dsize, rounds, T, us / (rounds * T), 3.0 * dsize * rounds * T / (us * 1e-6), all ? "true" : "false");
+              "\"slowest_round_us\": %.1f, \"round_trip_ok\": %s}\n",
+              T, dsize, rounds, T, us / (rounds * T), 3.0 * dsize * rounds * T / (us * 1e-6), worst, all ? "true" : "false");
   ipcl::terminateContext();
   return all ? 0 : 1;
 }
@@ -112,6 +121,8 @@ static int threads_mul_mode(int T, size_t dsize, int rounds) {
   pk.setRandom(std::vector<BigNumber>(dsize, BigNumber(KAT_BENCH_R)));
   pk.setHS(BigNumber(KAT_BENCH_HS));
   std::vector<int> ok((size_t)T, 1);
+  std::vector<double> slowest((size_t)T, 0.0), slowest_call((size_t)T, 0.0);
+  std::vector<std::chrono::steady_clock::time_point> done_at((size_t)T);
   std::atomic<int> ready{0}, go{0};
   std::vector<std::thread> th;
   for (int t = 0; t < T; ++t)
@@ -129,22 +140,70 @@ static int threads_mul_mode(int T, size_t dsize, int rounds) {
           ready.fetch_add(1);
           while (!go.load()) std::this_thread::yield();
         }
+        const auto r0 = std::chrono::steady_clock::now();
         out = ct * pt;
+        const auto r1 = std::chrono::steady_clock::now();
         (void)out.getElement(0);
+        if (r >= 2) {
+          slowest[(size_t)t] = std::max(slowest[(size_t)t], std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - r0).count());
+          slowest_call[(size_t)t] = std::max(slowest_call[(size_t)t], std::chrono::duration<double, std::micro>(r1 - r0).count());
+        }
       }
+      done_at[(size_t)t] = std::chrono::steady_clock::now();   // (the check below is not part of the measurement)
       std::vector<BigNumber> d = sk.decrypt(out).getTexts();
-      for (size_t i = 0; i < dsize; ++i) ok[(size_t)t] &= d[i] == (m[i] * e[i]) % n;
+      size_t bad = 0, first = 0;
+      for (size_t i = 0; i < dsize; ++i)
+        if (!(d[i] == (m[i] * e[i]) % n)) {
+          if (!bad) first = i;
+          ++bad;
+        }
+      ok[(size_t)t] = bad == 0;
+      if (bad) {   // which of the two was wrong -- the product or the decrypt beside three others?  Once more, and from host copies
+        std::vector<BigNumber> d2 = sk.decrypt(out).getTexts();
+        std::vector<BigNumber> d3 = sk.decrypt(ipcl::CipherText(pk, out.getTexts())).getTexts();
+        size_t bad2 = 0, bad3 = 0;
+        for (size_t i = 0; i < dsize; ++i) {
+          bad2 += !(d2[i] == (m[i] * e[i]) % n);
+          bad3 += !(d3[i] == (m[i] * e[i]) % n);
+        }
+        std::fprintf(stderr, "thread %d: %zu of %zu products wrong (first at %zu); decrypted again: %zu wrong; from the host copy: %zu wrong\n",
+                     t, bad, dsize, first, bad2, bad3);
+        // what do the wrong values look like?  ranges, zeros, another thread's plaintexts (expected values are a function of t and i)
+        std::string ranges;
+        size_t zeros = 0, other = 0, again_same = 0;
+        for (size_t i = 0; i < dsize; ++i) {
+          const bool w = !(d[i] == (m[i] * e[i]) % n);
+          if (w && (i == 0 || d[i - 1] == (m[i - 1] * e[i - 1]) % n)) ranges += " " + std::to_string(i) + "-";
+          if (!w && i > 0 && !(d[i - 1] == (m[i - 1] * e[i - 1]) % n)) ranges += std::to_string(i - 1);
+          if (!w) continue;
+          zeros += d[i] == BigNumber::Zero();
+          again_same += d[i] == d2[i];
+          for (int u = 0; u < T; ++u) {
+            if (u == t) continue;
+            const BigNumber mu((unsigned int)(i * 1024 + (size_t)u + 1)), eu = Q - BigNumber((unsigned int)(i + 7 * (size_t)u));
+            other += d[i] == (mu * eu) % n;
+          }
+        }
+        std::fprintf(stderr, "thread %d: wrong ranges%s; zeros %zu, another thread's value at the same index %zu, same wrong value the second time %zu\n",
+                     t, ranges.c_str(), zeros, other, again_same);
+      }
     });
   while (ready.load() < T) std::this_thread::yield();
   const auto t0 = std::chrono::steady_clock::now();
   go.store(1);
   for (auto& x : th) x.join();
-  const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();   // (incl. the check decrypt)
+  double us = 0, worst = 0, worst_call = 0;
+  for (int t = 0; t < T; ++t) {
+    us = std::max(us, std::chrono::duration<double, std::micro>(done_at[(size_t)t] - t0).count());
+    worst = std::max(worst, slowest[(size_t)t]);
+    worst_call = std::max(worst_call, slowest_call[(size_t)t]);
+  }
   bool all = true;
   for (int v : ok) all = all && v;
-  std::printf("{\"what\": \"%d host threads, each CipherText * PlainText on a resident vector of %zu, %d rounds each (+ one check "
-              "decrypt)\", \"threads\": %d, \"us_per_mul\": %.1f, \"modexps_per_s\": %.1f, \"products_ok\": %s}\n",
-              T, dsize, rounds, T, us / (rounds * T), 1.0 * dsize * rounds * T / (us * 1e-6), all ? "true" : "false");
+  std::printf("{\"what\": \"%d host threads, each CipherText * PlainText on a resident vector of %zu, %d rounds each\", "
+              "\"threads\": %d, \"us_per_mul\": %.1f, \"modexps_per_s\": %.1f, \"slowest_round_us\": %.1f, \"slowest_operator_call_us\": %.1f, "
+              "\"products_ok\": %s}\n",
+              T, dsize, rounds, T, us / (rounds * T), 1.0 * dsize * rounds * T / (us * 1e-6), worst, worst_call, all ? "true" : "false");
   ipcl::terminateContext();
   return all ? 0 : 1;
 }
