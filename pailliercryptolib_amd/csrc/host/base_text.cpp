@@ -88,9 +88,21 @@ bool BaseText::adoptValues(const std::vector<BigNumber>& v) {
 
 void BaseText::ensureHost() const {
   if (m_host_valid) return;
+  std::shared_ptr<detail::DeviceBatch> dev;
+  {
+    std::lock_guard<std::mutex> lk(text_mu(this));
+    if (m_host_valid) return;
+    dev = m_dev;
+  }
+  // The download waits for the batch's kernels -- milliseconds -- so it runs OUTSIDE the lock: other objects share the slot
+  // (thread stacks lay the same variables out alike), and a thread that downloads in a loop holds the slot nearly all the
+  // time.  Round 6, four threads x CipherText * PlainText + getElement: in every second run one thread's operator* (which
+  // takes its operands' slots for an instant) starved behind another thread's downloads for 60-350 ms at a time, 1.45 against
+  // 2.0-2.7 ms per call (profiles/r06_place_pad.txt).  Two threads materialising the SAME text both download; one copy stays.
+  std::vector<BigNumber> texts = dev->download();
   std::lock_guard<std::mutex> lk(text_mu(this));
   if (m_host_valid) return;
-  m_texts = m_dev->download();
+  m_texts = std::move(texts);
   m_host_valid = true;
 }
 
