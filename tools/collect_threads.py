@@ -45,10 +45,11 @@ def main():
         for (op, n, t), v in table(rr, "PGPU_RR_ADAPT").items():
             out.append(f"{op:24s} {n:6d} {t:7d}   {fmt(v.get('3', [])):>28s}   {fmt(v.get('0', [])):>28s}")
     out += ["",
-            "Four threads are bimodal from run to run (CT x PT 1024 x 4: 1.47-1.53 ms in most runs, 1.9-2.8 ms in others; same kernels,",
-            "same durations, four distinct hardware queues in the rocprofv3 trace with GPU_MAX_HW_QUEUES = 4 and 8 alike): in the slow",
-            "runs one host thread issues nothing for 40-90 ms between two HIP calls (tools/run_threads_trace.sh, HIP API trace) -- host",
-            "scheduling on the shared box (256 logical CPUs, cgroup quota of 16, load average 15-25), not a GPU effect; not pursued."]
+            "All tables above are from the build with the two fixes this investigation led to: (1) BaseText::ensureHost downloads",
+            "outside its address-slot lock -- before, four threads were bimodal from run to run (CT x PT 1024 x 4: 1.45-1.5 ms in some",
+            "runs, 1.9-2.8 ms in others: one thread's operator* starved 60-350 ms behind another thread's download lock; all 16 of 16",
+            "runs 1.45 ms after the fix, tools/run_stall.sh); (2) workspaces grow through the block arena, not hipMallocAsync",
+            "(profiles/r06_thread_race.txt: a wrong-result race of four threads' first decrypts)."]
     open(os.path.join(ROOT, "profiles", "r06_place_pad.txt"), "w").write("\n".join(out) + "\n")
     print("\n".join(out))
     out = ["Small batches from several host threads through the ipcl:: API (2048-bit key), MI355X (tools/run_threads_small.sh)",
