@@ -81,6 +81,9 @@ def worker(t):
             _capi.check(L.pgpu_batch_decrypt_crt(sk._h, c, ctypes.byref(d)))
             got = down(d)
             assert got == m, ("roundtrip",) + tag + ([i for i in range(count) if got[i] != m[i]][:8],)
+            if cases[t] % 3 == 1:
+                got = pk.encrypt(m, r)            # the host-array entry point (pgpu_paillier_encrypt) against the resident path
+                assert got == ct, ("encrypt from host",) + tag + ([i for i in range(count) if got[i] != ct[i]][:8],)
             if cases[t] % 3 == 0:
                 got = sk.decrypt(ct)
                 assert got == m, ("decrypt from host",) + tag + ([i for i in range(count) if got[i] != m[i]][:8],)
