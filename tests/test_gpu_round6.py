@@ -232,15 +232,15 @@ def test_first_decrypts_of_four_threads_at_once(engine):
     """Four threads multiply 1024-element vectors and then decrypt their products for the first time, all at the same moment,
     with launches that share CUs (PGPU_PLACE_PAD=0): each decrypt is the launch that grows its stream's window-table
     workspace.  While workspaces grew through hipMallocAsync / hipFreeAsync, 2 % of such runs returned zeros for the tail of
-    a batch (profiles/r06_thread_race.txt); they grow through the block arena now.  Twenty runs, every product checked as
-    m * e mod n by the bench itself."""
+    a batch (profiles/r06_thread_race.txt); they grow through the block arena now.  150 runs of ~0.3 s (the old code failed one run
+    in fifty: a regression shows with probability ~0.95 per suite run), every product checked as m * e mod n by the bench itself."""
     import json
     import os
     import subprocess
     from pailliercryptolib_amd import build
     exe = build.build_api_bench()
     env = dict(os.environ, PGPU_PLACE_PAD="0")
-    for _ in range(20):
-        r = subprocess.run([exe, "--threads-mul", "4", "1024", "3"], capture_output=True, text=True, timeout=300, env=env)
+    for _ in range(150):
+        r = subprocess.run([exe, "--threads-mul", "4", "1024", "2"], capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
         assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["products_ok"] is True, r.stderr[-2000:]
