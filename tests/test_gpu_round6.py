@@ -232,8 +232,8 @@ def test_first_decrypts_of_four_threads_at_once(engine):
     """Four threads multiply 1024-element vectors and then decrypt their products for the first time, all at the same moment,
     with launches that share CUs (PGPU_PLACE_PAD=0): each decrypt is the launch that grows its stream's window-table
     workspace.  While workspaces grew through hipMallocAsync / hipFreeAsync, 2 % of such runs returned zeros for the tail of
-    a batch (profiles/r06_thread_race.txt); they grow through the block arena now.  150 runs of ~0.3 s (the old code failed one run
-    in fifty: a regression shows with probability ~0.95 per suite run), every product checked as m * e mod n by the bench itself."""
+    a batch (profiles/r06_thread_race.txt); they grow through the block arena now.  150 runs of ~0.3 s (the old code failed 15 of
+    400 such runs: a regression shows with probability 0.997 per suite run), every product checked as m * e mod n by the bench itself."""
     import json
     import os
     import subprocess
