@@ -77,6 +77,8 @@ int main() {
   pol::set_wave_policy(0);
   CHECK(!pol::wave_form_pays(16, 0));
   pol::set_wave_policy(1);
+  // threads on round-robin lanes keep the lone caller's forms below this launch size (capi.cpp: busy_other_lanes)
+  CHECK(pol::kRrAdaptMinCount == 4096 && pol::kRrAdaptMinCount <= 8192);   // (8192: the four-thread headline mode must stay adaptive)
   // windows
   CHECK(pol::pick_window(1024) == 5 && pol::pick_window(512) == 5 && pol::pick_window(33) == 3 && pol::pick_window(1) == 1);
   CHECK(pol::masked_decrypt_window() == 3);
